@@ -1,0 +1,149 @@
+"""ctypes binding of libcareless_hip.so (the C-ABI declared in include/careless_hip.h).
+
+The library is the only compute path of this package: if it is missing or cannot be loaded the import of any
+compute entry point raises -- there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcareless_hip.so")
+
+CL_MLP_TILE = 128
+CL_MLP_LMAX = 5
+CL_HIST_STRIDE = 8
+CL_SC_NLL, CL_SC_KL, CL_SC_GNORM2, CL_SC_GNORM2_SANE, CL_SC_COUNT = 0, 1, 2, 3, 4
+CL_LIK_NORMAL, CL_LIK_STUDENTT = 0, 1
+CL_BIJ_EXP, CL_BIJ_SOFTPLUS = 0, 1
+
+_vp = C.c_void_p
+
+
+class TnArgs(C.Structure):
+    """mirror of `cl_tn_args` (include/careless_hip.h)"""
+    _fields_ = [
+        ("q_loc_raw", _vp), ("q_scale_raw", _vp), ("low", _vp), ("centric", _vp), ("es", _vp),
+        ("R", C.c_int), ("S", C.c_int),
+        ("high", C.c_float), ("eps", C.c_float),
+        ("w_kl", C.c_float), ("kl_grad_mult", C.c_float),
+        ("kl_begin", C.c_int), ("kl_end", C.c_int),
+        ("u_f", _vp),
+        ("seed", C.c_ulonglong), ("step", C.c_uint),
+        ("z_f", _vp), ("dz_f", _vp), ("d_loc_raw", _vp), ("d_scale_raw", _vp),
+        ("scalars", _vp), ("stop_flag", _vp),
+    ]
+
+
+class MlpArgs(C.Structure):
+    """mirror of `cl_mlp_args` (include/careless_hip.h)"""
+    _fields_ = [
+        ("refl_id", _vp), ("image_id", _vp), ("meta_t", _vp), ("iobs", _vp), ("sig", _vp),
+        ("n_obs", C.c_int), ("n_pad", C.c_int),
+        ("obs_offset", C.c_longlong),
+        ("mlp", _vp),
+        ("d", C.c_int), ("w", C.c_int), ("L", C.c_int),
+        ("leak", C.c_float),
+        ("img", _vp),
+        ("use_img", C.c_int),
+        ("z_f", _vp),
+        ("R", C.c_int), ("S", C.c_int),
+        ("lik_kind", C.c_int), ("dof", C.c_float), ("lik_const", C.c_float),
+        ("bij_kind", C.c_int), ("eps", C.c_float), ("shift", C.c_float),
+        ("w_ll", C.c_float),
+        ("eta", _vp),
+        ("seed", C.c_ulonglong), ("step", C.c_uint),
+        ("dz_f", _vp), ("d_img", _vp), ("partials", _vp), ("scalars", _vp),
+        ("ipred_out", _vp), ("loc_out", _vp), ("sig_out", _vp), ("dO_ext", _vp),
+        ("stop_flag", _vp),
+    ]
+
+
+class AdamArgs(C.Structure):
+    """mirror of `cl_adam_args` (include/careless_hip.h)"""
+    _fields_ = [
+        ("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp),
+        ("n", C.c_int),
+        ("alpha", C.c_float),
+        ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+        ("clipnorm", C.c_float), ("clipvalue", C.c_float), ("global_clipnorm", C.c_float),
+        ("seg_off", _vp),
+        ("nseg", C.c_int),
+        ("seg_sq", _vp), ("frozen", _vp), ("scalars", _vp), ("stop_flag", _vp),
+    ]
+
+
+EXPORTS = {
+    # name: (restype, argtypes)
+    "cl_version": (C.c_char_p, []),
+    "cl_abi_sizes": (None, [C.POINTER(C.c_size_t)]),
+    "cl_mlp_default_grid": (C.c_int, []),
+    "cl_mlp_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "cl_tn_forward": (C.c_int, [C.POINTER(TnArgs), _vp]),
+    "cl_tn_backward": (C.c_int, [C.POINTER(TnArgs), _vp]),
+    "cl_elbo_mono_fwd_bwd": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
+    "cl_mlp_forward": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
+    "cl_mlp_backward_ext": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
+    "cl_reduce_partials": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "cl_grad_sqnorm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "cl_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
+    "cl_step_finalize": (C.c_int, [_vp, C.c_float, _vp, C.c_int, _vp, _vp]),
+    "cl_debug_noise": (C.c_int, [C.c_ulonglong, C.c_uint, C.c_int, C.c_longlong, C.c_longlong, C.c_int, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class CarelessHipError(RuntimeError):
+    pass
+
+
+def get_lib() -> C.CDLL:
+    """Load libcareless_hip.so (once).  Raises CarelessHipError when the HIP extension is not built/loadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CarelessHipError(
+            f"{LIB_PATH} is missing: build it with `python -m careless_amd.build` (needs hipcc, targets gfx950). "
+            "careless_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise CarelessHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in EXPORTS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CarelessHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    sizes = (C.c_size_t * 3)()
+    lib.cl_abi_sizes(sizes)
+    mine = (C.sizeof(TnArgs), C.sizeof(MlpArgs), C.sizeof(AdamArgs))
+    if tuple(sizes) != mine:
+        raise CarelessHipError(f"ABI mismatch between careless_amd/_lib.py {mine} and the library {tuple(sizes)}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    """Turn a C-ABI return code into an exception."""
+    if code == 0:
+        return
+    if code == -2:
+        raise NotImplementedError(
+            f"{what}: scaler geometry not supported by the fused gfx950 kernel "
+            f"(needs 1 <= mlp_layers <= {CL_MLP_LMAX}, mlp_width <= 64, metadata width <= 64)")
+    if code < 0:
+        raise ValueError(f"{what}: invalid argument (code {code})")
+    raise CarelessHipError(f"{what}: HIP error {code}")
+
+
+def ptr(t) -> Optional[int]:
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return t.data_ptr()

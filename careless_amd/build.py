@@ -1,0 +1,65 @@
+"""Build libcareless_hip.so for gfx950 with hipcc (in-tree; the .so travels with the source tree).
+
+    python -m careless_amd.build            # rebuild if any source is newer than the library
+    python -m careless_amd.build --force
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcareless_hip.so")
+SOURCES = ["cl_api.hip", "elbo_mlp.hip", "elbo_elem.hip"]
+HEADERS = ["cl_math.h", "cl_kernels.h", os.path.join("..", "..", "include", "careless_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libcareless_hip.so cannot be built on this machine")
+    return exe
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile every HIP source for gfx950 and link the shared library.  Returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(o)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    for o in objs:
+        os.remove(o)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,106 @@
+// extern "C" boundary of libcareless_hip.so (declared in include/careless_hip.h): argument checks + launches.
+#include <hip/hip_runtime.h>
+#include "cl_kernels.h"
+
+extern "C" {
+
+const char* cl_version(void) { return "careless_hip 0.1.0 (gfx950)"; }
+
+void cl_abi_sizes(size_t out[3]) {
+    out[0] = sizeof(cl_tn_args);
+    out[1] = sizeof(cl_mlp_args);
+    out[2] = sizeof(cl_adam_args);
+}
+
+int cl_mlp_default_grid(void) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return cus;
+}
+
+size_t cl_mlp_param_count(int d, int w, int L) {
+    if (d < 1 || w < 1 || L < 1) return 0;
+    return (size_t)w * d + w + (size_t)(L - 1) * ((size_t)w * w + w) + 2 * (size_t)w + 2;
+}
+
+static int check_mlp(const cl_mlp_args* a) {
+    if (a == nullptr) return -1;
+    if (a->meta_t == nullptr || a->mlp == nullptr) return -1;
+    if (a->n_obs <= 0 || a->n_pad < a->n_obs || a->n_pad % CL_MLP_TILE != 0) return -1;
+    return 0;
+}
+
+int cl_elbo_mono_fwd_bwd(const cl_mlp_args* a, int grid, void* stream) {
+    if (int e = check_mlp(a)) return e;
+    if (a->refl_id == nullptr || a->iobs == nullptr || a->sig == nullptr || a->z_f == nullptr || a->dz_f == nullptr ||
+        a->partials == nullptr || a->scalars == nullptr || a->S < 1 || a->R < 1)
+        return -1;
+    if (a->use_img && (a->image_id == nullptr || a->img == nullptr || a->d_img == nullptr)) return -1;
+    return cl_launch_mlp(*a, 0, grid, (hipStream_t)stream);
+}
+
+int cl_mlp_forward(const cl_mlp_args* a, int grid, void* stream) {
+    if (int e = check_mlp(a)) return e;
+    if (a->loc_out == nullptr || a->sig_out == nullptr) return -1;
+    return cl_launch_mlp(*a, 1, grid, (hipStream_t)stream);
+}
+
+int cl_mlp_backward_ext(const cl_mlp_args* a, int grid, void* stream) {
+    if (int e = check_mlp(a)) return e;
+    if (a->dO_ext == nullptr || a->partials == nullptr) return -1;
+    return cl_launch_mlp(*a, 2, grid, (hipStream_t)stream);
+}
+
+int cl_reduce_partials(const float* partials, int nparts, int P, float* grad_mlp, const int* stop_flag, void* stream) {
+    if (partials == nullptr || grad_mlp == nullptr || nparts < 1 || P < 1) return -1;
+    return cl_launch_reduce_partials(partials, nparts, P, grad_mlp, stop_flag, (hipStream_t)stream);
+}
+
+static int check_tn(const cl_tn_args* a) {
+    if (a == nullptr || a->q_loc_raw == nullptr || a->q_scale_raw == nullptr || a->low == nullptr ||
+        a->centric == nullptr || a->es == nullptr || a->R < 1 || a->S < 1)
+        return -1;
+    return 0;
+}
+
+int cl_tn_forward(const cl_tn_args* a, void* stream) {
+    if (int e = check_tn(a)) return e;
+    if (a->z_f == nullptr || a->scalars == nullptr) return -1;
+    return cl_launch_tn_forward(*a, (hipStream_t)stream);
+}
+
+int cl_tn_backward(const cl_tn_args* a, void* stream) {
+    if (int e = check_tn(a)) return e;
+    if (a->dz_f == nullptr || a->d_loc_raw == nullptr || a->d_scale_raw == nullptr) return -1;
+    return cl_launch_tn_backward(*a, (hipStream_t)stream);
+}
+
+int cl_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
+                   const int* stop_flag, void* stream) {
+    if (g == nullptr || scalars == nullptr || n < 1) return -1;
+    if (seg_sq != nullptr && (seg_off == nullptr || nseg < 1)) return -1;
+    return cl_launch_grad_sqnorm(g, n, seg_off, nseg, seg_sq, scalars, stop_flag, (hipStream_t)stream);
+}
+
+int cl_adam_step(const cl_adam_args* a, void* stream) {
+    if (a == nullptr || a->p == nullptr || a->g == nullptr || a->m == nullptr || a->v == nullptr || a->n < 1) return -1;
+    if ((a->clipnorm > 0.0f || a->frozen != nullptr) && (a->seg_off == nullptr || a->nseg < 1)) return -1;
+    if (a->clipnorm > 0.0f && a->seg_sq == nullptr) return -1;
+    if (a->global_clipnorm > 0.0f && a->scalars == nullptr) return -1;
+    return cl_launch_adam(*a, (hipStream_t)stream);
+}
+
+int cl_step_finalize(const double* scalars, float kl_weight_or_one, double* history, int step_index, int* stop_flag,
+                     void* stream) {
+    if (scalars == nullptr || history == nullptr || step_index < 0) return -1;
+    return cl_launch_finalize(scalars, kl_weight_or_one, history, step_index, CL_HIST_STRIDE, stop_flag, (hipStream_t)stream);
+}
+
+int cl_debug_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
+                   void* stream) {
+    if (out == nullptr || S < 1 || n < 1) return -1;
+    return cl_launch_noise(seed, step, S, n, offset, kind, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,18 @@
+// Internal launch interface between the C-ABI layer (cl_api.hip) and the kernels.  The argument structs are the
+// public ones of include/careless_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/careless_hip.h"
+
+int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st);
+int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st);
+int cl_launch_tn_forward(const cl_tn_args& a, hipStream_t st);
+int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st);
+int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
+                          const int* stop_flag, hipStream_t st);
+int cl_launch_adam(const cl_adam_args& a, hipStream_t st);
+int cl_launch_finalize(const double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,
+                       hipStream_t st);
+int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
+                    hipStream_t st);

@@ -1,0 +1,216 @@
+// Scalar fp32 math of the ELBO path: truncated-normal surrogate posterior, Wilson prior, Normal / Student-T
+// likelihood, scale bijectors and the counter-based RNG.  Every kernel in this directory gets its per-element
+// arithmetic from here, so the formulas are written (and unit-checked) once.
+//
+// The functions are plain inline C++ with a CL_HD qualifier so the same text also compiles with g++ for the
+// CPU-side formula check in tests/ (tests/host_math_check.cpp); the product only ever runs them on the GPU.
+//
+// Reference semantics (paths relative to the reference checkout; [3P] = recalled TFP/Keras behaviour):
+//   careless/models/merging/surrogate_posteriors.py:45-131   truncated normal q(F)
+//   careless/models/priors/wilson.py:13-57                   Wilson prior
+//   careless/models/likelihoods/mono.py:10-37                Normal / Student-T likelihood
+//   careless/models/scaling/nn.py:10-25                      NormalLayer scale bijector
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define CL_HD __host__ __device__ __forceinline__
+#else
+#define CL_HD inline
+#endif
+
+#define CL_LOG_2PI_F 1.8378770664093453f
+#define CL_INV_SQRT2_F 0.70710678118654752f
+#define CL_INV_SQRT_2PI_F 0.3989422804014327f
+#define CL_TINY_F 1.17549435e-38f          // np.finfo(float32).tiny  [3P: clip in TFP's sample gradient]
+#define CL_EPS_F 1.1920929e-07f            // np.finfo(float32).eps
+
+enum { CL_LIK_NORMAL = 0, CL_LIK_STUDENTT = 1 };
+enum { CL_BIJ_EXP = 0, CL_BIJ_SOFTPLUS = 1 };
+enum { CL_PRIOR_WILSON = 0, CL_PRIOR_DOUBLE_WILSON = 1 };
+
+// ---------------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator (Salmon et al. 2011).  counter = (index lo, index hi | stream, sample, step)
+// so every draw is a pure function of (seed, step, sample, global element index): results do not depend on the
+// number of GPUs or on the launch geometry.
+// ---------------------------------------------------------------------------------------------------------
+struct cl_u32x4 { uint32_t x, y, z, w; };
+
+CL_HD uint32_t cl_mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+CL_HD cl_u32x4 cl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = cl_mulhi32(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = cl_mulhi32(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    cl_u32x4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+
+// uniform in the open interval (0,1): 24 random bits, centred in their bin
+CL_HD float cl_u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+
+enum { CL_STREAM_QF = 1, CL_STREAM_SCALE = 2 };
+
+// uniform for the truncated-normal draw of reflection h, MC sample s
+CL_HD float cl_noise_uniform(uint64_t seed, uint32_t step, uint32_t s, uint64_t idx) {
+    const cl_u32x4 r = cl_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_QF << 28), s, step,
+                                        (uint32_t)seed, (uint32_t)(seed >> 32));
+    return cl_u01(r.x);
+}
+
+// standard normal for the scale draw of observation idx, MC sample s (Box-Muller on two words of one Philox block)
+CL_HD float cl_noise_normal(uint64_t seed, uint32_t step, uint32_t s, uint64_t idx) {
+    const cl_u32x4 r = cl_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_SCALE << 28), s, step,
+                                        (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u1 = cl_u01(r.x), u2 = cl_u01(r.y);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    return rad * cosf(6.283185307179586f * u2);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// normal cdf pieces
+// ---------------------------------------------------------------------------------------------------------
+CL_HD float cl_ndtr(float x) { return 0.5f * erfcf(-x * CL_INV_SQRT2_F); }
+CL_HD float cl_npdf(float x) { return CL_INV_SQRT_2PI_F * expf(-0.5f * x * x); }
+
+// Inverse normal cdf for p in (0, 0.5]: Wichura's AS241 PPND7 (about 7 significant digits), lower half only.
+CL_HD float cl_ndtri_lower(float p) {
+    const float q = p - 0.5f;
+    if (q >= -0.425f) {
+        const float r = 0.180625f - q * q;
+        const float num = ((5.9109374720e+01f * r + 1.5929113202e+02f) * r + 5.0434271938e+01f) * r + 3.3871327179e+00f;
+        const float den = ((6.7187563600e+01f * r + 7.8757757664e+01f) * r + 1.7895169469e+01f) * r + 1.0f;
+        return q * num / den;
+    }
+    float r = sqrtf(-logf(p));
+    float v;
+    if (r <= 5.0f) {
+        r -= 1.6f;
+        v = (((1.7023821103e-01f * r + 1.3067284816e+00f) * r + 2.7568153900e+00f) * r + 1.4234372777e+00f) /
+            ((1.2021132975e-01f * r + 7.3700164250e-01f) * r + 1.0f);
+    } else {
+        r -= 5.0f;
+        v = (((1.7337203997e-02f * r + 4.2868294337e-01f) * r + 3.0812263860e+00f) * r + 6.6579051150e+00f) /
+            ((1.2258202635e-02f * r + 2.4197894225e-01f) * r + 1.0f);
+    }
+    return -v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// truncated-normal surrogate posterior, one (reflection, sample) element
+// ---------------------------------------------------------------------------------------------------------
+struct cl_tn_elem {
+    float loc, scale;        // exp(a), exp(b) + eps          (surrogate_posteriors.py:120-130)
+    float alpha, beta;       // standardised bounds
+    float zn;                // Phi(beta) - Phi(alpha)
+    float e;                 // standardised sample
+    float y;                 // (z - loc) / scale, taken as e (or alpha when clamped) to avoid the cancellation in z - loc
+    float z;                 // max(low, loc + scale e)        (surrogate_posteriors.py:50-53)
+    float dz_dloc, dz_dscale;  // pathwise sample gradients [3P: TFP _std_samples_with_gradients]
+};
+
+CL_HD cl_tn_elem cl_tn_sample(float a_raw, float b_raw, float low, float high, float eps, float u) {
+    cl_tn_elem r;
+    r.loc = expf(a_raw);
+    r.scale = expf(b_raw) + eps;
+    const float inv = 1.0f / r.scale;
+    r.alpha = (low - r.loc) * inv;
+    r.beta = (high - r.loc) * inv;
+    const float up_b = 0.5f * erfcf(r.beta * CL_INV_SQRT2_F);      // Phi(-beta)
+    const float up_a = 0.5f * erfcf(r.alpha * CL_INV_SQRT2_F);     // Phi(-alpha)
+    r.zn = up_a - up_b;
+    const float lo_a = 0.5f * erfcf(-r.alpha * CL_INV_SQRT2_F);    // Phi(alpha)
+    const float p = lo_a + u * r.zn;
+    const float q = up_b + (1.0f - u) * r.zn;
+    float e = (p < 0.5f) ? cl_ndtri_lower(p) : -cl_ndtri_lower(q);
+    e = fminf(fmaxf(e, r.alpha), r.beta);
+    r.e = e;
+    const float s = r.loc + r.scale * e;
+    const bool pass = s > low;
+    r.z = pass ? s : low;
+    r.y = pass ? e : r.alpha;
+    float cdf = fminf(fmaxf(u, CL_TINY_F), 1.0f - CL_EPS_F);
+    const float dl = expf(0.5f * (e * e - r.alpha * r.alpha) + log1pf(-cdf));
+    const float du = expf(0.5f * (e * e - r.beta * r.beta) + logf(cdf));
+    r.dz_dloc = pass ? (1.0f - dl - du) : 0.0f;
+    r.dz_dscale = pass ? (e - r.alpha * dl - (du > 0.0f ? r.beta * du : 0.0f)) : 0.0f;
+    return r;
+}
+
+// log q(z) = -(0.5 y^2 + 0.5 log 2pi + log scale + log Z)   [3P: tfd.TruncatedNormal.log_prob]
+CL_HD float cl_tn_log_prob(const cl_tn_elem& t) {
+    const float y = t.y;
+    return -(0.5f * y * y + 0.5f * CL_LOG_2PI_F + logf(t.scale) + logf(t.zn));
+}
+
+// partial derivatives of log q(z; loc, scale) at fixed z, and d/dz
+CL_HD void cl_tn_log_prob_grads(const cl_tn_elem& t, float* dz, float* dloc, float* dscale) {
+    const float inv = 1.0f / t.scale;
+    const float y = t.y;
+    const float pa = cl_npdf(t.alpha);
+    const float pb = cl_npdf(t.beta);
+    const float bpb = (pb > 0.0f) ? t.beta * pb : 0.0f;
+    const float izn = 1.0f / t.zn;
+    *dz = -y * inv;
+    *dloc = y * inv - (pa - pb) * inv * izn;
+    *dscale = y * y * inv - inv - (t.alpha * pa - bpb) * inv * izn;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Wilson prior (wilson.py:13-57): centric HalfNormal(sqrt(eps Sigma)), acentric Weibull(2, sqrt(eps Sigma))
+// es = multiplicity * Sigma
+// ---------------------------------------------------------------------------------------------------------
+CL_HD float cl_wilson_log_prob(float z, bool centric, float es) {
+    if (centric) return -0.5f * z * z / es + 0.5f * logf(0.6366197723675814f) - 0.5f * logf(es);
+    return 0.6931471805599453f + logf(z) - logf(es) - z * z / es;
+}
+CL_HD float cl_wilson_dlog_prob_dz(float z, bool centric, float es) {
+    if (centric) return -z / es;
+    return 1.0f / z - 2.0f * z / es;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scale bijector of the scaler's NormalLayer (nn.py:22-25; manager.py:450-463): sigma = f(raw) + eps
+// ---------------------------------------------------------------------------------------------------------
+CL_HD float cl_softplus(float x) { return (x > 20.0f) ? x : log1pf(expf(x)); }
+CL_HD float cl_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+CL_HD float cl_scale_bij(float raw, int kind, float eps, float* dsig_draw) {
+    if (kind == CL_BIJ_EXP) {
+        const float ex = expf(raw);
+        *dsig_draw = ex;
+        return ex + eps;
+    }
+    *dsig_draw = cl_sigmoid(raw);
+    return cl_softplus(raw) + eps;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// likelihood of one prediction (mono.py:10-37).  Returns log p(ipred) and writes d log p / d ipred.
+// lik_const for Student-T = lgamma((nu+1)/2) - lgamma(nu/2) - 0.5 log(nu pi)   (computed on the host)
+// ---------------------------------------------------------------------------------------------------------
+CL_HD float cl_lik_log_prob(float ipred, float iobs, float sig, int kind, float dof, float lik_const, float* dll) {
+    const float inv = 1.0f / sig;
+    const float y = (ipred - iobs) * inv;
+    if (kind == CL_LIK_NORMAL) {
+        *dll = -y * inv;
+        return -0.5f * y * y - 0.5f * CL_LOG_2PI_F - logf(sig);
+    }
+    const float y2 = y * y;
+    *dll = -(dof + 1.0f) * y / (dof + y2) * inv;
+    return -0.5f * (dof + 1.0f) * log1pf(y2 / dof) - logf(sig) + lik_const;
+}

@@ -1,0 +1,222 @@
+// Per-reflection and per-parameter kernels of the ELBO step (gfx950): HBM-streaming, one pass each.
+//
+//   tn_forward_kernel     q(F) parameter transform + reparameterised truncated-normal sample z_f (S,R), and the
+//                         sample-based KL partial sums  sum_s [log q(z) - log p(z)]
+//                         [surrogate_posteriors.py:50-53,104-131; variational.py:123-139,154,173; wilson.py:50-57]
+//   tn_backward_kernel    chain rule from dL/dz_f (data term, accumulated by the fused MLP kernel) plus the KL
+//                         term's own derivatives back to the raw q parameters (a = log loc, b = log(scale - eps))
+//   grad_sqnorm_kernel    global (and per-tensor) squared L2 norm of the flat gradient   [variational.py:205]
+//   adam_kernel           non-finite -> 0, optional clipping, tf_keras Adam update       [variational.py:208-209, manager.py:494-501]
+//   finalize_kernel       per-step history record + the sticky stop flag               [variational.py:262-274]
+// Each kernel is bandwidth-trivial next to the fused MLP kernel (R = N/32); they exist to keep the whole step on
+// the device with no host round trip.
+#include <hip/hip_runtime.h>
+#include "cl_math.h"
+#include "cl_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// block-wide double sum -> one atomic per block
+__device__ __forceinline__ void block_atomic_add_d(double v, double* dst) {
+    __shared__ double sh[16];
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
+        atomicAdd(dst, s);
+    }
+}
+
+__device__ __forceinline__ float tn_uniform(const cl_tn_args& A, int h, int s) {
+    return A.u_f ? A.u_f[(size_t)h * A.S + s] : cl_noise_uniform(A.seed, A.step, (uint32_t)s, (uint64_t)h);
+}
+
+// log-density of the Wilson prior and its z-derivative for reflection h
+__device__ __forceinline__ float prior_lp(const cl_tn_args& A, int h, float z, float* dlp_dz) {
+    const bool c = A.centric[h] != 0;
+    const float es = A.es[h];
+    *dlp_dz = cl_wilson_dlog_prob_dz(z, c, es);
+    return cl_wilson_log_prob(z, c, es);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void tn_forward_kernel(const cl_tn_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    double kl = 0.0;
+    if (h < A.R) {
+        const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
+        const bool in_kl = (h >= A.kl_begin && h < A.kl_end);
+        for (int s = 0; s < A.S; ++s) {
+            const cl_tn_elem t = cl_tn_sample(a, b, low, A.high, A.eps, tn_uniform(A, h, s));
+            A.z_f[(size_t)h * A.S + s] = t.z;
+            if (in_kl) {
+                float dlp;
+                const float lq = cl_tn_log_prob(t);
+                const float lp = prior_lp(A, h, t.z, &dlp);
+                kl += (double)(lq - lp);
+            }
+        }
+    }
+    block_atomic_add_d(kl * (double)A.w_kl, A.scalars + CL_SC_KL);
+}
+
+__global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= A.R) return;
+    const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
+    const bool in_kl = (h >= A.kl_begin && h < A.kl_end);
+    const float wkl = in_kl ? A.w_kl * A.kl_grad_mult : 0.0f;
+    float gloc = 0.0f, gscale = 0.0f, loc = 0.0f, scale = 0.0f;
+    for (int s = 0; s < A.S; ++s) {
+        const cl_tn_elem t = cl_tn_sample(a, b, low, A.high, A.eps, tn_uniform(A, h, s));
+        loc = t.loc; scale = t.scale;
+        float dq_dz, dq_dloc, dq_dscale, dp_dz;
+        cl_tn_log_prob_grads(t, &dq_dz, &dq_dloc, &dq_dscale);
+        (void)prior_lp(A, h, t.z, &dp_dz);
+        const float gz = A.dz_f[(size_t)h * A.S + s] + wkl * (dq_dz - dp_dz);
+        gloc += gz * t.dz_dloc + wkl * dq_dloc;
+        gscale += gz * t.dz_dscale + wkl * dq_dscale;
+    }
+    // raw parameters: loc = exp(a), scale = exp(b) + eps
+    A.d_loc_raw[h] += gloc * loc;
+    A.d_scale_raw[h] += gscale * (scale - A.eps);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gradient norm, Adam
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int seg_of(const int* __restrict__ seg_off, int nseg, int i) {
+    int lo = 0, hi = nseg;               // seg_off has nseg + 1 entries
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, int n, const int* __restrict__ seg_off,
+                                                          int nseg, double* __restrict__ seg_sq, double* scalars,
+                                                          const int* stop_flag) {
+    if (stop_flag != nullptr && *stop_flag != 0) return;
+    double acc = 0.0, sane = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v = g[i];
+        const double v2 = (double)v * (double)v;
+        acc += v2;                                           // raw: a NaN gradient gives a NaN norm (variational.py:205)
+        const double s2 = isfinite(v) ? v2 : 0.0;           // what the optimizer's clipping sees (after :208)
+        sane += s2;
+        if (seg_sq != nullptr) atomicAdd(seg_sq + seg_of(seg_off, nseg, i), s2);
+    }
+    block_atomic_add_d(acc, scalars + CL_SC_GNORM2);
+    __syncthreads();
+    block_atomic_add_d(sane, scalars + CL_SC_GNORM2_SANE);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const cl_adam_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    float gscale = 1.0f;
+    if (A.global_clipnorm > 0.0f) {
+        // tf.clip_by_global_norm over the sanitised gradients [3P]: g * clip / max(norm, clip)
+        const float nrm = (float)sqrt(A.scalars[CL_SC_GNORM2_SANE]);
+        gscale = A.global_clipnorm / fmaxf(nrm, A.global_clipnorm);
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += gridDim.x * blockDim.x) {
+        if (A.frozen != nullptr && A.frozen[seg_of(A.seg_off, A.nseg, i)] != 0) continue;
+        float g = A.g[i];
+        if (!isfinite(g)) g = 0.0f;                                   // variational.py:208
+        if (A.clipnorm > 0.0f) {                                      // per-tensor tf.clip_by_norm [3P]
+            const float nrm = (float)sqrt(A.seg_sq[seg_of(A.seg_off, A.nseg, i)]);
+            if (nrm > A.clipnorm) g *= A.clipnorm / nrm;
+        }
+        g *= gscale;
+        if (A.clipvalue > 0.0f) g = fminf(fmaxf(g, -A.clipvalue), A.clipvalue);
+        float m = A.m[i], v = A.v[i];
+        m += (g - m) * (1.0f - A.beta1);
+        v += (g * g - v) * (1.0f - A.beta2);
+        A.m[i] = m;
+        A.v[i] = v;
+        A.p[i] -= m * A.alpha / (sqrtf(v) + A.adam_eps);
+    }
+}
+
+// one thread: write the history record of this step and update the sticky stop flag
+__global__ void finalize_kernel(const double* scalars, float kl_weight_or_one, double* history, int step_index,
+                                int hist_stride, int* stop_flag) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double* rec = history + (size_t)step_index * hist_stride;
+    if (stop_flag != nullptr && *stop_flag != 0) {
+        rec[0] = rec[1] = rec[2] = rec[3] = 0.0;
+        rec[4] = 1.0;                      // skipped
+        return;
+    }
+    const double nll = scalars[CL_SC_NLL], kl = scalars[CL_SC_KL];
+    const double gn = sqrt(scalars[CL_SC_GNORM2]);
+    rec[0] = nll + (double)kl_weight_or_one * kl;   // loss
+    rec[1] = kl;                                    // "F KLDiv"
+    rec[2] = nll;                                   // "NLL"
+    rec[3] = gn;                                    // "Grad Norm"
+    rec[4] = 0.0;
+    if (stop_flag != nullptr && !isfinite(gn)) *stop_flag = 1;     // variational.py:271-274
+}
+
+// debug / test aid: the noise the kernels would draw for (seed, step)
+__global__ void noise_kernel(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind,
+                             float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int s = 0; s < S; ++s)
+        out[(size_t)i * S + s] = (kind == 0) ? cl_noise_uniform(seed, step, (uint32_t)s, (uint64_t)(offset + i))
+                                             : cl_noise_normal(seed, step, (uint32_t)s, (uint64_t)(offset + i));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+int cl_launch_tn_forward(const cl_tn_args& a, hipStream_t st) {
+    if (a.R <= 0 || a.S <= 0) return -1;
+    hipLaunchKernelGGL(tn_forward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st) {
+    if (a.R <= 0 || a.S <= 0) return -1;
+    hipLaunchKernelGGL(tn_backward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
+                          const int* stop_flag, hipStream_t st) {
+    if (n <= 0) return -1;
+    int grid = (n + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, seg_off, nseg, seg_sq, scalars, stop_flag);
+    return (int)hipGetLastError();
+}
+int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
+    if (a.n <= 0) return -1;
+    int grid = (a.n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int cl_launch_finalize(const double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, scalars, klw, history, step_index, hist_stride, stop_flag);
+    return (int)hipGetLastError();
+}
+int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
+                    hipStream_t st) {
+    if (n <= 0) return -1;
+    hipLaunchKernelGGL(noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, step, S, n, offset, kind, out);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,574 @@
+// Fused scaling-model + likelihood kernel of the ELBO step (gfx950 / CDNA4 only).
+//
+// One launch does, for every observation of this rank's shard (reference call sites in brackets):
+//   forward   metadata -> L x [Dense(w) + LeakyReLU] -> Dense(2)            [careless/models/scaling/nn.py:92-120]
+//   sample    z_Sigma = a_img (loc + sigma eta + shift)                      [variational.py:157, image.py:53-63]
+//   predict   ipred = z_Sigma * z_f[refl_id]^2                               [variational.py:167]
+//   likeli.   Normal / Student-T log-prob, NLL partial sums                  [likelihoods/mono.py:10-37, variational.py:174-181]
+//   backward  d/d ipred -> atomics into dz_f and d(image scales); dO -> dgrad + wgrad of every Dense layer
+//                                                                            [variational.py:197-202 tape.gradient]
+// Nothing per-observation is written to HBM: activations stay in registers between forward and backward.
+//
+// Work decomposition (MI355X-first):
+//   * persistent workgroups (one per CU), 8 waves = two per SIMD, <= 256 registers each, so one wave's VALU / LDS
+//     work (LeakyReLU, staging, epilogue) overlaps its SIMD partner's MFMAs;
+//   * a workgroup walks tiles of 128 observations; in forward / dgrad a wave owns 16 observations and keeps the
+//     transposed activations H^T (feature x observation) in MFMA accumulator layout, so each layer's output tile
+//     IS the next layer's B operand (v_mfma_f32_16x16x4_f32: exact fp32; the k-grouping of every step is chosen
+//     to match the C layout: step (kb,t) contracts features 16kb + 4q + t, q = lane>>4);
+//   * weights live in LDS as W^T with row pitch w+4 (ds_read_b128 feeds 4 forward steps, ds_read_b32 feeds dgrad);
+//   * wgrad contracts over observations, which sit on the MFMA lane axis, so dZ_l and H_{l-1} are staged once
+//     through two LDS tiles [feature][128 obs (+4)]; each wave then accumulates its own 16x16 blocks of dW_l^T over
+//     the whole tile, in registers, across ALL tiles of the kernel (no per-tile global traffic for weight grads);
+//   * per-workgroup weight-gradient partials are written once at kernel end; a tiny second kernel sums them in a
+//     fixed order (deterministic).
+// Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
+#include <hip/hip_runtime.h>
+#include "cl_math.h"
+#include "cl_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CL_TILE CL_MLP_TILE
+#define CL_NW 8              // waves per workgroup
+#define CL_WOBS 16           // observations per wave in forward / dgrad
+#define CL_PB 132            // pitch of the [feature][obs] staging tiles (128 + 4)
+#define CL_SCR 160           // floats of per-wave scratch
+// compiler-level fence for memory operations: keeps hipcc from hoisting a whole layer of LDS operand reads
+// above the MFMAs that consume them
+#define CL_PIN() asm volatile("" ::: "memory")
+
+namespace {
+
+// LDS-only workgroup barrier: do not drain outstanding global atomics / loads (vmcnt) at every layer seam.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// ordering of one wave's own LDS traffic (cross-lane exchange through LDS inside a wave)
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int WP, int DP, int LMAX>
+struct SmemLayout {
+    static constexpr int PW = WP + 4;
+    static constexpr int PW1 = DP + 4;
+    static constexpr int HR = (WP > DP ? WP : DP);
+    static constexpr int oW1 = 0;
+    static constexpr int oW = oW1 + WP * PW1;
+    static constexpr int oWo = oW + (LMAX - 1) * WP * PW;
+    static constexpr int oB = oWo + 2 * WP;
+    static constexpr int oBo = oB + LMAX * WP;
+    static constexpr int oZ = oBo + 4;
+    static constexpr int oH = oZ + WP * CL_PB;
+    static constexpr int oS = oH + HR * CL_PB;
+    static constexpr int total = oS + CL_NW * CL_SCR;
+};
+
+// which 16x16 blocks of dW^T (OB x IB blocks) a wave accumulates, and over which part of the 128-observation tile
+template <int OB, int IB>
+struct WgradPlan {
+    static constexpr int NBK = OB * IB;
+    static constexpr int BPW = (NBK >= CL_NW) ? NBK / CL_NW : 1;      // blocks per wave (same o-block, consecutive i-blocks)
+    static constexpr int KPARTS = (NBK >= CL_NW) ? 1 : CL_NW / NBK;   // split of the observation axis
+    static constexpr int GROUPS = NBK / BPW;                          // distinct block groups
+    static constexpr int KLEN = CL_TILE / KPARTS;
+    static_assert(IB % BPW == 0, "blocks of one wave must share their o-block");
+    static_assert(BPW <= 2, "at most two accumulator blocks per wave and layer");
+};
+
+}  // namespace
+
+// MODE 0: full ELBO step (mono likelihood in the epilogue);  MODE 1: forward only (loc, sigma per observation);
+// MODE 2: forward recompute + backward from an externally supplied dL/d(loc, sigma) (Laue two-pass path).
+template <int WP, int DP, int LMAX, int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void elbo_mlp_kernel(const cl_mlp_args A) {
+    using SL = SmemLayout<WP, DP, LMAX>;
+    constexpr int FB = WP / 16;          // 16-feature blocks of a hidden layer
+    constexpr int KS1 = DP / 4;          // MFMA k-steps of the first layer (4 metadata features per step)
+    constexpr int IB1 = (DP + 15) / 16;  // 16-feature blocks of the metadata
+    constexpr int PW = SL::PW, PW1 = SL::PW1, PB = CL_PB;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const sW1 = smem + SL::oW1;
+    float* const sW = smem + SL::oW;
+    float* const sWo = smem + SL::oWo;
+    float* const sB = smem + SL::oB;
+    float* const sBo = smem + SL::oBo;
+    float* const sZ = smem + SL::oZ;
+    float* const sH = smem + SL::oH;
+
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;   // a previous step hit a non-finite gradient norm
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15;            // observation within the wave / MFMA row-or-column index
+    const int q = lane >> 4;            // k-group of the MFMA step
+    float* const sS = smem + SL::oS + wv * CL_SCR;
+    float* const sLoc = sS;
+    float* const sSig = sS + 16;
+    float* const sAim = sS + 32;
+    float* const sIo = sS + 48;
+    float* const sSg = sS + 64;
+    int* const sRid = reinterpret_cast<int*>(sS + 80);
+    float* const sDl = sS + 96;
+    float* const sDs = sS + 112;
+    float* const sDa = sS + 128;
+
+    const int d = A.d, w = A.w, L = A.L;
+    const float leak = A.leak;
+
+    // ---- stage the weights (global W^T layout, see cl_kernels.h) into padded LDS images, zero-filled ---------
+    {
+        const float* __restrict__ P = A.mlp;
+        for (int idx = tid; idx < WP * PW1; idx += 512) {
+            const int o = idx / PW1, i = idx - o * PW1;
+            sW1[idx] = (o < w && i < d) ? P[o * d + i] : 0.0f;
+        }
+        for (int idx = tid; idx < LMAX * WP; idx += 512) {
+            const int l = idx / WP, o = idx - l * WP;
+            float v = 0.0f;
+            if (l < L && o < w) v = (l == 0) ? P[w * d + o] : P[w * d + w + (l - 1) * (w * w + w) + w * w + o];
+            sB[idx] = v;
+        }
+        for (int l = 1; l < L; ++l) {
+            const float* __restrict__ Wl = P + w * d + w + (l - 1) * (w * w + w);
+            float* dst = sW + (l - 1) * WP * PW;
+            for (int idx = tid; idx < WP * PW; idx += 512) {
+                const int o = idx / PW, i = idx - o * PW;
+                dst[idx] = (o < w && i < w) ? Wl[o * w + i] : 0.0f;
+            }
+        }
+        const float* __restrict__ Wo = P + w * d + w + (L - 1) * (w * w + w);
+        for (int idx = tid; idx < 2 * WP; idx += 512) {
+            const int c = idx / WP, i = idx - c * WP;
+            sWo[idx] = (i < w) ? Wo[c * w + i] : 0.0f;
+        }
+        if (tid < 4) sBo[tid] = (tid < 2) ? Wo[2 * w + tid] : 0.0f;
+    }
+    __syncthreads();
+
+    // ---- accumulators that live across all tiles of this workgroup -----------------------------------------
+    f32x4 wacc[LMAX][2];
+    float bacc[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+        bacc[l] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wacc[l][b][t] = 0.0f;
+    }
+    float woacc0 = 0.0f, woacc1 = 0.0f, boacc0 = 0.0f, boacc1 = 0.0f;
+    float nll_acc = 0.0f;
+
+    const int ntiles = A.n_pad / CL_TILE;
+    const int S = A.S;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int gobs = tile * CL_TILE + CL_WOBS * wv + j;      // this lane's observation (all four k-groups)
+
+        // ================= forward =======================================================================
+        float h0[KS1];                     // metadata^T as B operand: step t holds feature 4t + q
+#pragma unroll
+        for (int t = 0; t < KS1; ++t) h0[t] = A.meta_t[(size_t)(4 * t + q) * A.n_pad + gobs];
+
+        f32x4 hs[LMAX][FB];                // post-activation H_l^T: block fb, reg t = feature 16fb + 4q + t, obs j
+        float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < L) {
+#pragma unroll
+                for (int mb = 0; mb < FB; ++mb) {
+                    f32x4 acc = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * mb + 4 * q);   // bias
+                    if (l == 0) {
+#pragma unroll
+                        for (int t = 0; t < KS1; ++t)
+                            acc = mfma4(sW1[(16 * mb + j) * PW1 + 4 * t + q], h0[t], acc);
+                    } else {
+                        const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
+#pragma unroll
+                        for (int kb = 0; kb < FB; ++kb) {
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Wl + (16 * mb + j) * PW + 16 * kb + 4 * q);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc = mfma4(a4[t], hs[l > 0 ? l - 1 : 0][kb][t], acc);
+                        }
+                    }
+                    CL_PIN();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hs[l][mb][t] = fmaxf(acc[t], leak * acc[t]);
+                }
+                if (l == L - 1) {
+                    // final Dense(2): every k-group holds a quarter of the features of observation j
+#pragma unroll
+                    for (int mb = 0; mb < FB; ++mb) {
+                        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sWo + 16 * mb + 4 * q);
+                        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sWo + WP + 16 * mb + 4 * q);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            o0 = fmaf(w0[t], hs[l][mb][t], o0);
+                            o1 = fmaf(w1[t], hs[l][mb][t], o1);
+                        }
+                    }
+                }
+            }
+        }
+        o0 += __shfl_xor(o0, 16);
+        o1 += __shfl_xor(o1, 16);
+        o0 += __shfl_xor(o0, 32);
+        o1 += __shfl_xor(o1, 32);
+        o0 += sBo[0];
+        o1 += sBo[1];
+
+        const bool valid = gobs < A.n_obs;
+        float dsig_draw;
+        const float sigma = cl_scale_bij(o1, A.bij_kind, A.eps, &dsig_draw);
+
+        if (MODE == 1) {
+            if (q == 0 && valid) {
+                A.loc_out[gobs] = o0;
+                A.sig_out[gobs] = sigma;
+            }
+            continue;
+        }
+
+        // ================= epilogue: sample, predict, likelihood, dL/dO =====================================
+        float dloc, draw;
+        if (MODE == 0) {
+            int img = 0;
+            if (q == 0) {
+                float aim = 1.0f;
+                int rid = -1;
+                float io = 0.0f, sg = 1.0f;
+                if (valid) {
+                    rid = A.refl_id[gobs];
+                    io = A.iobs[gobs];
+                    sg = A.sig[gobs];
+                    if (A.use_img) {
+                        img = A.image_id[gobs];
+                        aim = (img > 0) ? A.img[img - 1] : 1.0f;
+                    }
+                }
+                sLoc[j] = o0; sSig[j] = sigma; sAim[j] = aim; sIo[j] = io; sSg[j] = sg; sRid[j] = rid;
+                sDl[j] = 0.0f; sDs[j] = 0.0f; sDa[j] = 0.0f;
+            }
+            wave_lds_sync();
+            const int npairs = CL_WOBS * S;
+            for (int p = lane; p < npairs; p += 64) {
+                const int jj = p / S;
+                const int s = p - jj * S;
+                const int rid = sRid[jj];
+                if (rid >= 0) {
+                    const int gl = tile * CL_TILE + CL_WOBS * wv + jj;
+                    const float eta = A.eta ? A.eta[(size_t)gl * S + s]
+                                            : cl_noise_normal(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + gl));
+                    const float tq = sLoc[jj] + sSig[jj] * eta + A.shift;
+                    const float aim = sAim[jj];
+                    const float zs = aim * tq;
+                    const float zf = A.z_f[(size_t)rid * S + s];
+                    const float ipred = zs * zf * zf;
+                    if (A.ipred_out) A.ipred_out[(size_t)gl * S + s] = ipred;
+                    float dll;
+                    const float ll = cl_lik_log_prob(ipred, sIo[jj], sSg[jj], A.lik_kind, A.dof, A.lik_const, &dll);
+                    nll_acc -= ll * A.w_ll;
+                    const float gi = -dll * A.w_ll;                 // dNLL / d ipred
+                    const float dzs = gi * zf * zf;
+                    atomicAdd(A.dz_f + (size_t)rid * S + s, gi * zs * 2.0f * zf);
+                    const float dt = dzs * aim;
+                    atomicAdd(sDl + jj, dt);
+                    atomicAdd(sDs + jj, dt * eta);
+                    atomicAdd(sDa + jj, dzs * tq);
+                }
+            }
+            wave_lds_sync();
+            dloc = sDl[j];
+            draw = sDs[j] * dsig_draw;
+            if (q == 0) {
+                if (valid && A.use_img && img > 0) atomicAdd(A.d_img + (img - 1), sDa[j]);
+                boacc0 += dloc;
+                boacc1 += draw;
+            }
+            wave_lds_sync();
+            if (q == 0) sDs[j] = draw;          // sDl = dloc, sDs = draw: the dO tile for the Dense(2) wgrad
+        } else {
+            dloc = valid ? A.dO_ext[2 * (size_t)gobs] : 0.0f;
+            draw = valid ? A.dO_ext[2 * (size_t)gobs + 1] * dsig_draw : 0.0f;   // external grad is w.r.t. sigma
+            if (q == 0) {
+                sDl[j] = dloc; sDs[j] = draw;
+                boacc0 += dloc; boacc1 += draw;
+            }
+        }
+
+        // ================= backward =======================================================================
+        // tile seam: every wave must be done reading the staging tiles of the previous tile's last wgrad
+        lds_barrier();
+
+        f32x4 dH[FB];
+#pragma unroll
+        for (int l = LMAX - 1; l >= 0; --l) {
+            if (l == L - 1) {
+                // dH_L = W_o^T dO ; Dense(2) wgrad from the wave-private columns of the H staging tile
+#pragma unroll
+                for (int mb = 0; mb < FB; ++mb) {
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(sWo + 16 * mb + 4 * q);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(sWo + WP + 16 * mb + 4 * q);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dH[mb][t] = w0[t] * dloc + w1[t] * draw;
+                        sH[(16 * mb + 4 * q + t) * PB + CL_WOBS * wv + j] = hs[l][mb][t];
+                    }
+                }
+                wave_lds_sync();
+                if (lane < WP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 h4 = *reinterpret_cast<const f32x4*>(sH + lane * PB + CL_WOBS * wv + 4 * e);
+                        const f32x4 d0 = *reinterpret_cast<const f32x4*>(sDl + 4 * e);
+                        const f32x4 d1 = *reinterpret_cast<const f32x4*>(sDs + 4 * e);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            woacc0 = fmaf(h4[t], d0[t], woacc0);
+                            woacc1 = fmaf(h4[t], d1[t], woacc1);
+                        }
+                    }
+                }
+                wave_lds_sync();
+            }
+            if (l < L) {
+                // dZ_l = dH_l * lrelu'(H_l)   (sign of the post-activation == sign of the pre-activation)
+#pragma unroll
+                for (int mb = 0; mb < FB; ++mb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dH[mb][t] = (hs[l][mb][t] > 0.0f) ? dH[mb][t] : leak * dH[mb][t];
+
+                if (l < L - 1) lds_barrier();      // previous layer's wgrad reads are complete
+#pragma unroll
+                for (int mb = 0; mb < FB; ++mb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) sZ[(16 * mb + 4 * q + t) * PB + CL_WOBS * wv + j] = dH[mb][t];
+                if (l > 0) {
+#pragma unroll
+                    for (int mb = 0; mb < FB; ++mb)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            sH[(16 * mb + 4 * q + t) * PB + CL_WOBS * wv + j] = hs[l > 0 ? l - 1 : 0][mb][t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < KS1; ++t) sH[(4 * t + q) * PB + CL_WOBS * wv + j] = h0[t];
+                }
+                wave_lds_sync();
+                if (lane < WP) {                   // bias gradient: row sums of this wave's own columns of dZ
+                    float sb = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 z4 = *reinterpret_cast<const f32x4*>(sZ + lane * PB + CL_WOBS * wv + 4 * e);
+                        sb += (z4[0] + z4[1]) + (z4[2] + z4[3]);
+                    }
+                    bacc[l] += sb;
+                }
+                lds_barrier();                     // staging tiles complete for all 128 observations
+
+                // ---- wgrad: 16x16 blocks of dW_l^T[o][i] = sum_obs dZ[o][obs] H_in[i][obs] ---------------------
+                // step (g,t) contracts observations kbase + 16g + 4q + t: one ds_read_b128 feeds four steps
+                if (l == 0) {
+                    using WG = WgradPlan<FB, IB1>;
+                    const int grp = wv % WG::GROUPS, kp = wv / WG::GROUPS;
+                    const int ob = (grp * WG::BPW) / IB1, ib0 = (grp * WG::BPW) - ob * IB1;
+                    const float* pa = sZ + (16 * ob + j) * PB + kp * WG::KLEN + 4 * q;
+                    const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
+                    f32x4 acc0 = wacc[l][0], acc1 = wacc[l][1];
+#pragma unroll 2
+                    for (int g = 0; g < WG::KLEN / 16; ++g) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + 16 * g);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 16 * g);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc0 = mfma4(a4[t], b4[t], acc0);
+                        if (WG::BPW == 2) {
+                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(pb + 16 * PB + 16 * g);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc1 = mfma4(a4[t], c4[t], acc1);
+                        }
+                    }
+                    wacc[l][0] = acc0; wacc[l][1] = acc1;
+                } else {
+                    using WG = WgradPlan<FB, FB>;
+                    const int grp = wv % WG::GROUPS, kp = wv / WG::GROUPS;
+                    const int ob = (grp * WG::BPW) / FB, ib0 = (grp * WG::BPW) - ob * FB;
+                    const float* pa = sZ + (16 * ob + j) * PB + kp * WG::KLEN + 4 * q;
+                    const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
+                    f32x4 acc0 = wacc[l][0], acc1 = wacc[l][1];
+#pragma unroll 2
+                    for (int g = 0; g < WG::KLEN / 16; ++g) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + 16 * g);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 16 * g);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc0 = mfma4(a4[t], b4[t], acc0);
+                        if (WG::BPW == 2) {
+                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(pb + 16 * PB + 16 * g);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) acc1 = mfma4(a4[t], c4[t], acc1);
+                        }
+                    }
+                    wacc[l][0] = acc0; wacc[l][1] = acc1;
+                }
+                // ---- dgrad: dH_{l-1} = W_l dZ_l --------------------------------------------------------------
+                if (l > 0) {
+                    const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
+                    f32x4 dn[FB];
+#pragma unroll
+                    for (int mb = 0; mb < FB; ++mb) {
+                        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int kb = 0; kb < FB; ++kb)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                acc = mfma4(Wl[(16 * kb + 4 * q + t) * PW + 16 * mb + j], dH[kb][t], acc);
+                        dn[mb] = acc;
+                        CL_PIN();
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < FB; ++mb) dH[mb] = dn[mb];
+                }
+            }
+        }
+    }
+
+    if (MODE == 1) return;
+
+    // ================= flush the weight-gradient accumulators: LDS staging -> per-workgroup partial =========
+    __syncthreads();
+    const int offWo = w * d + w + (L - 1) * (w * w + w);
+    const int Ptot = offWo + 2 * w + 2;
+    for (int idx = tid; idx < Ptot; idx += 512) smem[idx] = 0.0f;
+    __syncthreads();
+    float bo0 = boacc0, bo1 = boacc1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bo0 += __shfl_xor(bo0, off);
+        bo1 += __shfl_xor(bo1, off);
+    }
+    for (int turn = 0; turn < CL_NW; ++turn) {   // fixed order of the eight waves: deterministic sums
+        if (wv == turn) {
+#pragma unroll
+            for (int l = 0; l < LMAX; ++l) {
+                if (l < L) {
+                    const int IBn = (l == 0) ? IB1 : FB;
+                    const int NBK = FB * IBn;
+                    const int BPW = (NBK >= CL_NW) ? NBK / CL_NW : 1;
+                    const int GROUPS = NBK / BPW;
+                    const int grp = wv % GROUPS;
+                    const int ob = (grp * BPW) / IBn, ib0 = (grp * BPW) - ob * IBn;
+                    const int in_dim = (l == 0) ? d : w;
+                    const int offW = (l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w));
+                    const int offB = offW + w * in_dim;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        if (b < BPW) {
+                            const int i = 16 * (ib0 + b) + j;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int o = 16 * ob + 4 * q + t;
+                                if (o < w && i < in_dim) smem[offW + o * in_dim + i] += wacc[l][b][t];
+                            }
+                        }
+                    }
+                    if (lane < w) smem[offB + lane] += bacc[l];
+                }
+            }
+            if (lane < w) {
+                smem[offWo + lane] += woacc0;
+                smem[offWo + w + lane] += woacc1;
+            }
+            if (lane == 0) {
+                smem[offWo + 2 * w] += bo0;
+                smem[offWo + 2 * w + 1] += bo1;
+            }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ part = A.partials + (size_t)blockIdx.x * Ptot;
+    for (int idx = tid; idx < Ptot; idx += 512) part[idx] = smem[idx];
+
+    if (MODE == 0) {
+        float v = nll_acc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) atomicAdd(A.scalars + CL_SC_NLL, (double)v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sum of the per-workgroup partials in a fixed order -> MLP slice of the flat gradient buffer
+// ---------------------------------------------------------------------------------------------------------
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int P, float* __restrict__ out,
+                                       const int* stop_flag) {
+    if (stop_flag != nullptr && *stop_flag != 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float s = 0.0f;
+    for (int g = 0; g < nparts; ++g) s += partials[(size_t)g * P + i];
+    out[i] += s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------------------
+template <int WP, int DP, int LMAX, int MODE>
+static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
+    using SL = SmemLayout<WP, DP, LMAX>;
+    const size_t sm_tiles = (size_t)SL::total * sizeof(float);
+    const size_t P = (size_t)a.w * a.d + a.w + (size_t)(a.L - 1) * (a.w * a.w + a.w) + 2 * a.w + 2;
+    size_t sm = sm_tiles;
+    if (MODE != 1 && P * sizeof(float) > sm) sm = P * sizeof(float);
+    if (sm > 160 * 1024) return -3;
+    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE>;
+    static size_t configured = 0;
+    if (configured < sm) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        configured = sm;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), sm, st, a);
+    return (int)hipGetLastError();
+}
+
+template <int MODE>
+static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
+    if (a.L < 1 || a.L > CL_MLP_LMAX || a.w < 1 || a.d < 1) return -2;
+    if (a.w > 64 || a.d > 64) return -2;
+    const int wp = (a.w <= 32) ? 32 : 64;
+    const int dp = (a.d <= 8) ? 8 : (a.d <= 32 ? 32 : 64);
+    if (wp == 32) {
+        if (dp == 8) return launch_one<32, 8, CL_MLP_LMAX, MODE>(a, grid, st);
+        if (dp == 32) return launch_one<32, 32, CL_MLP_LMAX, MODE>(a, grid, st);
+        return launch_one<32, 64, CL_MLP_LMAX, MODE>(a, grid, st);
+    }
+    if (dp == 8) return launch_one<64, 8, CL_MLP_LMAX, MODE>(a, grid, st);
+    if (dp == 32) return launch_one<64, 32, CL_MLP_LMAX, MODE>(a, grid, st);
+    return launch_one<64, 64, CL_MLP_LMAX, MODE>(a, grid, st);
+}
+
+int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (a.n_pad % CL_TILE != 0 || a.n_pad <= 0) return -1;
+    const int ntiles = a.n_pad / CL_TILE;
+    if (grid > ntiles) grid = ntiles;
+    if (grid < 1) return -1;
+    switch (mode) {
+        case 0: return launch_mode<0>(a, grid, st);
+        case 1: return launch_mode<1>(a, grid, st);
+        case 2: return launch_mode<2>(a, grid, st);
+    }
+    return -1;
+}
+
+int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 255) / 256), dim3(256), 0, st, partials, nparts, P, out, stop_flag);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,485 @@
+"""Host side of the MI355X ELBO engine: turns the plugin objects of a `VariationalMergingModel` plus the reference's
+`inputs` tuple into device buffers, and enqueues one ELBO training step as a fixed sequence of C-ABI calls.
+
+What one step replaces in the reference: `train_step_with_gradient_norm` (careless/models/merging/variational.py:185-224)
+= forward (`call`, :141-183), `tape.gradient`, `tf.linalg.global_norm`, non-finite sanitise, Adam.
+
+Step schedule (all on one HIP stream, no host synchronisation):
+    zero workspace -> cl_tn_forward -> cl_elbo_mono_fwd_bwd -> cl_reduce_partials -> cl_tn_backward
+    -> [all-reduce of the flat gradient, data-parallel only] -> cl_grad_sqnorm -> cl_adam_step -> cl_step_finalize
+
+HBM layout owned by the engine (see include/careless_hip.h):
+    params / m / v / grads : one flat fp32 vector  [ q_loc_raw (R) | q_scale_raw (R) | scaler W^T layout (P) | image scales (M-1) ]
+    workspace              : [ dz_f (R*S) | grads (n) + 4 | scalars (4 doubles) | per-tensor norms ]  -- one memset per step
+    observation shard      : refl_id i32, image_id i32, meta_t [d][n_pad], iobs, sig   (immutable)
+PyTorch is used for device memory, streams and torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from careless_amd import _lib
+from careless_amd._lib import AdamArgs, MlpArgs, TnArgs, check, ptr
+from careless_amd.models.base import BaseModel
+
+TILE = _lib.CL_MLP_TILE
+HISTORY_KEYS = ("loss", "F KLDiv", "NLL", "Grad Norm")
+
+
+def _np(x) -> np.ndarray:
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def require_gpu(what: str) -> torch.device:
+    """The product has no CPU path: every compute entry point calls this first."""
+    _lib.get_lib()
+    if not torch.cuda.is_available():
+        raise _lib.CarelessHipError(f"{what} needs an AMD GPU (gfx950); careless_amd has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------------------
+# data-parallel sharding of the observation axis
+# ------------------------------------------------------------------------------------------------------------
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    start: int        # first global observation of this rank
+    stop: int
+    kl_begin: int     # reflections whose KL term this rank owns
+    kl_end: int
+
+
+def make_shard(n_obs: int, n_refl: int, rank: int = 0, world: int = 1) -> Shard:
+    """Contiguous, near-equal split of the observations; the KL over the R reflections is split the same way so it
+    is counted exactly once after the gradient all-reduce."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    per = (n_obs + world - 1) // world
+    start, stop = min(rank * per, n_obs), min((rank + 1) * per, n_obs)
+    rper = (n_refl + world - 1) // world
+    return Shard(rank, world, start, stop, min(rank * rper, n_refl), min((rank + 1) * rper, n_refl))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# layout of the flat parameter vector
+# ------------------------------------------------------------------------------------------------------------
+@dataclass
+class FlatLayout:
+    R: int
+    P: int
+    n_img: int                 # M - 1 trainable image scales (0 when image scales are off)
+    seg_off: List[int]         # tensor boundaries (Keras trainable-variable granularity) for per-tensor clipnorm
+    seg_owner: List[str]       # "q" | "scaler" per tensor (for --freeze-*)
+
+    @property
+    def n(self) -> int:
+        return 2 * self.R + self.P + self.n_img
+
+    @property
+    def off_mlp(self) -> int:
+        return 2 * self.R
+
+    @property
+    def off_img(self) -> int:
+        return 2 * self.R + self.P
+
+
+def make_layout(R: int, d: int, w: int, L: int, n_img: int) -> FlatLayout:
+    seg, owner = [0, R, 2 * R], ["q", "q"]
+    off, fan_in = 2 * R, d
+    for _ in range(L):
+        off += w * fan_in; seg.append(off); owner.append("scaler")
+        off += w; seg.append(off); owner.append("scaler")
+        fan_in = w
+    off += 2 * fan_in; seg.append(off); owner.append("scaler")
+    off += 2; seg.append(off); owner.append("scaler")
+    P = off - 2 * R
+    if n_img > 0:
+        off += n_img; seg.append(off); owner.append("scaler")
+    return FlatLayout(R, P, n_img, seg, owner)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the engine
+# ------------------------------------------------------------------------------------------------------------
+class ElboEngine:
+    def __init__(self, model, inputs, seed: int = 1234, shard: Optional[Shard] = None, process_group=None,
+                 grid: Optional[int] = None):
+        self.device = require_gpu("ElboEngine")
+        self.lib = _lib.get_lib()
+        self.model = model
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.process_group = process_group
+        dev = self.device
+
+        from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
+        from careless_amd.models.priors.wilson import WilsonPrior
+        from careless_amd.models.likelihoods.mono import LocationScaleLikelihood
+        from careless_amd.models.scaling.image import HybridImageScaler
+        from careless_amd.models.scaling.nn import MetadataScaler
+
+        q, prior, lik, scaler = model.surrogate_posterior, model.prior, model.likelihood, model.scaling_model
+        if not isinstance(q, TruncatedNormal):
+            raise NotImplementedError(f"surrogate posterior {type(q).__name__} is not supported by the HIP engine")
+        if not isinstance(prior, WilsonPrior):
+            raise NotImplementedError(f"prior {type(prior).__name__} is not supported by the HIP engine yet")
+        if BaseModel.is_laue(inputs):
+            raise NotImplementedError("Laue (harmonic deconvolution) inputs are not supported by the HIP engine yet")
+        if not isinstance(lik, LocationScaleLikelihood) or lik.kind not in ("normal", "studentt"):
+            raise NotImplementedError(f"likelihood {type(lik).__name__} is not supported by the HIP engine yet")
+        if isinstance(scaler, HybridImageScaler):
+            mlp, img = scaler.mlp_scaler, scaler.image_scaler
+        elif isinstance(scaler, MetadataScaler):
+            mlp, img = scaler, None
+        else:
+            raise NotImplementedError(f"scaling model {type(scaler).__name__} is not supported by the HIP engine yet")
+        if model.scale_prior is not None:
+            raise NotImplementedError("scale_prior is never enabled by the reference CLI and is not supported")
+        self.q, self.prior, self.lik, self.mlp, self.img = q, prior, lik, mlp, img
+
+        # ---- observations -> device layout -------------------------------------------------------------
+        refl_id = _np(BaseModel.get_refl_id(inputs)).reshape(-1).astype(np.int64)
+        image_id = _np(BaseModel.get_image_id(inputs)).reshape(-1).astype(np.int64)
+        metadata = _np(BaseModel.get_metadata(inputs)).astype(np.float32)
+        metadata = metadata.reshape(len(refl_id), -1)
+        iobs = _np(BaseModel.get_intensities(inputs)).reshape(-1).astype(np.float32)
+        sig = _np(BaseModel.get_uncertainties(inputs)).reshape(-1).astype(np.float32)
+        self.N_total = int(len(refl_id))
+        self.R = int(q.loc_raw.numel())
+        if refl_id.size and (refl_id.min() < 0 or refl_id.max() >= self.R):
+            raise ValueError("refl_id outside the range of the surrogate posterior")
+        self.shard = shard if shard is not None else make_shard(self.N_total, self.R)
+        sl = slice(self.shard.start, self.shard.stop)
+        self.N = int(self.shard.stop - self.shard.start)
+        if self.N <= 0:
+            raise ValueError("empty observation shard")
+        self.d = int(metadata.shape[1])
+        self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
+        meta_t = np.zeros((self.d, self.n_pad), dtype=np.float32)
+        meta_t[:, : self.N] = metadata[sl].T
+        self.refl_id = torch.as_tensor(refl_id[sl].astype(np.int32), device=dev)
+        self.image_id = torch.as_tensor(image_id[sl].astype(np.int32), device=dev)
+        self.meta_t = torch.as_tensor(meta_t, device=dev)
+        self.iobs = torch.as_tensor(np.ascontiguousarray(iobs[sl]), device=dev)
+        self.sig = torch.as_tensor(np.ascontiguousarray(sig[sl]), device=dev)
+
+        # ---- per-reflection constants ----------------------------------------------------------------
+        self.low = q.low.to(dev, torch.float32).contiguous()
+        self.centric = torch.as_tensor(prior.centric.astype(np.uint8), device=dev)
+        self.es = torch.as_tensor(prior.eps_sigma, device=dev)
+        if self.centric.numel() != self.R or self.es.numel() != self.R:
+            raise ValueError("prior and surrogate posterior disagree on the number of reflections")
+
+        # ---- flat parameters; the plugin objects become views into them ----------------------------------
+        mlp.build(self.d)
+        self.w, self.L = mlp.width, mlp.n_layers
+        n_img = 0
+        if img is not None:
+            if image_id.size and image_id.max() >= img.max_images:
+                raise ValueError("image_id exceeds ImageScaler.max_images")
+            n_img = img.max_images - 1
+        self.layout = make_layout(self.R, self.d, self.w, self.L, n_img)
+        lay = self.layout
+        assert lay.P == mlp.param_count(self.d) == int(self.lib.cl_mlp_param_count(self.d, self.w, self.L))
+        self.params = torch.empty(lay.n, dtype=torch.float32, device=dev)
+        self.params[0:self.R] = q.loc_raw.to(dev)
+        self.params[self.R:2 * self.R] = q.scale_raw.to(dev)
+        self.params[lay.off_mlp:lay.off_mlp + lay.P] = mlp.flat.to(dev)
+        q.loc_raw = self.params[0:self.R]
+        q.scale_raw = self.params[self.R:2 * self.R]
+        q.low = self.low
+        mlp.flat = self.params[lay.off_mlp:lay.off_mlp + lay.P]
+        if n_img > 0:
+            self.params[lay.off_img:] = img._scales.to(dev)
+            img._scales = self.params[lay.off_img:lay.off_img + n_img]
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.t = 0                                  # optimizer iterations
+        self.seg_off = torch.as_tensor(np.asarray(lay.seg_off, dtype=np.int32), device=dev)
+        self.nseg = len(lay.seg_off) - 1
+
+        # ---- workspace -----------------------------------------------------------------------------------
+        self.S = int(model.mc_sample_size)
+        if self.S < 1:
+            raise ValueError("mc_sample_size must be >= 1")
+        self.grid = int(grid) if grid is not None else max(1, int(self.lib.cl_mlp_default_grid()))
+        self.grid = min(self.grid, self.n_pad // TILE)
+        RS = self.R * self.S
+        o_dz = 0
+        o_g = (RS + 3) // 4 * 4
+        o_sc = (o_g + lay.n + 4 + 3) // 4 * 4           # 4 doubles = 8 floats, 16-byte aligned
+        o_seg = o_sc + 8
+        tot = o_seg + 2 * self.nseg
+        self.ws = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self.dz_f = self.ws[o_dz:o_dz + RS]
+        self.grads_ext = self.ws[o_g:o_g + lay.n + 4]   # gradient + [nll, kl] tail for the all-reduce
+        self.grads = self.grads_ext[: lay.n]
+        self.scalars = self.ws[o_sc:o_sc + 8].view(torch.float64)
+        self.seg_sq = self.ws[o_seg:o_seg + 2 * self.nseg].view(torch.float64)
+        self.z_f = torch.empty(RS, dtype=torch.float32, device=dev)
+        self.partials = torch.empty(self.grid * lay.P, dtype=torch.float32, device=dev)
+        self.stop_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.frozen = torch.zeros(self.nseg, dtype=torch.uint8, device=dev)
+        self.history_buf: Optional[torch.Tensor] = None
+        self._keep = None
+        self.refresh_config()
+
+    # ------------------------------------------------------------------------------------------------------
+    def refresh_config(self):
+        """(Re)read the knobs that may change between train_model calls: trainable flags, kl weight, optimizer."""
+        m = self.model
+        fr = np.zeros(self.nseg, dtype=np.uint8)
+        for k, owner in enumerate(self.layout.seg_owner):
+            if owner == "q" and not self.q.trainable:
+                fr[k] = 1
+            if owner == "scaler" and not m.scaling_model.trainable:
+                fr[k] = 1
+        self.any_frozen = bool(fr.any())
+        self.frozen.copy_(torch.as_tensor(fr))
+        opt = m.optimizer
+        self.opt = opt
+        S, N, R = self.S, self.N_total, self.R
+        if m.kl_weight is None:                         # variational.py:172-174
+            self.w_ll, self.w_kl, self.kl_mult = 1.0 / S, 1.0 / S, 1.0
+        else:                                           # variational.py:175-177
+            self.w_ll, self.w_kl, self.kl_mult = 1.0 / (S * N), 1.0 / (S * R), float(m.kl_weight)
+        if self.lik.kind == "studentt":
+            nu = float(self.lik.dof)
+            self.lik_kind, self.dof = _lib.CL_LIK_STUDENTT, nu
+            self.lik_const = math.lgamma(0.5 * (nu + 1.0)) - math.lgamma(0.5 * nu) - 0.5 * math.log(nu * math.pi)
+        else:
+            self.lik_kind, self.dof, self.lik_const = _lib.CL_LIK_NORMAL, 0.0, 0.0
+        self.bij_kind = _lib.CL_BIJ_EXP if self.mlp.scale_bijector == "exp" else _lib.CL_BIJ_SOFTPLUS
+
+    # ------------------------------------------------------------------------------------------------------
+    def _tn_args(self, step: int, u_f) -> TnArgs:
+        lay = self.layout
+        a = TnArgs()
+        a.q_loc_raw = self.params.data_ptr()
+        a.q_scale_raw = self.params.data_ptr() + 4 * self.R
+        a.low = ptr(self.low); a.centric = ptr(self.centric); a.es = ptr(self.es)
+        a.R, a.S = self.R, self.S
+        a.high, a.eps = self.q.high, self.q.scale_shift
+        a.w_kl, a.kl_grad_mult = self.w_kl, self.kl_mult
+        a.kl_begin, a.kl_end = self.shard.kl_begin, self.shard.kl_end
+        a.u_f = ptr(u_f)
+        a.seed, a.step = self.seed, step & 0xFFFFFFFF
+        a.z_f = ptr(self.z_f); a.dz_f = ptr(self.dz_f)
+        a.d_loc_raw = self.grads.data_ptr()
+        a.d_scale_raw = self.grads.data_ptr() + 4 * self.R
+        a.scalars = ptr(self.scalars)
+        a.stop_flag = ptr(self.stop_flag)
+        return a
+
+    def _mlp_args(self, step: int, eta, ipred_out=None) -> MlpArgs:
+        lay = self.layout
+        a = MlpArgs()
+        a.refl_id = ptr(self.refl_id); a.image_id = ptr(self.image_id); a.meta_t = ptr(self.meta_t)
+        a.iobs = ptr(self.iobs); a.sig = ptr(self.sig)
+        a.n_obs, a.n_pad = self.N, self.n_pad
+        a.obs_offset = self.shard.start
+        a.mlp = self.params.data_ptr() + 4 * lay.off_mlp
+        a.d, a.w, a.L = self.d, self.w, self.L
+        a.leak = self.mlp.leakiness
+        a.use_img = 1 if lay.n_img > 0 else 0
+        a.img = (self.params.data_ptr() + 4 * lay.off_img) if lay.n_img > 0 else None
+        a.z_f = ptr(self.z_f)
+        a.R, a.S = self.R, self.S
+        a.lik_kind, a.dof, a.lik_const = self.lik_kind, self.dof, self.lik_const
+        a.bij_kind, a.eps = self.bij_kind, self.mlp.epsilon
+        a.shift = self.mlp.scale_multiplier or 0.0
+        a.w_ll = self.w_ll
+        a.eta = ptr(eta)
+        a.seed, a.step = self.seed, step & 0xFFFFFFFF
+        a.dz_f = ptr(self.dz_f)
+        a.d_img = (self.grads.data_ptr() + 4 * lay.off_img) if lay.n_img > 0 else None
+        a.partials = ptr(self.partials)
+        a.scalars = ptr(self.scalars)
+        a.ipred_out = ptr(ipred_out)
+        a.stop_flag = ptr(self.stop_flag)
+        return a
+
+    def _noise_to_device(self, u_f, eta):
+        """Injected noise arrives in the reference's (S, R) / (S, N_total) orientation; device layout is [R][S] / [N][S]."""
+        du = de = None
+        if u_f is not None:
+            u = torch.as_tensor(_np(u_f), dtype=torch.float32).reshape(self.S, self.R)
+            du = u.t().contiguous().to(self.device)
+        if eta is not None:
+            e = torch.as_tensor(_np(eta), dtype=torch.float32).reshape(self.S, self.N_total)
+            de = e[:, self.shard.start:self.shard.stop].t().contiguous().to(self.device)
+        return du, de
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward_backward(self, step: int, u_f=None, eta=None, ipred_out=None):
+        """Enqueue the loss + gradient part of a step (everything up to, not including, the optimizer)."""
+        lib, st = self.lib, _stream()
+        self.ws.zero_()
+        tn = self._tn_args(step, u_f)
+        check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
+        ma = self._mlp_args(step, eta, ipred_out)
+        check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), self.grid, st), "cl_elbo_mono_fwd_bwd")
+        lay = self.layout
+        check(lib.cl_reduce_partials(ptr(self.partials), self.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
+                                     ptr(self.stop_flag), st), "cl_reduce_partials")
+        check(lib.cl_tn_backward(C.byref(tn), st), "cl_tn_backward")
+        if self.shard.world > 1:
+            self._allreduce()
+        self._keep = (u_f, eta, ipred_out)
+
+    def _allreduce(self):
+        import torch.distributed as dist
+        n = self.layout.n
+        self.grads_ext[n:n + 2] = self.scalars[:2].to(torch.float32)
+        dist.all_reduce(self.grads_ext, op=dist.ReduceOp.SUM, group=self.process_group)
+        self.scalars[:2] = self.grads_ext[n:n + 2].to(torch.float64)
+
+    def optimizer_step(self, step_index: int):
+        lib, st, opt = self.lib, _stream(), self.opt
+        n = self.layout.n
+        clipnorm = float(opt.clipnorm or 0.0)
+        use_seg = clipnorm > 0.0
+        check(lib.cl_grad_sqnorm(ptr(self.grads), n, ptr(self.seg_off), self.nseg, ptr(self.seg_sq) if use_seg else None,
+                                 ptr(self.scalars), ptr(self.stop_flag), st), "cl_grad_sqnorm")
+        self.t += 1
+        t = self.t
+        a = AdamArgs()
+        a.p = ptr(self.params); a.g = ptr(self.grads); a.m = ptr(self.adam_m); a.v = ptr(self.adam_v)
+        a.n = n
+        a.alpha = opt.learning_rate * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
+        a.beta1, a.beta2, a.adam_eps = opt.beta_1, opt.beta_2, opt.epsilon
+        a.clipnorm, a.clipvalue = clipnorm, float(opt.clipvalue or 0.0)
+        a.global_clipnorm = float(opt.global_clipnorm or 0.0)
+        a.seg_off, a.nseg = ptr(self.seg_off), self.nseg
+        a.seg_sq = ptr(self.seg_sq)
+        a.frozen = ptr(self.frozen) if self.any_frozen else None
+        a.scalars = ptr(self.scalars)
+        a.stop_flag = ptr(self.stop_flag)
+        check(lib.cl_adam_step(C.byref(a), st), "cl_adam_step")
+        check(lib.cl_step_finalize(ptr(self.scalars), self.kl_mult, ptr(self.history_buf), step_index,
+                                   ptr(self.stop_flag), st), "cl_step_finalize")
+
+    def alloc_history(self, steps: int):
+        self.history_buf = torch.zeros(max(1, steps) * _lib.CL_HIST_STRIDE, dtype=torch.float64, device=self.device)
+        self.stop_flag.zero_()
+
+    def train_step(self, step_index: int, u_f=None, eta=None):
+        """One full ELBO step; `step_index` indexes the history buffer, the noise key is the optimizer iteration."""
+        self.forward_backward(self.t, u_f, eta)
+        self.optimizer_step(step_index)
+
+    def read_history(self, steps: int) -> Dict[str, List[float]]:
+        """Synchronise and convert the device history to the reference's dict of lists (variational.py:262-268).
+        Steps after the first non-finite gradient norm were skipped on the device and are dropped, which reproduces
+        the reference's early `break` (:271-274)."""
+        h = self.history_buf.view(-1, _lib.CL_HIST_STRIDE)[:steps].cpu().numpy()
+        keep = h[:, 4] == 0.0
+        h = h[keep]
+        out = {"Grad Norm": h[:, 3].tolist()}
+        out["loss"] = h[:, 0].tolist()
+        out["F KLDiv"] = h[:, 1].tolist()
+        out["NLL"] = h[:, 2].tolist()
+        return out
+
+    # -- accessors used by tests -----------------------------------------------------------------------------
+    def loss_terms(self) -> Dict[str, float]:
+        s = self.scalars.cpu().numpy()
+        return {"nll": float(s[0]), "kl": float(s[1]), "loss": float(s[0] + self.kl_mult * s[1])}
+
+    def grad_tensors(self) -> List[torch.Tensor]:
+        """Gradients split per trainable tensor, in the oracle's order and Keras shapes
+        [q_loc_raw, q_scale_raw, W_0 (in,out), b_0, ..., W_o, b_o, image scales]."""
+        lay, g = self.layout, self.grads
+        out = [g[0:self.R], g[self.R:2 * self.R]]
+        base = lay.off_mlp
+        for off, o, i, boff in self.mlp.layer_slices(self.d):
+            out.append(g[base + off: base + off + o * i].view(o, i).t())
+            out.append(g[base + boff: base + boff + o])
+        if lay.n_img > 0:
+            out.append(g[lay.off_img: lay.off_img + lay.n_img])
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# stand-alone helpers behind the plugin protocol methods
+# ------------------------------------------------------------------------------------------------------------
+def tn_sample(q, n: int, seed=None, u_f=None) -> torch.Tensor:
+    """`TruncatedNormal.sample(n)` -> (n, R) via `cl_tn_forward` (Philox noise unless `u_f` (n,R) is injected)."""
+    dev = require_gpu("TruncatedNormal.sample")
+    lib = _lib.get_lib()
+    R = q.loc_raw.numel()
+    loc_raw = q.loc_raw.to(dev, torch.float32).contiguous()
+    scale_raw = q.scale_raw.to(dev, torch.float32).contiguous()
+    low = q.low.to(dev, torch.float32).contiguous()
+    centric = torch.zeros(R, dtype=torch.uint8, device=dev)
+    es = torch.ones(R, dtype=torch.float32, device=dev)
+    z = torch.empty(R * n, dtype=torch.float32, device=dev)
+    sc = torch.zeros(_lib.CL_SC_COUNT, dtype=torch.float64, device=dev)
+    du = None
+    if u_f is not None:
+        du = torch.as_tensor(_np(u_f), dtype=torch.float32).reshape(n, R).t().contiguous().to(dev)
+    a = TnArgs()
+    a.q_loc_raw, a.q_scale_raw, a.low, a.centric, a.es = ptr(loc_raw), ptr(scale_raw), ptr(low), ptr(centric), ptr(es)
+    a.R, a.S = R, n
+    a.high, a.eps = q.high, q.scale_shift
+    a.w_kl, a.kl_grad_mult = 0.0, 0.0
+    a.kl_begin, a.kl_end = 0, 0
+    a.u_f = ptr(du)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    a.seed, a.step = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+    a.z_f, a.scalars = ptr(z), ptr(sc)
+    check(lib.cl_tn_forward(C.byref(a), _stream()), "cl_tn_forward")
+    return z.view(R, n).t()
+
+
+def scaler_forward(mlp, metadata):
+    """loc, sigma of the scaler's Normal for every row of `metadata` via `cl_mlp_forward`."""
+    dev = require_gpu("MLPScaler.call")
+    lib = _lib.get_lib()
+    md = _np(metadata).astype(np.float32)
+    md = md.reshape(md.shape[0], -1) if md.ndim > 1 else md.reshape(-1, 1)
+    N, d = md.shape
+    mlp.build(d)
+    if mlp.flat.device != dev:
+        mlp.flat = mlp.flat.to(dev)
+    n_pad = ((N + TILE - 1) // TILE) * TILE
+    meta_t = np.zeros((d, n_pad), dtype=np.float32)
+    meta_t[:, :N] = md.T
+    meta_t = torch.as_tensor(meta_t, device=dev)
+    loc = torch.empty(N, dtype=torch.float32, device=dev)
+    sig = torch.empty(N, dtype=torch.float32, device=dev)
+    a = MlpArgs()
+    a.meta_t, a.n_obs, a.n_pad = ptr(meta_t), N, n_pad
+    a.mlp = ptr(mlp.flat)
+    a.d, a.w, a.L, a.leak = d, mlp.width, mlp.n_layers, mlp.leakiness
+    a.bij_kind = _lib.CL_BIJ_EXP if mlp.scale_bijector == "exp" else _lib.CL_BIJ_SOFTPLUS
+    a.eps = mlp.epsilon
+    a.S, a.R = 1, 1
+    a.loc_out, a.sig_out = ptr(loc), ptr(sig)
+    grid = min(max(1, int(lib.cl_mlp_default_grid())), n_pad // TILE)
+    check(lib.cl_mlp_forward(C.byref(a), grid, _stream()), "cl_mlp_forward")
+    return loc, sig
+
+
+def debug_noise(seed: int, step: int, S: int, n: int, offset: int = 0, kind: int = 1) -> torch.Tensor:
+    """The noise the kernels draw for (seed, step): kind 0 = q(F) uniforms [n][S], kind 1 = scale normals [n][S]."""
+    dev = require_gpu("debug_noise")
+    out = torch.empty(n * S, dtype=torch.float32, device=dev)
+    check(_lib.get_lib().cl_debug_noise(int(seed) & 0xFFFFFFFFFFFFFFFF, step, S, n, offset, kind, ptr(out), _stream()),
+          "cl_debug_noise")
+    return out.view(n, S)

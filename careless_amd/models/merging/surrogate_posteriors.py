@@ -1,0 +1,152 @@
+"""Learnable surrogate posterior over structure-factor amplitudes.
+
+Mirror of `careless/models/merging/surrogate_posteriors.py:11-131` (reference): `TruncatedNormal` with
+`from_loc_and_scale` (loc = Exp(raw), scale = Shift(eps)(Exp(raw))), `sample` clamped at `low`, `log_prob`, `mean`,
+`stddev`, `moment_4`.  Sampling, log-prob and their gradients on the training path run in the HIP kernels
+`cl_tn_forward` / `cl_tn_backward`; the moment accessors used by the output step are closed forms in torch.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+def _t(x, device=None):
+    if torch.is_tensor(x):
+        return x.detach().to(dtype=torch.float32, device=device)
+    return torch.as_tensor(np.asarray(x, dtype=np.float32), device=device)
+
+
+def _ndtr(x):
+    return torch.special.ndtr(x)
+
+
+class SurrogatePosterior:
+    """Base class for learnable variational distributions over structure factor amplitudes."""
+    trainable = True
+
+    def moment_4(self):
+        raise NotImplementedError("The fourth moment of this distribution is not implemented yet.")
+
+
+class TruncatedNormal(SurrogatePosterior):
+    def __init__(self, loc_raw, scale_raw, low, high=1e10, scale_shift=1e-7):
+        """Holds the *raw* trainable vectors a = log(loc), b = log(scale - scale_shift)."""
+        self.loc_raw = _t(loc_raw)
+        self.scale_raw = _t(scale_raw)
+        low = _t(low)
+        self.low = low.expand_as(self.loc_raw).contiguous() if low.dim() == 0 or low.numel() == 1 else low
+        self.high = float(high)
+        self.scale_shift = float(scale_shift)
+        self.trainable = True
+
+    @classmethod
+    def from_loc_and_scale(cls, loc, scale, low=0.0, high=1e10, scale_shift=1e-7):
+        """Instantiate a learnable distribution with the reference's bijectors (surrogate_posteriors.py:104-131)."""
+        loc = np.asarray(loc.detach().cpu() if torch.is_tensor(loc) else loc, dtype=np.float64)
+        scale = np.asarray(scale.detach().cpu() if torch.is_tensor(scale) else scale, dtype=np.float64)
+        return cls(np.log(loc).astype(np.float32), np.log(scale - scale_shift).astype(np.float32), low, high, scale_shift)
+
+    # -- parameters ---------------------------------------------------------------------------------------
+    @property
+    def loc(self):
+        return torch.exp(self.loc_raw)
+
+    @property
+    def scale(self):
+        return torch.exp(self.scale_raw) + self.scale_shift
+
+    @property
+    def parameters(self):
+        return {"loc": self.loc, "scale": self.scale, "low": self.low, "high": self.high}
+
+    def parameter_properties(self):
+        return {"loc": None, "scale": None, "low": None, "high": None}
+
+    @property
+    def trainable_variables(self):
+        return [self.loc_raw, self.scale_raw] if self.trainable else []
+
+    def save_weights(self, path):
+        torch.save({"loc_raw": self.loc_raw.detach().cpu(), "scale_raw": self.scale_raw.detach().cpu()}, path)
+
+    def load_weights(self, path):
+        st = torch.load(path)
+        self.loc_raw.copy_(st["loc_raw"])
+        self.scale_raw.copy_(st["scale_raw"])
+
+    # -- distribution protocol ------------------------------------------------------------------------------
+    def sample(self, sample_shape=(), seed=None):
+        """max(low, TruncatedNormal sample) (surrogate_posteriors.py:50-53); runs `cl_tn_forward` on the GPU."""
+        from careless_amd.engine import tn_sample
+        n = 1 if sample_shape in ((), None) else int(sample_shape)
+        z = tn_sample(self, n, seed=seed)
+        return z[0] if sample_shape in ((), None) else z
+
+    def _std_bounds(self):
+        loc, scale = self.loc, self.scale
+        return (self.low - loc) / scale, (self.high - loc) / scale
+
+    def log_prob(self, z):
+        z = _t(z, self.loc_raw.device)
+        loc, scale = self.loc, self.scale
+        a, b = self._std_bounds()
+        zn = _ndtr(-a) - _ndtr(-b)
+        y = (z - loc) / scale
+        lp = -(0.5 * y * y + 0.5 * math.log(2 * math.pi) + torch.log(scale) + torch.log(zn))
+        return torch.where((z < self.low) | (z > self.high), torch.full_like(lp, -math.inf), lp)
+
+    def mean(self):
+        loc, scale = self.loc.double(), self.scale.double()
+        a, b = (self.low.double() - loc) / scale, (self.high - loc) / scale
+        zn = _ndtr(-a) - _ndtr(-b)
+        pa = torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+        pb = torch.exp(-0.5 * b * b) / math.sqrt(2 * math.pi)
+        return (loc + scale * (pa - pb) / zn).float()
+
+    def variance(self):
+        loc, scale = self.loc.double(), self.scale.double()
+        a, b = (self.low.double() - loc) / scale, (self.high - loc) / scale
+        zn = _ndtr(-a) - _ndtr(-b)
+        pa = torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
+        pb = torch.exp(-0.5 * b * b) / math.sqrt(2 * math.pi)
+        bpb = torch.where(pb > 0, b * pb, torch.zeros_like(pb))
+        r = (pa - pb) / zn
+        return (scale * scale * (1.0 + (a * pa - bpb) / zn - r * r)).float()
+
+    def stddev(self):
+        return torch.sqrt(self.variance())
+
+    def moment_4(self, high=np.inf, method="scipy"):
+        """Fourth raw moment (surrogate_posteriors.py:55-102).  'scipy' = scipy.stats.truncnorm.moment,
+        'tf' = the closed form of `_tf_moment_4` (evaluated here in torch, fp64)."""
+        if method == "scipy":
+            from scipy.stats import truncnorm
+            loc = self.loc.detach().cpu().numpy().astype(np.float64)
+            scale = self.scale.detach().cpu().numpy().astype(np.float64)
+            low = self.low.detach().cpu().numpy().astype(np.float64)
+            hi = self.high if high is None else high
+            a, b = (low - loc) / scale, (hi - loc) / scale
+            return truncnorm.moment(4, a, b, loc, scale)
+        if method == "tf":
+            mu, sigma = self.loc.double(), self.scale.double()
+            a = self.low.double()
+            if high is None:
+                high = self.high
+            z_a = (a - mu) / sigma
+            pdf = lambda z: torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+            aterm = (a ** 3 + a * a * mu + a * mu * mu + sigma * sigma * (3 * a + 5 * mu) + mu ** 3) * pdf(z_a)
+            if high == np.inf:
+                bterm = 0.0
+                nb = torch.ones_like(mu)
+            else:
+                b = torch.as_tensor(float(high), dtype=torch.float64, device=mu.device)
+                z_b = (b - mu) / sigma
+                bterm = (b ** 3 + b * b * mu + b * mu * mu + sigma * sigma * (3 * b + 5 * mu) + mu ** 3) * pdf(z_b)
+                nb = _ndtr(z_b)
+            num = bterm - aterm
+            den = nb - _ndtr(z_a)
+            return (mu ** 4 + 6 * mu * mu * sigma * sigma + 3 * sigma ** 4 - sigma * num / den).cpu().numpy()
+        raise ValueError(f"Unknown method {method} for computing moment_4")

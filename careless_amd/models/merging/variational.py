@@ -1,0 +1,139 @@
+"""Variational merging model: the training driver of careless on MI355X.
+
+Mirror of `careless/models/merging/variational.py:11-275` (reference): same constructor, `train_model` signature and
+returned history (`{"Grad Norm", "loss", "F KLDiv", "NLL"}` lists, early stop on a non-finite gradient norm),
+`__call__(inputs) -> ipred (S, N)`, `scale_mean_stddev`, `prediction_mean_stddev`.  The per-step arithmetic is the HIP
+engine (careless_amd/engine.py -> libcareless_hip.so); there is no eager / CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from careless_amd.models.base import BaseModel
+from careless_amd.optimizers import Adam
+
+
+class VariationalMergingModel(BaseModel):
+    """Merge data with a posterior parameterized by a surrogate distribution."""
+
+    def __init__(self, surrogate_posterior, prior, likelihood, scaling_model, mc_sample_size=1, kl_weight=None,
+                 scale_kl_weight=None, scale_prior=None):
+        super().__init__()
+        self.prior = prior
+        self.surrogate_posterior = surrogate_posterior
+        self.likelihood = likelihood
+        self.scaling_model = scaling_model
+        self.mc_sample_size = mc_sample_size
+        self.kl_weight = kl_weight
+        self.scale_kl_weight = scale_kl_weight
+        self.scale_prior = scale_prior
+        self.optimizer = Adam()
+        self.seed = 1234              # careless/args/tf_options.py:50-54
+        self._engine = None
+        self._engine_inputs = None
+        self._dist = None             # (rank, world, process_group) for data-parallel runs
+
+    # -- keras-like surface -------------------------------------------------------------------------------
+    def compile(self, optimizer=None, run_eagerly=None, **kwargs):
+        """`model.compile(opt, run_eagerly=...)` (reference io/manager.py:503-506); run_eagerly has no meaning here."""
+        if optimizer is None or optimizer == "Adam":
+            optimizer = Adam()
+        self.optimizer = optimizer
+        return self
+
+    def set_data_parallel(self, rank: int, world: int, process_group=None):
+        """Shard the observations of every later `train_model` call over `world` ranks (one process per GPU)."""
+        self._dist = (int(rank), int(world), process_group)
+        self._engine = None
+
+    @property
+    def trainable_variables(self):
+        return self.surrogate_posterior.trainable_variables + self.scaling_model.trainable_variables
+
+    # -- engine management -------------------------------------------------------------------------------
+    def engine(self, inputs):
+        from careless_amd.engine import ElboEngine, make_shard
+        if self._engine is None or self._engine_inputs is not inputs:
+            shard = None
+            pg = None
+            if self._dist is not None:
+                n = int(np.asarray(BaseModel.get_refl_id(inputs).shape)[0])
+                rank, world, pg = self._dist
+                shard = make_shard(n, int(self.surrogate_posterior.loc_raw.numel()), rank, world)
+            self._engine = ElboEngine(self, inputs, seed=self.seed, shard=shard, process_group=pg)
+            self._engine_inputs = inputs
+        else:
+            self._engine.refresh_config()
+        return self._engine
+
+    # -- forward ------------------------------------------------------------------------------------------
+    def call(self, inputs, u_f=None, eta=None):
+        """Predictions `ipred` (S, N) for one draw of q(F) and q(Sigma) (reference variational.py:141-183)."""
+        eng = self.engine(inputs)
+        du, de = eng._noise_to_device(u_f, eta)
+        ipred = torch.empty(eng.N * eng.S, dtype=torch.float32, device=eng.device)
+        eng.forward_backward(eng.t, du, de, ipred_out=ipred)
+        return ipred.view(eng.N, eng.S).t()
+
+    # -- training ------------------------------------------------------------------------------------------
+    def train_model(self, data, steps, message=None, format_string="{:0.2e}", validation_data=None,
+                    validation_frequency=10, progress=True, use_custom_train_step=True, jit_compile=None,
+                    reduce_retracing=False, noise=None):
+        """Full-batch ELBO optimisation for `steps` iterations (reference variational.py:226-275).
+
+        `noise`: optional callable step -> (u_f (S,R), eta (S,N)) injecting the Monte-Carlo noise (parity tests);
+        by default the kernels draw it with the counter-based generator keyed by (seed, iteration)."""
+        if validation_data is not None:
+            raise NotImplementedError("validation_data (NLL_val) is not supported by the HIP engine yet")
+        eng = self.engine(data)
+        eng.alloc_history(steps)
+        bar = None
+        if progress:
+            try:
+                from tqdm import trange
+                bar = trange(steps, desc=message)
+            except Exception:
+                bar = None
+        check_every = 50
+        done = 0
+        for i in range(steps):
+            u_f = eta = None
+            if noise is not None:
+                u_f, eta = noise(i)
+                u_f, eta = eng._noise_to_device(u_f, eta)
+            eng.train_step(i, u_f, eta)
+            done = i + 1
+            if bar is not None:
+                bar.update(1)
+            if (i + 1) % check_every == 0 and int(eng.stop_flag.item()) != 0:
+                break
+        if bar is not None:
+            bar.close()
+        history = eng.read_history(done)
+        if len(history["loss"]) < done or (len(history["Grad Norm"]) and not np.isfinite(history["Grad Norm"][-1])):
+            print("Encountered numerical issues, terminating optimization early!")
+        return history
+
+    # -- output-step helpers ---------------------------------------------------------------------------------
+    def scale_mean_stddev(self, inputs):
+        """Moments of the posterior scale of every observation (reference variational.py:47-78)."""
+        dist = self.scaling_model(inputs)
+        return dist.mean().cpu().numpy(), dist.stddev().cpu().numpy()
+
+    def prediction_mean_stddev(self, inputs):
+        """E[I] and sd[I] of every observation under the current model (reference variational.py:80-121)."""
+        refl_id = torch.as_tensor(np.asarray(
+            self.get_refl_id(inputs).cpu() if torch.is_tensor(self.get_refl_id(inputs)) else self.get_refl_id(inputs)
+        ).reshape(-1).astype(np.int64))
+        q = self.surrogate_posterior
+        dist = self.scaling_model(inputs)
+        smean, sstd = dist.mean().double().cpu(), dist.stddev().double().cpu()
+        f2 = (q.mean().double() ** 2 + q.stddev().double() ** 2).cpu()
+        iexp = smean * f2[refl_id]
+        f4 = torch.as_tensor(np.asarray(q.moment_4(method="scipy"), dtype=np.float64))
+        s2 = smean ** 2 + sstd ** 2
+        ivar = f4[refl_id] * s2 - iexp * iexp
+        return iexp.numpy().astype(np.float32), np.sqrt(ivar.numpy()).astype(np.float32)

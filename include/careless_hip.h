@@ -1,0 +1,155 @@
+/* careless_hip.h -- C-ABI of the MI355X (gfx950) ELBO engine: libcareless_hip.so
+ *
+ * This is the drop-in boundary for the per-step Monte-Carlo ELBO of rs-station/careless.  The reference has no FFI on
+ * this path: the work is a chain of TensorFlow / TFP ops issued from Python.  Each entry point below replaces the
+ * op chain of the cited reference lines (paths relative to the reference checkout) and is what a maintainer would bind
+ * from Python with ctypes.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (hipMalloc'ed / torch.Tensor.data_ptr()), row-major, contiguous, owned by the
+ *     caller and never retained after the call returns;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); every call only enqueues;
+ *   - return value: 0 = ok, < 0 = invalid argument (-1 shape, -2 unsupported scaler geometry, -3 LDS budget),
+ *     > 0 = hipError_t from the launch;  nothing throws, nothing allocates persistent device memory;
+ *   - no global mutable state besides the loaded code object: calls are re-entrant across streams;
+ *   - a NULL noise pointer (u_f / eta) selects the in-kernel counter-based generator keyed by
+ *     (seed, step, sample, global element index), so results are independent of the number of GPUs.
+ *
+ * Device data layout (what the host mirror `careless_amd` prepares once per data set)
+ *   z_f, dz_f, u_f       [R][S]   reflection-major, MC sample fastest
+ *   eta, ipred_out       [N][S]
+ *   meta_t               [d][n_pad] feature-major metadata, n_pad = N rounded up to CL_MLP_TILE, zero padded
+ *   scaler parameters    "W^T layout": per Dense layer the kernel transposed (rows = output units) then its bias:
+ *                        Wt0[w][d] b0[w] | Wtl[w][w] bl[w] (l = 1..L-1) | Wto[2][w] bo[2]
+ *   flat parameters      [ q_loc_raw (R) | q_scale_raw (R) | scaler (P) | image scales (M-1) ]
+ */
+#ifndef CARELESS_HIP_H
+#define CARELESS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CL_MLP_TILE 128   /* observations per workgroup tile */
+#define CL_MLP_LMAX 5     /* deepest scaler of the fused kernel */
+#define CL_HIST_STRIDE 8  /* doubles per history record: loss, F KLDiv, NLL, Grad Norm, skipped, 3 spare */
+
+/* indices into the double-precision scalar block of one step */
+enum { CL_SC_NLL = 0, CL_SC_KL = 1, CL_SC_GNORM2 = 2, CL_SC_GNORM2_SANE = 3, CL_SC_COUNT = 4 };
+
+/* --- surrogate posterior + prior ------------------------------------------------------------------------------
+ * replaces: TruncatedNormal.from_loc_and_scale/.sample/.log_prob  (careless/models/merging/surrogate_posteriors.py:104-131, 50-53, 20-21)
+ *           WilsonPrior.log_prob                                  (careless/models/priors/wilson.py:50-57)
+ *           VariationalMergingModel.add_kl_div                    (careless/models/merging/variational.py:123-139)      */
+typedef struct cl_tn_args {
+    const float* q_loc_raw;     /* [R] a = log(loc)                        */
+    const float* q_scale_raw;   /* [R] b = log(scale - eps)                */
+    const float* low;           /* [R] lower truncation (io/manager.py:434) */
+    const unsigned char* centric; /* [R] 0/1                               */
+    const float* es;            /* [R] multiplicity * Sigma                */
+    int R, S;
+    float high, eps;
+    float w_kl;                 /* weight of every KL element in the reported KL: 1/S (sum) or 1/(S R) (mean)   */
+    float kl_grad_mult;         /* extra weight of the KL in the loss: 1, or --kl-weight                        */
+    int kl_begin, kl_end;       /* reflection range whose KL this rank owns (data-parallel: counted once)       */
+    const float* u_f;           /* [R][S] injected uniforms or NULL                                             */
+    unsigned long long seed; unsigned step;
+    float* z_f;                 /* [R][S] out (forward)                                                          */
+    const float* dz_f;          /* [R][S] in  (backward): dL/dz_f of the data term                               */
+    float* d_loc_raw;           /* [R] += (backward)                                                             */
+    float* d_scale_raw;         /* [R] += (backward)                                                             */
+    double* scalars;            /* [CL_SC_COUNT]: forward adds the weighted KL into scalars[CL_SC_KL]            */
+    const int* stop_flag;       /* optional device int: non-zero => skip (numerical failure in an earlier step)  */
+} cl_tn_args;
+
+int cl_tn_forward(const cl_tn_args* args, void* stream);
+int cl_tn_backward(const cl_tn_args* args, void* stream);
+
+/* --- scaler + likelihood -----------------------------------------------------------------------------------------
+ * replaces: MLPScaler.call / MetadataScaler / NormalLayer        (careless/models/scaling/nn.py:10-120)
+ *           ImageScaler.call / HybridImageScaler.call            (careless/models/scaling/image.py:27-63)
+ *           VariationalMergingModel.call gather + predict        (careless/models/merging/variational.py:156-167)
+ *           NormalLikelihood / StudentTLikelihood log_prob       (careless/models/likelihoods/mono.py:10-37)
+ *           tape.gradient of all of the above                    (careless/models/merging/variational.py:197-202) */
+typedef struct cl_mlp_args {
+    const int* refl_id;         /* [n_obs]                                    */
+    const int* image_id;        /* [n_obs]                                    */
+    const float* meta_t;        /* [d][n_pad]                                 */
+    const float* iobs;          /* [n_obs]                                    */
+    const float* sig;           /* [n_obs]                                    */
+    int n_obs, n_pad;
+    long long obs_offset;       /* global index of the shard's first observation (noise key) */
+    const float* mlp;           /* scaler parameters, W^T layout              */
+    int d, w, L;
+    float leak;
+    const float* img;           /* [M-1] trainable image scales (image 0 pinned to 1, image.py:23-25) */
+    int use_img;
+    const float* z_f;           /* [R][S]                                      */
+    int R, S;
+    int lik_kind; float dof, lik_const;   /* CL_LIK_*; lik_const = lgamma((nu+1)/2) - lgamma(nu/2) - log(nu pi)/2 */
+    int bij_kind; float eps, shift;       /* CL_BIJ_*; sigma = f(raw) + eps; shift = tfb.Shift(std(Iobs)) (nn.py:84-87) */
+    float w_ll;                 /* weight of every log-likelihood term: 1/S or 1/(S N_total) */
+    const float* eta;           /* [n_obs][S] injected normals or NULL         */
+    unsigned long long seed; unsigned step;
+    float* dz_f;                /* [R][S] += dL/dz_f                           */
+    float* d_img;               /* [M-1]  += dL/d(image scale)                 */
+    float* partials;            /* [grid][P] per-workgroup scaler gradient partials (workspace) */
+    double* scalars;            /* [CL_SC_COUNT]: adds NLL into scalars[CL_SC_NLL] */
+    float* ipred_out;           /* optional [n_obs][S]                         */
+    float* loc_out;             /* cl_mlp_forward: [n_obs]                     */
+    float* sig_out;             /* cl_mlp_forward: [n_obs]                     */
+    const float* dO_ext;        /* cl_mlp_backward_ext: [n_obs][2] dL/d(loc, sigma) */
+    const int* stop_flag;
+} cl_mlp_args;
+
+enum { CL_LIK_NORMAL_ = 0, CL_LIK_STUDENTT_ = 1 };
+enum { CL_BIJ_EXP_ = 0, CL_BIJ_SOFTPLUS_ = 1 };
+
+int cl_mlp_default_grid(void);                       /* workgroups of a persistent launch = CUs of the current device */
+size_t cl_mlp_param_count(int d, int w, int L);      /* P */
+int cl_elbo_mono_fwd_bwd(const cl_mlp_args* args, int grid, void* stream);
+int cl_mlp_forward(const cl_mlp_args* args, int grid, void* stream);
+int cl_mlp_backward_ext(const cl_mlp_args* args, int grid, void* stream);
+/* grad_mlp[P] += sum over the `nparts` workgroup partials, in index order (deterministic) */
+int cl_reduce_partials(const float* partials, int nparts, int P, float* grad_mlp, const int* stop_flag, void* stream);
+
+/* --- gradient norm, sanitise, clip, Adam -------------------------------------------------------------------------
+ * replaces: tf.linalg.global_norm, tf.where(is_finite), optimizer.apply_gradients (variational.py:202-209)
+ *           tfk.optimizers.Adam(lr, b1, b2, clipnorm, clipvalue, global_clipnorm) (careless/io/manager.py:494-501) */
+typedef struct cl_adam_args {
+    float* p; const float* g; float* m; float* v;   /* [n] each */
+    int n;
+    float alpha;                /* lr sqrt(1-b2^t)/(1-b1^t), computed on the host from the step count */
+    float beta1, beta2, adam_eps;
+    float clipnorm, clipvalue, global_clipnorm;     /* <= 0: off */
+    const int* seg_off;         /* [nseg+1] tensor boundaries in the flat buffer */
+    int nseg;
+    const double* seg_sq;       /* [nseg] per-tensor squared norms (only read when clipnorm > 0) */
+    const unsigned char* frozen; /* optional [nseg]: 1 = tensor is not trainable (--freeze-*) */
+    const double* scalars;
+    const int* stop_flag;
+} cl_adam_args;
+
+int cl_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
+                   const int* stop_flag, void* stream);
+int cl_adam_step(const cl_adam_args* args, void* stream);
+/* history[step_index] = {loss, F KLDiv, NLL, Grad Norm, skipped}; sets *stop_flag when the norm is not finite
+ * (careless/models/merging/variational.py:262-274) */
+int cl_step_finalize(const double* scalars, float kl_weight_or_one, double* history, int step_index, int* stop_flag,
+                     void* stream);
+
+/* --- diagnostics -------------------------------------------------------------------------------------------------- */
+const char* cl_version(void);
+/* sizeof(cl_tn_args), sizeof(cl_mlp_args), sizeof(cl_adam_args): lets a binding verify its struct mirrors */
+void cl_abi_sizes(size_t out[3]);
+/* out[n][S]: kind 0 = the uniforms of cl_tn_*, kind 1 = the normals of cl_elbo_mono_fwd_bwd, for (seed, step) */
+int cl_debug_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CARELESS_HIP_H */

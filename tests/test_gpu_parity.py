@@ -1,0 +1,141 @@
+"""GPU parity tests: the HIP ELBO engine (through the C-ABI) against the fp64 CPU oracle on identical inputs and
+identical injected Monte-Carlo noise.  Tolerance per BASELINE.json north_star: index gathers bit-exact, ELBO and
+gradients within 1e-4 relative (fp32 engine vs fp64 oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import elbo_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+RTOL_LOSS = 1e-4       # north_star tolerance on the ELBO
+RTOL_GRAD = 2e-4       # tensor-level (max-norm) relative tolerance on every gradient tensor
+
+CASES = {
+    "mlp2x32_normal_img_S3": dict(N=300, R=40, d0=5, L=2, w=32, S=3),
+    "mlp5x64_studentt_posenc_S8": dict(N=1000, R=64, d0=5, posenc=True, L=5, w=64, S=8, likelihood="studentt", dof=4.0,
+                                       outliers=True),
+    "mlp5x64_normal_S1_noimg": dict(N=513, R=33, d0=5, L=5, w=64, S=1, use_image_scales=False),
+    "mlp3x20_softplus_shift_S2": dict(N=257, R=50, d0=6, L=3, w=20, S=2, bijector="softplus", shift=3.5),
+    "mlp1x64_d40_S1": dict(N=200, R=17, d0=40, L=1, w=64, S=1),
+    "mlp4x48_klweight_S4": dict(N=640, R=100, d0=5, L=4, w=48, S=4, kl_weight=0.5, likelihood="studentt", dof=12.0),
+}
+
+
+def _run_case(kw):
+    L, w = kw["L"], kw["w"]
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64),
+                                        torch.as_tensor(eta, dtype=torch.float64))
+    model = util.build_model(data, cfg, params, L, w)
+    inputs = util.reference_inputs(data)
+    ipred = model(inputs, u_f=u_f, eta=eta)
+    eng = model._engine
+    torch.cuda.synchronize()
+    terms = eng.loss_terms()
+    return out, grads, ipred.cpu().numpy(), terms, [g.cpu().numpy() for g in eng.grad_tensors()], eng
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_loss_and_gradients_match_oracle(name):
+    out, grads, ipred, terms, g_hip, eng = _run_case(CASES[name])
+    assert abs(terms["nll"] - float(out["nll"])) <= RTOL_LOSS * abs(float(out["nll"])), (terms, float(out["nll"]))
+    assert abs(terms["kl"] - float(out["kl"])) <= RTOL_LOSS * max(abs(float(out["kl"])), 1.0), (terms, float(out["kl"]))
+    assert abs(terms["loss"] - float(out["loss"])) <= RTOL_LOSS * abs(float(out["loss"]))
+    assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
+    assert len(g_hip) == len(grads)
+    errs = [util.rel_err(a, b.numpy()) for a, b in zip(g_hip, grads)]
+    assert max(errs) < RTOL_GRAD, errs
+
+
+def test_refl_gather_is_bit_exact():
+    """ipred = z_scale * z_f[refl_id]^2: with loc=1, sigma~0 and no image scales, ipred/1 must equal z_f[refl_id]^2 exactly."""
+    kw = dict(N=300, R=40, d0=5, L=2, w=32, S=2, use_image_scales=False, perturb=0.0)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    # make the scaler output exactly loc = 1, raw = -80 (sigma = eps): zero weights, bias (1, -80)
+    for wt in params.mlp_w:
+        wt.zero_()
+    params.mlp_b[-1][0] = 1.0
+    params.mlp_b[-1][1] = -80.0
+    cfg.epsilon = 0.0
+    model = util.build_model(data, cfg, params, 2, 32)
+    model.surrogate_posterior.scale_shift = 1e-7
+    ipred = model(util.reference_inputs(data), u_f=u_f, eta=np.zeros_like(eta)).cpu().numpy()
+    eng = model._engine
+    z_f = eng.z_f.view(eng.R, eng.S).t().cpu().numpy()            # (S, R)
+    rid = np.asarray(data["refl_id"])
+    expect = (z_f[:, rid].astype(np.float32) ** 2).astype(np.float32)
+    assert np.array_equal(ipred, expect * np.float32(1.0))
+
+
+def test_adam_trajectory_matches_oracle():
+    kw = dict(N=384, R=48, d0=5, L=2, w=32, S=2)
+    data, cfg, params, x, u_f0, eta0 = util.make_problem(**kw)
+    steps = 20
+    rng = np.random.default_rng(11)
+    noises = [(rng.random((2, 48)).astype(np.float32), rng.normal(size=(2, 384)).astype(np.float32)) for _ in range(steps)]
+    model = util.build_model(data, cfg, params, 2, 32)
+    hist = model.train_model(util.reference_inputs(data), steps, progress=False, noise=lambda i: noises[i])
+    p = params.clone()
+    st = O.AdamState.zeros_like(p.tensors())
+    ref = [O.train_step(p, x, cfg, st, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+           for u, e in noises]
+    for k in ("loss", "NLL", "F KLDiv", "Grad Norm"):
+        a = np.array(hist[k]); b = np.array([r[k] for r in ref])
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) < 2e-4, (k, a, b)
+    q = model.surrogate_posterior
+    assert util.rel_err(q.loc_raw.cpu().numpy(), p.q_loc_raw.numpy()) < 1e-4
+    assert util.rel_err(q.scale_raw.cpu().numpy(), p.q_scale_raw.numpy()) < 1e-4
+    eng = model._engine
+    for a, b in zip(eng.mlp.weights, [t for pair in zip(p.mlp_w, p.mlp_b) for t in pair]):
+        assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
+
+
+def test_philox_mode_matches_oracle_on_dumped_noise():
+    """Production mode draws the noise in-kernel; dump the same stream with cl_debug_noise and replay it through the oracle."""
+    from careless_amd.engine import debug_noise
+    kw = dict(N=300, R=40, d0=5, L=2, w=32, S=3)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    model = util.build_model(data, cfg, params, 2, 32)
+    model.seed = 4321
+    ipred = model(util.reference_inputs(data))
+    eng = model._engine
+    torch.cuda.synchronize()
+    u = debug_noise(4321, 0, 3, 40, 0, kind=0).t().cpu().numpy()      # (S, R)
+    e = debug_noise(4321, 0, 3, 300, 0, kind=1).t().cpu().numpy()     # (S, N)
+    assert 0.0 < u.min() and u.max() < 1.0
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u, dtype=torch.float64),
+                                        torch.as_tensor(e, dtype=torch.float64))
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(out["loss"])) <= 1e-4 * abs(float(out["loss"]))
+    errs = [util.rel_err(a.cpu().numpy(), b.numpy()) for a, b in zip(eng.grad_tensors(), grads)]
+    assert max(errs) < RTOL_GRAD, errs
+
+
+def test_noise_statistics_and_shard_independence():
+    from careless_amd.engine import debug_noise
+    e = debug_noise(1, 5, 4, 200000, 0, kind=1).cpu().numpy()
+    assert abs(e.mean()) < 5e-3 and abs(e.std() - 1.0) < 5e-3
+    u = debug_noise(1, 5, 4, 200000, 0, kind=0).cpu().numpy()
+    assert abs(u.mean() - 0.5) < 3e-3 and abs(u.var() - 1.0 / 12.0) < 2e-3
+    # keyed by the GLOBAL index: a shard starting at 1000 sees the same numbers
+    part = debug_noise(1, 5, 4, 500, 1000, kind=1).cpu().numpy()
+    assert np.array_equal(part, e[1000:1500])
+    assert not np.array_equal(debug_noise(1, 6, 4, 500, 0, kind=1).cpu().numpy(), e[:500])
+
+
+def test_scaler_forward_and_tn_sample():
+    kw = dict(N=300, R=40, d0=5, L=5, w=64, S=1)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    model = util.build_model(data, cfg, params, 5, 64)
+    dist = model.scaling_model.mlp_scaler(util.reference_inputs(data))
+    o = O.mlp_forward(x.metadata, params.mlp_w, params.mlp_b, cfg.leakiness)
+    assert util.rel_err(dist.loc.cpu().numpy(), o[:, 0].numpy()) < 1e-5
+    assert util.rel_err(dist.scale.cpu().numpy(), O.scale_bijector(o[:, 1], "exp", cfg.epsilon).numpy()) < 1e-5
+    from careless_amd.engine import tn_sample
+    z = tn_sample(model.surrogate_posterior, 1, u_f=u_f).cpu().numpy()
+    loc, scale = O.tn_loc_scale(params.q_loc_raw, params.q_scale_raw, cfg.epsilon)
+    zo = O.tn_sample(loc, scale, x.low, torch.tensor(cfg.high, dtype=torch.float64), torch.as_tensor(u_f, dtype=torch.float64))
+    assert util.rel_err(z, zo.numpy()) < 1e-5

@@ -1,0 +1,71 @@
+"""Shared helpers of the parity tests: build the same problem for the oracle (fp64, CPU) and for the HIP engine."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import elbo_oracle as O
+
+
+def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, likelihood="normal", dof=None,
+                 bijector="exp", shift=0.0, use_image_scales=True, kl_weight=None, perturb=0.05, seed=7,
+                 outliers=False, **opt):
+    data = O.make_synthetic(N, R=R, d0=d0, posenc=posenc, n_images=n_images, seed=seed, outliers=outliers)
+    cfg = O.ElboConfig(mc_samples=S, likelihood=likelihood, dof=dof, scale_bijector=bijector, scale_shift=shift,
+                       use_image_scales=use_image_scales, kl_weight=kl_weight, **opt)
+    rng = np.random.default_rng(seed + 1)
+    params = O.init_params(data, cfg, L, w, perturb=perturb, rng=rng)
+    x = O.inputs_from_numpy(data)
+    u_f = rng.random((S, R)).astype(np.float32)
+    eta = rng.normal(size=(S, N)).astype(np.float32)
+    return data, cfg, params, x, u_f, eta
+
+
+def reference_inputs(data):
+    """The `inputs` tuple in BaseModel.input_index order with the reference's shapes/dtypes (formatter.py:382-394)."""
+    col = lambda a, t: np.asarray(a).astype(t)[:, None]
+    return (col(data["refl_id"], np.int64), col(data["image_id"], np.int64), col(data["file_id"], np.int64),
+            np.asarray(data["metadata"], dtype=np.float32), col(data["iobs"], np.float32), col(data["sigiobs"], np.float32))
+
+
+def build_model(data, cfg: O.ElboConfig, params: O.ElboParams, L, w):
+    """careless_amd model holding exactly the oracle's parameters."""
+    from careless_amd.models.likelihoods.mono import NormalLikelihood, StudentTLikelihood
+    from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
+    from careless_amd.models.merging.variational import VariationalMergingModel
+    from careless_amd.models.priors.wilson import WilsonPrior
+    from careless_amd.models.scaling.image import HybridImageScaler, ImageScaler
+    from careless_amd.models.scaling.nn import MLPScaler
+    from careless_amd.optimizers import Adam
+
+    prior = WilsonPrior(data["centric"], data["multiplicity"], 1.0)
+    low = (1e-32 * ~np.asarray(data["centric"], dtype=bool)).astype(np.float32)
+    q = TruncatedNormal(params.q_loc_raw.numpy().astype(np.float32), params.q_scale_raw.numpy().astype(np.float32),
+                        low, high=cfg.high, scale_shift=cfg.epsilon)
+    lik = NormalLikelihood() if cfg.likelihood == "normal" else StudentTLikelihood(cfg.dof)
+    mlp = MLPScaler(L, w, leakiness=cfg.leakiness, epsilon=cfg.epsilon, scale_bijector=cfg.scale_bijector,
+                    scale_multiplier=(cfg.scale_shift if cfg.scale_shift else None))
+    d = np.asarray(data["metadata"]).shape[1]
+    mlp.build(d)
+    ws = []
+    for wt, b in zip(params.mlp_w, params.mlp_b):
+        ws += [wt.numpy().astype(np.float32), b.numpy().astype(np.float32)]
+    mlp.set_weights(ws)
+    if cfg.use_image_scales:
+        img = ImageScaler(int(data["n_images"]))
+        img._scales.copy_(torch.as_tensor(params.img_raw.numpy().astype(np.float32)))
+        scaler = HybridImageScaler(mlp, img)
+    else:
+        scaler = mlp
+    model = VariationalMergingModel(q, prior, lik, scaler, mc_sample_size=cfg.mc_samples, kl_weight=cfg.kl_weight)
+    model.compile(Adam(cfg.learning_rate, cfg.beta_1, cfg.beta_2, cfg.adam_epsilon, clipnorm=cfg.clipnorm,
+                       clipvalue=cfg.clipvalue, global_clipnorm=cfg.global_clipnorm))
+    return model
+
+
+def rel_err(a, b):
+    """max |a-b| / max|b| -- tensor-level relative error."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = max(float(np.max(np.abs(b))), 1e-30)
+    return float(np.max(np.abs(a - b)) / den)
