@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- reflections/sec per ELBO step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-cpu-baseline]
+
+One "step" = one full-batch ELBO step (forward + backward + gradient norm + Adam) over all observations of the
+workload -- what the reference runs per iteration of `train_model` (careless/models/merging/variational.py:255-256).
+Workload at every N: BASELINE.json configs[2] (10 M observations, Student-T likelihood, positional-encoding metadata,
+5x64 scaler, mc-samples 8), observations sharded over the ranks (strong scaling), one all-reduce of the flat gradient.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="mono_10M_studentt_posenc_5x64_S8")
+    ap.add_argument("--nobs", type=int, default=None, help="override the number of observations (debugging)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(workload: str, n_sample: int):
+    """The oracle (fp32 PyTorch-CPU restatement of the reference graph -- NOT TensorFlow) timed on this box's host
+    cores on a bounded sample of the same workload.  Reported beside the GPU number, never the thing shipped."""
+    import torch
+    from careless_amd.workloads import WORKLOADS
+    from oracle import elbo_oracle as O
+    spec = WORKLOADS[workload]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    data = O.make_synthetic(n_sample, d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"])
+    cfg = O.ElboConfig(mc_samples=spec["S"], likelihood="normal" if spec["dof"] is None else "studentt", dof=spec["dof"])
+    dt = torch.float32
+    x = O.inputs_from_numpy(data, dtype=dt)
+    p = O.init_params(data, cfg, spec["L"], spec["w"], dtype=dt)
+    st = O.AdamState.zeros_like(p.tensors())
+    g = torch.Generator().manual_seed(0)
+    R, S = int(data["n_refl"]), spec["S"]
+    times = []
+    for i in range(4):
+        u = torch.rand(S, R, generator=g, dtype=dt).clamp(1e-6, 1 - 1e-6)
+        eta = torch.randn(S, n_sample, generator=g, dtype=dt)
+        t0 = time.perf_counter()
+        O.train_step(p, x, cfg, st, u, eta)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": n_sample / t, "unit": "reflections/s", "cores": cores, "kind": "port",
+            "sample": f"{n_sample} observations of the same workload, median of 3 steps after 1 warm-up, "
+                      f"fp32 PyTorch-CPU restatement of the reference graph (not TensorFlow), torch {torch.__version__}"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from careless_amd.workloads import flops_per_obs, bytes_per_obs, make_workload
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    model, inputs, data, spec = make_workload(args.workload, N=args.nobs)
+    if world > 1:
+        model.set_data_parallel(rank, world)
+    eng = model.engine(inputs)
+    steps_total = args.warmup + args.steps
+    eng.alloc_history(steps_total)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.train_step(i)
+    sync()
+    # the dominant kernel is timed live with events on the stream it is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    orig = eng.lib.cl_elbo_mono_fwd_bwd
+    slot = {"i": 0}
+
+    def timed_kernel(*a):
+        e0, e1 = ev[slot["i"]]
+        e0.record()
+        rc = orig(*a)
+        e1.record()
+        slot["i"] += 1
+        return rc
+
+    class _LibProxy:
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, k):
+            return timed_kernel if k == "cl_elbo_mono_fwd_bwd" else getattr(self._lib, k)
+
+    real_lib = eng.lib
+    eng.lib = _LibProxy(real_lib)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(args.warmup + i)
+    sync()
+    t1 = time.perf_counter()
+    eng.lib = real_lib
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    hist = eng.read_history(steps_total)
+    finite = bool(np.all(np.isfinite(hist["loss"]))) and len(hist["loss"]) == steps_total
+
+    if rank == 0:
+        N = spec["N"]
+        ms = 1e3 * elapsed / args.steps
+        F = flops_per_obs(spec["d"], spec["w"], spec["L"])
+        B = bytes_per_obs(spec["d"], spec["S"])
+        achieved = F * eng.N / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "reflections/sec per ELBO step", "value": N / (elapsed / args.steps), "unit": "reflections/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "n_obs": N, "n_refl": spec["R"], "n_images": spec["M"],
+                       "metadata_width": spec["d"], "mlp": f"{spec['L']}x{spec['w']}", "mc_samples": spec["S"],
+                       "likelihood": "normal" if spec["dof"] is None else f"studentt(dof={spec['dof']})",
+                       "prior": "wilson", "image_scales": True, "noise": "in-kernel philox",
+                       "parallelism": f"obs-shard x{world}" if world > 1 else "single",
+                       "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
+            "roofline": {"bound": "mfma", "kernel": "elbo_mlp_kernel (cl_elbo_mono_fwd_bwd)", "achieved": achieved,
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                         "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
+                         "hbm_secondary": {"achieved_GBps": B * eng.N / (kern_ms * 1e-3) / 1e9, "bytes_per_obs": B}},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

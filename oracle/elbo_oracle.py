@@ -503,64 +503,10 @@ def train_step(p: ElboParams, x: ElboInputs, cfg: ElboConfig, st: AdamState, u_f
 
 
 # --------------------------------------------------------------------------------------------------
-# synthetic problems  (SURVEY section 8d generator, shared by tests, smoke and bench)
+# synthetic problems: the deterministic generator of SURVEY 8(d) lives in careless_amd/synthetic.py (plain numpy,
+# no compute path) so that bench.py can build its workload without touching the oracle; re-exported here.
 # --------------------------------------------------------------------------------------------------
-def positional_encoding(x: np.ndarray, L: int) -> np.ndarray:
-    """`careless/utils/positional_encoding.py:3-17`: each column min-max scaled to [-1, 1]; angles
-    pi 2^l p ordered column-major-then-frequency; output = [cos(all angles), sin(all angles)]."""
-    p = np.asarray(x, dtype=np.float64)
-    lo, hi = p.min(0), p.max(0)
-    p = 2.0 * (p - lo) / (hi - lo) - 1.0
-    freqs = np.pi * 2.0 ** np.arange(L, dtype=np.float64)
-    ang = np.stack([p[:, c, None] * freqs[None, :] for c in range(p.shape[1])], axis=1).reshape(p.shape[0], -1)
-    return np.concatenate([np.cos(ang), np.sin(ang)], axis=-1)
-
-
-def standardize_metadata(m: np.ndarray) -> np.ndarray:
-    """`careless/io/formatter.py:41-57`: per-column (x - mean) / std."""
-    m = np.asarray(m, dtype=np.float64)
-    return (m - m.mean(0)) / m.std(0)
-
-
-def make_synthetic(N: int, R: Optional[int] = None, d0: int = 5, posenc: bool = False, posenc_L: int = 4,
-                   outliers: bool = False, seed: int = 1234, n_images: Optional[int] = None):
-    """Deterministic synthetic mono problem of SURVEY 8(d).  Returns a dict of numpy arrays in the reference's
-    dtypes: ids int64, data float32 (io/formatter.py:382-394)."""
-    rng = np.random.default_rng(seed)
-    if R is None:
-        R = max(1, N // 32)
-    centric = rng.random(R) < 0.1
-    mult = rng.choice(np.array([1.0, 2.0, 3.0, 4.0, 6.0]), size=R, p=[0.9, 0.05, 0.02, 0.02, 0.01])
-    # F_true ~ Wilson(centric, eps, Sigma=1)
-    sig = np.sqrt(mult)
-    f_c = np.abs(rng.normal(size=R)) * sig
-    f_a = sig * np.sqrt(-np.log1p(-rng.random(R)))
-    f_true = np.where(centric, f_c, f_a)
-    refl_id = np.concatenate([np.arange(min(R, N)), rng.integers(0, R, size=max(0, N - R))]).astype(np.int64)
-    M = n_images if n_images is not None else max(1, N // 1000)
-    image_id = np.sort(rng.integers(0, M, size=N)).astype(np.int64)
-    inv_d2 = rng.uniform(0.01, 0.25, size=N)
-    hkl = rng.integers(-40, 40, size=(N, 3)).astype(np.float64)
-    extra = rng.uniform(0, 1, size=(N, max(0, d0 - 4)))
-    raw = np.concatenate([inv_d2[:, None], hkl, extra], axis=1)[:, :d0]
-    meta = standardize_metadata(raw)
-    if posenc:
-        xy = rng.uniform(0, 2048, size=(N, 2))
-        meta = np.concatenate([meta, positional_encoding(xy, posenc_L)], axis=1)
-    g = np.exp(rng.normal(0.0, 0.2, size=M))
-    K = np.exp(-5.0 * inv_d2) * g[image_id]
-    i_true = K * f_true[refl_id] ** 2 * 1e3
-    sigi = np.sqrt(i_true + 25.0)
-    iobs = i_true + sigi * rng.normal(size=N)
-    if outliers:
-        n_out = int(0.02 * N)
-        idx = rng.choice(N, size=n_out, replace=False)
-        iobs[idx] = i_true[idx] + 10.0 * sigi[idx] * rng.standard_t(2.0, size=n_out)
-    return dict(
-        refl_id=refl_id, image_id=image_id, file_id=np.zeros(N, dtype=np.int64),
-        metadata=meta.astype(np.float32), iobs=iobs.astype(np.float32), sigiobs=sigi.astype(np.float32),
-        centric=centric, multiplicity=mult.astype(np.float32), n_images=M, n_refl=R,
-    )
+from careless_amd.synthetic import make_synthetic, positional_encoding, standardize_metadata  # noqa: E402,F401
 
 
 def inputs_from_numpy(d: Dict, dtype=torch.float64, sigma=1.0) -> ElboInputs:
