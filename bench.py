@@ -39,8 +39,10 @@ def cpu_baseline(workload: str, n_sample: int):
     from careless_amd.workloads import WORKLOADS
     from oracle import elbo_oracle as O
     spec = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     data = O.make_synthetic(n_sample, d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"])
     cfg = O.ElboConfig(mc_samples=spec["S"], likelihood="normal" if spec["dof"] is None else "studentt", dof=spec["dof"])
     dt = torch.float32
@@ -49,16 +51,26 @@ def cpu_baseline(workload: str, n_sample: int):
     st = O.AdamState.zeros_like(p.tensors())
     g = torch.Generator().manual_seed(0)
     R, S = int(data["n_refl"]), spec["S"]
-    times = []
-    for i in range(4):
+    def one_step():
         u = torch.rand(S, R, generator=g, dtype=dt).clamp(1e-6, 1 - 1e-6)
         eta = torch.randn(S, n_sample, generator=g, dtype=dt)
         t0 = time.perf_counter()
         O.train_step(p, x, cfg, st, u, eta)
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
+        return time.perf_counter() - t0
+
+    # be fair to the CPU: more threads than physical cores (or than the cgroup grants) only slows torch down, so try
+    # a few thread counts on one step each and keep the fastest for the timed run
+    best, cores = None, avail
+    for nt in sorted({avail, min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True):
+        torch.set_num_threads(nt)
+        one_step()
+        tt = one_step()
+        if best is None or tt < best:
+            best, cores = tt, nt
+    torch.set_num_threads(cores)
+    t = float(np.median([one_step() for _ in range(3)]))
     return {"value": n_sample / t, "unit": "reflections/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} observations of the same workload, median of 3 steps after 1 warm-up, "
+            "sample": f"{n_sample} observations of the same workload, median of 3 steps after warm-up, {cores} torch threads (best of a small sweep), "
                       f"fp32 PyTorch-CPU restatement of the reference graph (not TensorFlow), torch {torch.__version__}"}
 
 

@@ -109,6 +109,9 @@ def get_lib() -> C.CDLL:
         raise CarelessHipError(
             f"{LIB_PATH} is missing: build it with `python -m careless_amd.build` (needs hipcc, targets gfx950). "
             "careless_amd has no CPU fallback.")
+    # torch ships its own libamdhip64; import it first so this library binds to the SAME HIP runtime (two runtimes in
+    # one process cannot share streams or device memory: launches then fail with hipErrorNoDevice)
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the machine

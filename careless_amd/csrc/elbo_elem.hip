@@ -186,11 +186,13 @@ __global__ void noise_kernel(unsigned long long seed, unsigned step, int S, long
 // ---------------------------------------------------------------------------------------------------------
 int cl_launch_tn_forward(const cl_tn_args& a, hipStream_t st) {
     if (a.R <= 0 || a.S <= 0) return -1;
+    (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(tn_forward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st) {
     if (a.R <= 0 || a.S <= 0) return -1;
+    (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(tn_backward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
@@ -199,6 +201,7 @@ int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, d
     if (n <= 0) return -1;
     int grid = (n + 255) / 256;
     if (grid > 1024) grid = 1024;
+    (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, seg_off, nseg, seg_sq, scalars, stop_flag);
     return (int)hipGetLastError();
 }
@@ -206,17 +209,20 @@ int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
     if (a.n <= 0) return -1;
     int grid = (a.n + 255) / 256;
     if (grid > 2048) grid = 2048;
+    (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int cl_launch_finalize(const double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,
                        hipStream_t st) {
+    (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, scalars, klw, history, step_index, hist_stride, stop_flag);
     return (int)hipGetLastError();
 }
 int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
                     hipStream_t st) {
     if (n <= 0) return -1;
+    (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, step, S, n, offset, kind, out);
     return (int)hipGetLastError();
 }

@@ -178,7 +178,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         // ================= forward =======================================================================
         float h0[KS1];                     // metadata^T as B operand: step t holds feature 4t + q
 #pragma unroll
-        for (int t = 0; t < KS1; ++t) h0[t] = A.meta_t[(size_t)(4 * t + q) * A.n_pad + gobs];
+        for (int t = 0; t < KS1; ++t) h0[t] = (4 * t + q < d) ? A.meta_t[(size_t)(4 * t + q) * A.n_pad + gobs] : 0.0f;
 
         f32x4 hs[LMAX][FB];                // post-activation H_l^T: block fb, reg t = feature 16fb + 4q + t, obs j
         float o0 = 0.0f, o1 = 0.0f;
@@ -535,6 +535,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         configured = sm;
     }
+    (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), sm, st, a);
     return (int)hipGetLastError();
 }
@@ -569,6 +570,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
 }
 
 int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st) {
+    (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 255) / 256), dim3(256), 0, st, partials, nparts, P, out, stop_flag);
     return (int)hipGetLastError();
 }
