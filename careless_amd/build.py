@@ -34,17 +34,24 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP source for gfx950 and link the shared library.  Returns the library path."""
+def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> str:
+    """Compile every HIP source for gfx950 and link the shared library.  Returns the library path.
+    `stamps=True` builds the diagnostic variant libcareless_hip_stamps.so (in-kernel phase timers, -DCL_STAMPS)."""
+    if stamps:
+        return _build(os.path.join(LIBDIR, "libcareless_hip_stamps.so"), ["-DCL_STAMPS"], verbose)
     if not force and not needs_build():
         return LIB
+    return _build(LIB, [], verbose)
+
+
+def _build(LIB: str, extra, verbose: bool) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-c", os.path.join(CSRC, s), "-o", o]
+        o = os.path.join(LIBDIR, s.replace(".hip", ".o") + ("s" if extra else ""))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + list(extra) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
@@ -62,4 +69,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

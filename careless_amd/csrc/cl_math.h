@@ -73,13 +73,42 @@ CL_HD float cl_noise_uniform(uint64_t seed, uint32_t step, uint32_t s, uint64_t 
     return cl_u01(r.x);
 }
 
-// standard normal for the scale draw of observation idx, MC sample s (Box-Muller on two words of one Philox block)
-CL_HD float cl_noise_normal(uint64_t seed, uint32_t step, uint32_t s, uint64_t idx) {
-    const cl_u32x4 r = cl_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_SCALE << 28), s, step,
+// fast device forms of the transcendental pieces of the noise generator (1-ulp hardware approximations are ample for
+// Monte-Carlo noise; the oracle is always fed the numbers the device actually drew, via cl_debug_noise)
+#if defined(__HIP_DEVICE_COMPILE__)
+CL_HD float cl_fast_log(float x) { return __logf(x); }
+CL_HD float cl_fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+CL_HD void cl_fast_sincos_rev(float rev, float* s, float* c) { *s = __builtin_amdgcn_sinf(rev); *c = __builtin_amdgcn_cosf(rev); }
+CL_HD float cl_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+#else
+CL_HD float cl_fast_log(float x) { return logf(x); }
+CL_HD float cl_fast_sqrt(float x) { return sqrtf(x); }
+CL_HD void cl_fast_sincos_rev(float rev, float* s, float* c) { *s = sinf(6.283185307179586f * rev); *c = cosf(6.283185307179586f * rev); }
+CL_HD float cl_fast_rcp(float x) { return 1.0f / x; }
+#endif
+
+// Standard normals for the scale draw of observation idx.  One Philox block + one Box-Muller transform serve TWO
+// MC samples: samples s and s+4 (same s & 3, consecutive s >> 2) are the cosine and the sine branch of one pair, because
+// a lane of the fused kernel handles exactly the samples s = q, q+4, q+8, ... of its observation.
+CL_HD void cl_noise_normal_pair(uint64_t seed, uint32_t step, uint32_t s_even, uint64_t idx, float* n_cos, float* n_sin) {
+    // s_even = the sample index of the cosine branch: (s >> 2) even
+    const uint32_t key = ((s_even >> 3) << 2) | (s_even & 3u);
+    const cl_u32x4 r = cl_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_SCALE << 28), key, step,
                                         (uint32_t)seed, (uint32_t)(seed >> 32));
     const float u1 = cl_u01(r.x), u2 = cl_u01(r.y);
-    const float rad = sqrtf(-2.0f * logf(u1));
-    return rad * cosf(6.283185307179586f * u2);
+    const float rad = cl_fast_sqrt(-2.0f * cl_fast_log(u1));
+    float sn, cs;
+    cl_fast_sincos_rev(u2, &sn, &cs);
+    *n_cos = rad * cs;
+    *n_sin = rad * sn;
+}
+
+// standard normal for the scale draw of observation idx, MC sample s
+CL_HD float cl_noise_normal(uint64_t seed, uint32_t step, uint32_t s, uint64_t idx) {
+    float a, b;
+    const uint32_t kk = s >> 2;
+    cl_noise_normal_pair(seed, step, ((kk & ~1u) << 2) | (s & 3u), idx, &a, &b);
+    return (kk & 1u) ? b : a;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -213,4 +242,24 @@ CL_HD float cl_lik_log_prob(float ipred, float iobs, float sig, int kind, float 
     const float y2 = y * y;
     *dll = -(dof + 1.0f) * y / (dof + y2) * inv;
     return -0.5f * (dof + 1.0f) * log1pf(y2 / dof) - logf(sig) + lik_const;
+}
+
+// log(1 + x) for x >= 0 from the hardware log: log(u) + (x - (u - 1)) / u with u = fl(1 + x) (the correction term restores
+// the bits of x lost in forming u), relative error ~1e-7
+CL_HD float cl_log1p_pos(float x) {
+    const float u = 1.0f + x;
+    return cl_fast_log(u) + (x - (u - 1.0f)) * cl_fast_rcp(u);
+}
+
+// same, with 1/sig and log(sig) hoisted by the caller (they are per-observation, the prediction is per MC sample)
+CL_HD float cl_lik_log_prob2(float ipred, float iobs, float inv_sig, float log_sig, int kind, float dof, float lik_const,
+                             float* dll) {
+    const float y = (ipred - iobs) * inv_sig;
+    if (kind == CL_LIK_NORMAL) {
+        *dll = -y * inv_sig;
+        return -0.5f * y * y - 0.5f * CL_LOG_2PI_F - log_sig;
+    }
+    const float y2 = y * y;
+    *dll = -(dof + 1.0f) * y / (dof + y2) * inv_sig;
+    return -0.5f * (dof + 1.0f) * cl_log1p_pos(y2 / dof) - log_sig + lik_const;
 }

@@ -33,10 +33,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CL_NW 8              // waves per workgroup
 #define CL_WOBS 16           // observations per wave in forward / dgrad
 #define CL_PB 132            // pitch of the [feature][obs] staging tiles (128 + 4)
-#define CL_SCR 160           // floats of per-wave scratch
+#define CL_SCR 32            // floats of per-wave scratch (the dO tile)
 // compiler-level fence for memory operations: keeps hipcc from hoisting a whole layer of LDS operand reads
 // above the MFMAs that consume them
 #define CL_PIN() asm volatile("" ::: "memory")
+
+// Diagnostic build only (-DCL_STAMPS, scripts/stamps.py): per-wave cycle shares of the phases of a tile.  The shipped
+// library is built without it and executes no stamp.
+#ifdef CL_STAMPS
+#define CL_NPH 16
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+        st_acc[k] += t_ - st_last;                                                                 \
+        st_last = t_;                                                                              \
+    } while (0)
+#define STAMP_VM(k)                                                                                \
+    do {                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+        STAMP(k);                                                                                  \
+    } while (0)
+#else
+#define STAMP(k)
+#define STAMP_VM(k)
+#endif
 
 namespace {
 
@@ -112,15 +133,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     const int j = lane & 15;            // observation within the wave / MFMA row-or-column index
     const int q = lane >> 4;            // k-group of the MFMA step
     float* const sS = smem + SL::oS + wv * CL_SCR;
-    float* const sLoc = sS;
-    float* const sSig = sS + 16;
-    float* const sAim = sS + 32;
-    float* const sIo = sS + 48;
-    float* const sSg = sS + 64;
-    int* const sRid = reinterpret_cast<int*>(sS + 80);
-    float* const sDl = sS + 96;
-    float* const sDs = sS + 112;
-    float* const sDa = sS + 128;
+    float* const sDl = sS;              // per-wave dO tile: dL/dloc [16], dL/draw [16]
+    float* const sDs = sS + 16;
 
     const int d = A.d, w = A.w, L = A.L;
     const float leak = A.leak;
@@ -171,6 +185,34 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 
     const int ntiles = A.n_pad / CL_TILE;
     const int S = A.S;
+#ifdef CL_STAMPS
+    unsigned long long st_acc[CL_NPH];
+#pragma unroll
+    for (int k = 0; k < CL_NPH; ++k) st_acc[k] = 0;
+    unsigned long long st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+
+    // static priority for the younger half (the second wave of every SIMD loses VALU arbitration otherwise)
+    if (wv >= CL_NW / 2) __builtin_amdgcn_s_setprio(1);
+
+    // per-observation inputs of a tile, loaded one tile ahead so their HBM latency hides under the backward pass
+    float h0n[KS1];
+    int ridn = -1, imgn = 0;
+    float ion = 0.0f, sgn = 1.0f;
+    auto prefetch = [&](int tile) {
+        const int g = tile * CL_TILE + CL_WOBS * wv + j;
+#pragma unroll
+        for (int t = 0; t < KS1; ++t) h0n[t] = (4 * t + q < d) ? A.meta_t[(size_t)(4 * t + q) * A.n_pad + g] : 0.0f;
+        ridn = -1; imgn = 0; ion = 0.0f; sgn = 1.0f;
+        if (MODE == 0 && g < A.n_obs) {
+            ridn = A.refl_id[g];
+            ion = A.iobs[g];
+            sgn = A.sig[g];
+            if (A.use_img) imgn = A.image_id[g];
+        }
+    };
+    if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int gobs = tile * CL_TILE + CL_WOBS * wv + j;      // this lane's observation (all four k-groups)
@@ -178,32 +220,57 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         // ================= forward =======================================================================
         float h0[KS1];                     // metadata^T as B operand: step t holds feature 4t + q
 #pragma unroll
-        for (int t = 0; t < KS1; ++t) h0[t] = (4 * t + q < d) ? A.meta_t[(size_t)(4 * t + q) * A.n_pad + gobs] : 0.0f;
-
+        for (int t = 0; t < KS1; ++t) h0[t] = h0n[t];
+        const int rid = ridn, img = imgn;
+        const float io = ion, sg = sgn;
+        // gathers that depend on the prefetched ids: issued now, consumed in the epilogue (latency hides under forward)
+        float aim = 1.0f, zf0 = 0.0f, zf1 = 0.0f, et0 = 0.0f, et1 = 0.0f;
+        if (MODE == 0 && rid >= 0) {
+            if (A.use_img && img > 0) aim = A.img[img - 1];
+            if (q < S) zf0 = A.z_f[(size_t)rid * S + q];
+            if (q + 4 < S) zf1 = A.z_f[(size_t)rid * S + q + 4];
+            if (A.eta != nullptr) {
+                if (q < S) et0 = A.eta[(size_t)gobs * S + q];
+                if (q + 4 < S) et1 = A.eta[(size_t)gobs * S + q + 4];
+            }
+        }
+        STAMP_VM(0);
         f32x4 hs[LMAX][FB];                // post-activation H_l^T: block fb, reg t = feature 16fb + 4q + t, obs j
         float o0 = 0.0f, o1 = 0.0f;
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             if (l < L) {
+                // two output blocks at a time: two independent accumulator chains keep the MFMA pipe at its issue rate
+                // (a single 16x16x4 chain is paced by the 40-cycle dependent latency, not the 32-cycle issue interval)
 #pragma unroll
-                for (int mb = 0; mb < FB; ++mb) {
-                    f32x4 acc = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * mb + 4 * q);   // bias
+                for (int mb = 0; mb < FB; mb += 2) {
+                    f32x4 acc0 = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * mb + 4 * q);         // bias
+                    f32x4 acc1 = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * (mb + 1) + 4 * q);
                     if (l == 0) {
 #pragma unroll
-                        for (int t = 0; t < KS1; ++t)
-                            acc = mfma4(sW1[(16 * mb + j) * PW1 + 4 * t + q], h0[t], acc);
+                        for (int t = 0; t < KS1; ++t) {
+                            acc0 = mfma4(sW1[(16 * mb + j) * PW1 + 4 * t + q], h0[t], acc0);
+                            acc1 = mfma4(sW1[(16 * (mb + 1) + j) * PW1 + 4 * t + q], h0[t], acc1);
+                        }
                     } else {
                         const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
 #pragma unroll
                         for (int kb = 0; kb < FB; ++kb) {
-                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Wl + (16 * mb + j) * PW + 16 * kb + 4 * q);
+                            const f32x4 a40 = *reinterpret_cast<const f32x4*>(Wl + (16 * mb + j) * PW + 16 * kb + 4 * q);
+                            const f32x4 a41 = *reinterpret_cast<const f32x4*>(Wl + (16 * (mb + 1) + j) * PW + 16 * kb + 4 * q);
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) acc = mfma4(a4[t], hs[l > 0 ? l - 1 : 0][kb][t], acc);
+                            for (int t = 0; t < 4; ++t) {
+                                acc0 = mfma4(a40[t], hs[l > 0 ? l - 1 : 0][kb][t], acc0);
+                                acc1 = mfma4(a41[t], hs[l > 0 ? l - 1 : 0][kb][t], acc1);
+                            }
                         }
                     }
                     CL_PIN();
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) hs[l][mb][t] = fmaxf(acc[t], leak * acc[t]);
+                    for (int t = 0; t < 4; ++t) {
+                        hs[l][mb][t] = fmaxf(acc0[t], leak * acc0[t]);
+                        hs[l][mb + 1][t] = fmaxf(acc1[t], leak * acc1[t]);
+                    }
                 }
                 if (l == L - 1) {
                     // final Dense(2): every k-group holds a quarter of the features of observation j
@@ -227,6 +294,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         o0 += sBo[0];
         o1 += sBo[1];
 
+        STAMP(1);
         const bool valid = gobs < A.n_obs;
         float dsig_draw;
         const float sigma = cl_scale_bij(o1, A.bij_kind, A.eps, &dsig_draw);
@@ -236,79 +304,85 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 A.loc_out[gobs] = o0;
                 A.sig_out[gobs] = sigma;
             }
+            if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
             continue;
         }
 
         // ================= epilogue: sample, predict, likelihood, dL/dO =====================================
         float dloc, draw;
         if (MODE == 0) {
-            int img = 0;
-            if (q == 0) {
-                float aim = 1.0f;
-                int rid = -1;
-                float io = 0.0f, sg = 1.0f;
-                if (valid) {
-                    rid = A.refl_id[gobs];
-                    io = A.iobs[gobs];
-                    sg = A.sig[gobs];
-                    if (A.use_img) {
-                        img = A.image_id[gobs];
-                        aim = (img > 0) ? A.img[img - 1] : 1.0f;
+            // lane (j, q) handles MC samples s = q, q+4, ... of observation j; partial sums are combined over q below
+            float pdl = 0.0f, pds = 0.0f, pda = 0.0f;
+            STAMP(11);
+            if (rid >= 0) {
+                const float inv_sg = 1.0f / sg;
+                const float log_sg = logf(sg);
+                int k = 0;
+                float eta_sin = 0.0f;
+                for (int s = q; s < S; s += 4, ++k) {
+                    float eta;
+                    if (A.eta != nullptr) {
+                        eta = (k == 0) ? et0 : ((k == 1) ? et1 : A.eta[(size_t)gobs * S + s]);
+                    } else if ((k & 1) == 0) {       // one Philox block + Box-Muller pair serves samples s and s + 4
+                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + gobs), &eta, &eta_sin);
+                    } else {
+                        eta = eta_sin;
                     }
-                }
-                sLoc[j] = o0; sSig[j] = sigma; sAim[j] = aim; sIo[j] = io; sSg[j] = sg; sRid[j] = rid;
-                sDl[j] = 0.0f; sDs[j] = 0.0f; sDa[j] = 0.0f;
-            }
-            wave_lds_sync();
-            const int npairs = CL_WOBS * S;
-            for (int p = lane; p < npairs; p += 64) {
-                const int jj = p / S;
-                const int s = p - jj * S;
-                const int rid = sRid[jj];
-                if (rid >= 0) {
-                    const int gl = tile * CL_TILE + CL_WOBS * wv + jj;
-                    const float eta = A.eta ? A.eta[(size_t)gl * S + s]
-                                            : cl_noise_normal(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + gl));
-                    const float tq = sLoc[jj] + sSig[jj] * eta + A.shift;
-                    const float aim = sAim[jj];
+                    const float zf = (k == 0) ? zf0 : ((k == 1) ? zf1 : A.z_f[(size_t)rid * S + s]);
+                    const float tq = o0 + sigma * eta + A.shift;
                     const float zs = aim * tq;
-                    const float zf = A.z_f[(size_t)rid * S + s];
                     const float ipred = zs * zf * zf;
-                    if (A.ipred_out) A.ipred_out[(size_t)gl * S + s] = ipred;
+                    if (A.ipred_out) A.ipred_out[(size_t)gobs * S + s] = ipred;
                     float dll;
-                    const float ll = cl_lik_log_prob(ipred, sIo[jj], sSg[jj], A.lik_kind, A.dof, A.lik_const, &dll);
+                    const float ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, A.lik_kind, A.dof, A.lik_const, &dll);
                     nll_acc -= ll * A.w_ll;
                     const float gi = -dll * A.w_ll;                 // dNLL / d ipred
                     const float dzs = gi * zf * zf;
                     atomicAdd(A.dz_f + (size_t)rid * S + s, gi * zs * 2.0f * zf);
                     const float dt = dzs * aim;
-                    atomicAdd(sDl + jj, dt);
-                    atomicAdd(sDs + jj, dt * eta);
-                    atomicAdd(sDa + jj, dzs * tq);
+                    pdl += dt;
+                    pds += dt * eta;
+                    pda += dzs * tq;
                 }
             }
-            wave_lds_sync();
-            dloc = sDl[j];
-            draw = sDs[j] * dsig_draw;
+            pdl += __shfl_xor(pdl, 16); pds += __shfl_xor(pds, 16); pda += __shfl_xor(pda, 16);
+            pdl += __shfl_xor(pdl, 32); pds += __shfl_xor(pds, 32); pda += __shfl_xor(pda, 32);
+            dloc = pdl;
+            draw = pds * dsig_draw;
+            STAMP(12);
+            if (A.use_img) {
+                // image ids are sorted, so the 16 observations of a wave almost always share one image: reduce in the
+                // wave and issue ONE atomic instead of 16 same-address ones (which serialise in the L2 atomic unit)
+                const int img0 = __builtin_amdgcn_readfirstlane(img);
+                if (__all(img == img0)) {
+                    float v = (q == 0 && rid >= 0) ? pda : 0.0f;
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    if (lane == 0 && img0 > 0) atomicAdd(A.d_img + (img0 - 1), v);
+                } else if (q == 0 && rid >= 0 && img > 0) {
+                    atomicAdd(A.d_img + (img - 1), pda);
+                }
+            }
             if (q == 0) {
-                if (valid && A.use_img && img > 0) atomicAdd(A.d_img + (img - 1), sDa[j]);
                 boacc0 += dloc;
                 boacc1 += draw;
             }
-            wave_lds_sync();
-            if (q == 0) sDs[j] = draw;          // sDl = dloc, sDs = draw: the dO tile for the Dense(2) wgrad
+            STAMP(13);
         } else {
             dloc = valid ? A.dO_ext[2 * (size_t)gobs] : 0.0f;
             draw = valid ? A.dO_ext[2 * (size_t)gobs + 1] * dsig_draw : 0.0f;   // external grad is w.r.t. sigma
             if (q == 0) {
-                sDl[j] = dloc; sDs[j] = draw;
                 boacc0 += dloc; boacc1 += draw;
             }
         }
+        // next tile's inputs: in flight during the whole backward pass
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 
         // ================= backward =======================================================================
         // tile seam: every wave must be done reading the staging tiles of the previous tile's last wgrad
+        STAMP(2);
         lds_barrier();
+        STAMP(3);
+        if (q == 0) { sDl[j] = dloc; sDs[j] = draw; }      // the dO tile for the Dense(2) wgrad (wave-private)
 
         f32x4 dH[FB];
 #pragma unroll
@@ -340,6 +414,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     }
                 }
                 wave_lds_sync();
+                STAMP(4);
             }
             if (l < L) {
                 // dZ_l = dH_l * lrelu'(H_l)   (sign of the post-activation == sign of the pre-activation)
@@ -348,7 +423,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dH[mb][t] = (hs[l][mb][t] > 0.0f) ? dH[mb][t] : leak * dH[mb][t];
 
-                if (l < L - 1) lds_barrier();      // previous layer's wgrad reads are complete
+                STAMP(5);
+                if (l < L - 1) lds_barrier();      // barrier A: the previous layer's wgrad reads are complete
+                STAMP(6);
 #pragma unroll
                 for (int mb = 0; mb < FB; ++mb)
 #pragma unroll
@@ -373,7 +450,30 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     }
                     bacc[l] += sb;
                 }
-                lds_barrier();                     // staging tiles complete for all 128 observations
+                // ---- dgrad: dH_{l-1} = W_l dZ_l.  Register + weight-image only, so it runs BEFORE barrier B and
+                //      overlaps the other waves' staging writes ---------------------------------------------------
+                f32x4 dn[FB];
+                if (l > 0) {
+                    const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
+#pragma unroll
+                    for (int mb = 0; mb < FB; mb += 2) {
+                        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int kb = 0; kb < FB; ++kb)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const float* wr = Wl + (16 * kb + 4 * q + t) * PW + j;
+                                acc0 = mfma4(wr[16 * mb], dH[kb][t], acc0);
+                                acc1 = mfma4(wr[16 * (mb + 1)], dH[kb][t], acc1);
+                            }
+                        dn[mb] = acc0;
+                        dn[mb + 1] = acc1;
+                        CL_PIN();
+                    }
+                }
+                STAMP(7);
+                lds_barrier();                     // barrier B: staging tiles complete for all 128 observations
+                STAMP(8);
 
                 // ---- wgrad: 16x16 blocks of dW_l^T[o][i] = sum_obs dZ[o][obs] H_in[i][obs] ---------------------
                 // step (g,t) contracts observations kbase + 16g + 4q + t: one ds_read_b128 feeds four steps
@@ -418,27 +518,22 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     }
                     wacc[l][0] = acc0; wacc[l][1] = acc1;
                 }
-                // ---- dgrad: dH_{l-1} = W_l dZ_l --------------------------------------------------------------
+                STAMP(9);
                 if (l > 0) {
-                    const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
-                    f32x4 dn[FB];
-#pragma unroll
-                    for (int mb = 0; mb < FB; ++mb) {
-                        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                        for (int kb = 0; kb < FB; ++kb)
-#pragma unroll
-                            for (int t = 0; t < 4; ++t)
-                                acc = mfma4(Wl[(16 * kb + 4 * q + t) * PW + 16 * mb + j], dH[kb][t], acc);
-                        dn[mb] = acc;
-                        CL_PIN();
-                    }
 #pragma unroll
                     for (int mb = 0; mb < FB; ++mb) dH[mb] = dn[mb];
                 }
+                STAMP(10);
             }
         }
     }
+#ifdef CL_STAMPS
+    if (MODE == 0 && A.loc_out != nullptr && lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.loc_out) + ((size_t)blockIdx.x * CL_NW + wv) * CL_NPH;
+#pragma unroll
+        for (int k = 0; k < CL_NPH; ++k) dbg[k] = st_acc[k];
+    }
+#endif
 
     if (MODE == 1) return;
 
