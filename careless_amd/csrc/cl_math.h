@@ -61,8 +61,9 @@ CL_HD cl_u32x4 cl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
     return o;
 }
 
-// uniform in the open interval (0,1): 24 random bits, centred in their bin
-CL_HD float cl_u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+// uniform in the open interval (0,1): 23 random bits, centred in their bin (k + 0.5 is exact in fp32 for k < 2^23, so the
+// result never rounds to 0 or 1)
+CL_HD float cl_u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f; }
 
 enum { CL_STREAM_QF = 1, CL_STREAM_SCALE = 2 };
 

@@ -342,11 +342,8 @@ class ElboEngine:
         self._keep = (u_f, eta, ipred_out)
 
     def _allreduce(self):
-        import torch.distributed as dist
-        n = self.layout.n
-        self.grads_ext[n:n + 2] = self.scalars[:2].to(torch.float32)
-        dist.all_reduce(self.grads_ext, op=dist.ReduceOp.SUM, group=self.process_group)
-        self.scalars[:2] = self.grads_ext[n:n + 2].to(torch.float64)
+        from careless_amd.distributed import allreduce_flat_
+        allreduce_flat_(self.grads_ext, self.scalars, self.layout.n, self.process_group)
 
     def optimizer_step(self, step_index: int):
         lib, st, opt = self.lib, _stream(), self.opt

@@ -139,3 +139,57 @@ def test_scaler_forward_and_tn_sample():
     loc, scale = O.tn_loc_scale(params.q_loc_raw, params.q_scale_raw, cfg.epsilon)
     zo = O.tn_sample(loc, scale, x.low, torch.tensor(cfg.high, dtype=torch.float64), torch.as_tensor(u_f, dtype=torch.float64))
     assert util.rel_err(z, zo.numpy()) < 1e-5
+
+
+# --- the committed golden vectors (tests/golden/*.npz) through the HIP engine ------------------------------------------
+from tests.test_golden import FILES as GOLDEN_FILES, load_case as load_golden  # noqa: E402
+import os  # noqa: E402
+
+
+@pytest.mark.parametrize("path", GOLDEN_FILES, ids=[os.path.basename(f) for f in GOLDEN_FILES])
+def test_hip_engine_reproduces_golden_vectors(path):
+    z, kw, data, cfg, params = load_golden(path)
+    model = util.build_model(data, cfg, params, kw["L"], kw["w"])
+    inputs = util.reference_inputs(data)
+    ipred = model(inputs, u_f=z["u_f"], eta=z["eta"]).cpu().numpy()
+    eng = model._engine
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(z["loss"])) <= RTOL_LOSS * abs(float(z["loss"]))
+    assert abs(t["nll"] - float(z["nll"])) <= RTOL_LOSS * abs(float(z["nll"]))
+    assert abs(t["kl"] - float(z["kl"])) <= RTOL_LOSS * max(abs(float(z["kl"])), 1.0)
+    assert util.rel_err(ipred, z["ipred"]) < 1e-4
+    errs = [util.rel_err(g.cpu().numpy(), z[f"grad_{i:02d}"]) for i, g in enumerate(eng.grad_tensors())]
+    assert max(errs) < RTOL_GRAD, errs
+    from tests.golden.make_golden import STEPS
+    model2 = util.build_model(data, cfg, params, kw["L"], kw["w"])
+    hist = model2.train_model(inputs, STEPS, progress=False, noise=lambda i: (z["traj_u"][i], z["traj_eta"][i]))
+    assert np.max(np.abs(np.array(hist["loss"]) - z["traj_loss"]) / np.abs(z["traj_loss"])) < RTOL_LOSS
+    assert np.max(np.abs(np.array(hist["Grad Norm"]) - z["traj_gnorm"]) / np.abs(z["traj_gnorm"])) < 2e-4
+    finals = [model2.surrogate_posterior.loc_raw, model2.surrogate_posterior.scale_raw] + list(model2._engine.mlp.weights)
+    if cfg.use_image_scales:
+        finals.append(model2._engine.img._scales)
+    for i, tns in enumerate(finals):
+        assert util.rel_err(tns.cpu().numpy(), z[f"final_{i:02d}"]) < 2e-4, i
+
+
+def test_full_size_properties_1M():
+    """BASELINE configs[1] at full size (1 M observations): properties that need no oracle -- determinism of the
+    deterministic parts, linearity of the gradient in the loss weight, finite loss, loss decreases over a few steps."""
+    from careless_amd.workloads import make_workload
+    model, inputs, data, spec = make_workload("mono_1M_normal_5x64_S1")
+    eng = model.engine(inputs)
+    eng.forward_backward(0)
+    torch.cuda.synchronize()
+    a = eng.loss_terms()
+    g1 = eng.grads.clone()
+    kl1 = a["kl"]
+    eng.forward_backward(0)
+    torch.cuda.synchronize()
+    b = eng.loss_terms()
+    assert b["kl"] == kl1                                     # the KL path has no atomics: bitwise repeatable
+    assert abs(a["nll"] - b["nll"]) <= 1e-9 * abs(a["nll"])   # NLL partials are summed in fp64
+    assert torch.allclose(eng.grads, g1, rtol=1e-3, atol=1e-3 * float(g1.abs().max()))  # float-atomic order only
+    # same noise key, different S-independent check: every reflection observed -> dz_f has no exact zeros in observed slots
+    assert bool(torch.isfinite(eng.grads).all()) and float(eng.grads.abs().max()) > 0
+    hist = model.train_model(inputs, 5, progress=False)
+    assert len(hist["loss"]) == 5 and all(np.isfinite(hist["loss"])) and hist["loss"][-1] < hist["loss"][0]

@@ -1,0 +1,174 @@
+"""Host-side logic of careless_amd that needs no GPU: the input-tuple contract, the flat parameter layout, sharding,
+plugin classes, and that libcareless_hip.so loads and exports every symbol include/careless_hip.h declares.  CPU only."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from careless_amd import _lib
+from careless_amd.engine import make_layout, make_shard
+from careless_amd.models.base import BaseModel
+from careless_amd.models.likelihoods.mono import NormalLikelihood, StudentTLikelihood
+from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
+from careless_amd.models.merging.variational import VariationalMergingModel
+from careless_amd.models.priors.wilson import WilsonPrior
+from careless_amd.models.scaling.image import HybridImageScaler, ImageScaler
+from careless_amd.models.scaling.nn import MLPScaler
+from careless_amd.workloads import bytes_per_obs, flops_per_obs, make_workload, reference_inputs
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --- input contract (reference tests/models/test_base_model.py:6-28) -----------------------------------------
+def test_base_model_contract():
+    assert BaseModel.input_index == {"refl_id": 0, "image_id": 1, "file_id": 2, "metadata": 3, "intensities": 4,
+                                     "uncertainties": 5, "wavelength": 6, "harmonic_id": 7}
+    data = util.make_problem(N=50, R=8)[0]
+    mono = reference_inputs(data)
+    assert not BaseModel.is_laue(mono)
+    laue = mono + (np.ones((50, 1), np.float32), np.zeros((50, 1), np.int64))
+    assert BaseModel.is_laue(laue)
+    for name, idx in BaseModel.input_index.items():
+        assert BaseModel.get_name_by_index(idx) == name
+        assert BaseModel.get_index_by_name(name) == idx
+        assert BaseModel.get_input_by_name(laue, name) is laue[idx]
+    assert BaseModel.get_metadata(mono).shape == (50, 5) and BaseModel.get_metadata(mono).dtype == np.float32
+    assert BaseModel.get_refl_id(mono).dtype == np.int64 and BaseModel.get_refl_id(mono).shape == (50, 1)
+    with pytest.raises(ValueError):
+        BaseModel.get_index_by_name("nope")
+    with pytest.raises(ValueError):
+        BaseModel.get_name_by_index(99)
+    with pytest.raises(ValueError):
+        BaseModel.get_harmonic_id(mono)
+    batched = tuple(a[None] for a in mono)          # a leading batch axis of 1 is squeezed (base.py:79-80)
+    assert BaseModel.get_metadata(batched).shape == (50, 5)
+
+
+# --- flat layout / sharding ---------------------------------------------------------------------------------------
+def test_flat_layout_matches_scaler_and_library():
+    lay = make_layout(R=100, d=21, w=64, L=5, n_img=9)
+    mlp = MLPScaler(5, 64)
+    assert lay.P == mlp.param_count(21) == 21 * 64 + 64 + 4 * (64 * 64 + 64) + 2 * 64 + 2
+    assert lay.n == 200 + lay.P + 9
+    assert lay.seg_off[0] == 0 and lay.seg_off[-1] == lay.n and len(lay.seg_owner) == len(lay.seg_off) - 1
+    assert lay.seg_owner[:2] == ["q", "q"] and set(lay.seg_owner[2:]) == {"scaler"}
+    assert np.all(np.diff(lay.seg_off) > 0)
+    assert int(_lib.get_lib().cl_mlp_param_count(21, 64, 5)) == lay.P
+
+
+def test_shards_partition_observations_and_reflections():
+    for N, R, W in [(1000, 31, 1), (1001, 31, 2), (999, 7, 4), (12345, 400, 8)]:
+        sh = [make_shard(N, R, r, W) for r in range(W)]
+        assert sh[0].start == 0 and sh[-1].stop == N and sh[0].kl_begin == 0 and sh[-1].kl_end == R
+        for a, b in zip(sh[:-1], sh[1:]):
+            assert a.stop == b.start and a.kl_end == b.kl_begin
+        assert max(s.stop - s.start for s in sh) - min(s.stop - s.start for s in sh) <= W
+    with pytest.raises(ValueError):
+        make_shard(10, 3, 2, 2)
+
+
+# --- plugin classes -----------------------------------------------------------------------------------------------
+def test_scaler_parameter_views_and_identity_init():
+    s = MLPScaler(3, 8)
+    s.build(5)
+    ws = s.weights
+    assert [tuple(w.shape) for w in ws] == [(5, 8), (8,), (8, 8), (8,), (8, 8), (8,), (8, 2), (2,)]
+    assert torch.equal(ws[0], torch.eye(5, 8)) and torch.equal(ws[6], torch.eye(8, 2)) and float(ws[1].abs().sum()) == 0.0
+    ws[2][1, 3] = 7.0                                # views: Keras (in,out) element lands at W^T[out][in] of the flat buffer
+    off = s.layer_slices()[1][0]
+    assert float(s.flat[off + 3 * 8 + 1]) == 7.0
+    with pytest.raises(ValueError):
+        MLPScaler(2, 4, scale_bijector="tanh")
+    with pytest.raises(ValueError):
+        s.build(6)
+
+
+def test_image_scaler_pins_first_image():
+    im = ImageScaler(4)
+    assert im.scales.tolist() == [1.0, 1.0, 1.0, 1.0] and im._scales.numel() == 3
+    im._scales[:] = torch.tensor([2.0, 3.0, 4.0])
+    ids = np.array([[0], [1], [3], [3]])
+    inputs = (ids, ids, ids, np.zeros((4, 2), np.float32), np.zeros((4, 1), np.float32), np.ones((4, 1), np.float32))
+    assert im(inputs).tolist() == [1.0, 2.0, 4.0, 4.0]
+
+
+def test_wilson_prior_and_truncated_normal_host_protocol():
+    from scipy import stats
+    c = np.array([True, False, False])
+    eps = np.array([1.0, 2.0, 1.0])
+    p = WilsonPrior(c, eps, 1.0)
+    E = np.array([0.5, 1.0, 2.0])
+    ref = np.where(c, stats.halfnorm.logpdf(E, scale=np.sqrt(eps)), stats.weibull_min.logpdf(E, 2.0, scale=np.sqrt(eps)))
+    assert np.allclose(p.log_prob(E), ref, rtol=1e-6)
+    q = TruncatedNormal.from_loc_and_scale(p.mean(), p.stddev(), low=(1e-32 * ~c).astype(np.float32))
+    assert len(q.trainable_variables) == 2 and q.trainable_variables[0].shape == (3,)      # reference test_truncated_normal.py:15-17
+    assert np.allclose(q.loc.numpy(), p.mean(), rtol=1e-6) and np.allclose(q.scale.numpy(), p.stddev(), rtol=1e-6)
+    loc, scale = q.loc.numpy().astype(float), q.scale.numpy().astype(float)
+    a = (q.low.numpy() - loc) / scale
+    assert np.allclose(q.mean().numpy(), stats.truncnorm.mean(a, np.inf, loc, scale), rtol=1e-5)
+    assert np.allclose(q.stddev().numpy(), stats.truncnorm.std(a, np.inf, loc, scale), rtol=1e-4)
+    m4 = stats.truncnorm.moment(4, a, np.inf, loc, scale)
+    assert np.allclose(q.moment_4(method="scipy"), m4, rtol=1e-5)                          # reference test_truncated_normal.py:29-42
+    assert np.allclose(q.moment_4(method="tf"), m4, rtol=1e-5)
+    with pytest.raises(ValueError):
+        q.moment_4(method="nope")
+    q.trainable = False
+    assert q.trainable_variables == []
+
+
+def test_likelihood_objects_match_scipy():
+    from scipy import stats
+    data = util.make_problem(N=40, R=8)[0]
+    inputs = reference_inputs(data)
+    x = np.asarray(data["iobs"]) + 3.0
+    assert np.allclose(NormalLikelihood()(inputs).log_prob(x), stats.norm.logpdf(x, data["iobs"], data["sigiobs"]), rtol=1e-5)
+    assert np.allclose(StudentTLikelihood(4.0)(inputs).log_prob(x), stats.t.logpdf(x, 4.0, data["iobs"], data["sigiobs"]), rtol=1e-5)
+
+
+def test_workload_bookkeeping():
+    assert flops_per_obs(5, 64, 5) == 100992 and flops_per_obs(21, 64, 5) == 107136
+    assert bytes_per_obs(5, 1) == 44 and bytes_per_obs(21, 8) == 164
+    model, inputs, data, spec = make_workload("mono_1M_normal_5x64_S1", N=2000)
+    assert spec["d"] == 5 and spec["R"] == 62 and inputs[3].shape == (2000, 5) and inputs[0].dtype == np.int64
+    assert isinstance(model.scaling_model, HybridImageScaler) and model.mc_sample_size == 1
+    assert np.all(np.diff(inputs[1][:, 0]) >= 0)                                          # image ids sorted
+    assert set(np.unique(inputs[0][:, 0])) == set(range(62))                              # every reflection observed
+
+
+# --- the C-ABI library -----------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "careless_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cl_[a-z0-9_]+)\s*\(", hdr))
+    assert {"cl_tn_forward", "cl_tn_backward", "cl_elbo_mono_fwd_bwd", "cl_mlp_forward", "cl_adam_step"} <= declared
+    lib = _lib.get_lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/careless_hip.h but not exported"
+        assert name in _lib.EXPORTS, f"{name} not bound in careless_amd/_lib.py"
+    assert lib.cl_version().startswith(b"careless_hip")
+
+
+def test_compute_entry_points_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    data, cfg, params, x, u_f, eta = util.make_problem(N=64, R=8, L=2, w=8, S=1)
+    model = util.build_model(data, cfg, params, 2, 8)
+    with pytest.raises(_lib.CarelessHipError):
+        model.train_model(reference_inputs(data), 1, progress=False)
+    with pytest.raises(_lib.CarelessHipError):
+        model.surrogate_posterior.sample(2)
+    with pytest.raises(_lib.CarelessHipError):
+        model.scaling_model(reference_inputs(data))
+
+
+def test_unsupported_plugins_are_rejected_not_emulated():
+    class Odd:
+        pass
+    data, cfg, params, x, u_f, eta = util.make_problem(N=64, R=8, L=2, w=8, S=1)
+    model = util.build_model(data, cfg, params, 2, 8)
+    model.likelihood = Odd()
+    with pytest.raises((NotImplementedError, _lib.CarelessHipError)):
+        model.train_model(reference_inputs(data), 1, progress=False)

@@ -1,0 +1,214 @@
+"""Pins the CPU oracle (oracle/elbo_oracle.py) BEFORE it is trusted as the checker of the HIP kernels:
+  * the reference's own closed-form known-answer tests, restated (reference tests cited per test);
+  * scipy.stats closed forms for every density on the path;
+  * finite differences for the truncated-normal pathwise gradient and the full ELBO gradient.
+CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+from scipy import special, stats
+
+from oracle import elbo_oracle as O
+
+T = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64))
+
+
+def test_wilson_centric_closed_form():
+    """reference tests/models/priors/test_wilson.py:13-20: Centric pdf = sqrt(2/pi) exp(-E^2/2)"""
+    E = np.linspace(0.1, 3.0, 100)
+    p = (2.0 / np.pi) ** 0.5 * np.exp(-0.5 * E ** 2)
+    lp = O.wilson_log_prob(T(E), torch.ones(100, dtype=torch.bool), T(np.ones(100)), T(1.0)).numpy()
+    assert np.allclose(np.log(p), lp, rtol=1e-12, atol=1e-12)
+    assert np.allclose(stats.halfnorm.logpdf(E), lp)
+
+
+def test_wilson_acentric_closed_form():
+    """reference tests/models/priors/test_wilson.py:22-29: Acentric pdf = 2 E exp(-E^2)"""
+    E = np.linspace(0.1, 3.0, 100)
+    p = 2.0 * E * np.exp(-E ** 2)
+    lp = O.wilson_log_prob(T(E), torch.zeros(100, dtype=torch.bool), T(np.ones(100)), T(1.0)).numpy()
+    assert np.allclose(np.log(p), lp, rtol=1e-12, atol=1e-12)
+    assert np.allclose(stats.weibull_min.logpdf(E, 2.0), lp)
+
+
+def test_wilson_multiplicity_sigma_and_moments():
+    rng = np.random.default_rng(0)
+    eps = rng.integers(1, 6, 50).astype(float)
+    sig = rng.uniform(0.2, 2.0, 50)
+    z = rng.uniform(0.05, 3.0, 50)
+    c = rng.random(50) < 0.5
+    lp = O.wilson_log_prob(T(z), torch.as_tensor(c), T(eps), T(sig)).numpy()
+    ref = np.where(c, stats.halfnorm.logpdf(z, scale=np.sqrt(eps * sig)),
+                   stats.weibull_min.logpdf(z, 2.0, scale=np.sqrt(eps * sig)))
+    assert np.allclose(lp, ref)
+    m, s = O.wilson_mean(c, eps, 1.0), O.wilson_stddev(c, eps, 1.0)
+    assert np.allclose(m, np.where(c, stats.halfnorm.mean(scale=np.sqrt(eps)), stats.weibull_min.mean(2.0, scale=np.sqrt(eps))))
+    assert np.allclose(s, np.where(c, stats.halfnorm.std(scale=np.sqrt(eps)), stats.weibull_min.std(2.0, scale=np.sqrt(eps))))
+
+
+def test_truncated_normal_moment_4_vs_scipy():
+    """reference tests/models/merging/test_truncated_normal.py:29-42 (rtol 1e-5), closed form of surrogate_posteriors.py:55-73"""
+    rng = np.random.default_rng(1)
+    loc, scale = rng.random((2, 100))
+    scale = scale + 1e-3
+    mom4 = O.tn_moment_4(T(loc), T(scale), T(np.zeros(100))).numpy()
+    a, b = (0.0 - loc) / scale, np.inf
+    assert np.allclose(mom4, stats.truncnorm.moment(4, a, b, loc, scale), rtol=1e-5)
+
+
+def test_truncated_normal_logprob_mean_var_vs_scipy():
+    rng = np.random.default_rng(2)
+    loc = rng.uniform(0.05, 3.0, 200)
+    scale = loc * 10 ** rng.uniform(-2, 0.3, 200)
+    low = np.where(rng.random(200) < 0.2, 0.0, 1e-32)
+    z = loc + scale * rng.normal(size=200)
+    z = np.abs(z) + 1e-3
+    a, b = (low - loc) / scale, (1e10 - loc) / scale
+    lp = O.tn_log_prob(T(z), T(loc), T(scale), T(low), T(1e10)).numpy()
+    assert np.allclose(lp, stats.truncnorm.logpdf(z, a, b, loc, scale), rtol=1e-9, atol=1e-9)
+    assert np.allclose(O.tn_mean(T(loc), T(scale), T(low), T(1e10)).numpy(), stats.truncnorm.mean(a, b, loc, scale), rtol=1e-8)
+    assert np.allclose(O.tn_variance(T(loc), T(scale), T(low), T(1e10)).numpy(), stats.truncnorm.var(a, b, loc, scale), rtol=1e-6)
+
+
+def test_truncated_normal_sampler_is_inverse_cdf_and_distribution():
+    rng = np.random.default_rng(3)
+    loc, scale, low = np.array([0.8]), np.array([0.5]), np.array([0.0])
+    u = rng.random((20000, 1))
+    z = O.tn_sample(T(loc), T(scale), T(low), T(1e10), T(u)).numpy()[:, 0]
+    a = (low - loc) / scale
+    assert np.allclose(z, stats.truncnorm.ppf(u[:, 0], a[0], np.inf, loc[0], scale[0]), rtol=1e-7, atol=1e-9)
+    assert stats.kstest(z, lambda x: stats.truncnorm.cdf(x, a[0], np.inf, loc[0], scale[0])).pvalue > 1e-3
+    assert z.min() >= 0.0
+
+
+def test_truncated_normal_pathwise_gradient_vs_finite_differences():
+    """TFP's sample-gradient formula (dl, du) equals the derivative of the inverse-CDF map at fixed u."""
+    rng = np.random.default_rng(4)
+    n = 300
+    loc = rng.uniform(0.05, 3.0, n)
+    scale = loc * 10 ** rng.uniform(-1.5, 0.3, n)
+    low = np.full(n, 1e-32)
+    u = rng.uniform(0.01, 0.99, (1, n))
+    tl, ts = T(loc).requires_grad_(True), T(scale).requires_grad_(True)
+    z = O.tn_sample(tl, ts, T(low), T(1e10), T(u))
+    gl, gs = torch.autograd.grad(z.sum(), [tl, ts])
+    f = lambda l, s: stats.truncnorm.ppf(u[0], (low - l) / s, np.inf, l, s)
+    h = 1e-6
+    fd_l = (f(loc + h, scale) - f(loc - h, scale)) / (2 * h)
+    fd_s = (f(loc, scale + h) - f(loc, scale - h)) / (2 * h)
+    assert np.allclose(gl.numpy(), fd_l, rtol=1e-5, atol=1e-7)
+    assert np.allclose(gs.numpy(), fd_s, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("dof", [1.0, 2.0, 4.0, 16.0])
+def test_likelihoods_vs_scipy(dof):
+    """reference tests/models/likelihoods/test_mono.py:12-51: likelihood.log_prob == Normal / StudentT density"""
+    rng = np.random.default_rng(5)
+    iobs, sig = rng.normal(size=300) * 50, rng.uniform(0.5, 20, 300)
+    x = iobs + sig * rng.standard_t(3, size=(2, 300))
+    assert np.allclose(O.normal_log_prob(T(x), T(iobs), T(sig)).numpy(), stats.norm.logpdf(x, iobs, sig))
+    assert np.allclose(O.studentt_log_prob(T(x), dof, T(iobs), T(sig)).numpy(), stats.t.logpdf(x, dof, iobs, sig))
+
+
+def test_laue_convolve_sums_harmonics():
+    """reference tests/models/likelihoods/test_laue.py:11-36: convolve(iobs[hid]/count[hid]) reproduces iobs, also batched"""
+    rng = np.random.default_rng(6)
+    hid = np.sort(rng.integers(0, 40, 100))
+    _, hid = np.unique(hid, return_inverse=True)
+    G = hid.max() + 1
+    iobs = np.zeros(100)
+    iobs[:G] = rng.uniform(1, 10, G)
+    ipred = iobs[hid] / np.bincount(hid)[hid]
+    conv = O.laue_convolve(T(ipred), torch.as_tensor(hid)).numpy()
+    assert np.allclose(conv[:G], iobs[:G]) and np.all(conv[G:] == 0)
+    conv3 = O.laue_convolve(T(np.stack([ipred] * 3)), torch.as_tensor(hid)).numpy()
+    assert np.allclose(conv3, conv[None, :])
+
+
+def test_rice_and_folded_normal_vs_scipy():
+    """careless/utils/distributions.py:278-283 (Rice), :333-335 (FoldedNormal)"""
+    rng = np.random.default_rng(7)
+    x, nu, s = rng.uniform(0.1, 4, 200), rng.uniform(0.0, 3, 200), rng.uniform(0.3, 1.5, 200)
+    assert np.allclose(O.rice_log_prob(T(x), T(nu), T(s)).numpy(), stats.rice.logpdf(x, nu / s, scale=s), rtol=1e-8, atol=1e-8)
+    assert np.allclose(O.folded_normal_log_prob(T(x), T(nu), T(s)).numpy(), stats.foldnorm.logpdf(x, nu / s, scale=s), rtol=1e-8, atol=1e-8)
+
+
+def test_mlp_identity_init_and_forward():
+    """nn.py:62-78: identity kernels (also non-square), zero bias => output = first two metadata columns after LeakyReLU"""
+    ws, bs = O.mlp_identity_init(5, 8, 3)
+    assert [w.shape for w in ws] == [(5, 8), (8, 8), (8, 8), (8, 2)]
+    x = np.random.default_rng(8).normal(size=(10, 5))
+    out = O.mlp_forward(T(x), [T(w) for w in ws], [T(b) for b in bs], 0.01).numpy()
+    lr = lambda v: np.where(v > 0, v, 0.01 * v)
+    assert np.allclose(out, lr(lr(lr(x[:, :2]))))
+
+
+def test_scale_bijectors():
+    raw = T(np.linspace(-5, 5, 11))
+    assert np.allclose(O.scale_bijector(raw, "exp", 1e-7).numpy(), np.exp(raw.numpy()) + 1e-7)
+    assert np.allclose(O.scale_bijector(raw, "softplus", 1e-7).numpy(), np.log1p(np.exp(raw.numpy())) + 1e-7)
+    with pytest.raises(ValueError):
+        O.scale_bijector(raw, "tanh", 0.0)
+
+
+def test_elbo_gradient_vs_finite_differences():
+    from tests import util
+    data, cfg, params, x, u_f, eta = util.make_problem(N=64, R=8, L=2, w=8, S=2, likelihood="studentt", dof=4.0)
+    u, e = T(u_f), T(eta)
+    out, grads = O.elbo_value_and_grads(params, x, cfg, u, e)
+    f = lambda: float(O.elbo_forward(params, x, cfg, u, e)["loss"])
+    rng = np.random.default_rng(9)
+    for t, g in zip(params.tensors(), grads):
+        for _ in range(3):
+            idx = tuple(int(rng.integers(0, n)) for n in t.shape)
+            h = 1e-6 * max(1.0, abs(float(t[idx])))
+            v = float(t[idx])
+            t[idx] = v + h; fp = f()
+            t[idx] = v - h; fm = f()
+            t[idx] = v
+            fd = (fp - fm) / (2 * h)
+            assert abs(fd - float(g[idx])) <= 1e-5 * max(abs(fd), 1.0) + 1e-6, (idx, fd, float(g[idx]))
+
+
+def test_adam_first_step_and_clipping():
+    """tf_keras Adam: first update = -lr * g / (|g| + eps * sqrt(...)) ~ -lr sign(g); clip variants"""
+    cfg = O.ElboConfig()
+    p = [T([1.0, -2.0, 3.0])]
+    g = [T([0.5, -4.0, 0.0])]
+    st = O.AdamState.zeros_like(p)
+    O.adam_apply(p, g, st, cfg)
+    alpha = 1e-3 * math.sqrt(1 - 0.99) / (1 - 0.9)
+    m, v = 0.1 * g[0], 0.01 * g[0] ** 2
+    assert torch.allclose(p[0], T([1.0, -2.0, 3.0]) - m * alpha / (torch.sqrt(v) + 1e-7))
+    gs = [T([3.0, 4.0]), T([0.3])]
+    c = O.clip_grads(gs, O.ElboConfig(clipnorm=1.0))
+    assert torch.allclose(c[0], T([0.6, 0.8])) and torch.allclose(c[1], T([0.3]))
+    c = O.clip_grads(gs, O.ElboConfig(global_clipnorm=1.0))
+    n = math.sqrt(25 + 0.09)
+    assert torch.allclose(c[0], T([3.0, 4.0]) / n) and torch.allclose(c[1], T([0.3]) / n)
+    c = O.clip_grads(gs, O.ElboConfig(clipvalue=0.5))
+    assert torch.allclose(c[0], T([0.5, 0.5])) and torch.allclose(c[1], T([0.3]))
+
+
+def test_loss_reductions_sum_vs_kl_weight():
+    """variational.py:172-177: default = sums / S; with kl_weight = means and weighted KL"""
+    from tests import util
+    data, cfg, params, x, u_f, eta = util.make_problem(N=64, R=8, L=2, w=8, S=3)
+    a = O.elbo_forward(params, x, cfg, T(u_f), T(eta))
+    cfg2 = O.ElboConfig(mc_samples=3, kl_weight=0.25)
+    b = O.elbo_forward(params, x, cfg2, T(u_f), T(eta))
+    assert np.isclose(float(a["nll"]) / 64, float(b["nll"]))
+    assert np.isclose(float(a["kl"]) / 8, float(b["kl"]))
+    assert np.isclose(float(b["loss"]), float(b["nll"]) + 0.25 * float(b["kl"]))
+
+
+def test_positional_encoding_layout():
+    """careless/utils/positional_encoding.py:3-17"""
+    x = np.array([[0.0, 10.0], [1.0, 20.0], [2.0, 30.0]])
+    pe = O.positional_encoding(x, 2)
+    p = np.array([[-1.0, -1.0], [0.0, 0.0], [1.0, 1.0]])
+    ang = np.stack([np.pi * p[:, 0], 2 * np.pi * p[:, 0], np.pi * p[:, 1], 2 * np.pi * p[:, 1]], axis=1)
+    assert pe.shape == (3, 8)
+    assert np.allclose(pe, np.concatenate([np.cos(ang), np.sin(ang)], axis=1))
