@@ -81,6 +81,7 @@ EXPORTS = {
     "cl_abi_sizes": (None, [C.POINTER(C.c_size_t)]),
     "cl_mlp_default_grid": (C.c_int, []),
     "cl_mlp_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "cl_mlp_meta_rows": (C.c_int, [C.c_int]),
     "cl_tn_forward": (C.c_int, [C.POINTER(TnArgs), _vp]),
     "cl_tn_backward": (C.c_int, [C.POINTER(TnArgs), _vp]),
     "cl_elbo_mono_fwd_bwd": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),

@@ -19,6 +19,8 @@ int cl_mlp_default_grid(void) {
     return cus;
 }
 
+int cl_mlp_meta_rows(int d) { return d < 1 ? 0 : ((d + 3) & ~3); }
+
 size_t cl_mlp_param_count(int d, int w, int L) {
     if (d < 1 || w < 1 || L < 1) return 0;
     return (size_t)w * d + w + (size_t)(L - 1) * ((size_t)w * w + w) + 2 * (size_t)w + 2;

@@ -51,8 +51,9 @@ CL_HD cl_u32x4 cl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t 
 #pragma unroll
 #endif
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = cl_mulhi32(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = cl_mulhi32(M1, c2), lo1 = M1 * c2;
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;      // one 32x32->64 multiply each (v_mad_u64_u32)
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += W0; k1 += W1;

@@ -32,7 +32,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CL_TILE CL_MLP_TILE
 #define CL_NW 8              // waves per workgroup
 #define CL_WOBS 16           // observations per wave in forward / dgrad
-#define CL_PB 132            // pitch of the [feature][obs] staging tiles (128 + 4)
+#define CL_PB 136            // pitch of the [feature][obs] staging tiles (128 + 8): conflict-free ds_read_b128 in wgrad;
+                             // the 2-way conflict it leaves on the ds_write_b32 staging writes costs no LDS cycles
 #define CL_SCR 32            // floats of per-wave scratch (the dO tile)
 // compiler-level fence for memory operations: keeps hipcc from hoisting a whole layer of LDS operand reads
 // above the MFMAs that consume them
@@ -69,6 +70,23 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ void wave_lds_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+}
+
+// (wave-uniform base pointer) + (32-bit per-lane BYTE offset): the form hipcc lowers to `global_* v, v_off, s[base:base+1]`
+// with no 64-bit per-lane address arithmetic (and nothing to keep live or spill across the tile loop)
+template <class T>
+__device__ __forceinline__ T ld_uo(const T* base, unsigned byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ T* ptr_uo(T* base, unsigned byte_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+// make a wave-uniform int opaque to loop-strength reduction (keeps per-tile base pointers in SGPRs, recomputed per tile)
+__device__ __forceinline__ int opaque_uniform(int v) {
+    v = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(v));
+    return v;
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -200,16 +218,51 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     float h0n[KS1];
     int ridn = -1, imgn = 0;
     float ion = 0.0f, sgn = 1.0f;
-    auto prefetch = [&](int tile) {
-        const int g = tile * CL_TILE + CL_WOBS * wv + j;
+    // epilogue lane map: lane -> (observation je = lane>>2, sample slot qe = lane&3): the MC samples of one observation sit
+    // in adjacent lanes, so z_f / eta / ipred accesses and the dz_f atomics of an observation coalesce into one request
+    const int je = lane >> 2, qe = lane & 3;
+    // All global accesses below are written as (wave-uniform pointer)[32-bit lane offset] so hipcc emits the
+    // SGPR-base + VGPR-offset addressing form.  (With 64-bit per-lane addresses it kept one address pair per load live
+    // across the tile, spilled them, and every reload cost an s_waitcnt vmcnt(0) behind the epilogue's atomics.)
+    // Streaming inputs go through buffer loads: SGPR descriptor + 32-bit VGPR byte offset + SGPR tile offset.  No 64-bit
+    // per-lane addresses exist (hipcc otherwise keeps one address pair per load live across the tile loop, spills them, and
+    // every reload costs an s_waitcnt vmcnt(0) behind the epilogue's atomics), and the hardware range check returns 0 for
+    // the padded metadata rows (feature >= d) and for observations past n_obs.
+    const unsigned lane_obs = CL_WOBS * wv + j;                 // observation of this lane inside the tile (MFMA map)
+    const unsigned lane_obs_e = CL_WOBS * wv + je;               // ... in the epilogue lane map
+    const unsigned lane_obs_eb = 4u * lane_obs_e;
+    const unsigned n_pad_u = (unsigned)A.n_pad;
+    const int d4 = (d + 3) & ~3;                                // meta_t has d4 rows (rows >= d are zero): cl_mlp_meta_rows()
+    const __amdgpu_buffer_rsrc_t r_meta = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A.meta_t), 0, (int)(4u * (unsigned)d4 * n_pad_u), 0x00020000);
+    const unsigned lane_meta_b = 4u * ((unsigned)q * n_pad_u + lane_obs);   // the ONE per-lane byte offset of all metadata loads
+    const int row4_b = 16 * A.n_pad;                            // bytes between feature groups (4 rows)
+    auto load_meta = [&](int tile, float (&dst)[KS1]) {
+        const int soff = tile * (CL_TILE * 4);
 #pragma unroll
-        for (int t = 0; t < KS1; ++t) h0n[t] = (4 * t + q < d) ? A.meta_t[(size_t)(4 * t + q) * A.n_pad + g] : 0.0f;
-        ridn = -1; imgn = 0; ion = 0.0f; sgn = 1.0f;
-        if (MODE == 0 && g < A.n_obs) {
-            ridn = A.refl_id[g];
-            ion = A.iobs[g];
-            sgn = A.sig[g];
-            if (A.use_img) imgn = A.image_id[g];
+        for (int t = 0; t < KS1; ++t) {
+            dst[t] = 0.0f;
+            if (4 * t < d4)                                     // wave-uniform
+                dst[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_meta, (int)lane_meta_b, soff + t * row4_b, 0));
+        }
+    };
+    const int nb_obs = 4 * A.n_obs;
+    const __amdgpu_buffer_rsrc_t r_rid = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(A.refl_id), 0, MODE == 0 ? nb_obs : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_io = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.iobs), 0, MODE == 0 ? nb_obs : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_sg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.sig), 0, MODE == 0 ? nb_obs : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(A.image_id), 0, (MODE == 0 && A.use_img) ? nb_obs : 0, 0x00020000);
+    auto prefetch = [&](int tile_in) {
+        const int tile = __builtin_amdgcn_readfirstlane(tile_in);
+        const int soff = tile * (CL_TILE * 4);                  // byte offset of the tile inside a per-observation array
+        load_meta(tile, h0n);
+        if (MODE == 0) {
+            const bool ok = tile * CL_TILE + (int)lane_obs_e < A.n_obs;
+            const int rr = (int)__builtin_amdgcn_raw_buffer_load_b32(r_rid, (int)lane_obs_eb, soff, 0);
+            ridn = ok ? rr : -1;
+            ion = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_io, (int)lane_obs_eb, soff, 0));
+            const float ss = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_sg, (int)lane_obs_eb, soff, 0));
+            sgn = ok ? ss : 1.0f;
+            imgn = (int)__builtin_amdgcn_raw_buffer_load_b32(r_img, (int)lane_obs_eb, soff, 0);
         }
     };
     if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
@@ -225,13 +278,19 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         const float io = ion, sg = sgn;
         // gathers that depend on the prefetched ids: issued now, consumed in the epilogue (latency hides under forward)
         float aim = 1.0f, zf0 = 0.0f, zf1 = 0.0f, et0 = 0.0f, et1 = 0.0f;
+        const int gobs_e = tile * CL_TILE + CL_WOBS * wv + je;   // the observation this lane handles in the epilogue
+        const unsigned zoff = 4u * (unsigned)rid * (unsigned)S;     // z_f / dz_f BYTE offset of this lane's reflection
+        const unsigned eoff = 4u * lane_obs_e * (unsigned)S;        // eta / ipred BYTE offset inside the tile
+        const int tile_u = opaque_uniform(tile);
+        const float* __restrict__ eta_t = A.eta ? A.eta + (size_t)tile_u * CL_TILE * S : nullptr;
+        float* __restrict__ ipred_t = A.ipred_out ? A.ipred_out + (size_t)tile_u * CL_TILE * S : nullptr;
         if (MODE == 0 && rid >= 0) {
-            if (A.use_img && img > 0) aim = A.img[img - 1];
-            if (q < S) zf0 = A.z_f[(size_t)rid * S + q];
-            if (q + 4 < S) zf1 = A.z_f[(size_t)rid * S + q + 4];
-            if (A.eta != nullptr) {
-                if (q < S) et0 = A.eta[(size_t)gobs * S + q];
-                if (q + 4 < S) et1 = A.eta[(size_t)gobs * S + q + 4];
+            if (A.use_img && img > 0) aim = ld_uo(A.img, 4u * (unsigned)(img - 1));
+            if (qe < S) zf0 = ld_uo(A.z_f, zoff + 4u * qe);
+            if (qe + 4 < S) zf1 = ld_uo(A.z_f, zoff + 4u * (qe + 4));
+            if (eta_t != nullptr) {
+                if (qe < S) et0 = ld_uo(eta_t, eoff + 4u * qe);
+                if (qe + 4 < S) et1 = ld_uo(eta_t, eoff + 4u * (qe + 4));
             }
         }
         STAMP_VM(0);
@@ -311,7 +370,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         // ================= epilogue: sample, predict, likelihood, dL/dO =====================================
         float dloc, draw;
         if (MODE == 0) {
-            // lane (j, q) handles MC samples s = q, q+4, ... of observation j; partial sums are combined over q below
+            // move the scaler outputs from the MFMA lane map (observation lane&15) to the epilogue lane map (lane>>2)
+            const float o0e = __shfl(o0, je);
+            const float sige = __shfl(sigma, je);
             float pdl = 0.0f, pds = 0.0f, pda = 0.0f;
             STAMP(11);
             if (rid >= 0) {
@@ -319,49 +380,51 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 const float log_sg = logf(sg);
                 int k = 0;
                 float eta_sin = 0.0f;
-                for (int s = q; s < S; s += 4, ++k) {
+                for (int s = qe; s < S; s += 4, ++k) {
                     float eta;
-                    if (A.eta != nullptr) {
-                        eta = (k == 0) ? et0 : ((k == 1) ? et1 : A.eta[(size_t)gobs * S + s]);
+                    if (eta_t != nullptr) {
+                        eta = (k == 0) ? et0 : ((k == 1) ? et1 : ld_uo(eta_t, eoff + 4u * s));
                     } else if ((k & 1) == 0) {       // one Philox block + Box-Muller pair serves samples s and s + 4
-                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + gobs), &eta, &eta_sin);
+                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + gobs_e), &eta, &eta_sin);
                     } else {
                         eta = eta_sin;
                     }
-                    const float zf = (k == 0) ? zf0 : ((k == 1) ? zf1 : A.z_f[(size_t)rid * S + s]);
-                    const float tq = o0 + sigma * eta + A.shift;
+                    const float zf = (k == 0) ? zf0 : ((k == 1) ? zf1 : ld_uo(A.z_f, zoff + 4u * s));
+                    const float tq = o0e + sige * eta + A.shift;
                     const float zs = aim * tq;
                     const float ipred = zs * zf * zf;
-                    if (A.ipred_out) A.ipred_out[(size_t)gobs * S + s] = ipred;
+                    if (ipred_t) *ptr_uo(ipred_t, eoff + 4u * s) = ipred;
                     float dll;
                     const float ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, A.lik_kind, A.dof, A.lik_const, &dll);
                     nll_acc -= ll * A.w_ll;
                     const float gi = -dll * A.w_ll;                 // dNLL / d ipred
                     const float dzs = gi * zf * zf;
-                    atomicAdd(A.dz_f + (size_t)rid * S + s, gi * zs * 2.0f * zf);
+                    atomicAdd(ptr_uo(A.dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
                     const float dt = dzs * aim;
                     pdl += dt;
                     pds += dt * eta;
                     pda += dzs * tq;
                 }
             }
-            pdl += __shfl_xor(pdl, 16); pds += __shfl_xor(pds, 16); pda += __shfl_xor(pda, 16);
-            pdl += __shfl_xor(pdl, 32); pds += __shfl_xor(pds, 32); pda += __shfl_xor(pda, 32);
-            dloc = pdl;
-            draw = pds * dsig_draw;
+            pdl += __shfl_xor(pdl, 1); pds += __shfl_xor(pds, 1); pda += __shfl_xor(pda, 1);
+            pdl += __shfl_xor(pdl, 2); pds += __shfl_xor(pds, 2); pda += __shfl_xor(pda, 2);
             STAMP(12);
             if (A.use_img) {
                 // image ids are sorted, so the 16 observations of a wave almost always share one image: reduce in the
                 // wave and issue ONE atomic instead of 16 same-address ones (which serialise in the L2 atomic unit)
                 const int img0 = __builtin_amdgcn_readfirstlane(img);
-                if (__all(img == img0)) {
-                    float v = (q == 0 && rid >= 0) ? pda : 0.0f;
-                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                    if (lane == 0 && img0 > 0) atomicAdd(A.d_img + (img0 - 1), v);
-                } else if (q == 0 && rid >= 0 && img > 0) {
-                    atomicAdd(A.d_img + (img - 1), pda);
+                if (__all(img == img0 || rid < 0)) {
+                    float v = (qe == 0 && rid >= 0) ? pda : 0.0f;
+#pragma unroll
+                    for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off);
+                    if (lane == 0 && img0 > 0) atomicAdd(ptr_uo(A.d_img, 4u * (unsigned)(img0 - 1)), v);
+                } else if (qe == 0 && rid >= 0 && img > 0) {
+                    atomicAdd(ptr_uo(A.d_img, 4u * (unsigned)(img - 1)), pda);
                 }
             }
+            // back to the MFMA lane map: lane (j, q) needs dL/dloc and dL/dsigma of observation j, held by lanes 4j..4j+3
+            dloc = __shfl(pdl, 4 * j);
+            draw = __shfl(pds, 4 * j) * dsig_draw;
             if (q == 0) {
                 boacc0 += dloc;
                 boacc1 += draw;
@@ -375,6 +438,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             }
         }
         // next tile's inputs: in flight during the whole backward pass
+        STAMP(14);
         if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 
         // ================= backward =======================================================================
@@ -437,8 +501,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         for (int t = 0; t < 4; ++t)
                             sH[(16 * mb + 4 * q + t) * PB + CL_WOBS * wv + j] = hs[l > 0 ? l - 1 : 0][mb][t];
                 } else {
+                    // the metadata tile is re-read (L2 hit) rather than kept in registers through the whole backward pass
+                    float h0s[KS1];
+                    load_meta(__builtin_amdgcn_readfirstlane(tile), h0s);
 #pragma unroll
-                    for (int t = 0; t < KS1; ++t) sH[(4 * t + q) * PB + CL_WOBS * wv + j] = h0[t];
+                    for (int t = 0; t < KS1; ++t) sH[(4 * t + q) * PB + CL_WOBS * wv + j] = h0s[t];
                 }
                 wave_lds_sync();
                 if (lane < WP) {                   // bias gradient: row sums of this wave's own columns of dZ
@@ -484,7 +551,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const float* pa = sZ + (16 * ob + j) * PB + kp * WG::KLEN + 4 * q;
                     const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
                     f32x4 acc0 = wacc[l][0], acc1 = wacc[l][1];
-#pragma unroll 2
+#pragma unroll 4
                     for (int g = 0; g < WG::KLEN / 16; ++g) {
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + 16 * g);
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 16 * g);
@@ -504,7 +571,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const float* pa = sZ + (16 * ob + j) * PB + kp * WG::KLEN + 4 * q;
                     const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
                     f32x4 acc0 = wacc[l][0], acc1 = wacc[l][1];
-#pragma unroll 2
+#pragma unroll 4
                     for (int g = 0; g < WG::KLEN / 16; ++g) {
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + 16 * g);
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 16 * g);

@@ -169,8 +169,8 @@ class ElboEngine:
             raise ValueError("empty observation shard")
         self.d = int(metadata.shape[1])
         self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
-        meta_t = np.zeros((self.d, self.n_pad), dtype=np.float32)
-        meta_t[:, : self.N] = metadata[sl].T
+        meta_t = np.zeros((int(self.lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
+        meta_t[: self.d, : self.N] = metadata[sl].T
         self.refl_id = torch.as_tensor(refl_id[sl].astype(np.int32), device=dev)
         self.image_id = torch.as_tensor(image_id[sl].astype(np.int32), device=dev)
         self.meta_t = torch.as_tensor(meta_t, device=dev)
@@ -455,8 +455,8 @@ def scaler_forward(mlp, metadata):
     if mlp.flat.device != dev:
         mlp.flat = mlp.flat.to(dev)
     n_pad = ((N + TILE - 1) // TILE) * TILE
-    meta_t = np.zeros((d, n_pad), dtype=np.float32)
-    meta_t[:, :N] = md.T
+    meta_t = np.zeros((int(lib.cl_mlp_meta_rows(d)), n_pad), dtype=np.float32)
+    meta_t[:d, :N] = md.T
     meta_t = torch.as_tensor(meta_t, device=dev)
     loc = torch.empty(N, dtype=torch.float32, device=dev)
     sig = torch.empty(N, dtype=torch.float32, device=dev)

@@ -18,7 +18,8 @@
  * Device data layout (what the host mirror `careless_amd` prepares once per data set)
  *   z_f, dz_f, u_f       [R][S]   reflection-major, MC sample fastest
  *   eta, ipred_out       [N][S]
- *   meta_t               [d][n_pad] feature-major metadata, n_pad = N rounded up to CL_MLP_TILE, zero padded
+ *   meta_t               [cl_mlp_meta_rows(d)][n_pad] feature-major metadata (rows >= d and observations >= N are zero),
+ *                        n_pad = N rounded up to CL_MLP_TILE
  *   scaler parameters    "W^T layout": per Dense layer the kernel transposed (rows = output units) then its bias:
  *                        Wt0[w][d] b0[w] | Wtl[w][w] bl[w] (l = 1..L-1) | Wto[2][w] bo[2]
  *   flat parameters      [ q_loc_raw (R) | q_scale_raw (R) | scaler (P) | image scales (M-1) ]
@@ -77,7 +78,7 @@ int cl_tn_backward(const cl_tn_args* args, void* stream);
 typedef struct cl_mlp_args {
     const int* refl_id;         /* [n_obs]                                    */
     const int* image_id;        /* [n_obs]                                    */
-    const float* meta_t;        /* [d][n_pad]                                 */
+    const float* meta_t;        /* [cl_mlp_meta_rows(d)][n_pad]               */
     const float* iobs;          /* [n_obs]                                    */
     const float* sig;           /* [n_obs]                                    */
     int n_obs, n_pad;
@@ -110,6 +111,7 @@ enum { CL_BIJ_EXP_ = 0, CL_BIJ_SOFTPLUS_ = 1 };
 
 int cl_mlp_default_grid(void);                       /* workgroups of a persistent launch = CUs of the current device */
 size_t cl_mlp_param_count(int d, int w, int L);      /* P */
+int cl_mlp_meta_rows(int d);                         /* rows of meta_t: d rounded up to a multiple of 4 (one MFMA k-step) */
 int cl_elbo_mono_fwd_bwd(const cl_mlp_args* args, int grid, void* stream);
 int cl_mlp_forward(const cl_mlp_args* args, int grid, void* stream);
 int cl_mlp_backward_ext(const cl_mlp_args* args, int grid, void* stream);

@@ -25,9 +25,9 @@ for i in range(3):
     eng.train_step(i)
 torch.cuda.synchronize()
 d = dbg.view(eng.grid, 8, NPH).cpu().numpy().astype(np.float64)
-names = ["load(h0)+vmwait", "fwd", "epilogue", "seam barrier", "top: dH init + Dense2 wgrad", "dZ", "barrier A", "stage writes + bias",
+names = ["load(h0)+vmwait", "fwd", "prefetch issue", "seam barrier", "top: dH init + Dense2 wgrad", "dZ", "barrier A", "stage writes + bias",
          "barrier B", "wgrad", "dgrad(copy)", "epi: dense2 combine+bijector", "epi: sample loop", "epi: reduce+img atomic",
-         "-", "-"]
+         "epi: tail before prefetch", "-"]
 tot = d.sum(-1).mean()
 tiles = (eng.n_pad // 128) / eng.grid
 print(f"workload {wl} nobs {nobs}: mean cycles per wave {tot:.0f}, per tile {tot / tiles:.0f} (100 MHz ticks x? see note)")
