@@ -18,6 +18,7 @@ CL_HIST_STRIDE = 8
 CL_SC_NLL, CL_SC_KL, CL_SC_GNORM2, CL_SC_GNORM2_SANE, CL_SC_COUNT = 0, 1, 2, 3, 4
 CL_LIK_NORMAL, CL_LIK_STUDENTT = 0, 1
 CL_BIJ_EXP, CL_BIJ_SOFTPLUS = 0, 1
+CL_PRIOR_WILSON, CL_PRIOR_DOUBLE_WILSON = 0, 1
 
 _vp = C.c_void_p
 
@@ -34,6 +35,8 @@ class TnArgs(C.Structure):
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("z_f", _vp), ("dz_f", _vp), ("d_loc_raw", _vp), ("d_scale_raw", _vp),
         ("scalars", _vp), ("stop_flag", _vp),
+        ("prior_kind", C.c_int),
+        ("parent_ids", _vp), ("root", _vp), ("dw_r", _vp), ("dz_f_out", _vp),
     ]
 
 
@@ -84,6 +87,7 @@ EXPORTS = {
     "cl_mlp_meta_rows": (C.c_int, [C.c_int]),
     "cl_tn_forward": (C.c_int, [C.POINTER(TnArgs), _vp]),
     "cl_tn_backward": (C.c_int, [C.POINTER(TnArgs), _vp]),
+    "cl_dw_prior_forward": (C.c_int, [C.POINTER(TnArgs), _vp]),
     "cl_elbo_mono_fwd_bwd": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
     "cl_mlp_forward": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
     "cl_mlp_backward_ext": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),

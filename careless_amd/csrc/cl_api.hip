@@ -63,6 +63,8 @@ static int check_tn(const cl_tn_args* a) {
     if (a == nullptr || a->q_loc_raw == nullptr || a->q_scale_raw == nullptr || a->low == nullptr ||
         a->centric == nullptr || a->es == nullptr || a->R < 1 || a->S < 1)
         return -1;
+    if (a->prior_kind == CL_PRIOR_DOUBLE_WILSON_ && (a->parent_ids == nullptr || a->root == nullptr || a->dw_r == nullptr)) return -1;
+    if (a->prior_kind != CL_PRIOR_DOUBLE_WILSON_ && a->prior_kind != CL_PRIOR_WILSON_) return -1;
     return 0;
 }
 
@@ -76,6 +78,14 @@ int cl_tn_backward(const cl_tn_args* a, void* stream) {
     if (int e = check_tn(a)) return e;
     if (a->dz_f == nullptr || a->d_loc_raw == nullptr || a->d_scale_raw == nullptr) return -1;
     return cl_launch_tn_backward(*a, (hipStream_t)stream);
+}
+
+int cl_dw_prior_forward(const cl_tn_args* a, void* stream) {
+    if (int e = check_tn(a)) return e;
+    if (a->prior_kind != CL_PRIOR_DOUBLE_WILSON_ || a->parent_ids == nullptr || a->root == nullptr || a->dw_r == nullptr ||
+        a->z_f == nullptr || a->dz_f_out == nullptr || a->scalars == nullptr)
+        return -1;
+    return cl_launch_dw_forward(*a, (hipStream_t)stream);
 }
 
 int cl_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,

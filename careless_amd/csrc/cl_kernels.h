@@ -9,6 +9,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st);
 int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st);
 int cl_launch_tn_forward(const cl_tn_args& a, hipStream_t st);
 int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st);
+int cl_launch_dw_forward(const cl_tn_args& a, hipStream_t st);
 int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
                           const int* stop_flag, hipStream_t st);
 int cl_launch_adam(const cl_adam_args& a, hipStream_t st);

@@ -265,3 +265,80 @@ CL_HD float cl_lik_log_prob2(float ipred, float iobs, float inv_sig, float log_s
     *dll = -(dof + 1.0f) * y / (dof + y2) * inv_sig;
     return -0.5f * (dof + 1.0f) * cl_log1p_pos(y2 / dof) - log_sig + lik_const;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Double-Wilson prior pieces (careless/models/priors/wilson.py:146-175; careless/utils/distributions.py:228-348):
+// exponentially scaled Bessel functions by Chebyshev series on the cephes intervals (|x| <= 8, |x| > 8); coefficients are a
+// numerical Chebyshev interpolation of scipy.special.i0e / i1e (relative error < 2e-8 before fp32 rounding)
+// ---------------------------------------------------------------------------------------------------------
+CL_HD float cl_cheb(float t, const float* c, int n) {      // Clenshaw: c0 + c1 T1(t) + ...
+    float b1 = 0.0f, b2 = 0.0f;
+    for (int k = n - 1; k >= 1; --k) {
+        const float b0 = 2.0f * t * b1 - b2 + c[k];
+        b2 = b1; b1 = b0;
+    }
+    return t * b1 - b2 + c[0];
+}
+CL_HD void cl_i0e_i1e(float x, float* i0e, float* i1e) {
+    const float A0[18] = {3.383976372e-01f, -3.046826723e-01f, 1.716209015e-01f, -9.490109705e-02f, 4.930528424e-02f, -2.373741481e-02f,
+                          1.054646039e-02f, -4.324309995e-03f, 1.639475617e-03f, -5.763755745e-04f, 1.885028851e-04f, -5.754195009e-05f,
+                          1.644844799e-05f, -4.416737873e-06f, 1.117384585e-06f, -2.670621174e-07f, 6.037319241e-08f, -1.248127081e-08f};
+    const float B0[8] = {4.022452055e-01f, 3.369116478e-03f, 6.889758345e-05f, 2.891370136e-06f, 2.048911412e-07f, 2.266848402e-08f,
+                         3.409447656e-09f, 5.255593183e-10f};
+    const float A1[18] = {1.262935932e-01f, -1.764165184e-01f, 1.026436587e-01f, -5.294598121e-02f, 2.472644903e-02f, -1.056408489e-02f,
+                          4.156422944e-03f, -1.513572451e-03f, 5.122859562e-04f, -1.617608158e-04f, 4.781565108e-05f, -1.327316366e-05f,
+                          3.470251301e-06f, -8.568719762e-07f, 2.003291532e-07f, -4.444860747e-08f, 9.369801317e-09f, -1.820614997e-09f};
+    const float B1[8] = {3.892881175e-01f, -9.761097491e-03f, -1.105889387e-04f, -3.882564401e-06f, -2.512229042e-07f, -2.631672406e-08f,
+                         -3.849506242e-09f, -5.915003765e-10f};
+    const float ax = fabsf(x);
+    if (ax <= 8.0f) {
+        const float t = 0.5f * (0.5f * ax - 2.0f);
+        *i0e = cl_cheb(t, A0, 18);
+        *i1e = x * cl_cheb(t, A1, 18);
+    } else {
+        const float t = 0.5f * (32.0f / ax - 2.0f);
+        const float rs = 1.0f / sqrtf(ax);
+        *i0e = cl_cheb(t, B0, 8) * rs;
+        const float v = cl_cheb(t, B1, 8) * rs;
+        *i1e = (x < 0.0f) ? -v : v;
+    }
+}
+
+// Rice(nu, sigma) log-density at x > 0 (distributions.py:278-283) and its derivatives w.r.t. x and nu
+CL_HD float cl_rice_log_prob(float x, float nu, float sigma, float* dx, float* dnu) {
+    const float is2 = 1.0f / (sigma * sigma);
+    const float arg = x * nu * is2;
+    float i0e, i1e;
+    cl_i0e_i1e(arg, &i0e, &i1e);
+    const float ratio = i1e / i0e;                       // I1/I0
+    *dx = 1.0f / x - x * is2 + nu * is2 * ratio;
+    *dnu = -nu * is2 + x * is2 * ratio;
+    return logf(x) - 2.0f * logf(sigma) - 0.5f * (x * x + nu * nu) * is2 + logf(i0e) + fabsf(arg);
+}
+
+// FoldedNormal(loc, scale) log-density at x >= 0 (distributions.py:333-335): log[N(x; loc, scale) + N(-x; loc, scale)]
+CL_HD float cl_folded_normal_log_prob(float x, float loc, float scale, float* dx, float* dloc) {
+    const float inv = 1.0f / scale;
+    const float ya = (x - loc) * inv, yb = (-x - loc) * inv;
+    const float la = -0.5f * ya * ya, lb = -0.5f * yb * yb;
+    const float m = fmaxf(la, lb);
+    const float ea = expf(la - m), eb = expf(lb - m);
+    const float den = ea + eb;
+    const float wa = ea / den, wb = eb / den;
+    // d la/dx = -ya/scale ; d lb/dx = +yb/scale ; d la/dloc = ya/scale ; d lb/dloc = yb/scale
+    *dx = (-wa * ya + wb * yb) * inv;
+    *dloc = (wa * ya + wb * yb) * inv;
+    return m + logf(den) - 0.5f * CL_LOG_2PI_F - logf(scale);
+}
+
+// conditional prior of a non-root reflection of the double-Wilson model (wilson.py:146-175)
+CL_HD float cl_dw_log_prob(float z, float z_parent, bool has_parent, float r, bool centric, float es, float* dz, float* dzp) {
+    const float loc = has_parent ? z_parent * r : 0.0f;
+    const float var = (centric ? es : 0.5f * es) * (1.0f - r * r);
+    const float scale = sqrtf(var);
+    float dloc, lp;
+    if (centric) lp = cl_folded_normal_log_prob(z, loc, scale, dz, &dloc);
+    else lp = cl_rice_log_prob(z, loc, scale, dz, &dloc);
+    *dzp = has_parent ? dloc * r : 0.0f;
+    return lp;
+}

@@ -57,13 +57,15 @@ __global__ __launch_bounds__(256) void tn_forward_kernel(const cl_tn_args A) {
     if (h < A.R) {
         const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
         const bool in_kl = (h >= A.kl_begin && h < A.kl_end);
+        const bool dw_child = (A.prior_kind == CL_PRIOR_DOUBLE_WILSON_) && (A.root[h] == 0);
         for (int s = 0; s < A.S; ++s) {
             const cl_tn_elem t = cl_tn_sample(a, b, low, A.high, A.eps, tn_uniform(A, h, s));
             A.z_f[(size_t)h * A.S + s] = t.z;
             if (in_kl) {
                 float dlp;
                 const float lq = cl_tn_log_prob(t);
-                const float lp = prior_lp(A, h, t.z, &dlp);
+                // non-root reflections of a double-Wilson model get their conditional prior in dw_forward_kernel (needs z_parent)
+                const float lp = dw_child ? 0.0f : prior_lp(A, h, t.z, &dlp);
                 kl += (double)(lq - lp);
             }
         }
@@ -78,13 +80,21 @@ __global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
     const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
     const bool in_kl = (h >= A.kl_begin && h < A.kl_end);
     const float wkl = in_kl ? A.w_kl * A.kl_grad_mult : 0.0f;
+    const bool dw_child = (A.prior_kind == CL_PRIOR_DOUBLE_WILSON_) && (A.root[h] == 0);
     float gloc = 0.0f, gscale = 0.0f, loc = 0.0f, scale = 0.0f;
     for (int s = 0; s < A.S; ++s) {
         const cl_tn_elem t = cl_tn_sample(a, b, low, A.high, A.eps, tn_uniform(A, h, s));
         loc = t.loc; scale = t.scale;
         float dq_dz, dq_dloc, dq_dscale, dp_dz;
         cl_tn_log_prob_grads(t, &dq_dz, &dq_dloc, &dq_dscale);
-        (void)prior_lp(A, h, t.z, &dp_dz);
+        if (dw_child) {
+            const int par = A.parent_ids[h];
+            const float zp = (par >= 0) ? A.z_f[(size_t)par * A.S + s] : 0.0f;
+            float dzp;
+            (void)cl_dw_log_prob(t.z, zp, par >= 0, A.dw_r[h], A.centric[h] != 0, A.es[h], &dp_dz, &dzp);
+        } else {
+            (void)prior_lp(A, h, t.z, &dp_dz);
+        }
         const float gz = A.dz_f[(size_t)h * A.S + s] + wkl * (dq_dz - dp_dz);
         gloc += gz * t.dz_dloc + wkl * dq_dloc;
         gscale += gz * t.dz_dscale + wkl * dq_dscale;
@@ -92,6 +102,29 @@ __global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
     // raw parameters: loc = exp(a), scale = exp(b) + eps
     A.d_loc_raw[h] += gloc * loc;
     A.d_scale_raw[h] += gscale * (scale - A.eps);
+}
+
+// Double-Wilson conditional prior of the non-root reflections: -log p(z_h | z_parent) into the KL, and its derivative
+// w.r.t. the parent's sample scattered into dz_f (the child's own derivative is taken in tn_backward_kernel).
+__global__ __launch_bounds__(256) void dw_forward_kernel(const cl_tn_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    double kl = 0.0;
+    if (h < A.R && A.root[h] == 0 && h >= A.kl_begin && h < A.kl_end) {
+        const int par = A.parent_ids[h];
+        const float r = A.dw_r[h], es = A.es[h];
+        const bool c = A.centric[h] != 0;
+        const float wg = A.w_kl * A.kl_grad_mult;
+        for (int s = 0; s < A.S; ++s) {
+            const float z = A.z_f[(size_t)h * A.S + s];
+            const float zp = (par >= 0) ? A.z_f[(size_t)par * A.S + s] : 0.0f;
+            float dz, dzp;
+            const float lp = cl_dw_log_prob(z, zp, par >= 0, r, c, es, &dz, &dzp);
+            kl -= (double)lp;
+            if (par >= 0) atomicAdd(A.dz_f_out + (size_t)par * A.S + s, -wg * dzp);
+        }
+    }
+    block_atomic_add_d(kl * (double)A.w_kl, A.scalars + CL_SC_KL);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -194,6 +227,12 @@ int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st) {
     if (a.R <= 0 || a.S <= 0) return -1;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(tn_backward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int cl_launch_dw_forward(const cl_tn_args& a, hipStream_t st) {
+    if (a.R <= 0 || a.S <= 0) return -1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(dw_forward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,

@@ -127,7 +127,7 @@ class ElboEngine:
         dev = self.device
 
         from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
-        from careless_amd.models.priors.wilson import WilsonPrior
+        from careless_amd.models.priors.wilson import DoubleWilsonPrior, WilsonPrior
         from careless_amd.models.likelihoods.mono import LocationScaleLikelihood
         from careless_amd.models.scaling.image import HybridImageScaler
         from careless_amd.models.scaling.nn import MetadataScaler
@@ -135,7 +135,7 @@ class ElboEngine:
         q, prior, lik, scaler = model.surrogate_posterior, model.prior, model.likelihood, model.scaling_model
         if not isinstance(q, TruncatedNormal):
             raise NotImplementedError(f"surrogate posterior {type(q).__name__} is not supported by the HIP engine")
-        if not isinstance(prior, WilsonPrior):
+        if not isinstance(prior, (WilsonPrior, DoubleWilsonPrior)):
             raise NotImplementedError(f"prior {type(prior).__name__} is not supported by the HIP engine yet")
         if BaseModel.is_laue(inputs):
             raise NotImplementedError("Laue (harmonic deconvolution) inputs are not supported by the HIP engine yet")
@@ -183,6 +183,13 @@ class ElboEngine:
         self.es = torch.as_tensor(prior.eps_sigma, device=dev)
         if self.centric.numel() != self.R or self.es.numel() != self.R:
             raise ValueError("prior and surrogate posterior disagree on the number of reflections")
+        self.double_wilson = isinstance(prior, DoubleWilsonPrior)
+        if self.double_wilson:
+            if prior.reflids.size != self.R or (prior.reflids >= self.R).any():
+                raise ValueError("DoubleWilsonPrior.reflids does not match the surrogate posterior")
+            self.parent_ids = torch.as_tensor(prior.reflids.astype(np.int32), device=dev)
+            self.root = torch.as_tensor(prior.root.astype(np.uint8), device=dev)
+            self.dw_r = torch.as_tensor(prior.r_per_reflection, device=dev)
 
         # ---- flat parameters; the plugin objects become views into them ----------------------------------
         mlp.build(self.d)
@@ -283,6 +290,10 @@ class ElboEngine:
         a.d_scale_raw = self.grads.data_ptr() + 4 * self.R
         a.scalars = ptr(self.scalars)
         a.stop_flag = ptr(self.stop_flag)
+        if self.double_wilson:
+            a.prior_kind = _lib.CL_PRIOR_DOUBLE_WILSON
+            a.parent_ids, a.root, a.dw_r = ptr(self.parent_ids), ptr(self.root), ptr(self.dw_r)
+            a.dz_f_out = ptr(self.dz_f)
         return a
 
     def _mlp_args(self, step: int, eta, ipred_out=None) -> MlpArgs:
@@ -331,6 +342,8 @@ class ElboEngine:
         self.ws.zero_()
         tn = self._tn_args(step, u_f)
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
+        if self.double_wilson:
+            check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")
         ma = self._mlp_args(step, eta, ipred_out)
         check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), self.grid, st), "cl_elbo_mono_fwd_bwd")
         lay = self.layout

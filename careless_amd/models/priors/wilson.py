@@ -59,3 +59,67 @@ class WilsonPrior(Prior):
         s = np.sqrt(self.eps_sigma.astype(np.float64))
         return np.where(self.centric, s * math.sqrt(1.0 - 2.0 / math.pi),
                         s * math.sqrt(1.0 - math.pi / 4.0)).astype(np.float32)
+
+
+class DoubleWilsonPrior(Prior):
+    """Multivariate "double-Wilson" prior: every reflection of a non-root ASU is conditioned on its parent reflection
+    (reference `careless/models/priors/wilson.py:82-175`, maths in reference `doc/double_wilson.md`).
+
+    The reference constructor derives the parent lookup (`reflids`) from a `ReciprocalASUCollection` with
+    reciprocalspaceship / gemmi, which is formatter territory (out of scope here); this class therefore takes the
+    already-derived arrays.  `parents` / `r_values` keep the reference's meaning (one entry per ASU).
+
+    reflids : (R,) int, id of the parent reflection, -1 where the parent is absent
+    root    : (R,) bool, True for reflections of root ASUs (plain Wilson prior)
+    asu_ids : (R,) int, ASU of every reflection
+    """
+
+    def __init__(self, centric, epsilon, reflids, root, asu_ids, r_values, parents=None, sigma=1.0, optimize_r=False):
+        super().__init__()
+        if optimize_r:
+            raise NotImplementedError("--optimize-double-wilson-r is not supported by the HIP engine yet")
+        self.parents = parents
+        self.optimize_r = False
+        self.r = np.array(r_values, dtype=np.float32)
+        for r in self.r:
+            if (r >= 1.0) or (r <= -1.0):                  # reference io/manager.py:415-419
+                raise ValueError(f"Supplied --double-wilson-r value {r} outside of allowed range (-1, 1)")
+        self.centric = np.array(centric, dtype=bool)
+        self.multiplicity = np.array(epsilon, dtype=np.float32)
+        self.asu_ids = np.array(asu_ids).reshape(-1).astype(np.int64)
+        self.sigma = np.array(sigma, dtype=np.float32)
+        self.reflids = np.array(reflids).reshape(-1).astype(np.int64)
+        self.absent = self.reflids == -1
+        self.root = np.array(root, dtype=bool)
+        self.wilson_prior = WilsonPrior(self.centric, self.multiplicity, sigma)
+
+    @property
+    def eps_sigma(self):
+        return self.wilson_prior.eps_sigma
+
+    @property
+    def r_per_reflection(self) -> np.ndarray:
+        return self.r[self.asu_ids].astype(np.float32)
+
+    def mean(self):
+        return self.wilson_prior.mean()
+
+    def stddev(self):
+        return self.wilson_prior.stddev()
+
+    def log_prob(self, z):
+        """Host-side evaluation (float64 numpy/scipy) of reference wilson.py:146-175, for users and tests."""
+        from scipy import special
+        z = np.asarray(z, dtype=np.float64)
+        r = self.r_per_reflection.astype(np.float64)
+        mask = self.reflids >= 0
+        zp = np.where(mask, z[..., np.where(mask, self.reflids, 0)], 0.0)
+        loc = np.where(self.absent, 0.0, zp * r)
+        es = self.eps_sigma.astype(np.float64)
+        scale = np.where(self.centric, np.sqrt(es * (1 - r * r)), np.sqrt(0.5 * es * (1 - r * r)))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            arg = z * loc / scale ** 2
+            rice = np.log(z) - 2 * np.log(scale) - (z * z + loc * loc) / (2 * scale ** 2) + np.log(special.i0e(arg)) + np.abs(arg)
+            fn = np.logaddexp(-0.5 * ((z - loc) / scale) ** 2, -0.5 * ((-z - loc) / scale) ** 2) - 0.5 * math.log(2 * math.pi) - np.log(scale)
+        p_dw = np.where(self.centric, fn, rice)
+        return np.where(self.root, self.wilson_prior.log_prob(z), p_dw).astype(np.float32)

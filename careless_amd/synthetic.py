@@ -68,3 +68,24 @@ def make_synthetic(N: int, R: Optional[int] = None, d0: int = 5, posenc: bool = 
         metadata=meta.astype(np.float32), iobs=iobs.astype(np.float32), sigiobs=sigi.astype(np.float32),
         centric=centric, multiplicity=mult.astype(np.float32), n_images=M, n_refl=R,
     )
+
+
+def make_synthetic_double_wilson(N: int, R_half: Optional[int] = None, r: float = 0.9, p_absent: float = 0.05, seed: int = 1234,
+                                 **kw) -> Dict:
+    """Two ASUs of equal size: ASU 0 is the root, every reflection of ASU 1 has its ASU-0 twin as parent
+    with probability 1 - p_absent (else -1); observations are split between the two by `file_id`."""
+    R_half = R_half if R_half is not None else max(1, N // 64)
+    d = make_synthetic(N, R=2 * R_half, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 17)
+    R = 2 * R_half
+    # ASU 1 shares centric / multiplicity with its parent twin
+    d["centric"] = np.concatenate([d["centric"][:R_half], d["centric"][:R_half]])
+    d["multiplicity"] = np.concatenate([d["multiplicity"][:R_half], d["multiplicity"][:R_half]])
+    parent = np.arange(R_half)
+    parent = np.where(rng.random(R_half) < p_absent, -1, parent)
+    d["parent_ids"] = np.concatenate([np.arange(R_half), parent]).astype(np.int64)   # root rows hold their own id (reference :114)
+    d["root"] = np.concatenate([np.ones(R_half, bool), np.zeros(R_half, bool)])
+    d["asu_ids"] = np.concatenate([np.zeros(R_half, np.int64), np.ones(R_half, np.int64)])
+    d["dw_r"] = np.array([0.0, r], dtype=np.float32)
+    d["file_id"] = (d["refl_id"] >= R_half).astype(np.int64)
+    return d

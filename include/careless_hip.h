@@ -64,10 +64,20 @@ typedef struct cl_tn_args {
     float* d_scale_raw;         /* [R] += (backward)                                                             */
     double* scalars;            /* [CL_SC_COUNT]: forward adds the weighted KL into scalars[CL_SC_KL]            */
     const int* stop_flag;       /* optional device int: non-zero => skip (numerical failure in an earlier step)  */
+    /* double-Wilson prior (careless/models/priors/wilson.py:82-175); all NULL / 0 for the plain Wilson prior        */
+    int prior_kind;             /* CL_PRIOR_WILSON_ | CL_PRIOR_DOUBLE_WILSON_                                       */
+    const int* parent_ids;      /* [R] reflection id of the parent in the parent ASU, -1 = absent (`reflids`)       */
+    const unsigned char* root;  /* [R] 1 = reflection of a root ASU (plain Wilson prior)                            */
+    const float* dw_r;          /* [R] correlation r of the reflection's ASU with its parent (`r[asu_ids]`)         */
+    float* dz_f_out;            /* [R][S] += -w dlogp/dz_parent (cl_dw_prior_forward); the same buffer as dz_f      */
 } cl_tn_args;
+enum { CL_PRIOR_WILSON_ = 0, CL_PRIOR_DOUBLE_WILSON_ = 1 };
 
 int cl_tn_forward(const cl_tn_args* args, void* stream);
 int cl_tn_backward(const cl_tn_args* args, void* stream);
+/* double-Wilson only, after cl_tn_forward: adds -w log p(z_h | z_parent) of every non-root reflection to the KL and scatters
+ * its derivative w.r.t. the parent's sample into dz_f_out (replaces DoubleWilsonPrior.log_prob, wilson.py:146-175)          */
+int cl_dw_prior_forward(const cl_tn_args* args, void* stream);
 
 /* --- scaler + likelihood -----------------------------------------------------------------------------------------
  * replaces: MLPScaler.call / MetadataScaler / NormalLayer        (careless/models/scaling/nn.py:10-120)

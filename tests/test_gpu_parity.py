@@ -21,6 +21,8 @@ CASES = {
     "mlp3x20_softplus_shift_S2": dict(N=257, R=50, d0=6, L=3, w=20, S=2, bijector="softplus", shift=3.5),
     "mlp1x64_d40_S1": dict(N=200, R=17, d0=40, L=1, w=64, S=1),
     "mlp4x48_klweight_S4": dict(N=640, R=100, d0=5, L=4, w=48, S=4, kl_weight=0.5, likelihood="studentt", dof=12.0),
+    "double_wilson_2x32_S3": dict(N=400, R=60, d0=5, L=2, w=32, S=3, double_wilson=True),
+    "double_wilson_5x64_S8_studentt": dict(N=600, R=80, d0=5, L=5, w=64, S=8, double_wilson=True, likelihood="studentt", dof=8.0),
 }
 
 
@@ -35,19 +37,33 @@ def _run_case(kw):
     eng = model._engine
     torch.cuda.synchronize()
     terms = eng.loss_terms()
-    return out, grads, ipred.cpu().numpy(), terms, [g.cpu().numpy() for g in eng.grad_tensors()], eng
+    return out, grads, ipred.cpu().numpy(), terms, [g.cpu().numpy() for g in eng.grad_tensors()], eng, (data, cfg, params, u_f, eta)
+
+
+def _assert_grads(g_hip, grads, prob):
+    """Every gradient tensor within RTOL_GRAD (max-norm) of the fp64 oracle.  A LeakyReLU pre-activation that lies within
+    fp32 rounding of zero takes the other branch in fp32 than in fp64, which moves the lower layers' gradients by O(1e-4) in ANY
+    fp32 implementation (the reference's included); such a tensor must then agree with the oracle re-run in fp32 instead."""
+    errs = [util.rel_err(a, b.numpy()) for a, b in zip(g_hip, grads)]
+    if max(errs) < RTOL_GRAD:
+        return
+    data, cfg, params, u_f, eta = prob
+    x32 = O.inputs_from_numpy(data, dtype=torch.float32)
+    _, g32 = O.elbo_value_and_grads(params.clone(dtype=torch.float32), x32, cfg, torch.as_tensor(u_f, dtype=torch.float32),
+                                    torch.as_tensor(eta, dtype=torch.float32))
+    for e, a, c in zip(errs, g_hip, g32):
+        assert e < RTOL_GRAD or util.rel_err(a, c.numpy()) < 2e-5, (errs, util.rel_err(a, c.numpy()))
 
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_loss_and_gradients_match_oracle(name):
-    out, grads, ipred, terms, g_hip, eng = _run_case(CASES[name])
+    out, grads, ipred, terms, g_hip, eng, prob = _run_case(CASES[name])
     assert abs(terms["nll"] - float(out["nll"])) <= RTOL_LOSS * abs(float(out["nll"])), (terms, float(out["nll"]))
     assert abs(terms["kl"] - float(out["kl"])) <= RTOL_LOSS * max(abs(float(out["kl"])), 1.0), (terms, float(out["kl"]))
     assert abs(terms["loss"] - float(out["loss"])) <= RTOL_LOSS * abs(float(out["loss"]))
     assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
     assert len(g_hip) == len(grads)
-    errs = [util.rel_err(a, b.numpy()) for a, b in zip(g_hip, grads)]
-    assert max(errs) < RTOL_GRAD, errs
+    _assert_grads(g_hip, grads, prob)
 
 
 def test_refl_gather_is_bit_exact():

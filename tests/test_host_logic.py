@@ -172,3 +172,16 @@ def test_unsupported_plugins_are_rejected_not_emulated():
     model.likelihood = Odd()
     with pytest.raises((NotImplementedError, _lib.CarelessHipError)):
         model.train_model(reference_inputs(data), 1, progress=False)
+
+
+def test_double_wilson_prior_host_matches_oracle_and_validates_r():
+    from careless_amd.models.priors.wilson import DoubleWilsonPrior
+    from oracle import elbo_oracle as O
+    data, cfg, params, x, u_f, eta = util.make_problem(N=200, R=40, S=2, double_wilson=True)
+    out = O.elbo_forward(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64))
+    prior = DoubleWilsonPrior(data["centric"], data["multiplicity"], data["parent_ids"], data["root"], data["asu_ids"], data["dw_r"])
+    ref = O.double_wilson_log_prob(out["z_f"], x.centric, x.multiplicity, x.sigma, x.parent_ids, x.root, x.asu_ids, x.dw_r)
+    assert np.allclose(prior.log_prob(out["z_f"].numpy()), ref.numpy(), rtol=1e-5, atol=1e-5)
+    assert (data["parent_ids"] == -1).any()
+    with pytest.raises(ValueError):                       # reference io/manager.py:415-419 (test_cli.py:92-110)
+        DoubleWilsonPrior(data["centric"], data["multiplicity"], data["parent_ids"], data["root"], data["asu_ids"], [0.0, 1.0])

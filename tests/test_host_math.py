@@ -111,3 +111,31 @@ def test_noise_generator_statistics(hm):
     hm.hm_noise(n, ctypes.c_ulonglong(1234), 7, 1, ctypes.c_ulonglong(0), fp(un), fp(a))
     hm.hm_noise(n, ctypes.c_ulonglong(1234), 7, 5, ctypes.c_ulonglong(0), fp(un), fp(b))   # the sine partner of sample 1
     assert abs(np.corrcoef(a, b)[0, 1]) < 0.01 and abs(np.corrcoef(a * a, b * b)[0, 1]) < 0.01
+
+
+def test_bessel_and_double_wilson_conditional(hm):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.linspace(0, 8, 3000), np.linspace(8, 3000, 3000)]).astype(np.float32)
+    a, b = np.empty_like(x), np.empty_like(x)
+    hm.hm_bessel(len(x), fp(x), fp(a), fp(b))
+    assert np.max(np.abs(a - special.i0e(x.astype(float))) / special.i0e(x.astype(float))) < 2e-6
+    assert np.max(np.abs(b - special.i1e(x.astype(float))) / np.maximum(special.i1e(x.astype(float)), 1e-3)) < 5e-6
+    n = 10000
+    z, zp = rng.uniform(0.05, 4, n).astype(np.float32), rng.uniform(0.05, 4, n).astype(np.float32)
+    has = (rng.random(n) < 0.9).astype(np.int32)
+    r = rng.uniform(0.0, 0.97, n).astype(np.float32)
+    c = (rng.random(n) < 0.3).astype(np.int32)
+    es = rng.choice([1.0, 2.0, 3.0], n).astype(np.float32)
+    lp, dz, dzp = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+    hm.hm_dw(n, fp(z), fp(zp), fp(has), fp(r), fp(c), fp(es), fp(lp), fp(dz), fp(dzp))
+    T = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float64))
+    zt, zpt = T(z).requires_grad_(True), T(zp).requires_grad_(True)
+    cb, hb = torch.as_tensor(c.astype(bool)), torch.as_tensor(has.astype(bool))
+    loc = torch.where(hb, zpt * T(r), torch.zeros(n, dtype=torch.float64))
+    scale = torch.where(cb, torch.sqrt(T(es) * (1 - T(r) ** 2)), torch.sqrt(0.5 * T(es) * (1 - T(r) ** 2)))
+    ref = torch.where(cb, O.folded_normal_log_prob(zt, loc, scale), O.rice_log_prob(zt, loc, scale))
+    g = torch.autograd.grad(ref.sum(), [zt, zpt])
+    nat = lambda v: np.maximum(np.abs(v), 1.0)
+    assert np.max(np.abs(lp - ref.detach().numpy()) / nat(ref.detach().numpy())) < 1e-4
+    assert np.max(np.abs(dz - g[0].numpy()) / nat(g[0].numpy())) < 1e-4
+    assert np.max(np.abs(dzp - g[1].numpy()) / nat(g[1].numpy())) < 1e-4

@@ -9,10 +9,15 @@ from oracle import elbo_oracle as O
 
 def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, likelihood="normal", dof=None,
                  bijector="exp", shift=0.0, use_image_scales=True, kl_weight=None, perturb=0.05, seed=7,
-                 outliers=False, **opt):
-    data = O.make_synthetic(N, R=R, d0=d0, posenc=posenc, n_images=n_images, seed=seed, outliers=outliers)
+                 outliers=False, double_wilson=False, **opt):
+    if double_wilson:
+        data = O.make_synthetic_double_wilson(N, R_half=R // 2, d0=d0, posenc=posenc, n_images=n_images, seed=seed,
+                                              outliers=outliers)
+    else:
+        data = O.make_synthetic(N, R=R, d0=d0, posenc=posenc, n_images=n_images, seed=seed, outliers=outliers)
     cfg = O.ElboConfig(mc_samples=S, likelihood=likelihood, dof=dof, scale_bijector=bijector, scale_shift=shift,
-                       use_image_scales=use_image_scales, kl_weight=kl_weight, **opt)
+                       use_image_scales=use_image_scales, kl_weight=kl_weight,
+                       prior="double_wilson" if double_wilson else "wilson", **opt)
     rng = np.random.default_rng(seed + 1)
     params = O.init_params(data, cfg, L, w, perturb=perturb, rng=rng)
     x = O.inputs_from_numpy(data)
@@ -33,12 +38,16 @@ def build_model(data, cfg: O.ElboConfig, params: O.ElboParams, L, w):
     from careless_amd.models.likelihoods.mono import NormalLikelihood, StudentTLikelihood
     from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
     from careless_amd.models.merging.variational import VariationalMergingModel
-    from careless_amd.models.priors.wilson import WilsonPrior
+    from careless_amd.models.priors.wilson import DoubleWilsonPrior, WilsonPrior
     from careless_amd.models.scaling.image import HybridImageScaler, ImageScaler
     from careless_amd.models.scaling.nn import MLPScaler
     from careless_amd.optimizers import Adam
 
-    prior = WilsonPrior(data["centric"], data["multiplicity"], 1.0)
+    if cfg.prior == "double_wilson":
+        prior = DoubleWilsonPrior(data["centric"], data["multiplicity"], data["parent_ids"], data["root"], data["asu_ids"],
+                                  data["dw_r"], parents=[None, 0])
+    else:
+        prior = WilsonPrior(data["centric"], data["multiplicity"], 1.0)
     low = (1e-32 * ~np.asarray(data["centric"], dtype=bool)).astype(np.float32)
     q = TruncatedNormal(params.q_loc_raw.numpy().astype(np.float32), params.q_scale_raw.numpy().astype(np.float32),
                         low, high=cfg.high, scale_shift=cfg.epsilon)
