@@ -64,6 +64,22 @@ class MlpArgs(C.Structure):
     ]
 
 
+class LaueArgs(C.Structure):
+    """mirror of `cl_laue_args` (include/careless_hip.h)"""
+    _fields_ = [
+        ("refl_id", _vp), ("image_id", _vp), ("harmonic_id", _vp), ("loc", _vp), ("sigma", _vp), ("iobs", _vp), ("sig", _vp),
+        ("n_obs", C.c_int),
+        ("obs_offset", C.c_longlong),
+        ("img", _vp), ("use_img", C.c_int),
+        ("z_f", _vp), ("R", C.c_int), ("S", C.c_int),
+        ("lik_kind", C.c_int), ("dof", C.c_float), ("lik_const", C.c_float),
+        ("shift", C.c_float), ("w_ll", C.c_float),
+        ("eta", _vp),
+        ("seed", C.c_ulonglong), ("step", C.c_uint),
+        ("iconv", _vp), ("dz_f", _vp), ("d_img", _vp), ("dO", _vp), ("scalars", _vp), ("ipred_out", _vp), ("stop_flag", _vp),
+    ]
+
+
 class AdamArgs(C.Structure):
     """mirror of `cl_adam_args` (include/careless_hip.h)"""
     _fields_ = [
@@ -91,6 +107,9 @@ EXPORTS = {
     "cl_elbo_mono_fwd_bwd": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
     "cl_mlp_forward": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
     "cl_mlp_backward_ext": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
+    "cl_laue_predict": (C.c_int, [C.POINTER(LaueArgs), _vp]),
+    "cl_laue_likelihood": (C.c_int, [C.POINTER(LaueArgs), _vp]),
+    "cl_laue_backward": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_reduce_partials": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "cl_grad_sqnorm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "cl_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
@@ -128,9 +147,9 @@ def get_lib() -> C.CDLL:
             raise CarelessHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    sizes = (C.c_size_t * 3)()
+    sizes = (C.c_size_t * 4)()
     lib.cl_abi_sizes(sizes)
-    mine = (C.sizeof(TnArgs), C.sizeof(MlpArgs), C.sizeof(AdamArgs))
+    mine = (C.sizeof(TnArgs), C.sizeof(MlpArgs), C.sizeof(AdamArgs), C.sizeof(LaueArgs))
     if tuple(sizes) != mine:
         raise CarelessHipError(f"ABI mismatch between careless_amd/_lib.py {mine} and the library {tuple(sizes)}")
     _lib = lib

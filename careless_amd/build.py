@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcareless_hip.so")
-SOURCES = ["cl_api.hip", "elbo_mlp.hip", "elbo_elem.hip"]
+SOURCES = ["cl_api.hip", "elbo_mlp.hip", "elbo_elem.hip", "elbo_laue.hip"]
 HEADERS = ["cl_math.h", "cl_kernels.h", os.path.join("..", "..", "include", "careless_hip.h")]
 ARCH = "gfx950"
 

@@ -6,11 +6,16 @@ extern "C" {
 
 const char* cl_version(void) { return "careless_hip 0.1.0 (gfx950)"; }
 
-void cl_abi_sizes(size_t out[3]) {
+void cl_abi_sizes(size_t out[4]) {
     out[0] = sizeof(cl_tn_args);
     out[1] = sizeof(cl_mlp_args);
     out[2] = sizeof(cl_adam_args);
+    out[3] = sizeof(cl_laue_args);
 }
+
+int cl_laue_predict(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_predict(*a, (hipStream_t)stream) : -1; }
+int cl_laue_likelihood(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_likelihood(*a, (hipStream_t)stream) : -1; }
+int cl_laue_backward(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_backward(*a, (hipStream_t)stream) : -1; }
 
 int cl_mlp_default_grid(void) {
     int dev = 0, cus = 0;

@@ -17,3 +17,6 @@ int cl_launch_finalize(const double* scalars, float klw, double* history, int st
                        hipStream_t st);
 int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
                     hipStream_t st);
+int cl_launch_laue_predict(const cl_laue_args& a, hipStream_t st);
+int cl_launch_laue_likelihood(const cl_laue_args& a, hipStream_t st);
+int cl_launch_laue_backward(const cl_laue_args& a, hipStream_t st);

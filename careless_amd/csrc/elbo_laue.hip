@@ -1,0 +1,119 @@
+// Laue (polychromatic) likelihood path of the ELBO step (gfx950): harmonic deconvolution.
+//
+// Reference: `ConvolvedLikelihood.convolve / .log_prob`, `LaueBase.call` (careless/models/likelihoods/laue.py:9-47):
+//     iconv = scatter_nd(harmonic_id, ipred^T, shape (N,S))^T      -- predictions of the rows that share a harmonic id SUM
+//     ll    = base.log_prob(iconv)  over ALL N slots               -- slots >= G keep iconv = 0 and add a constant
+// where Iobs / SigIobs are valid in slots [0,G) and padded beyond (careless/io/formatter.py:637-640).
+//
+// The likelihood of a row depends on the other rows of its harmonic group, so the step is split around the group sum:
+//   cl_mlp_forward            scaler loc / sigma per row                            (fused MFMA kernel, forward only)
+//   laue_predict_kernel       sample, predict, atomicAdd into iconv[harmonic_id][s]
+//   laue_likelihood_kernel    log-prob per slot, NLL partial sums, dNLL/diconv written in place of iconv
+//   laue_backward_kernel      broadcast dNLL/diconv back to the rows -> dz_f / image-scale atomics, dL/d(loc, sigma) per row
+//   cl_mlp_backward_ext       scaler backward from that dL/d(loc, sigma)            (fused MFMA kernel, MODE 2)
+// All three kernels here are streaming (HBM-bound, a few tens of bytes per row and sample).
+#include <hip/hip_runtime.h>
+#include "cl_math.h"
+#include "cl_kernels.h"
+
+namespace {
+__device__ __forceinline__ float laue_eta(const cl_laue_args& A, int i, int s) {
+    return A.eta ? A.eta[(size_t)i * A.S + s] : cl_noise_normal(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + i));
+}
+__device__ __forceinline__ double wave_sum_d2(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void laue_predict_kernel(const cl_laue_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long long)A.n_obs * A.S) return;
+    const int i = (int)(p / A.S), s = (int)(p - (long long)i * A.S);
+    const int rid = A.refl_id[i];
+    float aim = 1.0f;
+    if (A.use_img) { const int im = A.image_id[i]; if (im > 0) aim = A.img[im - 1]; }
+    const float tq = A.loc[i] + A.sigma[i] * laue_eta(A, i, s) + A.shift;
+    const float zf = A.z_f[(size_t)rid * A.S + s];
+    const float ipred = aim * tq * zf * zf;
+    if (A.ipred_out) A.ipred_out[p] = ipred;
+    atomicAdd(A.iconv + (size_t)A.harmonic_id[i] * A.S + s, ipred);
+}
+
+__global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double nll = 0.0;
+    if (p < (long long)A.n_obs * A.S) {
+        const int g = (int)(p / A.S);
+        float dll;
+        const float ll = cl_lik_log_prob(A.iconv[p], A.iobs[g], A.sig[g], A.lik_kind, A.dof, A.lik_const, &dll);
+        nll = -(double)ll * (double)A.w_ll;
+        A.iconv[p] = -dll * A.w_ll;                  // dNLL / d iconv[g][s]
+    }
+    __shared__ double sh[4];
+    nll = wave_sum_d2(nll);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = nll;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(A.scalars + CL_SC_NLL, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n_obs) return;
+    const int rid = A.refl_id[i], hid = A.harmonic_id[i];
+    float aim = 1.0f;
+    int im = 0;
+    if (A.use_img) { im = A.image_id[i]; if (im > 0) aim = A.img[im - 1]; }
+    const float loc = A.loc[i], sigma = A.sigma[i];
+    float dloc = 0.0f, dsig = 0.0f, da = 0.0f;
+    for (int s = 0; s < A.S; ++s) {
+        const float eta = laue_eta(A, i, s);
+        const float tq = loc + sigma * eta + A.shift;
+        const float zf = A.z_f[(size_t)rid * A.S + s];
+        const float gi = A.iconv[(size_t)hid * A.S + s];
+        const float dzs = gi * zf * zf;
+        atomicAdd(A.dz_f + (size_t)rid * A.S + s, gi * aim * tq * 2.0f * zf);
+        const float dt = dzs * aim;
+        dloc += dt;
+        dsig += dt * eta;
+        da += dzs * tq;
+    }
+    A.dO[2 * (size_t)i] = dloc;
+    A.dO[2 * (size_t)i + 1] = dsig;
+    if (A.use_img && im > 0) atomicAdd(A.d_img + (im - 1), da);
+}
+
+static int laue_check(const cl_laue_args& a) {
+    if (a.n_obs <= 0 || a.S <= 0 || a.refl_id == nullptr || a.harmonic_id == nullptr || a.loc == nullptr || a.sigma == nullptr ||
+        a.z_f == nullptr || a.iconv == nullptr)
+        return -1;
+    if (a.use_img && (a.image_id == nullptr || a.img == nullptr)) return -1;
+    return 0;
+}
+
+int cl_launch_laue_predict(const cl_laue_args& a, hipStream_t st) {
+    if (int e = laue_check(a)) return e;
+    const long long n = (long long)a.n_obs * a.S;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(laue_predict_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int cl_launch_laue_likelihood(const cl_laue_args& a, hipStream_t st) {
+    if (int e = laue_check(a)) return e;
+    if (a.iobs == nullptr || a.sig == nullptr || a.scalars == nullptr) return -1;
+    const long long n = (long long)a.n_obs * a.S;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(laue_likelihood_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int cl_launch_laue_backward(const cl_laue_args& a, hipStream_t st) {
+    if (int e = laue_check(a)) return e;
+    if (a.dz_f == nullptr || a.dO == nullptr || (a.use_img && a.d_img == nullptr)) return -1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(laue_backward_kernel, dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from careless_amd import _lib
-from careless_amd._lib import AdamArgs, MlpArgs, TnArgs, check, ptr
+from careless_amd._lib import AdamArgs, LaueArgs, MlpArgs, TnArgs, check, ptr
 from careless_amd.models.base import BaseModel
 
 TILE = _lib.CL_MLP_TILE
@@ -137,9 +137,12 @@ class ElboEngine:
             raise NotImplementedError(f"surrogate posterior {type(q).__name__} is not supported by the HIP engine")
         if not isinstance(prior, (WilsonPrior, DoubleWilsonPrior)):
             raise NotImplementedError(f"prior {type(prior).__name__} is not supported by the HIP engine yet")
-        if BaseModel.is_laue(inputs):
-            raise NotImplementedError("Laue (harmonic deconvolution) inputs are not supported by the HIP engine yet")
-        if not isinstance(lik, LocationScaleLikelihood) or lik.kind not in ("normal", "studentt"):
+        from careless_amd.models.likelihoods.laue import LaueBase
+        self.laue = BaseModel.is_laue(inputs)
+        if self.laue != isinstance(lik, LaueBase):
+            raise ValueError("Laue inputs (8-tuple with harmonic_id) need a careless_amd.models.likelihoods.laue likelihood, "
+                             "monochromatic inputs a careless_amd.models.likelihoods.mono one")
+        if not isinstance(lik, (LocationScaleLikelihood, LaueBase)) or lik.kind not in ("normal", "studentt"):
             raise NotImplementedError(f"likelihood {type(lik).__name__} is not supported by the HIP engine yet")
         if isinstance(scaler, HybridImageScaler):
             mlp, img = scaler.mlp_scaler, scaler.image_scaler
@@ -163,6 +166,8 @@ class ElboEngine:
         if refl_id.size and (refl_id.min() < 0 or refl_id.max() >= self.R):
             raise ValueError("refl_id outside the range of the surrogate posterior")
         self.shard = shard if shard is not None else make_shard(self.N_total, self.R)
+        if self.laue and self.shard.world > 1:
+            raise NotImplementedError("data-parallel Laue runs need a shard-by-harmonic-group split, not supported yet")
         sl = slice(self.shard.start, self.shard.stop)
         self.N = int(self.shard.stop - self.shard.start)
         if self.N <= 0:
@@ -176,6 +181,11 @@ class ElboEngine:
         self.meta_t = torch.as_tensor(meta_t, device=dev)
         self.iobs = torch.as_tensor(np.ascontiguousarray(iobs[sl]), device=dev)
         self.sig = torch.as_tensor(np.ascontiguousarray(sig[sl]), device=dev)
+        if self.laue:
+            hid = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1).astype(np.int64)
+            if hid.size and (hid.min() < 0 or hid.max() >= self.N_total):
+                raise ValueError("harmonic_id outside [0, N)")
+            self.harmonic_id = torch.as_tensor(hid[sl].astype(np.int32), device=dev)
 
         # ---- per-reflection constants ----------------------------------------------------------------
         self.low = q.low.to(dev, torch.float32).contiguous()
@@ -240,6 +250,11 @@ class ElboEngine:
         self.z_f = torch.empty(RS, dtype=torch.float32, device=dev)
         self.partials = torch.empty(self.grid * lay.P, dtype=torch.float32, device=dev)
         self.stop_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self.laue:
+            self.laue_loc = torch.empty(self.N, dtype=torch.float32, device=dev)
+            self.laue_sig = torch.empty(self.N, dtype=torch.float32, device=dev)
+            self.laue_iconv = torch.empty(self.N * self.S, dtype=torch.float32, device=dev)
+            self.laue_dO = torch.empty(self.N * 2, dtype=torch.float32, device=dev)
         self.frozen = torch.zeros(self.nseg, dtype=torch.uint8, device=dev)
         self.history_buf: Optional[torch.Tensor] = None
         self._keep = None
@@ -345,7 +360,10 @@ class ElboEngine:
         if self.double_wilson:
             check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")
         ma = self._mlp_args(step, eta, ipred_out)
-        check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), self.grid, st), "cl_elbo_mono_fwd_bwd")
+        if self.laue:
+            self._laue_passes(ma, step, eta, ipred_out, st)
+        else:
+            check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), self.grid, st), "cl_elbo_mono_fwd_bwd")
         lay = self.layout
         check(lib.cl_reduce_partials(ptr(self.partials), self.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
                                      ptr(self.stop_flag), st), "cl_reduce_partials")
@@ -353,6 +371,31 @@ class ElboEngine:
         if self.shard.world > 1:
             self._allreduce()
         self._keep = (u_f, eta, ipred_out)
+
+    def _laue_passes(self, ma: MlpArgs, step: int, eta, ipred_out, st):
+        """Harmonic deconvolution (reference likelihoods/laue.py:9-47): scaler forward, predict + group sums, likelihood on
+        the slots, gradient broadcast back to the rows, scaler backward from dL/d(loc, sigma)."""
+        lib = self.lib
+        ma.loc_out, ma.sig_out = ptr(self.laue_loc), ptr(self.laue_sig)
+        check(lib.cl_mlp_forward(C.byref(ma), self.grid, st), "cl_mlp_forward")
+        self.laue_iconv.zero_()
+        la = LaueArgs()
+        la.refl_id, la.image_id, la.harmonic_id = ptr(self.refl_id), ptr(self.image_id), ptr(self.harmonic_id)
+        la.loc, la.sigma, la.iobs, la.sig = ptr(self.laue_loc), ptr(self.laue_sig), ptr(self.iobs), ptr(self.sig)
+        la.n_obs, la.obs_offset = self.N, self.shard.start
+        la.img, la.use_img = ma.img, ma.use_img
+        la.z_f, la.R, la.S = ptr(self.z_f), self.R, self.S
+        la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
+        la.shift, la.w_ll = ma.shift, self.w_ll
+        la.eta = ptr(eta)
+        la.seed, la.step = self.seed, step & 0xFFFFFFFF
+        la.iconv, la.dz_f, la.d_img, la.dO = ptr(self.laue_iconv), ptr(self.dz_f), ma.d_img, ptr(self.laue_dO)
+        la.scalars, la.ipred_out, la.stop_flag = ptr(self.scalars), ptr(ipred_out), ptr(self.stop_flag)
+        check(lib.cl_laue_predict(C.byref(la), st), "cl_laue_predict")
+        check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
+        check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")
+        ma.dO_ext = ptr(self.laue_dO)
+        check(lib.cl_mlp_backward_ext(C.byref(ma), self.grid, st), "cl_mlp_backward_ext")
 
     def _allreduce(self):
         from careless_amd.distributed import allreduce_flat_

@@ -1,0 +1,71 @@
+"""Laue (polychromatic) likelihoods.
+
+Mirror of `careless/models/likelihoods/laue.py:9-100` (reference): `likelihood(inputs)` returns a `ConvolvedLikelihood` whose
+`convolve(value)` sums the predictions of rows that share a `harmonic_id` and whose `log_prob(value)` evaluates the base
+distribution on the convolved predictions over ALL N slots.  These host objects serve users and tests; on the training path the
+engine reads `kind` / `dof` and runs the harmonic deconvolution in HIP (careless_amd/csrc/elbo_laue.hip).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from careless_amd.models.likelihoods.base import Likelihood
+from careless_amd.models.likelihoods.mono import _BoundLocationScale, _squeeze
+
+
+class ConvolvedLikelihood:
+    """Convolved log probability object for Laue data (reference laue.py:9-34)."""
+
+    def __init__(self, distribution, harmonic_id):
+        self.harmonic_id = np.asarray(_squeeze(harmonic_id)).reshape(-1).astype(np.int64)
+        self.distribution = distribution
+
+    def convolve(self, value):
+        """value: (n_predictions,) or (b, n_predictions); duplicates sum, untouched slots stay 0 (scatter_nd)."""
+        value = np.asarray(value.detach().cpu() if hasattr(value, "detach") else value)
+        out = np.zeros_like(value)
+        if value.ndim == 1:
+            np.add.at(out, self.harmonic_id, value)
+        else:
+            for b in range(value.shape[0]):
+                np.add.at(out[b], self.harmonic_id, value[b])
+        return out
+
+    def mean(self, *args, **kwargs):
+        return self.distribution.mean(*args, **kwargs)
+
+    def stddev(self, *args, **kwargs):
+        return self.distribution.stddev(*args, **kwargs)
+
+    def log_prob(self, value):
+        return self.distribution.log_prob(self.convolve(value))
+
+
+class LaueBase(Likelihood):
+    kind = None
+    dof = None
+
+    def dist(self, inputs):
+        raise NotImplementedError("Extensions of this class must implement dist(inputs)")
+
+    def call(self, inputs):
+        return ConvolvedLikelihood(self.dist(inputs), self.get_harmonic_id(inputs))
+
+
+class NormalLikelihood(LaueBase):
+    kind = "normal"
+
+    def dist(self, inputs):
+        return _BoundLocationScale("normal", _squeeze(self.get_intensities(inputs)), _squeeze(self.get_uncertainties(inputs)))
+
+
+class StudentTLikelihood(LaueBase):
+    kind = "studentt"
+
+    def __init__(self, dof):
+        super().__init__()
+        self.dof = dof
+
+    def dist(self, inputs):
+        return _BoundLocationScale("studentt", _squeeze(self.get_intensities(inputs)),
+                                   _squeeze(self.get_uncertainties(inputs)), dof=self.dof)

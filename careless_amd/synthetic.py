@@ -89,3 +89,38 @@ def make_synthetic_double_wilson(N: int, R_half: Optional[int] = None, r: float 
     d["dw_r"] = np.array([0.0, r], dtype=np.float32)
     d["file_id"] = (d["refl_id"] >= R_half).astype(np.int64)
     return d
+
+
+def make_synthetic_laue(N: int, R: Optional[int] = None, seed: int = 1234, n_images: Optional[int] = None, pad: float = 1.0) -> Dict:
+    """Polychromatic problem: N expanded rows, harmonic multiplicity {1: .80, 2: .15, 3: .05}; the rows of a
+    group share image and observed intensity; Iobs / SigIobs live in slots [0,G) ordered by harmonic id and are padded with `pad`
+    beyond (careless/io/formatter.py:617,637-640); metadata gets the wavelength as a sixth column."""
+    rng = np.random.default_rng(seed)
+    sizes = []
+    tot = 0
+    while tot < N:
+        k = int(rng.choice([1, 2, 3], p=[0.8, 0.15, 0.05]))
+        k = min(k, N - tot)
+        sizes.append(k)
+        tot += k
+    G = len(sizes)
+    hid = np.repeat(np.arange(G), sizes).astype(np.int64)
+    d = make_synthetic(N, R=R, d0=5, seed=seed, n_images=n_images)
+    # rows of one harmonic group come from one image
+    img_g = np.sort(rng.integers(0, d["n_images"], size=G))
+    d["image_id"] = img_g[hid].astype(np.int64)
+    wl = rng.uniform(1.0, 1.2, size=N)
+    meta = np.concatenate([np.asarray(d["metadata"], dtype=np.float64), ((wl - wl.mean()) / wl.std())[:, None]], axis=1)
+    d["metadata"] = meta.astype(np.float32)
+    d["wavelength"] = wl.astype(np.float32)
+    i_row = np.asarray(d["iobs"], dtype=np.float64)
+    i_grp = np.bincount(hid, weights=np.maximum(i_row, 0.0), minlength=G)
+    s_grp = np.sqrt(np.abs(i_grp) + 25.0)
+    iobs = np.full(N, pad, dtype=np.float32)
+    sig = np.full(N, pad, dtype=np.float32)
+    iobs[:G] = (i_grp + s_grp * rng.normal(size=G)).astype(np.float32)
+    sig[:G] = s_grp.astype(np.float32)
+    d["iobs"], d["sigiobs"] = iobs, sig
+    d["harmonic_id"] = hid
+    d["n_groups"] = G
+    return d

@@ -128,6 +128,40 @@ int cl_mlp_backward_ext(const cl_mlp_args* args, int grid, void* stream);
 /* grad_mlp[P] += sum over the `nparts` workgroup partials, in index order (deterministic) */
 int cl_reduce_partials(const float* partials, int nparts, int P, float* grad_mlp, const int* stop_flag, void* stream);
 
+/* --- Laue harmonic deconvolution -----------------------------------------------------------------------------------
+ * replaces: ConvolvedLikelihood.convolve / .log_prob, LaueBase.call (careless/models/likelihoods/laue.py:9-47) and their gradient.
+ * Call order inside a step: cl_mlp_forward -> cl_laue_predict -> cl_laue_likelihood -> cl_laue_backward -> cl_mlp_backward_ext.
+ * iobs / sig hold one entry per SLOT: valid in [0,G), padding beyond (careless/io/formatter.py:637-640); every slot counts.   */
+typedef struct cl_laue_args {
+    const int* refl_id;         /* [n_obs]                                   */
+    const int* image_id;        /* [n_obs]                                   */
+    const int* harmonic_id;     /* [n_obs] in [0, n_obs)                     */
+    const float* loc;           /* [n_obs] scaler mean  (cl_mlp_forward)     */
+    const float* sigma;         /* [n_obs] scaler sigma (cl_mlp_forward)     */
+    const float* iobs;          /* [n_obs] per slot                          */
+    const float* sig;           /* [n_obs] per slot                          */
+    int n_obs;
+    long long obs_offset;
+    const float* img; int use_img;
+    const float* z_f; int R, S;
+    int lik_kind; float dof, lik_const;
+    float shift, w_ll;
+    const float* eta;           /* [n_obs][S] injected normals or NULL       */
+    unsigned long long seed; unsigned step;
+    float* iconv;               /* [n_obs][S] zeroed by the caller; predict accumulates the group sums, likelihood overwrites
+                                   them with dNLL/diconv                     */
+    float* dz_f;                /* [R][S] +=                                 */
+    float* d_img;               /* [M-1] +=                                  */
+    float* dO;                  /* [n_obs][2] dL/d(loc, sigma) for cl_mlp_backward_ext */
+    double* scalars;
+    float* ipred_out;           /* optional [n_obs][S]                       */
+    const int* stop_flag;
+} cl_laue_args;
+
+int cl_laue_predict(const cl_laue_args* args, void* stream);
+int cl_laue_likelihood(const cl_laue_args* args, void* stream);
+int cl_laue_backward(const cl_laue_args* args, void* stream);
+
 /* --- gradient norm, sanitise, clip, Adam -------------------------------------------------------------------------
  * replaces: tf.linalg.global_norm, tf.where(is_finite), optimizer.apply_gradients (variational.py:202-209)
  *           tfk.optimizers.Adam(lr, b1, b2, clipnorm, clipvalue, global_clipnorm) (careless/io/manager.py:494-501) */
@@ -155,8 +189,8 @@ int cl_step_finalize(const double* scalars, float kl_weight_or_one, double* hist
 
 /* --- diagnostics -------------------------------------------------------------------------------------------------- */
 const char* cl_version(void);
-/* sizeof(cl_tn_args), sizeof(cl_mlp_args), sizeof(cl_adam_args): lets a binding verify its struct mirrors */
-void cl_abi_sizes(size_t out[3]);
+/* sizeof(cl_tn_args), sizeof(cl_mlp_args), sizeof(cl_adam_args), sizeof(cl_laue_args): lets a binding verify its mirrors */
+void cl_abi_sizes(size_t out[4]);
 /* out[n][S]: kind 0 = the uniforms of cl_tn_*, kind 1 = the normals of cl_elbo_mono_fwd_bwd, for (seed, step) */
 int cl_debug_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
                    void* stream);

@@ -506,8 +506,8 @@ def train_step(p: ElboParams, x: ElboInputs, cfg: ElboConfig, st: AdamState, u_f
 # synthetic problems: the deterministic generator of SURVEY 8(d) lives in careless_amd/synthetic.py (plain numpy,
 # no compute path) so that bench.py can build its workload without touching the oracle; re-exported here.
 # --------------------------------------------------------------------------------------------------
-from careless_amd.synthetic import (make_synthetic, make_synthetic_double_wilson, positional_encoding,  # noqa: E402,F401
-                                    standardize_metadata)
+from careless_amd.synthetic import (make_synthetic, make_synthetic_double_wilson, make_synthetic_laue,  # noqa: E402,F401
+                                    positional_encoding, standardize_metadata)
 
 
 def inputs_from_numpy(d: Dict, dtype=torch.float64, sigma=1.0) -> ElboInputs:

@@ -21,6 +21,8 @@ CASES = {
     "mlp3x20_softplus_shift_S2": dict(N=257, R=50, d0=6, L=3, w=20, S=2, bijector="softplus", shift=3.5),
     "mlp1x64_d40_S1": dict(N=200, R=17, d0=40, L=1, w=64, S=1),
     "mlp4x48_klweight_S4": dict(N=640, R=100, d0=5, L=4, w=48, S=4, kl_weight=0.5, likelihood="studentt", dof=12.0),
+    "laue_2x32_normal_S3": dict(N=400, R=40, L=2, w=32, S=3, laue=True),
+    "laue_5x64_studentt_S2_noimg": dict(N=700, R=64, L=5, w=64, S=2, laue=True, likelihood="studentt", dof=6.0, use_image_scales=False),
     "double_wilson_2x32_S3": dict(N=400, R=60, d0=5, L=2, w=32, S=3, double_wilson=True),
     "double_wilson_5x64_S8_studentt": dict(N=600, R=80, d0=5, L=5, w=64, S=8, double_wilson=True, likelihood="studentt", dof=8.0),
 }
@@ -209,3 +211,51 @@ def test_full_size_properties_1M():
     assert bool(torch.isfinite(eng.grads).all()) and float(eng.grads.abs().max()) > 0
     hist = model.train_model(inputs, 5, progress=False)
     assert len(hist["loss"]) == 5 and all(np.isfinite(hist["loss"])) and hist["loss"][-1] < hist["loss"][0]
+
+
+@pytest.mark.parametrize("clip", [dict(clipnorm=0.5), dict(clipvalue=0.01), dict(global_clipnorm=1.0)])
+def test_clipping_modes_match_oracle(clip):
+    """tfk.optimizers.Adam(clipnorm= / clipvalue= / global_clipnorm=) (reference io/manager.py:494-501, tests/test_cli.py:196-208)"""
+    kw = dict(N=300, R=40, d0=5, L=2, w=32, S=2, **clip)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    steps = 4
+    rng = np.random.default_rng(5)
+    noises = [(rng.random((2, 40)).astype(np.float32), rng.normal(size=(2, 300)).astype(np.float32)) for _ in range(steps)]
+    model = util.build_model(data, cfg, params, 2, 32)
+    hist = model.train_model(util.reference_inputs(data), steps, progress=False, noise=lambda i: noises[i])
+    p = params.clone()
+    st = O.AdamState.zeros_like(p.tensors())
+    ref = [O.train_step(p, x, cfg, st, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+           for u, e in noises]
+    assert np.allclose(hist["loss"], [r["loss"] for r in ref], rtol=1e-4)
+    assert np.allclose(hist["Grad Norm"], [r["Grad Norm"] for r in ref], rtol=2e-4)
+    assert util.rel_err(model.surrogate_posterior.loc_raw.cpu().numpy(), p.q_loc_raw.numpy()) < 1e-4
+    for a, b in zip(model._engine.mlp.weights, [t for pair in zip(p.mlp_w, p.mlp_b) for t in pair]):
+        assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
+
+
+def test_freeze_flags_and_early_stop():
+    """--freeze-scales / --freeze-structure-factors (careless.py:48-56) and the non-finite-norm break (variational.py:271-274)"""
+    kw = dict(N=300, R=40, d0=5, L=2, w=32, S=1)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    model = util.build_model(data, cfg, params, 2, 32)
+    inputs = util.reference_inputs(data)
+    model.scaling_model.trainable = False
+    w0 = model.scaling_model.mlp_scaler.flat.clone()
+    model.train_model(inputs, 3, progress=False)
+    assert torch.equal(model.scaling_model.mlp_scaler.flat.cpu(), w0.cpu())              # scaler frozen
+    assert not torch.equal(model.surrogate_posterior.loc_raw.cpu(), torch.as_tensor(params.q_loc_raw.numpy().astype(np.float32)))
+    model.scaling_model.trainable = True
+    model.surrogate_posterior.trainable = False
+    q0 = model.surrogate_posterior.loc_raw.clone()
+    model.train_model(inputs, 2, progress=False)
+    assert torch.equal(model.surrogate_posterior.loc_raw, q0)
+    assert not torch.equal(model.scaling_model.mlp_scaler.flat.cpu(), w0.cpu())
+    # a NaN observation makes the gradient norm NaN at the first step: that step is recorded, later ones are not run
+    bad = dict(data)
+    bad["iobs"] = np.array(data["iobs"], copy=True)
+    bad["iobs"][7] = np.nan
+    model2 = util.build_model(bad, cfg, params, 2, 32)
+    hist = model2.train_model(util.reference_inputs(bad), 120, progress=False)
+    assert len(hist["loss"]) == 1 and not np.isfinite(hist["Grad Norm"][0])
+    assert bool(torch.isfinite(model2.surrogate_posterior.loc_raw).all())               # non-finite grads were zeroed (:208)

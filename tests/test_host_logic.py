@@ -185,3 +185,24 @@ def test_double_wilson_prior_host_matches_oracle_and_validates_r():
     assert (data["parent_ids"] == -1).any()
     with pytest.raises(ValueError):                       # reference io/manager.py:415-419 (test_cli.py:92-110)
         DoubleWilsonPrior(data["centric"], data["multiplicity"], data["parent_ids"], data["root"], data["asu_ids"], [0.0, 1.0])
+
+
+def test_laue_likelihood_convolve_known_answer():
+    """reference tests/models/likelihoods/test_laue.py:11-36: convolve(iobs[hid] / count[hid]) reproduces iobs on the slots"""
+    from careless_amd.models.likelihoods import laue
+    from scipy import stats
+    data = util.make_problem(N=120, R=16, laue=True)[0]
+    inputs = util.reference_inputs(data)
+    assert BaseModel.is_laue(inputs) and len(inputs) == 8
+    hid = data["harmonic_id"]
+    G = data["n_groups"]
+    fake = (data["iobs"][hid] / np.bincount(hid)[hid]).astype(np.float32)
+    lk = laue.NormalLikelihood()(inputs)
+    conv = lk.convolve(fake)
+    assert np.allclose(conv[:G], data["iobs"][:G], rtol=1e-5) and np.all(conv[G:] == 0)
+    lp = lk.log_prob(fake)
+    assert np.allclose(lp[:G], stats.norm.logpdf(data["iobs"][:G], data["iobs"][:G], data["sigiobs"][:G]), rtol=1e-5)
+    assert np.allclose(lp[G:], stats.norm.logpdf(0.0, 1.0, 1.0))          # the padded-slot constant (formatter.py:637-640)
+    assert np.allclose(lk.convolve(np.stack([fake] * 3)), conv[None, :])   # batched (reference :33-36)
+    lt = laue.StudentTLikelihood(4.0)(inputs).log_prob(fake)
+    assert np.allclose(lt[:G], stats.t.logpdf(data["iobs"][:G], 4.0, data["iobs"][:G], data["sigiobs"][:G]), rtol=1e-5)
