@@ -28,6 +28,7 @@ def parse():
     ap.add_argument("--workload", default="mono_10M_studentt_posenc_5x64_S8")
     ap.add_argument("--nobs", type=int, default=None, help="override the number of observations (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient all-reduce even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     return ap.parse_args()
 
@@ -87,20 +88,25 @@ def main():
     from careless_amd.workloads import flops_per_obs, bytes_per_obs, make_workload
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist and os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
+        os.environ["NCCL_DEBUG"] = "WARN"       # RCCL's banner goes to stdout and would trail the JSON line
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     model, inputs, data, spec = make_workload(args.workload, N=args.nobs)
-    if world > 1:
+    if use_dist:
         model.set_data_parallel(rank, world)
     eng = model.engine(inputs)
+    eng.force_allreduce = bool(args.force_dist)
     steps_total = args.warmup + args.steps
     eng.alloc_history(steps_total)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -136,13 +142,14 @@ def main():
     t1 = time.perf_counter()
     eng.lib = real_lib
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     hist = eng.read_history(steps_total)
     finite = bool(np.all(np.isfinite(hist["loss"]))) and len(hist["loss"]) == steps_total
 
+    out = None
     if rank == 0:
         N = spec["N"]
         ms = 1e3 * elapsed / args.steps
@@ -166,10 +173,12 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)          # the ONE JSON line, after any library chatter
 
 
 if __name__ == "__main__":

@@ -368,7 +368,7 @@ class ElboEngine:
         check(lib.cl_reduce_partials(ptr(self.partials), self.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
                                      ptr(self.stop_flag), st), "cl_reduce_partials")
         check(lib.cl_tn_backward(C.byref(tn), st), "cl_tn_backward")
-        if self.shard.world > 1:
+        if self.shard.world > 1 or getattr(self, "force_allreduce", False):
             self._allreduce()
         self._keep = (u_f, eta, ipred_out)
 
