@@ -89,8 +89,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
-    if use_dist and os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
-        os.environ["NCCL_DEBUG"] = "WARN"       # RCCL's banner goes to stdout and would trail the JSON line
+    if use_dist:
+        # RCCL writes its NCCL_DEBUG chatter (version banner, warnings) to stdout through C stdio, where it interleaves with
+        # the JSON line: send it to a file instead
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -177,8 +179,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        try:                                        # push out whatever RCCL left in C stdio (version banner) first
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         sys.stdout.flush()
-        print(json.dumps(out), flush=True)          # the ONE JSON line, after any library chatter
+        print(json.dumps(out), flush=True)          # the ONE JSON line, last on stdout
 
 
 if __name__ == "__main__":
