@@ -13,7 +13,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libcareless_hip.so")
 
 CL_MLP_TILE = 128
-CL_MLP_LMAX = 5
 CL_HIST_STRIDE = 8
 CL_SC_NLL, CL_SC_KL, CL_SC_GNORM2, CL_SC_GNORM2_SANE, CL_SC_COUNT = 0, 1, 2, 3, 4
 CL_LIK_NORMAL, CL_LIK_STUDENTT = 0, 1
@@ -101,6 +100,7 @@ EXPORTS = {
     "cl_mlp_default_grid": (C.c_int, []),
     "cl_mlp_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "cl_mlp_meta_rows": (C.c_int, [C.c_int]),
+    "cl_mlp_max_layers": (C.c_int, [C.c_int]),
     "cl_tn_forward": (C.c_int, [C.POINTER(TnArgs), _vp]),
     "cl_tn_backward": (C.c_int, [C.POINTER(TnArgs), _vp]),
     "cl_dw_prior_forward": (C.c_int, [C.POINTER(TnArgs), _vp]),
@@ -163,7 +163,7 @@ def check(code: int, what: str) -> None:
     if code == -2:
         raise NotImplementedError(
             f"{what}: scaler geometry not supported by the fused gfx950 kernel "
-            f"(needs 1 <= mlp_layers <= {CL_MLP_LMAX}, mlp_width <= 64, metadata width <= 64)")
+            "(needs mlp_width <= 64, metadata width <= 64 and mlp_layers <= 20 / 10 / 5 for width <= 16 / 32 / 64)")
     if code < 0:
         raise ValueError(f"{what}: invalid argument (code {code})")
     raise CarelessHipError(f"{what}: HIP error {code}")

@@ -188,13 +188,14 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     __syncthreads();
 
     // ---- accumulators that live across all tiles of this workgroup -----------------------------------------
-    f32x4 wacc[LMAX][2];
+    constexpr int WB = (FB >= 4) ? 2 : 1;     // 16x16 blocks of dW^T a wave accumulates per layer (WgradPlan::BPW)
+    f32x4 wacc[LMAX][WB];
     float bacc[LMAX];
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
         bacc[l] = 0.0f;
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WB; ++b)
 #pragma unroll
             for (int t = 0; t < 4; ++t) wacc[l][b][t] = 0.0f;
     }
@@ -299,28 +300,30 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             if (l < L) {
-                // two output blocks at a time: two independent accumulator chains keep the MFMA pipe at its issue rate
-                // (a single 16x16x4 chain is paced by the 40-cycle dependent latency, not the 32-cycle issue interval)
+                // two output blocks at a time (when the layer has them): two independent accumulator chains keep the MFMA
+                // pipe at its issue rate (one 16x16x4 chain is paced by the 40-cycle dependent latency, not the 32-cycle issue)
+                constexpr int MBS = (FB >= 2) ? 2 : 1;
 #pragma unroll
-                for (int mb = 0; mb < FB; mb += 2) {
+                for (int mb = 0; mb < FB; mb += MBS) {
+                    constexpr int MB1 = MBS - 1;           // offset of the second block of the pair (0: no second block)
                     f32x4 acc0 = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * mb + 4 * q);         // bias
-                    f32x4 acc1 = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * (mb + 1) + 4 * q);
+                    f32x4 acc1 = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * (mb + MB1) + 4 * q);
                     if (l == 0) {
 #pragma unroll
                         for (int t = 0; t < KS1; ++t) {
                             acc0 = mfma4(sW1[(16 * mb + j) * PW1 + 4 * t + q], h0[t], acc0);
-                            acc1 = mfma4(sW1[(16 * (mb + 1) + j) * PW1 + 4 * t + q], h0[t], acc1);
+                            if (MBS == 2) acc1 = mfma4(sW1[(16 * (mb + MB1) + j) * PW1 + 4 * t + q], h0[t], acc1);
                         }
                     } else {
                         const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
 #pragma unroll
                         for (int kb = 0; kb < FB; ++kb) {
                             const f32x4 a40 = *reinterpret_cast<const f32x4*>(Wl + (16 * mb + j) * PW + 16 * kb + 4 * q);
-                            const f32x4 a41 = *reinterpret_cast<const f32x4*>(Wl + (16 * (mb + 1) + j) * PW + 16 * kb + 4 * q);
+                            const f32x4 a41 = *reinterpret_cast<const f32x4*>(Wl + (16 * (mb + MB1) + j) * PW + 16 * kb + 4 * q);
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 acc0 = mfma4(a40[t], hs[l > 0 ? l - 1 : 0][kb][t], acc0);
-                                acc1 = mfma4(a41[t], hs[l > 0 ? l - 1 : 0][kb][t], acc1);
+                                if (MBS == 2) acc1 = mfma4(a41[t], hs[l > 0 ? l - 1 : 0][kb][t], acc1);
                             }
                         }
                     }
@@ -328,7 +331,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         hs[l][mb][t] = fmaxf(acc0[t], leak * acc0[t]);
-                        hs[l][mb + 1][t] = fmaxf(acc1[t], leak * acc1[t]);
+                        if (MBS == 2) hs[l][mb + MB1][t] = fmaxf(acc1[t], leak * acc1[t]);
                     }
                 }
                 if (l == L - 1) {
@@ -522,8 +525,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 f32x4 dn[FB];
                 if (l > 0) {
                     const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
+                    constexpr int MBS = (FB >= 2) ? 2 : 1;
 #pragma unroll
-                    for (int mb = 0; mb < FB; mb += 2) {
+                    for (int mb = 0; mb < FB; mb += MBS) {
+                        constexpr int MB1 = MBS - 1;
                         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                         for (int kb = 0; kb < FB; ++kb)
@@ -531,10 +536,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             for (int t = 0; t < 4; ++t) {
                                 const float* wr = Wl + (16 * kb + 4 * q + t) * PW + j;
                                 acc0 = mfma4(wr[16 * mb], dH[kb][t], acc0);
-                                acc1 = mfma4(wr[16 * (mb + 1)], dH[kb][t], acc1);
+                                if (MBS == 2) acc1 = mfma4(wr[16 * (mb + MB1)], dH[kb][t], acc1);
                             }
                         dn[mb] = acc0;
-                        dn[mb + 1] = acc1;
+                        if (MBS == 2) dn[mb + MB1] = acc1;
                         CL_PIN();
                     }
                 }
@@ -550,7 +555,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const int ob = (grp * WG::BPW) / IB1, ib0 = (grp * WG::BPW) - ob * IB1;
                     const float* pa = sZ + (16 * ob + j) * PB + kp * WG::KLEN + 4 * q;
                     const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
-                    f32x4 acc0 = wacc[l][0], acc1 = wacc[l][1];
+                    static_assert(WG::BPW <= WB, "accumulator blocks");
+                    f32x4 acc0 = wacc[l][0], acc1 = wacc[l][WB - 1];
 #pragma unroll 4
                     for (int g = 0; g < WG::KLEN / 16; ++g) {
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + 16 * g);
@@ -563,14 +569,16 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             for (int t = 0; t < 4; ++t) acc1 = mfma4(a4[t], c4[t], acc1);
                         }
                     }
-                    wacc[l][0] = acc0; wacc[l][1] = acc1;
+                    wacc[l][0] = acc0;
+                    if (WG::BPW == 2) wacc[l][WB - 1] = acc1;
                 } else {
                     using WG = WgradPlan<FB, FB>;
                     const int grp = wv % WG::GROUPS, kp = wv / WG::GROUPS;
                     const int ob = (grp * WG::BPW) / FB, ib0 = (grp * WG::BPW) - ob * FB;
                     const float* pa = sZ + (16 * ob + j) * PB + kp * WG::KLEN + 4 * q;
                     const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
-                    f32x4 acc0 = wacc[l][0], acc1 = wacc[l][1];
+                    static_assert(WG::BPW <= WB, "accumulator blocks");
+                    f32x4 acc0 = wacc[l][0], acc1 = wacc[l][WB - 1];
 #pragma unroll 4
                     for (int g = 0; g < WG::KLEN / 16; ++g) {
                         const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + 16 * g);
@@ -583,7 +591,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             for (int t = 0; t < 4; ++t) acc1 = mfma4(a4[t], c4[t], acc1);
                         }
                     }
-                    wacc[l][0] = acc0; wacc[l][1] = acc1;
+                    wacc[l][0] = acc0;
+                    if (WG::BPW == 2) wacc[l][WB - 1] = acc1;
                 }
                 STAMP(9);
                 if (l > 0) {
@@ -631,7 +640,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const int offW = (l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w));
                     const int offB = offW + w * in_dim;
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
+                    for (int b = 0; b < WB; ++b) {
                         if (b < BPW) {
                             const int i = 16 * (ib0 + b) + j;
 #pragma unroll
@@ -702,20 +711,24 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// Instantiated geometries: the padded width WP fixes how many layers of activations + weight-gradient blocks fit in the
+// 256-register budget of a wave: w <= 16 -> up to 20 layers (the CLI default scaler is 20 x 10), w <= 32 -> 10, w <= 64 -> 5.
+template <int WP, int LMAX, int MODE>
+static int launch_dp(const cl_mlp_args& a, int grid, hipStream_t st) {
+    if (a.L > LMAX) return -2;
+    const int dp = (a.d <= 8) ? 8 : (a.d <= 32 ? 32 : 64);
+    if (dp == 8) return launch_one<WP, 8, LMAX, MODE>(a, grid, st);
+    if (dp == 32) return launch_one<WP, 32, LMAX, MODE>(a, grid, st);
+    return launch_one<WP, 64, LMAX, MODE>(a, grid, st);
+}
+
 template <int MODE>
 static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
-    if (a.L < 1 || a.L > CL_MLP_LMAX || a.w < 1 || a.d < 1) return -2;
+    if (a.L < 1 || a.w < 1 || a.d < 1) return -2;
     if (a.w > 64 || a.d > 64) return -2;
-    const int wp = (a.w <= 32) ? 32 : 64;
-    const int dp = (a.d <= 8) ? 8 : (a.d <= 32 ? 32 : 64);
-    if (wp == 32) {
-        if (dp == 8) return launch_one<32, 8, CL_MLP_LMAX, MODE>(a, grid, st);
-        if (dp == 32) return launch_one<32, 32, CL_MLP_LMAX, MODE>(a, grid, st);
-        return launch_one<32, 64, CL_MLP_LMAX, MODE>(a, grid, st);
-    }
-    if (dp == 8) return launch_one<64, 8, CL_MLP_LMAX, MODE>(a, grid, st);
-    if (dp == 32) return launch_one<64, 32, CL_MLP_LMAX, MODE>(a, grid, st);
-    return launch_one<64, 64, CL_MLP_LMAX, MODE>(a, grid, st);
+    if (a.w <= 16) return launch_dp<16, CL_MLP_LMAX_W16, MODE>(a, grid, st);
+    if (a.w <= 32) return (a.L <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
+    return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }
 
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {

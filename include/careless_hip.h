@@ -35,7 +35,10 @@ extern "C" {
 #endif
 
 #define CL_MLP_TILE 128   /* observations per workgroup tile */
-#define CL_MLP_LMAX 5     /* deepest scaler of the fused kernel */
+/* deepest scaler the fused kernel is instantiated for, by hidden width (cl_mlp_max_layers) */
+#define CL_MLP_LMAX_W16 20 /* width <= 16 (the careless CLI default is 20 layers x width 10) */
+#define CL_MLP_LMAX_W32 10 /* width <= 32 */
+#define CL_MLP_LMAX_W64 5  /* width <= 64 */
 #define CL_HIST_STRIDE 8  /* doubles per history record: loss, F KLDiv, NLL, Grad Norm, skipped, 3 spare */
 
 /* indices into the double-precision scalar block of one step */
@@ -121,6 +124,7 @@ enum { CL_BIJ_EXP_ = 0, CL_BIJ_SOFTPLUS_ = 1 };
 
 int cl_mlp_default_grid(void);                       /* workgroups of a persistent launch = CUs of the current device */
 size_t cl_mlp_param_count(int d, int w, int L);      /* P */
+int cl_mlp_max_layers(int w);                        /* deepest supported scaler of hidden width w (0: width unsupported) */
 int cl_mlp_meta_rows(int d);                         /* rows of meta_t: d rounded up to a multiple of 4 (one MFMA k-step) */
 int cl_elbo_mono_fwd_bwd(const cl_mlp_args* args, int grid, void* stream);
 int cl_mlp_forward(const cl_mlp_args* args, int grid, void* stream);

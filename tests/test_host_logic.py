@@ -56,7 +56,10 @@ def test_flat_layout_matches_scaler_and_library():
     assert lay.seg_off[0] == 0 and lay.seg_off[-1] == lay.n and len(lay.seg_owner) == len(lay.seg_off) - 1
     assert lay.seg_owner[:2] == ["q", "q"] and set(lay.seg_owner[2:]) == {"scaler"}
     assert np.all(np.diff(lay.seg_off) > 0)
-    assert int(_lib.get_lib().cl_mlp_param_count(21, 64, 5)) == lay.P
+    lib = _lib.get_lib()
+    assert int(lib.cl_mlp_param_count(21, 64, 5)) == lay.P
+    assert [int(lib.cl_mlp_max_layers(w)) for w in (10, 16, 17, 32, 33, 64, 65)] == [20, 20, 10, 10, 5, 5, 0]
+    assert [int(lib.cl_mlp_meta_rows(d)) for d in (1, 4, 5, 21, 64)] == [4, 4, 8, 24, 64]
 
 
 def test_shards_partition_observations_and_reflections():
