@@ -114,6 +114,53 @@ def make_layout(R: int, d: int, w: int, L: int, n_img: int) -> FlatLayout:
 
 
 # ------------------------------------------------------------------------------------------------------------
+# device image of one set of observations (the training shard, or a validation set)
+# ------------------------------------------------------------------------------------------------------------
+class ObsData:
+    """refl_id / image_id int32 [N], meta_t fp32 [rows][n_pad], iobs / sig fp32 [N], optional harmonic_id + Laue work
+    buffers, and the per-launch workspace of the fused kernel (grid, gradient partials)."""
+
+    def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None):
+        refl_id = _np(BaseModel.get_refl_id(inputs)).reshape(-1).astype(np.int64)
+        image_id = _np(BaseModel.get_image_id(inputs)).reshape(-1).astype(np.int64)
+        metadata = _np(BaseModel.get_metadata(inputs)).astype(np.float32).reshape(len(refl_id), -1)
+        iobs = _np(BaseModel.get_intensities(inputs)).reshape(-1).astype(np.float32)
+        sig = _np(BaseModel.get_uncertainties(inputs)).reshape(-1).astype(np.float32)
+        self.N_total = int(len(refl_id))
+        stop = self.N_total if stop is None else stop
+        sl = slice(start, stop)
+        self.start, self.N = int(start), int(stop - start)
+        if self.N <= 0:
+            raise ValueError("empty observation shard")
+        if n_refl is not None and refl_id.size and (refl_id.min() < 0 or refl_id.max() >= n_refl):
+            raise ValueError("refl_id outside the range of the surrogate posterior")
+        if n_images is not None and image_id.size and image_id.max() >= n_images:
+            raise ValueError("image_id exceeds ImageScaler.max_images")
+        self.d = int(metadata.shape[1])
+        self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
+        meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
+        meta_t[: self.d, : self.N] = metadata[sl].T
+        self.refl_id = torch.as_tensor(refl_id[sl].astype(np.int32), device=device)
+        self.image_id = torch.as_tensor(image_id[sl].astype(np.int32), device=device)
+        self.meta_t = torch.as_tensor(meta_t, device=device)
+        self.iobs = torch.as_tensor(np.ascontiguousarray(iobs[sl]), device=device)
+        self.sig = torch.as_tensor(np.ascontiguousarray(sig[sl]), device=device)
+        self.laue = BaseModel.is_laue(inputs)
+        if self.laue:
+            hid = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1).astype(np.int64)
+            if hid.size and (hid.min() < 0 or hid.max() >= self.N_total):
+                raise ValueError("harmonic_id outside [0, N)")
+            self.harmonic_id = torch.as_tensor(hid[sl].astype(np.int32), device=device)
+            self.laue_loc = torch.empty(self.N, dtype=torch.float32, device=device)
+            self.laue_sig = torch.empty(self.N, dtype=torch.float32, device=device)
+            self.laue_iconv = torch.empty(self.N * S, dtype=torch.float32, device=device)
+            self.laue_dO = torch.empty(self.N * 2, dtype=torch.float32, device=device)
+        g = int(grid) if grid is not None else max(1, int(lib.cl_mlp_default_grid()))
+        self.grid = min(g, self.n_pad // TILE)
+        self.partials = torch.empty(self.grid * P, dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------------------------------------------------
 # the engine
 # ------------------------------------------------------------------------------------------------------------
 class ElboEngine:
@@ -154,38 +201,13 @@ class ElboEngine:
             raise NotImplementedError("scale_prior is never enabled by the reference CLI and is not supported")
         self.q, self.prior, self.lik, self.mlp, self.img = q, prior, lik, mlp, img
 
-        # ---- observations -> device layout -------------------------------------------------------------
-        refl_id = _np(BaseModel.get_refl_id(inputs)).reshape(-1).astype(np.int64)
-        image_id = _np(BaseModel.get_image_id(inputs)).reshape(-1).astype(np.int64)
-        metadata = _np(BaseModel.get_metadata(inputs)).astype(np.float32)
-        metadata = metadata.reshape(len(refl_id), -1)
-        iobs = _np(BaseModel.get_intensities(inputs)).reshape(-1).astype(np.float32)
-        sig = _np(BaseModel.get_uncertainties(inputs)).reshape(-1).astype(np.float32)
-        self.N_total = int(len(refl_id))
+        # ---- observations -> device layout (built after the layout is known, below) ---------------------------
         self.R = int(q.loc_raw.numel())
-        if refl_id.size and (refl_id.min() < 0 or refl_id.max() >= self.R):
-            raise ValueError("refl_id outside the range of the surrogate posterior")
+        self.N_total = int(_np(BaseModel.get_refl_id(inputs)).reshape(-1).shape[0])
+        self.d = int(_np(BaseModel.get_metadata(inputs)).reshape(self.N_total, -1).shape[1])
         self.shard = shard if shard is not None else make_shard(self.N_total, self.R)
         if self.laue and self.shard.world > 1:
             raise NotImplementedError("data-parallel Laue runs need a shard-by-harmonic-group split, not supported yet")
-        sl = slice(self.shard.start, self.shard.stop)
-        self.N = int(self.shard.stop - self.shard.start)
-        if self.N <= 0:
-            raise ValueError("empty observation shard")
-        self.d = int(metadata.shape[1])
-        self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
-        meta_t = np.zeros((int(self.lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
-        meta_t[: self.d, : self.N] = metadata[sl].T
-        self.refl_id = torch.as_tensor(refl_id[sl].astype(np.int32), device=dev)
-        self.image_id = torch.as_tensor(image_id[sl].astype(np.int32), device=dev)
-        self.meta_t = torch.as_tensor(meta_t, device=dev)
-        self.iobs = torch.as_tensor(np.ascontiguousarray(iobs[sl]), device=dev)
-        self.sig = torch.as_tensor(np.ascontiguousarray(sig[sl]), device=dev)
-        if self.laue:
-            hid = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1).astype(np.int64)
-            if hid.size and (hid.min() < 0 or hid.max() >= self.N_total):
-                raise ValueError("harmonic_id outside [0, N)")
-            self.harmonic_id = torch.as_tensor(hid[sl].astype(np.int32), device=dev)
 
         # ---- per-reflection constants ----------------------------------------------------------------
         self.low = q.low.to(dev, torch.float32).contiguous()
@@ -206,8 +228,6 @@ class ElboEngine:
         self.w, self.L = mlp.width, mlp.n_layers
         n_img = 0
         if img is not None:
-            if image_id.size and image_id.max() >= img.max_images:
-                raise ValueError("image_id exceeds ImageScaler.max_images")
             n_img = img.max_images - 1
         self.layout = make_layout(self.R, self.d, self.w, self.L, n_img)
         lay = self.layout
@@ -233,8 +253,8 @@ class ElboEngine:
         self.S = int(model.mc_sample_size)
         if self.S < 1:
             raise ValueError("mc_sample_size must be >= 1")
-        self.grid = int(grid) if grid is not None else max(1, int(self.lib.cl_mlp_default_grid()))
-        self.grid = min(self.grid, self.n_pad // TILE)
+        self.obs = ObsData(self.lib, inputs, self.shard.start, self.shard.stop, self.S, lay.P, dev, grid=grid, n_refl=self.R,
+                           n_images=(img.max_images if img is not None else None))
         RS = self.R * self.S
         o_dz = 0
         o_g = (RS + 3) // 4 * 4
@@ -248,17 +268,22 @@ class ElboEngine:
         self.scalars = self.ws[o_sc:o_sc + 8].view(torch.float64)
         self.seg_sq = self.ws[o_seg:o_seg + 2 * self.nseg].view(torch.float64)
         self.z_f = torch.empty(RS, dtype=torch.float32, device=dev)
-        self.partials = torch.empty(self.grid * lay.P, dtype=torch.float32, device=dev)
         self.stop_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        if self.laue:
-            self.laue_loc = torch.empty(self.N, dtype=torch.float32, device=dev)
-            self.laue_sig = torch.empty(self.N, dtype=torch.float32, device=dev)
-            self.laue_iconv = torch.empty(self.N * self.S, dtype=torch.float32, device=dev)
-            self.laue_dO = torch.empty(self.N * 2, dtype=torch.float32, device=dev)
         self.frozen = torch.zeros(self.nseg, dtype=torch.uint8, device=dev)
         self.history_buf: Optional[torch.Tensor] = None
         self._keep = None
         self.refresh_config()
+
+    # the training shard's arrays under their old names
+    N = property(lambda self: self.obs.N)
+    n_pad = property(lambda self: self.obs.n_pad)
+    grid = property(lambda self: self.obs.grid)
+    refl_id = property(lambda self: self.obs.refl_id)
+    image_id = property(lambda self: self.obs.image_id)
+    meta_t = property(lambda self: self.obs.meta_t)
+    iobs = property(lambda self: self.obs.iobs)
+    sig = property(lambda self: self.obs.sig)
+    partials = property(lambda self: self.obs.partials)
 
     # ------------------------------------------------------------------------------------------------------
     def refresh_config(self):
@@ -311,13 +336,14 @@ class ElboEngine:
             a.dz_f_out = ptr(self.dz_f)
         return a
 
-    def _mlp_args(self, step: int, eta, ipred_out=None) -> MlpArgs:
+    def _mlp_args(self, step: int, eta, ipred_out=None, obs: Optional[ObsData] = None) -> MlpArgs:
         lay = self.layout
+        obs = self.obs if obs is None else obs
         a = MlpArgs()
-        a.refl_id = ptr(self.refl_id); a.image_id = ptr(self.image_id); a.meta_t = ptr(self.meta_t)
-        a.iobs = ptr(self.iobs); a.sig = ptr(self.sig)
-        a.n_obs, a.n_pad = self.N, self.n_pad
-        a.obs_offset = self.shard.start
+        a.refl_id = ptr(obs.refl_id); a.image_id = ptr(obs.image_id); a.meta_t = ptr(obs.meta_t)
+        a.iobs = ptr(obs.iobs); a.sig = ptr(obs.sig)
+        a.n_obs, a.n_pad = obs.N, obs.n_pad
+        a.obs_offset = obs.start
         a.mlp = self.params.data_ptr() + 4 * lay.off_mlp
         a.d, a.w, a.L = self.d, self.w, self.L
         a.leak = self.mlp.leakiness
@@ -333,7 +359,7 @@ class ElboEngine:
         a.seed, a.step = self.seed, step & 0xFFFFFFFF
         a.dz_f = ptr(self.dz_f)
         a.d_img = (self.grads.data_ptr() + 4 * lay.off_img) if lay.n_img > 0 else None
-        a.partials = ptr(self.partials)
+        a.partials = ptr(obs.partials)
         a.scalars = ptr(self.scalars)
         a.ipred_out = ptr(ipred_out)
         a.stop_flag = ptr(self.stop_flag)
@@ -359,43 +385,69 @@ class ElboEngine:
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
         if self.double_wilson:
             check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")
-        ma = self._mlp_args(step, eta, ipred_out)
-        if self.laue:
-            self._laue_passes(ma, step, eta, ipred_out, st)
-        else:
-            check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), self.grid, st), "cl_elbo_mono_fwd_bwd")
-        lay = self.layout
-        check(lib.cl_reduce_partials(ptr(self.partials), self.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
-                                     ptr(self.stop_flag), st), "cl_reduce_partials")
+        self._data_term(self.obs, step, eta, ipred_out, st)
         check(lib.cl_tn_backward(C.byref(tn), st), "cl_tn_backward")
         if self.shard.world > 1 or getattr(self, "force_allreduce", False):
             self._allreduce()
         self._keep = (u_f, eta, ipred_out)
 
-    def _laue_passes(self, ma: MlpArgs, step: int, eta, ipred_out, st):
+    def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st):
+        """NLL of `obs` into scalars[NLL] and its gradient into dz_f / the flat gradient (scaler + image scales)."""
+        lib, lay = self.lib, self.layout
+        ma = self._mlp_args(step, eta, ipred_out, obs)
+        if self.laue:
+            self._laue_passes(ma, obs, step, eta, ipred_out, st)
+        else:
+            check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
+        check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
+                                     ptr(self.stop_flag), st), "cl_reduce_partials")
+
+    def evaluate_nll(self, obs: ObsData, key: int) -> float:
+        """NLL of another observation set under the current parameters with fresh Monte-Carlo noise -- what
+        `model.test_on_batch(validation_data)` reports as "NLL" (reference variational.py:257-260).  Uses the step workspace
+        (call it between steps); synchronises."""
+        lib, st = self.lib, _stream()
+        self.ws.zero_()
+        tn = self._tn_args(key, None)
+        check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
+        self._data_term(obs, key, None, None, st)
+        torch.cuda.synchronize()
+        return float(self.scalars[0].item())
+
+    def make_obs(self, inputs) -> ObsData:
+        """Device image of another observation set (validation data) for `evaluate_nll`."""
+        if BaseModel.is_laue(inputs) != self.laue:
+            raise ValueError("validation data and training data differ in kind (mono / Laue)")
+        o = ObsData(self.lib, inputs, 0, None, self.S, self.layout.P, self.device, n_refl=self.R,
+                    n_images=(self.img.max_images if self.img is not None else None))
+        if o.d != self.d:
+            raise ValueError("validation metadata width differs from the training data")
+        return o
+
+    def _laue_passes(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
         """Harmonic deconvolution (reference likelihoods/laue.py:9-47): scaler forward, predict + group sums, likelihood on
         the slots, gradient broadcast back to the rows, scaler backward from dL/d(loc, sigma)."""
         lib = self.lib
-        ma.loc_out, ma.sig_out = ptr(self.laue_loc), ptr(self.laue_sig)
-        check(lib.cl_mlp_forward(C.byref(ma), self.grid, st), "cl_mlp_forward")
-        self.laue_iconv.zero_()
+        ma.loc_out, ma.sig_out = ptr(obs.laue_loc), ptr(obs.laue_sig)
+        check(lib.cl_mlp_forward(C.byref(ma), obs.grid, st), "cl_mlp_forward")
+        obs.laue_iconv.zero_()
         la = LaueArgs()
-        la.refl_id, la.image_id, la.harmonic_id = ptr(self.refl_id), ptr(self.image_id), ptr(self.harmonic_id)
-        la.loc, la.sigma, la.iobs, la.sig = ptr(self.laue_loc), ptr(self.laue_sig), ptr(self.iobs), ptr(self.sig)
-        la.n_obs, la.obs_offset = self.N, self.shard.start
+        la.refl_id, la.image_id, la.harmonic_id = ptr(obs.refl_id), ptr(obs.image_id), ptr(obs.harmonic_id)
+        la.loc, la.sigma, la.iobs, la.sig = ptr(obs.laue_loc), ptr(obs.laue_sig), ptr(obs.iobs), ptr(obs.sig)
+        la.n_obs, la.obs_offset = obs.N, obs.start
         la.img, la.use_img = ma.img, ma.use_img
         la.z_f, la.R, la.S = ptr(self.z_f), self.R, self.S
         la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
         la.shift, la.w_ll = ma.shift, self.w_ll
         la.eta = ptr(eta)
         la.seed, la.step = self.seed, step & 0xFFFFFFFF
-        la.iconv, la.dz_f, la.d_img, la.dO = ptr(self.laue_iconv), ptr(self.dz_f), ma.d_img, ptr(self.laue_dO)
+        la.iconv, la.dz_f, la.d_img, la.dO = ptr(obs.laue_iconv), ptr(self.dz_f), ma.d_img, ptr(obs.laue_dO)
         la.scalars, la.ipred_out, la.stop_flag = ptr(self.scalars), ptr(ipred_out), ptr(self.stop_flag)
         check(lib.cl_laue_predict(C.byref(la), st), "cl_laue_predict")
         check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
         check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")
-        ma.dO_ext = ptr(self.laue_dO)
-        check(lib.cl_mlp_backward_ext(C.byref(ma), self.grid, st), "cl_mlp_backward_ext")
+        ma.dO_ext = ptr(obs.laue_dO)
+        check(lib.cl_mlp_backward_ext(C.byref(ma), obs.grid, st), "cl_mlp_backward_ext")
 
     def _allreduce(self):
         from careless_amd.distributed import allreduce_flat_

@@ -86,10 +86,12 @@ class VariationalMergingModel(BaseModel):
 
         `noise`: optional callable step -> (u_f (S,R), eta (S,N)) injecting the Monte-Carlo noise (parity tests);
         by default the kernels draw it with the counter-based generator keyed by (seed, iteration)."""
-        if validation_data is not None:
-            raise NotImplementedError("validation_data (NLL_val) is not supported by the HIP engine yet")
         eng = self.engine(data)
         eng.alloc_history(steps)
+        val_obs, val_scale, nll_val, val_hist = None, 1.0, float("nan"), []
+        if validation_data is not None:                       # reference variational.py:248-249, 257-260
+            val_obs = eng.make_obs(validation_data)
+            val_scale = eng.N_total / val_obs.N_total
         bar = None
         if progress:
             try:
@@ -105,6 +107,10 @@ class VariationalMergingModel(BaseModel):
                 u_f, eta = noise(i)
                 u_f, eta = eng._noise_to_device(u_f, eta)
             eng.train_step(i, u_f, eta)
+            if val_obs is not None:
+                if i % validation_frequency == 0:             # the stale value is re-logged in between (:257-260)
+                    nll_val = val_scale * eng.evaluate_nll(val_obs, (eng.t & 0x3FFFFFFF) | 0x40000000)
+                val_hist.append(nll_val)
             done = i + 1
             if bar is not None:
                 bar.update(1)
@@ -113,6 +119,8 @@ class VariationalMergingModel(BaseModel):
         if bar is not None:
             bar.close()
         history = eng.read_history(done)
+        if val_obs is not None:
+            history["NLL_val"] = val_hist[: len(history["loss"])]
         if len(history["loss"]) < done or (len(history["Grad Norm"]) and not np.isfinite(history["Grad Norm"][-1])):
             print("Encountered numerical issues, terminating optimization early!")
         return history
