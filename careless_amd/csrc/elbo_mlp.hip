@@ -678,14 +678,28 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 // ---------------------------------------------------------------------------------------------------------
 // sum of the per-workgroup partials in a fixed order -> MLP slice of the flat gradient buffer
 // ---------------------------------------------------------------------------------------------------------
-__global__ void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int P, float* __restrict__ out,
-                                       const int* stop_flag) {
+// block = 32 consecutive elements x 8 chunks of the partial list; a thread sums its chunk (coalesced 128-B rows), the 8 chunk
+// sums are combined through LDS in chunk order => the result does not depend on scheduling
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int P,
+                                                               float* __restrict__ out, const int* stop_flag) {
     if (stop_flag != nullptr && *stop_flag != 0) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    __shared__ float sh[8][33];
+    const int e = threadIdx.x & 31, c = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
+    const int per = (nparts + 7) / 8;
     float s = 0.0f;
-    for (int g = 0; g < nparts; ++g) s += partials[(size_t)g * P + i];
-    out[i] += s;
+    if (i < P) {
+        const int g1 = min(nparts, (c + 1) * per);
+        for (int g = c * per; g < g1; ++g) s += partials[(size_t)g * P + i];
+    }
+    sh[c][e] = s;
+    __syncthreads();
+    if (c == 0 && i < P) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][e];
+        out[i] += t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -746,6 +760,6 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
 
 int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st) {
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 255) / 256), dim3(256), 0, st, partials, nparts, P, out, stop_flag);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 31) / 32), dim3(256), 0, st, partials, nparts, P, out, stop_flag);
     return (int)hipGetLastError();
 }
