@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcareless_hip.so")
+LIB_PATH = os.environ.get("CARELESS_HIP_LIB") or os.path.join(_HERE, "lib", "libcareless_hip.so")   # env override: A/B builds
 
 CL_MLP_TILE = 128
 CL_HIST_STRIDE = 8

@@ -45,12 +45,15 @@ CL_HD uint32_t cl_mulhi32(uint32_t a, uint32_t b) {
 #endif
 }
 
-CL_HD cl_u32x4 cl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// `rounds` = 10 is the standard generator; 7 is the smallest count that passes BigCrush (Salmon et al., table 2) and is what the
+// in-kernel scale-noise draw uses (it is on the critical path of the epilogue)
+template <int ROUNDS>
+CL_HD cl_u32x4 cl_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;      // one 32x32->64 multiply each (v_mad_u64_u32)
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
@@ -70,7 +73,7 @@ enum { CL_STREAM_QF = 1, CL_STREAM_SCALE = 2 };
 
 // uniform for the truncated-normal draw of reflection h, MC sample s
 CL_HD float cl_noise_uniform(uint64_t seed, uint32_t step, uint32_t s, uint64_t idx) {
-    const cl_u32x4 r = cl_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_QF << 28), s, step,
+    const cl_u32x4 r = cl_philox4x32<10>((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_QF << 28), s, step,
                                         (uint32_t)seed, (uint32_t)(seed >> 32));
     return cl_u01(r.x);
 }
@@ -95,7 +98,7 @@ CL_HD float cl_fast_rcp(float x) { return 1.0f / x; }
 CL_HD void cl_noise_normal_pair(uint64_t seed, uint32_t step, uint32_t s_even, uint64_t idx, float* n_cos, float* n_sin) {
     // s_even = the sample index of the cosine branch: (s >> 2) even
     const uint32_t key = ((s_even >> 3) << 2) | (s_even & 3u);
-    const cl_u32x4 r = cl_philox4x32_10((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_SCALE << 28), key, step,
+    const cl_u32x4 r = cl_philox4x32<7>((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_SCALE << 28), key, step,
                                         (uint32_t)seed, (uint32_t)(seed >> 32));
     const float u1 = cl_u01(r.x), u2 = cl_u01(r.y);
     const float rad = cl_fast_sqrt(-2.0f * cl_fast_log(u1));

@@ -266,6 +266,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             imgn = (int)__builtin_amdgcn_raw_buffer_load_b32(r_img, (int)lane_obs_eb, soff, 0);
         }
     };
+    const int pf_layer = (L > 1) ? 1 : 0;
     if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -440,9 +441,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 boacc0 += dloc; boacc1 += draw;
             }
         }
-        // next tile's inputs: in flight during the whole backward pass
         STAMP(14);
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 
         // ================= backward =======================================================================
         // tile seam: every wave must be done reading the staging tiles of the previous tile's last wgrad
@@ -484,6 +483,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 STAMP(4);
             }
             if (l < L) {
+                // next tile's inputs: issued two layers before the end of the backward pass -- early enough to cover the HBM
+                // latency, late enough that the registers of the upper layers' activations are free again
+                if (l == pf_layer && tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
                 // dZ_l = dH_l * lrelu'(H_l)   (sign of the post-activation == sign of the pre-activation)
 #pragma unroll
                 for (int mb = 0; mb < FB; ++mb)
