@@ -15,8 +15,8 @@ eng = model.engine(inputs)
 NPH = 16
 dbg = torch.zeros(eng.grid * 8 * NPH, dtype=torch.int64, device=eng.device)
 orig = eng._mlp_args
-def patched(step, eta, ipred_out=None):
-    a = orig(step, eta, ipred_out)
+def patched(step, eta, ipred_out=None, obs=None):
+    a = orig(step, eta, ipred_out, obs)
     a.loc_out = dbg.data_ptr()
     return a
 eng._mlp_args = patched
