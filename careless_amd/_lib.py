@@ -60,6 +60,7 @@ class MlpArgs(C.Structure):
         ("dz_f", _vp), ("d_img", _vp), ("partials", _vp), ("scalars", _vp),
         ("ipred_out", _vp), ("loc_out", _vp), ("sig_out", _vp), ("dO_ext", _vp),
         ("stop_flag", _vp),
+        ("ev11", _vp), ("d_ev11", _vp),
     ]
 
 
@@ -76,6 +77,7 @@ class LaueArgs(C.Structure):
         ("eta", _vp),
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("iconv", _vp), ("dz_f", _vp), ("d_img", _vp), ("dO", _vp), ("scalars", _vp), ("ipred_out", _vp), ("stop_flag", _vp),
+        ("ev11", _vp), ("d_ev11", _vp),
     ]
 
 

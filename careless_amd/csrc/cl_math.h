@@ -345,3 +345,37 @@ CL_HD float cl_dw_log_prob(float z, float z_parent, bool has_parent, float r, bo
     *dzp = has_parent ? dloc * r : 0.0f;
     return lp;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Evans-2011 error model (`Ev11Likelihood`, careless/models/likelihoods/mono.py:39-73): the scale of the likelihood is
+//   sig_c = Sdfac * sqrt(SigIobs^2 + SdB * softplus(ipred) + Sdadd * softplus(ipred)^2),   Sd* = softplus(raw) trainable
+// Returns log p(ipred) and d/d ipred (through the location AND the scale) plus d/d(Sdfac, SdB, Sdadd).
+// ---------------------------------------------------------------------------------------------------------
+struct cl_ev11 { float sdfac, sdb, sdadd; };
+CL_HD float cl_lik_ev11(float ipred, float iobs, float sig, int kind, float dof, float lik_const, cl_ev11 p, float* dll,
+                        float* g_fac, float* g_b, float* g_add) {
+    const float sp = cl_softplus(ipred);
+    const float v = sig * sig + p.sdb * sp + p.sdadd * sp * sp;
+    const float rv = sqrtf(v);
+    const float sc = p.sdfac * rv;
+    const float inv = 1.0f / sc;
+    const float y = (ipred - iobs) * inv;
+    const float y2 = y * y;
+    float ll, dx, dsc;
+    if (kind == CL_LIK_NORMAL) {
+        ll = -0.5f * y2 - 0.5f * CL_LOG_2PI_F - logf(sc);
+        dx = -y * inv;
+        dsc = (y2 - 1.0f) * inv;
+    } else {
+        const float t = (dof + 1.0f) / (dof + y2);
+        ll = -0.5f * (dof + 1.0f) * log1pf(y2 / dof) - logf(sc) + lik_const;
+        dx = -t * y * inv;
+        dsc = (t * y2 - 1.0f) * inv;
+    }
+    const float hrv = 0.5f / rv;
+    *dll = dx + dsc * p.sdfac * (p.sdb + 2.0f * p.sdadd * sp) * hrv * cl_sigmoid(ipred);
+    *g_fac = dsc * rv;
+    *g_b = dsc * p.sdfac * sp * hrv;
+    *g_add = dsc * p.sdfac * sp * sp * hrv;
+    return ll;
+}

@@ -46,10 +46,19 @@ __global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     double nll = 0.0;
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
     if (p < (long long)A.n_obs * A.S) {
         const int g = (int)(p / A.S);
-        float dll;
-        const float ll = cl_lik_log_prob(A.iconv[p], A.iobs[g], A.sig[g], A.lik_kind, A.dof, A.lik_const, &dll);
+        float dll, ll;
+        if (A.ev11 != nullptr) {
+            cl_ev11 ev;
+            ev.sdfac = cl_softplus(A.ev11[0]); ev.sdadd = cl_softplus(A.ev11[1]); ev.sdb = cl_softplus(A.ev11[2]);
+            float gf, gb, ga;
+            ll = cl_lik_ev11(A.iconv[p], A.iobs[g], A.sig[g], A.lik_kind, A.dof, A.lik_const, ev, &dll, &gf, &gb, &ga);
+            g0 = -gf * A.w_ll * cl_sigmoid(A.ev11[0]); g1 = -ga * A.w_ll * cl_sigmoid(A.ev11[1]); g2 = -gb * A.w_ll * cl_sigmoid(A.ev11[2]);
+        } else {
+            ll = cl_lik_log_prob(A.iconv[p], A.iobs[g], A.sig[g], A.lik_kind, A.dof, A.lik_const, &dll);
+        }
         nll = -(double)ll * (double)A.w_ll;
         A.iconv[p] = -dll * A.w_ll;                  // dNLL / d iconv[g][s]
     }
@@ -58,6 +67,11 @@ __global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = nll;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(A.scalars + CL_SC_NLL, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (A.ev11 != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { g0 += __shfl_xor(g0, off); g1 += __shfl_xor(g1, off); g2 += __shfl_xor(g2, off); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(A.d_ev11 + 0, g0); atomicAdd(A.d_ev11 + 1, g1); atomicAdd(A.d_ev11 + 2, g2); }
+    }
 }
 
 __global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A) {

@@ -201,6 +201,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     }
     float woacc0 = 0.0f, woacc1 = 0.0f, boacc0 = 0.0f, boacc1 = 0.0f;
     float nll_acc = 0.0f;
+    // Evans-2011 error model: Sd* = softplus(raw); per-lane gradient accumulators
+    cl_ev11 ev = {1.0f, 0.0f, 0.0f};
+    float ev_g0 = 0.0f, ev_g1 = 0.0f, ev_g2 = 0.0f;
+    const bool use_ev11 = (MODE == 0) && (A.ev11 != nullptr);
+    if (use_ev11) { ev.sdfac = cl_softplus(A.ev11[0]); ev.sdadd = cl_softplus(A.ev11[1]); ev.sdb = cl_softplus(A.ev11[2]); }
 
     const int ntiles = A.n_pad / CL_TILE;
     const int S = A.S;
@@ -398,8 +403,14 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const float zs = aim * tq;
                     const float ipred = zs * zf * zf;
                     if (ipred_t) *ptr_uo(ipred_t, eoff + 4u * s) = ipred;
-                    float dll;
-                    const float ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, A.lik_kind, A.dof, A.lik_const, &dll);
+                    float dll, ll;
+                    if (use_ev11) {
+                        float gf, gb, ga;
+                        ll = cl_lik_ev11(ipred, io, sg, A.lik_kind, A.dof, A.lik_const, ev, &dll, &gf, &gb, &ga);
+                        ev_g0 -= gf * A.w_ll; ev_g1 -= ga * A.w_ll; ev_g2 -= gb * A.w_ll;     // order: Sdfac, Sdadd, SdB
+                    } else {
+                        ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, A.lik_kind, A.dof, A.lik_const, &dll);
+                    }
                     nll_acc -= ll * A.w_ll;
                     const float gi = -dll * A.w_ll;                 // dNLL / d ipred
                     const float dzs = gi * zf * zf;
@@ -674,6 +685,17 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         if (lane == 0) atomicAdd(A.scalars + CL_SC_NLL, (double)v);
+        if (use_ev11) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                ev_g0 += __shfl_xor(ev_g0, off); ev_g1 += __shfl_xor(ev_g1, off); ev_g2 += __shfl_xor(ev_g2, off);
+            }
+            if (lane == 0) {                         // d softplus(raw)/d raw = sigmoid(raw)
+                atomicAdd(A.d_ev11 + 0, ev_g0 * cl_sigmoid(A.ev11[0]));
+                atomicAdd(A.d_ev11 + 1, ev_g1 * cl_sigmoid(A.ev11[1]));
+                atomicAdd(A.d_ev11 + 2, ev_g2 * cl_sigmoid(A.ev11[2]));
+            }
+        }
     }
 }
 

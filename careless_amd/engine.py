@@ -83,10 +83,15 @@ class FlatLayout:
     P: int
     n_img: int                 # M - 1 trainable image scales (0 when image scales are off)
     seg_off: List[int]         # tensor boundaries (Keras trainable-variable granularity) for per-tensor clipnorm
-    seg_owner: List[str]       # "q" | "scaler" per tensor (for --freeze-*)
+    seg_owner: List[str]       # "q" | "scaler" | "likelihood" per tensor (for --freeze-*)
+    n_ev11: int = 0            # 3 with the Evans-2011 error model
 
     @property
     def n(self) -> int:
+        return 2 * self.R + self.P + self.n_img + self.n_ev11
+
+    @property
+    def off_ev11(self) -> int:
         return 2 * self.R + self.P + self.n_img
 
     @property
@@ -98,7 +103,7 @@ class FlatLayout:
         return 2 * self.R + self.P
 
 
-def make_layout(R: int, d: int, w: int, L: int, n_img: int) -> FlatLayout:
+def make_layout(R: int, d: int, w: int, L: int, n_img: int, n_ev11: int = 0) -> FlatLayout:
     seg, owner = [0, R, 2 * R], ["q", "q"]
     off, fan_in = 2 * R, d
     for _ in range(L):
@@ -110,7 +115,9 @@ def make_layout(R: int, d: int, w: int, L: int, n_img: int) -> FlatLayout:
     P = off - 2 * R
     if n_img > 0:
         off += n_img; seg.append(off); owner.append("scaler")
-    return FlatLayout(R, P, n_img, seg, owner)
+    for _ in range(n_ev11):              # Sdfac, Sdadd, SdB: three scalar variables (mono.py:42-44)
+        off += 1; seg.append(off); owner.append("likelihood")
+    return FlatLayout(R, P, n_img, seg, owner, n_ev11)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -229,7 +236,8 @@ class ElboEngine:
         n_img = 0
         if img is not None:
             n_img = img.max_images - 1
-        self.layout = make_layout(self.R, self.d, self.w, self.L, n_img)
+        self.ev11 = bool(getattr(lik, "ev11", False))
+        self.layout = make_layout(self.R, self.d, self.w, self.L, n_img, 3 if self.ev11 else 0)
         lay = self.layout
         assert lay.P == mlp.param_count(self.d) == int(self.lib.cl_mlp_param_count(self.d, self.w, self.L))
         self.params = torch.empty(lay.n, dtype=torch.float32, device=dev)
@@ -241,8 +249,11 @@ class ElboEngine:
         q.low = self.low
         mlp.flat = self.params[lay.off_mlp:lay.off_mlp + lay.P]
         if n_img > 0:
-            self.params[lay.off_img:] = img._scales.to(dev)
+            self.params[lay.off_img:lay.off_img + n_img] = img._scales.to(dev)
             img._scales = self.params[lay.off_img:lay.off_img + n_img]
+        if self.ev11:
+            self.params[lay.off_ev11:lay.off_ev11 + 3] = lik.raw.to(dev)
+            lik.raw = self.params[lay.off_ev11:lay.off_ev11 + 3]
         self.adam_m = torch.zeros_like(self.params)
         self.adam_v = torch.zeros_like(self.params)
         self.t = 0                                  # optimizer iterations
@@ -363,6 +374,9 @@ class ElboEngine:
         a.scalars = ptr(self.scalars)
         a.ipred_out = ptr(ipred_out)
         a.stop_flag = ptr(self.stop_flag)
+        if self.ev11:
+            a.ev11 = self.params.data_ptr() + 4 * lay.off_ev11
+            a.d_ev11 = self.grads.data_ptr() + 4 * lay.off_ev11
         return a
 
     def _noise_to_device(self, u_f, eta):
@@ -443,6 +457,7 @@ class ElboEngine:
         la.seed, la.step = self.seed, step & 0xFFFFFFFF
         la.iconv, la.dz_f, la.d_img, la.dO = ptr(obs.laue_iconv), ptr(self.dz_f), ma.d_img, ptr(obs.laue_dO)
         la.scalars, la.ipred_out, la.stop_flag = ptr(self.scalars), ptr(ipred_out), ptr(self.stop_flag)
+        la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
         check(lib.cl_laue_predict(C.byref(la), st), "cl_laue_predict")
         check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
         check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")
@@ -516,6 +531,8 @@ class ElboEngine:
             out.append(g[base + boff: base + boff + o])
         if lay.n_img > 0:
             out.append(g[lay.off_img: lay.off_img + lay.n_img])
+        if lay.n_ev11 > 0:
+            out.append(g[lay.off_ev11: lay.off_ev11 + lay.n_ev11])
         return out
 
 

@@ -69,3 +69,41 @@ class StudentTLikelihood(LaueBase):
     def dist(self, inputs):
         return _BoundLocationScale("studentt", _squeeze(self.get_intensities(inputs)),
                                    _squeeze(self.get_uncertainties(inputs)), dof=self.dof)
+
+
+class _Ev11Laue(LaueBase):
+    """Laue wrapper of the mono Evans-2011 likelihoods (reference laue.py:49-65): the error model sees the convolved prediction."""
+    ev11 = True
+    _mono_cls = None
+
+    def __init__(self, *args):
+        super().__init__()
+        from careless_amd.models.likelihoods import mono as _mono
+        self.mono = getattr(_mono, self._mono_cls)(*args)
+        self.kind, self.dof = self.mono.kind, self.mono.dof
+
+    @property
+    def raw(self):
+        return self.mono.raw
+
+    @raw.setter
+    def raw(self, v):
+        self.mono.raw = v
+
+    @property
+    def trainable_variables(self):
+        return self.mono.trainable_variables
+
+    def dist(self, inputs):
+        return self.mono(inputs)
+
+
+class NormalEv11Likelihood(_Ev11Laue):
+    _mono_cls = "NormalEv11Likelihood"
+
+
+class StudentTEv11Likelihood(_Ev11Laue):
+    _mono_cls = "StudentTEv11Likelihood"
+
+    def __init__(self, dof):
+        super().__init__(dof)

@@ -65,3 +65,60 @@ class StudentTLikelihood(LocationScaleLikelihood):
 
     def call(self, inputs):
         return _BoundLocationScale("studentt", *self.get_loc_and_scale(inputs), dof=self.dof)
+
+
+_SOFTPLUS_INV_ONE = float(np.log(np.e - 1.0))      # softplus(raw) == 1
+
+
+class Ev11Likelihood(LocationScaleLikelihood):
+    """Evans-2011 error model with three learnable scalars Sdfac, Sdadd, SdB (each Softplus-transformed, initial value 1):
+    sigma_c = Sdfac * sqrt(SigIobs^2 + SdB * softplus(ipred) + Sdadd * softplus(ipred)^2)  (reference mono.py:39-59)."""
+    ev11 = True
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        import torch
+        # raw (pre-softplus) values in the reference's variable order: Sdfac, Sdadd, SdB
+        self.raw = torch.full((3,), _SOFTPLUS_INV_ONE, dtype=torch.float32)
+        self.loc = None
+        self.scale = None
+
+    @property
+    def Sdfac(self):
+        return float(np.log1p(np.exp(float(self.raw[0]))))
+
+    @property
+    def Sdadd(self):
+        return float(np.log1p(np.exp(float(self.raw[1]))))
+
+    @property
+    def SdB(self):
+        return float(np.log1p(np.exp(float(self.raw[2]))))
+
+    @property
+    def trainable_variables(self):
+        return [self.raw]
+
+    def call(self, inputs):
+        self.loc, self.scale = self.get_loc_and_scale(inputs)
+        return self
+
+    def corrected_sigiobs(self, ipred):
+        ipred = np.asarray(ipred, dtype=np.float64)
+        sp = np.logaddexp(0.0, ipred)
+        return self.Sdfac * np.sqrt(np.square(self.scale) + self.SdB * sp + self.Sdadd * np.square(sp))
+
+    def log_prob(self, ipred):
+        return _BoundLocationScale(self.kind, self.loc, self.corrected_sigiobs(ipred), dof=self.dof).log_prob(ipred)
+
+
+class NormalEv11Likelihood(Ev11Likelihood):
+    kind = "normal"
+
+
+class StudentTEv11Likelihood(Ev11Likelihood):
+    kind = "studentt"
+
+    def __init__(self, dof, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.dof = dof

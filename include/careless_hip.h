@@ -117,6 +117,9 @@ typedef struct cl_mlp_args {
     float* sig_out;             /* cl_mlp_forward: [n_obs]                     */
     const float* dO_ext;        /* cl_mlp_backward_ext: [n_obs][2] dL/d(loc, sigma) */
     const int* stop_flag;
+    /* Evans-2011 error model (--refine-uncertainties; careless/models/likelihoods/mono.py:39-73): NULL = off */
+    const float* ev11;          /* [3] raw (pre-softplus) Sdfac, Sdadd, SdB                                   */
+    float* d_ev11;              /* [3] += dL/d raw                                                             */
 } cl_mlp_args;
 
 enum { CL_LIK_NORMAL_ = 0, CL_LIK_STUDENTT_ = 1 };
@@ -160,6 +163,8 @@ typedef struct cl_laue_args {
     double* scalars;
     float* ipred_out;           /* optional [n_obs][S]                       */
     const int* stop_flag;
+    const float* ev11;          /* [3] raw Sdfac, Sdadd, SdB or NULL (laue.py:49-65) */
+    float* d_ev11;              /* [3] +=                                     */
 } cl_laue_args;
 
 int cl_laue_predict(const cl_laue_args* args, void* stream);

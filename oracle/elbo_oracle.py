@@ -55,6 +55,7 @@ class ElboConfig:
     high: float = 1e10                  # surrogate_posteriors.py:105
     laue: bool = False                  # len(inputs) >= 8 (models/base.py:39-47)
     prior: str = "wilson"               # "wilson" | "double_wilson"
+    ev11: bool = False                  # --refine-uncertainties: Evans-2011 error model (likelihoods/mono.py:39-73)
     # Adam (manager.py:494-501; args/optimizer.py)
     learning_rate: float = 1e-3
     beta_1: float = 0.9
@@ -333,6 +334,7 @@ class ElboParams:
     mlp_b: List[torch.Tensor]
     img_raw: Optional[torch.Tensor] = None   # (M-1,)
     dw_r_raw: Optional[torch.Tensor] = None  # (n_asu,) pre-sigmoid, only with --optimize-double-wilson-r
+    ev11_raw: Optional[torch.Tensor] = None  # (3,) pre-softplus Sdfac, Sdadd, SdB (mono.py:42-44), only with cfg.ev11
 
     def tensors(self) -> List[torch.Tensor]:
         """Trainable tensors in the flat-buffer order the HIP engine uses."""
@@ -341,6 +343,8 @@ class ElboParams:
             out += [w, b]
         if self.img_raw is not None:
             out.append(self.img_raw)
+        if self.ev11_raw is not None:
+            out.append(self.ev11_raw)
         return out
 
     def clone(self, dtype=None, requires_grad=False) -> "ElboParams":
@@ -352,7 +356,7 @@ class ElboParams:
                 t = t.to(dtype)
             return t.requires_grad_(requires_grad)
         return ElboParams(c(self.q_loc_raw), c(self.q_scale_raw), [c(w) for w in self.mlp_w],
-                          [c(b) for b in self.mlp_b], c(self.img_raw), c(self.dw_r_raw))
+                          [c(b) for b in self.mlp_b], c(self.img_raw), c(self.dw_r_raw), c(self.ev11_raw))
 
 
 @dataclass
@@ -403,10 +407,15 @@ def elbo_forward(p: ElboParams, x: ElboInputs, cfg: ElboConfig, u_f: torch.Tenso
         ipred_l = laue_convolve(ipred, x.harmonic_id)                          # laue.py:33-34
     else:
         ipred_l = ipred
+    sig_l = x.sigiobs[None, :]
+    if cfg.ev11:                                                                # Ev11Likelihood.corrected_sigiobs (mono.py:51-59)
+        sd = torch.nn.functional.softplus(p.ev11_raw)
+        sp = torch.nn.functional.softplus(ipred_l)
+        sig_l = sd[0] * torch.sqrt(x.sigiobs[None, :] ** 2 + sd[2] * sp + sd[1] * sp * sp)
     if cfg.likelihood == "normal":
-        ll = normal_log_prob(ipred_l, x.iobs[None, :], x.sigiobs[None, :])
+        ll = normal_log_prob(ipred_l, x.iobs[None, :], sig_l)
     elif cfg.likelihood == "studentt":
-        ll = studentt_log_prob(ipred_l, float(cfg.dof), x.iobs[None, :], x.sigiobs[None, :])
+        ll = studentt_log_prob(ipred_l, float(cfg.dof), x.iobs[None, :], sig_l)
     else:
         raise ValueError(cfg.likelihood)
 
@@ -568,5 +577,10 @@ def init_params(d: Dict, cfg: ElboConfig, n_layers: int, width: Optional[int], d
     else:
         a32, b32 = a.astype(np.float32), b.astype(np.float32)
     t = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float32)).to(dtype)
+    ev = None
+    if cfg.ev11:                       # TransformedVariable(1., Softplus()) x 3 (mono.py:42-44)
+        ev = np.full(3, math.log(math.e - 1.0), dtype=np.float32)
+        if perturb > 0.0:
+            ev = (ev + perturb * rng.normal(size=3)).astype(np.float32)
     return ElboParams(t(a32), t(b32), [t(w_) for w_ in ws], [t(b_) for b_ in bs],
-                      t(img) if img is not None else None)
+                      t(img) if img is not None else None, None, t(ev) if ev is not None else None)

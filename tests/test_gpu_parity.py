@@ -24,6 +24,9 @@ CASES = {
     "cli_default_20x10_S1": dict(N=500, R=50, d0=5, L=20, w=10, S=1, perturb=0.02),
     "mlp8x24_S2_studentt": dict(N=300, R=30, d0=5, L=8, w=24, S=2, likelihood="studentt", dof=4.0, perturb=0.03),
     "mlp12x16_d21_S3": dict(N=260, R=30, d0=5, posenc=True, L=12, w=16, S=3, perturb=0.02),
+    "ev11_normal_2x32_S3": dict(N=400, R=40, d0=5, L=2, w=32, S=3, ev11=True),
+    "ev11_studentt_5x64_S8": dict(N=500, R=50, d0=5, L=5, w=64, S=8, ev11=True, likelihood="studentt", dof=8.0),
+    "ev11_laue_normal_2x32_S2": dict(N=400, R=40, L=2, w=32, S=2, laue=True, ev11=True),
     "laue_2x32_normal_S3": dict(N=400, R=40, L=2, w=32, S=3, laue=True),
     "laue_5x64_studentt_S2_noimg": dict(N=700, R=64, L=5, w=64, S=2, laue=True, likelihood="studentt", dof=6.0, use_image_scales=False),
     "double_wilson_2x32_S3": dict(N=400, R=60, d0=5, L=2, w=32, S=3, double_wilson=True),

@@ -209,3 +209,43 @@ def test_laue_likelihood_convolve_known_answer():
     assert np.allclose(lk.convolve(np.stack([fake] * 3)), conv[None, :])   # batched (reference :33-36)
     lt = laue.StudentTLikelihood(4.0)(inputs).log_prob(fake)
     assert np.allclose(lt[:G], stats.t.logpdf(data["iobs"][:G], 4.0, data["iobs"][:G], data["sigiobs"][:G]), rtol=1e-5)
+
+
+def test_get_results_matches_scipy_moments():
+    """reference io/manager.py:188-236: F, SigF, I, SigI (with the I/SigI cap), N, q parameters"""
+    from scipy import stats
+    from careless_amd.results import get_results
+    data, cfg, params, x, u_f, eta = util.make_problem(N=120, R=30, S=1)
+    model = util.build_model(data, cfg, params, 2, 32)
+    inputs = util.reference_inputs(data)
+    inputs = (inputs[0].copy(),) + inputs[1:]
+    inputs[0][inputs[0] == 29] = 0                       # make reflection 29 unobserved
+    res = get_results(model.surrogate_posterior, inputs)
+    q = model.surrogate_posterior
+    loc, scale = q.loc.numpy().astype(float), q.scale.numpy().astype(float)
+    a = (q.low.numpy() - loc) / scale
+    assert np.allclose(res["F"], stats.truncnorm.mean(a, np.inf, loc, scale), rtol=1e-5)
+    assert np.allclose(res["SigF"], stats.truncnorm.std(a, np.inf, loc, scale), rtol=1e-4)
+    assert np.allclose(res["I"], res["F"] ** 2 + res["SigF"] ** 2, rtol=1e-6)
+    f4 = stats.truncnorm.moment(4, a, np.inf, loc, scale)
+    expect = np.sqrt(np.maximum((res["I"] * 1e-5) ** 2, f4 - res["I"].astype(float) ** 2))
+    assert np.allclose(res["SigI"], expect, rtol=1e-3)
+    assert res["N"].sum() == 120 and res["N"][29] == 0 and not res["observed"][29] and res["observed"][:29].all()
+    assert set(["high", "loc", "low", "scale"]) <= set(res) and np.allclose(res["loc"], loc, rtol=1e-6)
+    assert np.all(res["high"] == np.float32(1e10))
+
+
+def test_ev11_host_likelihood_matches_scipy():
+    """reference likelihoods/mono.py:39-73: scale = Sdfac sqrt(sig^2 + SdB softplus(x) + Sdadd softplus(x)^2)"""
+    from scipy import stats
+    from careless_amd.models.likelihoods.mono import NormalEv11Likelihood, StudentTEv11Likelihood
+    data = util.make_problem(N=50, R=8)[0]
+    inputs = reference_inputs(data)
+    x = np.asarray(data["iobs"], dtype=np.float64) + 2.0
+    lk = NormalEv11Likelihood()
+    assert abs(lk.Sdfac - 1.0) < 1e-6 and abs(lk.Sdadd - 1.0) < 1e-6 and abs(lk.SdB - 1.0) < 1e-6 and len(lk.trainable_variables) == 1
+    sp = np.logaddexp(0, x)
+    sc = np.sqrt(np.asarray(data["sigiobs"], dtype=np.float64) ** 2 + sp + sp * sp)
+    assert np.allclose(lk(inputs).log_prob(x), stats.norm.logpdf(x, data["iobs"], sc), rtol=1e-5, atol=1e-5)
+    lt = StudentTEv11Likelihood(4.0)
+    assert np.allclose(lt(inputs).log_prob(x), stats.t.logpdf(x, 4.0, data["iobs"], sc), rtol=1e-5, atol=1e-5)

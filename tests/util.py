@@ -9,7 +9,7 @@ from oracle import elbo_oracle as O
 
 def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, likelihood="normal", dof=None,
                  bijector="exp", shift=0.0, use_image_scales=True, kl_weight=None, perturb=0.05, seed=7,
-                 outliers=False, double_wilson=False, laue=False, **opt):
+                 outliers=False, double_wilson=False, laue=False, ev11=False, **opt):
     if laue:
         data = O.make_synthetic_laue(N, R=R, n_images=n_images, seed=seed)
     elif double_wilson:
@@ -19,7 +19,7 @@ def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, li
         data = O.make_synthetic(N, R=R, d0=d0, posenc=posenc, n_images=n_images, seed=seed, outliers=outliers)
     cfg = O.ElboConfig(mc_samples=S, likelihood=likelihood, dof=dof, scale_bijector=bijector, scale_shift=shift,
                        use_image_scales=use_image_scales, kl_weight=kl_weight,
-                       prior="double_wilson" if double_wilson else "wilson", laue=laue, **opt)
+                       prior="double_wilson" if double_wilson else "wilson", laue=laue, ev11=ev11, **opt)
     rng = np.random.default_rng(seed + 1)
     params = O.init_params(data, cfg, L, w, perturb=perturb, rng=rng)
     x = O.inputs_from_numpy(data)
@@ -56,11 +56,13 @@ def build_model(data, cfg: O.ElboConfig, params: O.ElboParams, L, w):
     low = (1e-32 * ~np.asarray(data["centric"], dtype=bool)).astype(np.float32)
     q = TruncatedNormal(params.q_loc_raw.numpy().astype(np.float32), params.q_scale_raw.numpy().astype(np.float32),
                         low, high=cfg.high, scale_shift=cfg.epsilon)
-    if cfg.laue:
-        from careless_amd.models.likelihoods import laue as laue_lik
-        lik = laue_lik.NormalLikelihood() if cfg.likelihood == "normal" else laue_lik.StudentTLikelihood(cfg.dof)
+    from careless_amd.models.likelihoods import laue as laue_lik, mono as mono_lik
+    mod = laue_lik if cfg.laue else mono_lik
+    if cfg.ev11:
+        lik = mod.NormalEv11Likelihood() if cfg.likelihood == "normal" else mod.StudentTEv11Likelihood(cfg.dof)
+        lik.raw = torch.as_tensor(params.ev11_raw.numpy().astype(np.float32))
     else:
-        lik = NormalLikelihood() if cfg.likelihood == "normal" else StudentTLikelihood(cfg.dof)
+        lik = mod.NormalLikelihood() if cfg.likelihood == "normal" else mod.StudentTLikelihood(cfg.dof)
     mlp = MLPScaler(L, w, leakiness=cfg.leakiness, epsilon=cfg.epsilon, scale_bijector=cfg.scale_bijector,
                     scale_multiplier=(cfg.scale_shift if cfg.scale_shift else None))
     d = np.asarray(data["metadata"]).shape[1]
