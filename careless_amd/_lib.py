@@ -77,7 +77,7 @@ class LaueArgs(C.Structure):
         ("eta", _vp),
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("iconv", _vp), ("dz_f", _vp), ("d_img", _vp), ("dO", _vp), ("scalars", _vp), ("ipred_out", _vp), ("stop_flag", _vp),
-        ("ev11", _vp), ("d_ev11", _vp),
+        ("ev11", _vp), ("d_ev11", _vp), ("row_index", _vp),
     ]
 
 
@@ -166,6 +166,9 @@ def check(code: int, what: str) -> None:
         raise NotImplementedError(
             f"{what}: scaler geometry not supported by the fused gfx950 kernel "
             "(needs mlp_width <= 64, metadata width <= 64 and mlp_layers <= 20 / 10 / 5 for width <= 16 / 32 / 64)")
+    if code == -4:
+        raise ValueError(f"{what}: observation shard too large for one launch (metadata image or z_f >= 4 GiB): "
+                         "shard the observations over more GPUs")
     if code < 0:
         raise ValueError(f"{what}: invalid argument (code {code})")
     raise CarelessHipError(f"{what}: HIP error {code}")

@@ -18,7 +18,9 @@
 
 namespace {
 __device__ __forceinline__ float laue_eta(const cl_laue_args& A, int i, int s) {
-    return A.eta ? A.eta[(size_t)i * A.S + s] : cl_noise_normal(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + i));
+    if (A.eta) return A.eta[(size_t)i * A.S + s];
+    const uint64_t gidx = A.row_index ? (uint64_t)A.row_index[i] : (uint64_t)(A.obs_offset + i);
+    return cl_noise_normal(A.seed, A.step, (uint32_t)s, gidx);
 }
 __device__ __forceinline__ double wave_sum_d2(double v) {
 #pragma unroll

@@ -771,6 +771,9 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
 
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.n_pad % CL_TILE != 0 || a.n_pad <= 0) return -1;
+    // 32-bit byte offsets / buffer sizes inside the kernel: metadata image < 4 GiB, z_f < 4 GiB (shard further across GPUs otherwise)
+    const unsigned long long meta_bytes = 4ull * (unsigned long long)((a.d + 3) & ~3) * (unsigned long long)a.n_pad;
+    if (meta_bytes >= (1ull << 32) || 4ull * (unsigned long long)a.R * (unsigned long long)a.S >= (1ull << 32)) return -4;
     const int ntiles = a.n_pad / CL_TILE;
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) return -1;

@@ -74,6 +74,23 @@ def make_shard(n_obs: int, n_refl: int, rank: int = 0, world: int = 1) -> Shard:
     return Shard(rank, world, start, stop, min(rank * rper, n_refl), min((rank + 1) * rper, n_refl))
 
 
+def laue_group_shard(harmonic_id: np.ndarray, rank: int, world: int):
+    """Laue shards must keep every harmonic group on one rank (the invariant the reference enforces for its train/test split,
+    careless/io/manager.py:317-324).  Groups [g0, g1) go to `rank`, balanced by row count; the padded slots [G, N) are dealt out so
+    that every rank has exactly as many slots as rows.  Returns (g0, g1, pad0, pad1)."""
+    hid = np.asarray(harmonic_id).astype(np.int64)
+    N = len(hid)
+    G = int(hid.max()) + 1
+    counts = np.bincount(hid, minlength=G)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    bounds = [int(np.searchsorted(cum, N * r / world, side="left")) for r in range(world)] + [G]
+    bounds = np.clip(bounds, 0, G)
+    g0, g1 = int(bounds[rank]), int(bounds[rank + 1])
+    pads = [int(cum[bounds[r + 1]] - cum[bounds[r]]) - int(bounds[r + 1] - bounds[r]) for r in range(world)]
+    pad0 = G + int(sum(pads[:rank]))
+    return g0, g1, pad0, pad0 + pads[rank]
+
+
 # ------------------------------------------------------------------------------------------------------------
 # layout of the flat parameter vector
 # ------------------------------------------------------------------------------------------------------------
@@ -127,7 +144,8 @@ class ObsData:
     """refl_id / image_id int32 [N], meta_t fp32 [rows][n_pad], iobs / sig fp32 [N], optional harmonic_id + Laue work
     buffers, and the per-launch workspace of the fused kernel (grid, gradient partials)."""
 
-    def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None):
+    def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None,
+                 laue_groups=None):
         refl_id = _np(BaseModel.get_refl_id(inputs)).reshape(-1).astype(np.int64)
         image_id = _np(BaseModel.get_image_id(inputs)).reshape(-1).astype(np.int64)
         metadata = _np(BaseModel.get_metadata(inputs)).astype(np.float32).reshape(len(refl_id), -1)
@@ -135,7 +153,21 @@ class ObsData:
         sig = _np(BaseModel.get_uncertainties(inputs)).reshape(-1).astype(np.float32)
         self.N_total = int(len(refl_id))
         stop = self.N_total if stop is None else stop
-        sl = slice(start, stop)
+        self.laue = BaseModel.is_laue(inputs)
+        self.rows = None                      # explicit row list when the shard is not a contiguous range
+        if self.laue and laue_groups is not None:
+            hid_all = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1).astype(np.int64)
+            g0, g1, pad0, pad1 = laue_groups
+            self.rows = np.nonzero((hid_all >= g0) & (hid_all < g1))[0]
+            sl = self.rows
+            start, stop = 0, len(self.rows)
+            # per-slot arrays of this shard: its own groups first, then its share of the padded slots (formatter.py:637-640)
+            slot_idx = np.concatenate([np.arange(g0, g1), np.arange(pad0, pad1)])
+            assert len(slot_idx) == len(self.rows)
+            iobs_l, sig_l = iobs[slot_idx], sig[slot_idx]
+        else:
+            sl = slice(start, stop)
+            iobs_l, sig_l = iobs[sl], sig[sl]
         self.start, self.N = int(start), int(stop - start)
         if self.N <= 0:
             raise ValueError("empty observation shard")
@@ -150,14 +182,18 @@ class ObsData:
         self.refl_id = torch.as_tensor(refl_id[sl].astype(np.int32), device=device)
         self.image_id = torch.as_tensor(image_id[sl].astype(np.int32), device=device)
         self.meta_t = torch.as_tensor(meta_t, device=device)
-        self.iobs = torch.as_tensor(np.ascontiguousarray(iobs[sl]), device=device)
-        self.sig = torch.as_tensor(np.ascontiguousarray(sig[sl]), device=device)
-        self.laue = BaseModel.is_laue(inputs)
+        self.iobs = torch.as_tensor(np.ascontiguousarray(iobs_l), device=device)
+        self.sig = torch.as_tensor(np.ascontiguousarray(sig_l), device=device)
+        self.row_index = None
         if self.laue:
             hid = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1).astype(np.int64)
             if hid.size and (hid.min() < 0 or hid.max() >= self.N_total):
                 raise ValueError("harmonic_id outside [0, N)")
-            self.harmonic_id = torch.as_tensor(hid[sl].astype(np.int32), device=device)
+            hl = hid[sl]
+            if self.rows is not None:
+                hl = hl - laue_groups[0]
+                self.row_index = torch.as_tensor(self.rows.astype(np.int64), device=device)
+            self.harmonic_id = torch.as_tensor(hl.astype(np.int32), device=device)
             self.laue_loc = torch.empty(self.N, dtype=torch.float32, device=device)
             self.laue_sig = torch.empty(self.N, dtype=torch.float32, device=device)
             self.laue_iconv = torch.empty(self.N * S, dtype=torch.float32, device=device)
@@ -213,8 +249,9 @@ class ElboEngine:
         self.N_total = int(_np(BaseModel.get_refl_id(inputs)).reshape(-1).shape[0])
         self.d = int(_np(BaseModel.get_metadata(inputs)).reshape(self.N_total, -1).shape[1])
         self.shard = shard if shard is not None else make_shard(self.N_total, self.R)
+        self.laue_groups = None
         if self.laue and self.shard.world > 1:
-            raise NotImplementedError("data-parallel Laue runs need a shard-by-harmonic-group split, not supported yet")
+            self.laue_groups = laue_group_shard(_np(BaseModel.get_harmonic_id(inputs)).reshape(-1), self.shard.rank, self.shard.world)
 
         # ---- per-reflection constants ----------------------------------------------------------------
         self.low = q.low.to(dev, torch.float32).contiguous()
@@ -265,7 +302,7 @@ class ElboEngine:
         if self.S < 1:
             raise ValueError("mc_sample_size must be >= 1")
         self.obs = ObsData(self.lib, inputs, self.shard.start, self.shard.stop, self.S, lay.P, dev, grid=grid, n_refl=self.R,
-                           n_images=(img.max_images if img is not None else None))
+                           n_images=(img.max_images if img is not None else None), laue_groups=self.laue_groups)
         RS = self.R * self.S
         o_dz = 0
         o_g = (RS + 3) // 4 * 4
@@ -387,7 +424,10 @@ class ElboEngine:
             du = u.t().contiguous().to(self.device)
         if eta is not None:
             e = torch.as_tensor(_np(eta), dtype=torch.float32).reshape(self.S, self.N_total)
-            de = e[:, self.shard.start:self.shard.stop].t().contiguous().to(self.device)
+            if self.obs.rows is not None:
+                de = e[:, torch.as_tensor(self.obs.rows)].t().contiguous().to(self.device)
+            else:
+                de = e[:, self.shard.start:self.shard.stop].t().contiguous().to(self.device)
         return du, de
 
     # ------------------------------------------------------------------------------------------------------
@@ -401,8 +441,8 @@ class ElboEngine:
             check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")
         self._data_term(self.obs, step, eta, ipred_out, st)
         check(lib.cl_tn_backward(C.byref(tn), st), "cl_tn_backward")
-        if self.shard.world > 1 or getattr(self, "force_allreduce", False):
-            self._allreduce()
+        if (self.shard.world > 1 and not getattr(self, "local_only", False)) or getattr(self, "force_allreduce", False):
+            self._allreduce()        # local_only: a test hook that leaves the per-rank partial gradient in place
         self._keep = (u_f, eta, ipred_out)
 
     def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st):
@@ -458,6 +498,7 @@ class ElboEngine:
         la.iconv, la.dz_f, la.d_img, la.dO = ptr(obs.laue_iconv), ptr(self.dz_f), ma.d_img, ptr(obs.laue_dO)
         la.scalars, la.ipred_out, la.stop_flag = ptr(self.scalars), ptr(ipred_out), ptr(self.stop_flag)
         la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
+        la.row_index = ptr(obs.row_index)
         check(lib.cl_laue_predict(C.byref(la), st), "cl_laue_predict")
         check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
         check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")

@@ -9,7 +9,7 @@
  *   - all pointers are DEVICE pointers (hipMalloc'ed / torch.Tensor.data_ptr()), row-major, contiguous, owned by the
  *     caller and never retained after the call returns;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); every call only enqueues;
- *   - return value: 0 = ok, < 0 = invalid argument (-1 shape, -2 unsupported scaler geometry, -3 LDS budget),
+ *   - return value: 0 = ok, < 0 = invalid argument (-1 shape, -2 unsupported scaler geometry, -3 LDS budget, -4 shard >= 4 GiB),
  *     > 0 = hipError_t from the launch;  nothing throws, nothing allocates persistent device memory;
  *   - no global mutable state besides the loaded code object: calls are re-entrant across streams;
  *   - a NULL noise pointer (u_f / eta) selects the in-kernel counter-based generator keyed by
@@ -165,6 +165,8 @@ typedef struct cl_laue_args {
     const int* stop_flag;
     const float* ev11;          /* [3] raw Sdfac, Sdadd, SdB or NULL (laue.py:49-65) */
     float* d_ev11;              /* [3] +=                                     */
+    const long long* row_index; /* optional [n_obs]: global row number of every local row (noise key) when the shard is not a
+                                   contiguous range (data-parallel Laue keeps harmonic groups on one rank); NULL = obs_offset + i */
 } cl_laue_args;
 
 int cl_laue_predict(const cl_laue_args* args, void* stream);
