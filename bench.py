@@ -29,6 +29,8 @@ def parse():
     ap.add_argument("--nobs", type=int, default=None, help="override the number of observations (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient all-reduce even with one rank")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank "
+                                                      "control flow on a single-GPU box)")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
     return ap.parse_args()
 
@@ -87,7 +89,7 @@ def main():
     import torch.distributed as dist
     from careless_amd.workloads import flops_per_obs, bytes_per_obs, make_workload
 
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     use_dist = world > 1 or args.force_dist
     if use_dist:
         # RCCL writes its NCCL_DEBUG chatter (version banner, warnings) to stdout through C stdio, where it interleaves with
@@ -96,7 +98,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     model, inputs, data, spec = make_workload(args.workload, N=args.nobs)
     if use_dist:
