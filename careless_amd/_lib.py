@@ -91,7 +91,7 @@ class AdamArgs(C.Structure):
         ("clipnorm", C.c_float), ("clipvalue", C.c_float), ("global_clipnorm", C.c_float),
         ("seg_off", _vp),
         ("nseg", C.c_int),
-        ("seg_sq", _vp), ("frozen", _vp), ("scalars", _vp), ("stop_flag", _vp),
+        ("seg_sq", _vp), ("frozen", _vp), ("scalars", _vp), ("stop_flag", _vp), ("norm_out", _vp),
     ]
 
 

@@ -165,9 +165,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const cl_adam_args A) {
         const float nrm = (float)sqrt(A.scalars[CL_SC_GNORM2_SANE]);
         gscale = A.global_clipnorm / fmaxf(nrm, A.global_clipnorm);
     }
+    double acc = 0.0, sane = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += gridDim.x * blockDim.x) {
-        if (A.frozen != nullptr && A.frozen[seg_of(A.seg_off, A.nseg, i)] != 0) continue;
         float g = A.g[i];
+        if (A.norm_out != nullptr) {                                   // fused tf.linalg.global_norm (variational.py:205)
+            const double v2 = (double)g * (double)g;
+            acc += v2;
+            sane += isfinite(g) ? v2 : 0.0;
+        }
+        if (A.frozen != nullptr && A.frozen[seg_of(A.seg_off, A.nseg, i)] != 0) continue;
         if (!isfinite(g)) g = 0.0f;                                   // variational.py:208
         if (A.clipnorm > 0.0f) {                                      // per-tensor tf.clip_by_norm [3P]
             const float nrm = (float)sqrt(A.seg_sq[seg_of(A.seg_off, A.nseg, i)]);
@@ -181,6 +187,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const cl_adam_args A) {
         A.m[i] = m;
         A.v[i] = v;
         A.p[i] -= m * A.alpha / (sqrtf(v) + A.adam_eps);
+    }
+    if (A.norm_out != nullptr) {
+        block_atomic_add_d(acc, A.norm_out + CL_SC_GNORM2);
+        __syncthreads();
+        block_atomic_add_d(sane, A.norm_out + CL_SC_GNORM2_SANE);
     }
 }
 
@@ -247,7 +258,7 @@ int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, d
 int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
     if (a.n <= 0) return -1;
     int grid = (a.n + 255) / 256;
-    if (grid > 2048) grid = 2048;
+    if (grid > 512) grid = 512;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, a);
     return (int)hipGetLastError();

@@ -684,7 +684,15 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         float v = nll_acc;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (lane == 0) atomicAdd(A.scalars + CL_SC_NLL, (double)v);
+        // one fp64 atomic per workgroup (same-address atomics serialise at ~12 ns each): combine the 8 wave sums through LDS
+        __syncthreads();
+        if (lane == 0) smem[wv] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int k = 0; k < CL_NW; ++k) t += (double)smem[k];
+            atomicAdd(A.scalars + CL_SC_NLL, t);
+        }
         if (use_ev11) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {

@@ -514,8 +514,11 @@ class ElboEngine:
         n = self.layout.n
         clipnorm = float(opt.clipnorm or 0.0)
         use_seg = clipnorm > 0.0
-        check(lib.cl_grad_sqnorm(ptr(self.grads), n, ptr(self.seg_off), self.nseg, ptr(self.seg_sq) if use_seg else None,
-                                 ptr(self.scalars), ptr(self.stop_flag), st), "cl_grad_sqnorm")
+        # the clip modes that need the norm BEFORE the update get their own pass; otherwise the norm rides inside the Adam kernel
+        norm_first = use_seg or float(opt.global_clipnorm or 0.0) > 0.0
+        if norm_first:
+            check(lib.cl_grad_sqnorm(ptr(self.grads), n, ptr(self.seg_off), self.nseg, ptr(self.seg_sq) if use_seg else None,
+                                     ptr(self.scalars), ptr(self.stop_flag), st), "cl_grad_sqnorm")
         self.t += 1
         t = self.t
         a = AdamArgs()
@@ -530,6 +533,7 @@ class ElboEngine:
         a.frozen = ptr(self.frozen) if self.any_frozen else None
         a.scalars = ptr(self.scalars)
         a.stop_flag = ptr(self.stop_flag)
+        a.norm_out = None if norm_first else ptr(self.scalars)
         check(lib.cl_adam_step(C.byref(a), st), "cl_adam_step")
         check(lib.cl_step_finalize(ptr(self.scalars), self.kl_mult, ptr(self.history_buf), step_index,
                                    ptr(self.stop_flag), st), "cl_step_finalize")

@@ -188,6 +188,8 @@ typedef struct cl_adam_args {
     const unsigned char* frozen; /* optional [nseg]: 1 = tensor is not trainable (--freeze-*) */
     const double* scalars;
     const int* stop_flag;
+    double* norm_out;           /* optional [CL_SC_COUNT]: also accumulate the squared gradient norm here (replaces a separate
+                                   cl_grad_sqnorm launch when no norm-dependent clipping is configured)                      */
 } cl_adam_args;
 
 int cl_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
