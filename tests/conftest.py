@@ -10,3 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu`)")
+
+
+def pytest_sessionstart(session):
+    """The C-ABI library is a build artefact (git-ignored): build it once if this checkout does not have it yet, so the symbol /
+    ABI tests and the GPU tests do not depend on somebody having run `python -m careless_amd.build` first."""
+    from careless_amd import build as b
+    if b.needs_build():
+        try:
+            b.build(verbose=False)
+        except Exception as e:  # pragma: no cover - no hipcc on this machine
+            print(f"[conftest] could not build libcareless_hip.so: {e}", file=sys.stderr)
