@@ -36,6 +36,7 @@ class TnArgs(C.Structure):
         ("scalars", _vp), ("stop_flag", _vp),
         ("prior_kind", C.c_int),
         ("parent_ids", _vp), ("root", _vp), ("dw_r", _vp), ("dz_f_out", _vp),
+        ("dw_r_raw", _vp), ("asu_ids", _vp), ("d_dw_r_raw", _vp), ("n_asu", C.c_int),
     ]
 
 

@@ -73,7 +73,8 @@ static int check_tn(const cl_tn_args* a) {
     if (a == nullptr || a->q_loc_raw == nullptr || a->q_scale_raw == nullptr || a->low == nullptr ||
         a->centric == nullptr || a->es == nullptr || a->R < 1 || a->S < 1)
         return -1;
-    if (a->prior_kind == CL_PRIOR_DOUBLE_WILSON_ && (a->parent_ids == nullptr || a->root == nullptr || a->dw_r == nullptr)) return -1;
+    if (a->prior_kind == CL_PRIOR_DOUBLE_WILSON_ && (a->parent_ids == nullptr || a->root == nullptr)) return -1;
+    if (a->prior_kind == CL_PRIOR_DOUBLE_WILSON_ && a->dw_r == nullptr && (a->dw_r_raw == nullptr || a->asu_ids == nullptr)) return -1;
     if (a->prior_kind != CL_PRIOR_DOUBLE_WILSON_ && a->prior_kind != CL_PRIOR_WILSON_) return -1;
     return 0;
 }
@@ -92,9 +93,8 @@ int cl_tn_backward(const cl_tn_args* a, void* stream) {
 
 int cl_dw_prior_forward(const cl_tn_args* a, void* stream) {
     if (int e = check_tn(a)) return e;
-    if (a->prior_kind != CL_PRIOR_DOUBLE_WILSON_ || a->parent_ids == nullptr || a->root == nullptr || a->dw_r == nullptr ||
-        a->z_f == nullptr || a->dz_f_out == nullptr || a->scalars == nullptr)
-        return -1;
+    if (a->prior_kind != CL_PRIOR_DOUBLE_WILSON_ || a->z_f == nullptr || a->dz_f_out == nullptr || a->scalars == nullptr) return -1;
+    if (a->dw_r_raw != nullptr && (a->d_dw_r_raw == nullptr || a->n_asu < 1)) return -1;
     return cl_launch_dw_forward(*a, (hipStream_t)stream);
 }
 

@@ -307,8 +307,8 @@ CL_HD void cl_i0e_i1e(float x, float* i0e, float* i1e) {
     }
 }
 
-// Rice(nu, sigma) log-density at x > 0 (distributions.py:278-283) and its derivatives w.r.t. x and nu
-CL_HD float cl_rice_log_prob(float x, float nu, float sigma, float* dx, float* dnu) {
+// Rice(nu, sigma) log-density at x > 0 (distributions.py:278-283) and its derivatives w.r.t. x, nu and sigma
+CL_HD float cl_rice_log_prob(float x, float nu, float sigma, float* dx, float* dnu, float* dsigma) {
     const float is2 = 1.0f / (sigma * sigma);
     const float arg = x * nu * is2;
     float i0e, i1e;
@@ -316,11 +316,12 @@ CL_HD float cl_rice_log_prob(float x, float nu, float sigma, float* dx, float* d
     const float ratio = i1e / i0e;                       // I1/I0
     *dx = 1.0f / x - x * is2 + nu * is2 * ratio;
     *dnu = -nu * is2 + x * is2 * ratio;
+    *dsigma = (-2.0f + (x * x + nu * nu) * is2 - 2.0f * arg * ratio) / sigma;
     return logf(x) - 2.0f * logf(sigma) - 0.5f * (x * x + nu * nu) * is2 + logf(i0e) + fabsf(arg);
 }
 
 // FoldedNormal(loc, scale) log-density at x >= 0 (distributions.py:333-335): log[N(x; loc, scale) + N(-x; loc, scale)]
-CL_HD float cl_folded_normal_log_prob(float x, float loc, float scale, float* dx, float* dloc) {
+CL_HD float cl_folded_normal_log_prob(float x, float loc, float scale, float* dx, float* dloc, float* dscale) {
     const float inv = 1.0f / scale;
     const float ya = (x - loc) * inv, yb = (-x - loc) * inv;
     const float la = -0.5f * ya * ya, lb = -0.5f * yb * yb;
@@ -328,21 +329,24 @@ CL_HD float cl_folded_normal_log_prob(float x, float loc, float scale, float* dx
     const float ea = expf(la - m), eb = expf(lb - m);
     const float den = ea + eb;
     const float wa = ea / den, wb = eb / den;
-    // d la/dx = -ya/scale ; d lb/dx = +yb/scale ; d la/dloc = ya/scale ; d lb/dloc = yb/scale
+    // d la/dx = -ya/scale ; d lb/dx = +yb/scale ; d la/dloc = ya/scale ; d lb/dloc = yb/scale ; d l*/dscale = y*^2/scale
     *dx = (-wa * ya + wb * yb) * inv;
     *dloc = (wa * ya + wb * yb) * inv;
+    *dscale = (wa * ya * ya + wb * yb * yb - 1.0f) * inv;
     return m + logf(den) - 0.5f * CL_LOG_2PI_F - logf(scale);
 }
 
-// conditional prior of a non-root reflection of the double-Wilson model (wilson.py:146-175)
-CL_HD float cl_dw_log_prob(float z, float z_parent, bool has_parent, float r, bool centric, float es, float* dz, float* dzp) {
+// conditional prior of a non-root reflection of the double-Wilson model (wilson.py:146-175); dr = d log p / d r
+CL_HD float cl_dw_log_prob(float z, float z_parent, bool has_parent, float r, bool centric, float es, float* dz, float* dzp,
+                           float* dr) {
     const float loc = has_parent ? z_parent * r : 0.0f;
-    const float var = (centric ? es : 0.5f * es) * (1.0f - r * r);
-    const float scale = sqrtf(var);
-    float dloc, lp;
-    if (centric) lp = cl_folded_normal_log_prob(z, loc, scale, dz, &dloc);
-    else lp = cl_rice_log_prob(z, loc, scale, dz, &dloc);
+    const float c = centric ? es : 0.5f * es;
+    const float scale = sqrtf(c * (1.0f - r * r));
+    float dloc, dscale, lp;
+    if (centric) lp = cl_folded_normal_log_prob(z, loc, scale, dz, &dloc, &dscale);
+    else lp = cl_rice_log_prob(z, loc, scale, dz, &dloc, &dscale);
     *dzp = has_parent ? dloc * r : 0.0f;
+    *dr = (has_parent ? dloc * z_parent : 0.0f) - dscale * c * r / scale;
     return lp;
 }
 

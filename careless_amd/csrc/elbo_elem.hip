@@ -40,6 +40,11 @@ __device__ __forceinline__ float tn_uniform(const cl_tn_args& A, int h, int s) {
     return A.u_f ? A.u_f[(size_t)h * A.S + s] : cl_noise_uniform(A.seed, A.step, (uint32_t)s, (uint64_t)h);
 }
 
+// correlation r of reflection h with its parent: fixed (dw_r) or sigmoid of the trainable per-ASU value
+__device__ __forceinline__ float dw_r_of(const cl_tn_args& A, int h) {
+    return A.dw_r_raw ? cl_sigmoid(A.dw_r_raw[A.asu_ids[h]]) : A.dw_r[h];
+}
+
 // log-density of the Wilson prior and its z-derivative for reflection h
 __device__ __forceinline__ float prior_lp(const cl_tn_args& A, int h, float z, float* dlp_dz) {
     const bool c = A.centric[h] != 0;
@@ -90,8 +95,8 @@ __global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
         if (dw_child) {
             const int par = A.parent_ids[h];
             const float zp = (par >= 0) ? A.z_f[(size_t)par * A.S + s] : 0.0f;
-            float dzp;
-            (void)cl_dw_log_prob(t.z, zp, par >= 0, A.dw_r[h], A.centric[h] != 0, A.es[h], &dp_dz, &dzp);
+            float dzp, dr;
+            (void)cl_dw_log_prob(t.z, zp, par >= 0, dw_r_of(A, h), A.centric[h] != 0, A.es[h], &dp_dz, &dzp, &dr);
         } else {
             (void)prior_lp(A, h, t.z, &dp_dz);
         }
@@ -110,18 +115,39 @@ __global__ __launch_bounds__(256) void dw_forward_kernel(const cl_tn_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     double kl = 0.0;
+    float gr = 0.0f;                     // dL/dr of this reflection (trainable r only)
+    int asu = -1;
     if (h < A.R && A.root[h] == 0 && h >= A.kl_begin && h < A.kl_end) {
         const int par = A.parent_ids[h];
-        const float r = A.dw_r[h], es = A.es[h];
+        const float r = dw_r_of(A, h), es = A.es[h];
         const bool c = A.centric[h] != 0;
         const float wg = A.w_kl * A.kl_grad_mult;
         for (int s = 0; s < A.S; ++s) {
             const float z = A.z_f[(size_t)h * A.S + s];
             const float zp = (par >= 0) ? A.z_f[(size_t)par * A.S + s] : 0.0f;
-            float dz, dzp;
-            const float lp = cl_dw_log_prob(z, zp, par >= 0, r, c, es, &dz, &dzp);
+            float dz, dzp, dr;
+            const float lp = cl_dw_log_prob(z, zp, par >= 0, r, c, es, &dz, &dzp, &dr);
             kl -= (double)lp;
+            gr -= wg * dr;
             if (par >= 0) atomicAdd(A.dz_f_out + (size_t)par * A.S + s, -wg * dzp);
+        }
+        if (A.dw_r_raw) { asu = A.asu_ids[h]; gr *= r * (1.0f - r); }      // d sigmoid(raw) / d raw
+    }
+    if (A.dw_r_raw) {
+        // reflections are ordered by ASU, so a wave almost always holds one ASU: wave-reduce, one atomic per wave
+        const int a0 = __builtin_amdgcn_readfirstlane(asu);
+        if (__all(asu == a0 || asu < 0)) {
+            float v = (asu >= 0) ? gr : 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            const int any = __builtin_amdgcn_readfirstlane(__any(asu >= 0) ? 1 : 0);
+            // a0 may be -1 when lane 0 is inactive: take the ASU of the first active lane instead
+            int au = asu;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) au = max(au, __shfl_xor(au, off));
+            if (any && (threadIdx.x & 63) == 0) atomicAdd(A.d_dw_r_raw + au, v);
+        } else if (asu >= 0) {
+            atomicAdd(A.d_dw_r_raw + asu, gr);
         }
     }
     block_atomic_add_d(kl * (double)A.w_kl, A.scalars + CL_SC_KL);

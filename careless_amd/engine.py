@@ -102,9 +102,14 @@ class FlatLayout:
     seg_off: List[int]         # tensor boundaries (Keras trainable-variable granularity) for per-tensor clipnorm
     seg_owner: List[str]       # "q" | "scaler" | "likelihood" per tensor (for --freeze-*)
     n_ev11: int = 0            # 3 with the Evans-2011 error model
+    n_dwr: int = 0             # number of ASUs with --optimize-double-wilson-r
 
     @property
     def n(self) -> int:
+        return 2 * self.R + self.P + self.n_img + self.n_ev11 + self.n_dwr
+
+    @property
+    def off_dwr(self) -> int:
         return 2 * self.R + self.P + self.n_img + self.n_ev11
 
     @property
@@ -120,7 +125,7 @@ class FlatLayout:
         return 2 * self.R + self.P
 
 
-def make_layout(R: int, d: int, w: int, L: int, n_img: int, n_ev11: int = 0) -> FlatLayout:
+def make_layout(R: int, d: int, w: int, L: int, n_img: int, n_ev11: int = 0, n_dwr: int = 0) -> FlatLayout:
     seg, owner = [0, R, 2 * R], ["q", "q"]
     off, fan_in = 2 * R, d
     for _ in range(L):
@@ -134,7 +139,9 @@ def make_layout(R: int, d: int, w: int, L: int, n_img: int, n_ev11: int = 0) -> 
         off += n_img; seg.append(off); owner.append("scaler")
     for _ in range(n_ev11):              # Sdfac, Sdadd, SdB: three scalar variables (mono.py:42-44)
         off += 1; seg.append(off); owner.append("likelihood")
-    return FlatLayout(R, P, n_img, seg, owner, n_ev11)
+    if n_dwr > 0:                        # the double-Wilson r vector (wilson.py:105-110)
+        off += n_dwr; seg.append(off); owner.append("prior")
+    return FlatLayout(R, P, n_img, seg, owner, n_ev11, n_dwr)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -274,7 +281,9 @@ class ElboEngine:
         if img is not None:
             n_img = img.max_images - 1
         self.ev11 = bool(getattr(lik, "ev11", False))
-        self.layout = make_layout(self.R, self.d, self.w, self.L, n_img, 3 if self.ev11 else 0)
+        self.dw_trainable = self.double_wilson and prior.r_raw is not None
+        n_dwr = int(prior.r_raw.numel()) if self.dw_trainable else 0
+        self.layout = make_layout(self.R, self.d, self.w, self.L, n_img, 3 if self.ev11 else 0, n_dwr)
         lay = self.layout
         assert lay.P == mlp.param_count(self.d) == int(self.lib.cl_mlp_param_count(self.d, self.w, self.L))
         self.params = torch.empty(lay.n, dtype=torch.float32, device=dev)
@@ -291,6 +300,10 @@ class ElboEngine:
         if self.ev11:
             self.params[lay.off_ev11:lay.off_ev11 + 3] = lik.raw.to(dev)
             lik.raw = self.params[lay.off_ev11:lay.off_ev11 + 3]
+        if self.dw_trainable:
+            self.params[lay.off_dwr:lay.off_dwr + n_dwr] = prior.r_raw.to(dev)
+            prior.r_raw = self.params[lay.off_dwr:lay.off_dwr + n_dwr]
+            self.asu_ids = torch.as_tensor(prior.asu_ids.astype(np.int32), device=dev)
         self.adam_m = torch.zeros_like(self.params)
         self.adam_v = torch.zeros_like(self.params)
         self.t = 0                                  # optimizer iterations
@@ -382,6 +395,10 @@ class ElboEngine:
             a.prior_kind = _lib.CL_PRIOR_DOUBLE_WILSON
             a.parent_ids, a.root, a.dw_r = ptr(self.parent_ids), ptr(self.root), ptr(self.dw_r)
             a.dz_f_out = ptr(self.dz_f)
+            if self.dw_trainable:
+                a.dw_r_raw = self.params.data_ptr() + 4 * lay.off_dwr
+                a.d_dw_r_raw = self.grads.data_ptr() + 4 * lay.off_dwr
+                a.asu_ids, a.n_asu = ptr(self.asu_ids), lay.n_dwr
         return a
 
     def _mlp_args(self, step: int, eta, ipred_out=None, obs: Optional[ObsData] = None) -> MlpArgs:
@@ -541,9 +558,14 @@ class ElboEngine:
     def alloc_history(self, steps: int):
         self.history_buf = torch.zeros(max(1, steps) * _lib.CL_HIST_STRIDE, dtype=torch.float64, device=self.device)
         self.stop_flag.zero_()
+        self.rdw_hist = (torch.zeros(max(1, steps), self.layout.n_dwr, dtype=torch.float32, device=self.device)
+                         if self.dw_trainable else None)
 
     def train_step(self, step_index: int, u_f=None, eta=None):
         """One full ELBO step; `step_index` indexes the history buffer, the noise key is the optimizer iteration."""
+        if self.dw_trainable:           # the "rDW_i" metrics are the values used in this step's forward pass (wilson.py:173-174)
+            lay = self.layout
+            self.rdw_hist[step_index] = torch.sigmoid(self.params[lay.off_dwr:lay.off_dwr + lay.n_dwr])
         self.forward_backward(self.t, u_f, eta)
         self.optimizer_step(step_index)
 
@@ -558,6 +580,10 @@ class ElboEngine:
         out["loss"] = h[:, 0].tolist()
         out["F KLDiv"] = h[:, 1].tolist()
         out["NLL"] = h[:, 2].tolist()
+        if self.dw_trainable:
+            r = self.rdw_hist[:steps].cpu().numpy()[keep]
+            for i in range(r.shape[1]):
+                out[f"rDW_{i}"] = r[:, i].tolist()
         return out
 
     # -- accessors used by tests -----------------------------------------------------------------------------
@@ -578,6 +604,8 @@ class ElboEngine:
             out.append(g[lay.off_img: lay.off_img + lay.n_img])
         if lay.n_ev11 > 0:
             out.append(g[lay.off_ev11: lay.off_ev11 + lay.n_ev11])
+        if lay.n_dwr > 0:
+            out.append(g[lay.off_dwr: lay.off_dwr + lay.n_dwr])
         return out
 
 

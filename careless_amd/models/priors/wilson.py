@@ -76,14 +76,19 @@ class DoubleWilsonPrior(Prior):
 
     def __init__(self, centric, epsilon, reflids, root, asu_ids, r_values, parents=None, sigma=1.0, optimize_r=False):
         super().__init__()
-        if optimize_r:
-            raise NotImplementedError("--optimize-double-wilson-r is not supported by the HIP engine yet")
         self.parents = parents
-        self.optimize_r = False
-        self.r = np.array(r_values, dtype=np.float32)
-        for r in self.r:
+        self.optimize_r = bool(optimize_r)
+        r0 = np.array(r_values, dtype=np.float32)
+        for r in r0:
             if (r >= 1.0) or (r <= -1.0):                  # reference io/manager.py:415-419
                 raise ValueError(f"Supplied --double-wilson-r value {r} outside of allowed range (-1, 1)")
+        self._r_fixed = r0
+        self.r_raw = None
+        if self.optimize_r:
+            # tfu.TransformedVariable(r, tfb.Sigmoid()) (reference wilson.py:105-110): the trainable value is logit(r)
+            import torch
+            with np.errstate(divide="ignore"):
+                self.r_raw = torch.as_tensor(np.log(r0.astype(np.float64)) - np.log1p(-r0.astype(np.float64))).to(torch.float32)
         self.centric = np.array(centric, dtype=bool)
         self.multiplicity = np.array(epsilon, dtype=np.float32)
         self.asu_ids = np.array(asu_ids).reshape(-1).astype(np.int64)
@@ -96,6 +101,18 @@ class DoubleWilsonPrior(Prior):
     @property
     def eps_sigma(self):
         return self.wilson_prior.eps_sigma
+
+    @property
+    def r(self) -> np.ndarray:
+        """Current correlation per ASU (sigmoid of the trainable value when --optimize-double-wilson-r is on)."""
+        if self.r_raw is None:
+            return self._r_fixed
+        import torch
+        return torch.sigmoid(self.r_raw.detach().float()).cpu().numpy()
+
+    @property
+    def trainable_variables(self):
+        return [self.r_raw] if self.r_raw is not None else []
 
     @property
     def r_per_reflection(self) -> np.ndarray:

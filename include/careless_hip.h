@@ -73,6 +73,11 @@ typedef struct cl_tn_args {
     const unsigned char* root;  /* [R] 1 = reflection of a root ASU (plain Wilson prior)                            */
     const float* dw_r;          /* [R] correlation r of the reflection's ASU with its parent (`r[asu_ids]`)         */
     float* dz_f_out;            /* [R][S] += -w dlogp/dz_parent (cl_dw_prior_forward); the same buffer as dz_f      */
+    /* --optimize-double-wilson-r (wilson.py:105-110): r = sigmoid(raw) per ASU is trainable; NULL = fixed r (dw_r)      */
+    const float* dw_r_raw;      /* [n_asu] pre-sigmoid r                                                            */
+    const int* asu_ids;         /* [R] ASU of every reflection                                                      */
+    float* d_dw_r_raw;          /* [n_asu] += dL/d raw (cl_dw_prior_forward)                                        */
+    int n_asu;
 } cl_tn_args;
 enum { CL_PRIOR_WILSON_ = 0, CL_PRIOR_DOUBLE_WILSON_ = 1 };
 

@@ -56,6 +56,7 @@ class ElboConfig:
     laue: bool = False                  # len(inputs) >= 8 (models/base.py:39-47)
     prior: str = "wilson"               # "wilson" | "double_wilson"
     ev11: bool = False                  # --refine-uncertainties: Evans-2011 error model (likelihoods/mono.py:39-73)
+    optimize_dw_r: bool = False         # --optimize-double-wilson-r (priors/wilson.py:105-110)
     # Adam (manager.py:494-501; args/optimizer.py)
     learning_rate: float = 1e-3
     beta_1: float = 0.9
@@ -345,6 +346,8 @@ class ElboParams:
             out.append(self.img_raw)
         if self.ev11_raw is not None:
             out.append(self.ev11_raw)
+        if self.dw_r_raw is not None:
+            out.append(self.dw_r_raw)
         return out
 
     def clone(self, dtype=None, requires_grad=False) -> "ElboParams":
@@ -423,8 +426,9 @@ def elbo_forward(p: ElboParams, x: ElboInputs, cfg: ElboConfig, u_f: torch.Tenso
     if cfg.prior == "wilson":
         log_p = wilson_log_prob(z_f, x.centric, x.multiplicity, x.sigma)
     else:
+        dw_r = torch.sigmoid(p.dw_r_raw) if p.dw_r_raw is not None else x.dw_r        # wilson.py:105-110
         log_p = double_wilson_log_prob(z_f, x.centric, x.multiplicity, x.sigma, x.parent_ids, x.root,
-                                       x.asu_ids, x.dw_r)
+                                       x.asu_ids, dw_r)
     kl_e = log_q - log_p
     if kl_mask is not None:
         kl_e = kl_e[:, kl_mask]
@@ -582,5 +586,11 @@ def init_params(d: Dict, cfg: ElboConfig, n_layers: int, width: Optional[int], d
         ev = np.full(3, math.log(math.e - 1.0), dtype=np.float32)
         if perturb > 0.0:
             ev = (ev + perturb * rng.normal(size=3)).astype(np.float32)
+    dwr = None
+    if getattr(cfg, "optimize_dw_r", False):     # TransformedVariable(r, Sigmoid()): raw = logit(r); logit(0) = -inf for the root
+        with np.errstate(divide="ignore"):
+            r0 = np.asarray(d["dw_r"], dtype=np.float64)
+            dwr = (np.log(r0) - np.log1p(-r0)).astype(np.float32)
     return ElboParams(t(a32), t(b32), [t(w_) for w_ in ws], [t(b_) for b_ in bs],
-                      t(img) if img is not None else None, None, t(ev) if ev is not None else None)
+                      t(img) if img is not None else None, t(dwr) if dwr is not None else None,
+                      t(ev) if ev is not None else None)

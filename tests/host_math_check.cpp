@@ -23,8 +23,8 @@ void hm_lik(int n, const float* ip, const float* io, const float* sg, int kind, 
 void hm_bij(int n, const float* raw, int kind, float eps, float* sig, float* dsig) {
     for (int i = 0; i < n; ++i) sig[i] = cl_scale_bij(raw[i], kind, eps, dsig + i);
 }
-void hm_dw(int n, const float* z, const float* zp, const int* has, const float* r, const int* centric, const float* es, float* lp, float* dz, float* dzp) {
-    for (int i = 0; i < n; ++i) lp[i] = cl_dw_log_prob(z[i], zp[i], has[i] != 0, r[i], centric[i] != 0, es[i], dz + i, dzp + i);
+void hm_dw(int n, const float* z, const float* zp, const int* has, const float* r, const int* centric, const float* es, float* lp, float* dz, float* dzp, float* dr) {
+    for (int i = 0; i < n; ++i) lp[i] = cl_dw_log_prob(z[i], zp[i], has[i] != 0, r[i], centric[i] != 0, es[i], dz + i, dzp + i, dr + i);
 }
 void hm_bessel(int n, const float* x, float* i0e, float* i1e) { for (int i = 0; i < n; ++i) cl_i0e_i1e(x[i], i0e + i, i1e + i); }
 void hm_noise(int n, unsigned long long seed, unsigned step, unsigned s, unsigned long long idx0, float* un, float* nr) {

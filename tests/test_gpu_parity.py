@@ -30,6 +30,7 @@ CASES = {
     "laue_2x32_normal_S3": dict(N=400, R=40, L=2, w=32, S=3, laue=True),
     "laue_5x64_studentt_S2_noimg": dict(N=700, R=64, L=5, w=64, S=2, laue=True, likelihood="studentt", dof=6.0, use_image_scales=False),
     "double_wilson_2x32_S3": dict(N=400, R=60, d0=5, L=2, w=32, S=3, double_wilson=True),
+    "double_wilson_trainable_r_S4": dict(N=400, R=60, d0=5, L=2, w=32, S=4, double_wilson=True, optimize_dw_r=True),
     "double_wilson_5x64_S8_studentt": dict(N=600, R=80, d0=5, L=5, w=64, S=8, double_wilson=True, likelihood="studentt", dof=8.0),
 }
 
@@ -115,6 +116,29 @@ def test_adam_trajectory_matches_oracle():
     eng = model._engine
     for a, b in zip(eng.mlp.weights, [t for pair in zip(p.mlp_w, p.mlp_b) for t in pair]):
         assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
+
+
+def test_trainable_double_wilson_r_trajectory():
+    """--optimize-double-wilson-r: r = sigmoid(raw) follows the oracle's Adam trajectory and is logged as rDW_i
+    (reference priors/wilson.py:105-110, 173-174)."""
+    kw = dict(N=400, R=60, d0=5, L=2, w=32, S=4, double_wilson=True, optimize_dw_r=True)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    steps = 12
+    rng = np.random.default_rng(5)
+    noises = [(rng.random((4, 60)).astype(np.float32), rng.normal(size=(4, 400)).astype(np.float32)) for _ in range(steps)]
+    model = util.build_model(data, cfg, params, 2, 32)
+    hist = model.train_model(util.reference_inputs(data), steps, progress=False, noise=lambda i: noises[i])
+    p = params.clone()
+    st = O.AdamState.zeros_like(p.tensors())
+    r_ref = []
+    for u, e in noises:
+        r_ref.append(torch.sigmoid(p.dw_r_raw).numpy().copy())
+        O.train_step(p, x, cfg, st, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+    r_ref = np.array(r_ref)
+    assert np.all(np.array(hist["rDW_0"]) == 0.0)                       # the root ASU has no parent: r stays 0
+    assert np.max(np.abs(np.array(hist["rDW_1"]) - r_ref[:, 1])) < 2e-5
+    assert abs(r_ref[-1, 1] - r_ref[0, 1]) > 5e-4                        # it did move
+    assert np.allclose(model.prior.r, torch.sigmoid(p.dw_r_raw).numpy(), atol=2e-5)
 
 
 def test_philox_mode_matches_oracle_on_dumped_noise():

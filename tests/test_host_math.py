@@ -126,16 +126,17 @@ def test_bessel_and_double_wilson_conditional(hm):
     r = rng.uniform(0.0, 0.97, n).astype(np.float32)
     c = (rng.random(n) < 0.3).astype(np.int32)
     es = rng.choice([1.0, 2.0, 3.0], n).astype(np.float32)
-    lp, dz, dzp = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
-    hm.hm_dw(n, fp(z), fp(zp), fp(has), fp(r), fp(c), fp(es), fp(lp), fp(dz), fp(dzp))
+    lp, dz, dzp, dr = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+    hm.hm_dw(n, fp(z), fp(zp), fp(has), fp(r), fp(c), fp(es), fp(lp), fp(dz), fp(dzp), fp(dr))
     T = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float64))
-    zt, zpt = T(z).requires_grad_(True), T(zp).requires_grad_(True)
+    zt, zpt, rt = T(z).requires_grad_(True), T(zp).requires_grad_(True), T(r).requires_grad_(True)
     cb, hb = torch.as_tensor(c.astype(bool)), torch.as_tensor(has.astype(bool))
-    loc = torch.where(hb, zpt * T(r), torch.zeros(n, dtype=torch.float64))
-    scale = torch.where(cb, torch.sqrt(T(es) * (1 - T(r) ** 2)), torch.sqrt(0.5 * T(es) * (1 - T(r) ** 2)))
+    loc = torch.where(hb, zpt * rt, torch.zeros(n, dtype=torch.float64))
+    scale = torch.where(cb, torch.sqrt(T(es) * (1 - rt ** 2)), torch.sqrt(0.5 * T(es) * (1 - rt ** 2)))
     ref = torch.where(cb, O.folded_normal_log_prob(zt, loc, scale), O.rice_log_prob(zt, loc, scale))
-    g = torch.autograd.grad(ref.sum(), [zt, zpt])
+    g = torch.autograd.grad(ref.sum(), [zt, zpt, rt])
     nat = lambda v: np.maximum(np.abs(v), 1.0)
     assert np.max(np.abs(lp - ref.detach().numpy()) / nat(ref.detach().numpy())) < 1e-4
     assert np.max(np.abs(dz - g[0].numpy()) / nat(g[0].numpy())) < 1e-4
     assert np.max(np.abs(dzp - g[1].numpy()) / nat(g[1].numpy())) < 1e-4
+    assert np.max(np.abs(dr - g[2].numpy()) / nat(g[2].numpy())) < 2e-4

@@ -9,7 +9,7 @@ from oracle import elbo_oracle as O
 
 def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, likelihood="normal", dof=None,
                  bijector="exp", shift=0.0, use_image_scales=True, kl_weight=None, perturb=0.05, seed=7,
-                 outliers=False, double_wilson=False, laue=False, ev11=False, **opt):
+                 outliers=False, double_wilson=False, laue=False, ev11=False, optimize_dw_r=False, **opt):
     if laue:
         data = O.make_synthetic_laue(N, R=R, n_images=n_images, seed=seed)
     elif double_wilson:
@@ -19,7 +19,7 @@ def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, li
         data = O.make_synthetic(N, R=R, d0=d0, posenc=posenc, n_images=n_images, seed=seed, outliers=outliers)
     cfg = O.ElboConfig(mc_samples=S, likelihood=likelihood, dof=dof, scale_bijector=bijector, scale_shift=shift,
                        use_image_scales=use_image_scales, kl_weight=kl_weight,
-                       prior="double_wilson" if double_wilson else "wilson", laue=laue, ev11=ev11, **opt)
+                       prior="double_wilson" if double_wilson else "wilson", laue=laue, ev11=ev11, optimize_dw_r=optimize_dw_r, **opt)
     rng = np.random.default_rng(seed + 1)
     params = O.init_params(data, cfg, L, w, perturb=perturb, rng=rng)
     x = O.inputs_from_numpy(data)
@@ -50,7 +50,9 @@ def build_model(data, cfg: O.ElboConfig, params: O.ElboParams, L, w):
 
     if cfg.prior == "double_wilson":
         prior = DoubleWilsonPrior(data["centric"], data["multiplicity"], data["parent_ids"], data["root"], data["asu_ids"],
-                                  data["dw_r"], parents=[None, 0])
+                                  data["dw_r"], parents=[None, 0], optimize_r=cfg.optimize_dw_r)
+        if cfg.optimize_dw_r:
+            prior.r_raw = torch.as_tensor(params.dw_r_raw.numpy().astype(np.float32))
     else:
         prior = WilsonPrior(data["centric"], data["multiplicity"], 1.0)
     low = (1e-32 * ~np.asarray(data["centric"], dtype=bool)).astype(np.float32)
