@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank "
                                                       "control flow on a single-GPU box)")
     ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: run rank 0's shard of a W-rank job on this one GPU "
+                                                             "(per-rank step time of the strong-scaling runs; not a bench line)")
     return ap.parse_args()
 
 
@@ -104,7 +106,9 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     model, inputs, data, spec = make_workload(args.workload, N=args.nobs)
-    if use_dist:
+    if args.sim_world > 1:
+        model.set_data_parallel(0, args.sim_world)
+    elif use_dist:
         model.set_data_parallel(rank, world)
     eng = model.engine(inputs)
     eng.force_allreduce = bool(args.force_dist)
@@ -178,6 +182,9 @@ def main():
                          "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
                          "hbm_secondary": {"achieved_GBps": B * eng.N / (kern_ms * 1e-3) / 1e9, "bytes_per_obs": B}},
         }
+        if args.sim_world > 1:
+            out["diagnostic"] = f"rank 0 shard of a simulated {args.sim_world}-rank job: value is NOT a throughput of this workload"
+            out["value"] = None
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
     if use_dist:

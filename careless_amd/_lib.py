@@ -62,6 +62,7 @@ class MlpArgs(C.Structure):
         ("ipred_out", _vp), ("loc_out", _vp), ("sig_out", _vp), ("dO_ext", _vp),
         ("stop_flag", _vp),
         ("ev11", _vp), ("d_ev11", _vp),
+        ("imgl", _vp), ("d_imgl", _vp), ("n_imgl", C.c_int), ("n_images", C.c_int), ("tile_img", _vp), ("row_map", _vp),
     ]
 
 

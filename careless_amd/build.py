@@ -14,7 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcareless_hip.so")
-SOURCES = ["cl_api.hip", "elbo_mlp.hip", "elbo_elem.hip", "elbo_laue.hip"]
+# (source, object stem, extra flags): elbo_mlp.hip is compiled twice -- Dense-only scalers and the per-image-layer variant
+UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=0"]), ("elbo_mlp.hip", "elbo_mlp_imgl", ["-DCL_IMGL=1"]),
+         ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", [])]
+SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["cl_math.h", "cl_kernels.h", os.path.join("..", "..", "include", "careless_hip.h")]
 ARCH = "gfx950"
 
@@ -49,9 +52,9 @@ def _build(LIB: str, extra, verbose: bool) -> str:
     hipcc = _hipcc()
     objs = []
     procs = []
-    for s in SOURCES:
-        o = os.path.join(LIBDIR, s.replace(".hip", ".o") + ("s" if extra else ""))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + list(extra) + ["-c", os.path.join(CSRC, s), "-o", o]
+    for s, stem, flags in UNITS:
+        o = os.path.join(LIBDIR, stem + ".o" + ("s" if extra else ""))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + list(extra) + flags + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -125,7 +125,12 @@ struct WgradPlan {
 
 // MODE 0: full ELBO step (mono likelihood in the epilogue);  MODE 1: forward only (loc, sigma per observation);
 // MODE 2: forward recompute + backward from an externally supplied dL/d(loc, sigma) (Laue two-pass path).
-template <int WP, int DP, int LMAX, int MODE>
+// IMGL: NeuralImageScaler (careless/models/scaling/image.py:66-125): the Dense layers are followed by A.n_imgl layers whose
+// (w x w) kernel and bias belong to the IMAGE of the observation.  The observation axis is packed so that a tile holds one
+// image (A.tile_img); a workgroup walks a CONTIGUOUS range of tiles, keeps the current image's matrices in the LDS slots
+// of layers [A.L, A.L + n_imgl) and its weight-gradient sums in the same register accumulators as any other layer, and
+// swaps both (atomicAdd of the sums into the image's gradient, reload) only when the image changes.
+template <int WP, int DP, int LMAX, int MODE, bool IMGL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void elbo_mlp_kernel(const cl_mlp_args A) {
     using SL = SmemLayout<WP, DP, LMAX>;
@@ -154,7 +159,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     float* const sDl = sS;              // per-wave dO tile: dL/dloc [16], dL/draw [16]
     float* const sDs = sS + 16;
 
-    const int d = A.d, w = A.w, L = A.L;
+    const int d = A.d, w = A.w;
+    const int Ld = A.L;                              // Dense layers (parameters in A.mlp)
+    const int L = IMGL ? A.L + A.n_imgl : A.L;       // all hidden layers (Dense + per-image)
     const float leak = A.leak;
 
     // ---- stage the weights (global W^T layout, see cl_kernels.h) into padded LDS images, zero-filled ---------
@@ -167,10 +174,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         for (int idx = tid; idx < LMAX * WP; idx += 512) {
             const int l = idx / WP, o = idx - l * WP;
             float v = 0.0f;
-            if (l < L && o < w) v = (l == 0) ? P[w * d + o] : P[w * d + w + (l - 1) * (w * w + w) + w * w + o];
+            if (l < Ld && o < w) v = (l == 0) ? P[w * d + o] : P[w * d + w + (l - 1) * (w * w + w) + w * w + o];
             sB[idx] = v;
         }
-        for (int l = 1; l < L; ++l) {
+        for (int l = 1; l < Ld; ++l) {
             const float* __restrict__ Wl = P + w * d + w + (l - 1) * (w * w + w);
             float* dst = sW + (l - 1) * WP * PW;
             for (int idx = tid; idx < WP * PW; idx += 512) {
@@ -178,7 +185,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 dst[idx] = (o < w && i < w) ? Wl[o * w + i] : 0.0f;
             }
         }
-        const float* __restrict__ Wo = P + w * d + w + (L - 1) * (w * w + w);
+        const float* __restrict__ Wo = P + w * d + w + (Ld - 1) * (w * w + w);
         for (int idx = tid; idx < 2 * WP; idx += 512) {
             const int c = idx / WP, i = idx - c * WP;
             sWo[idx] = (i < w) ? Wo[c * w + i] : 0.0f;
@@ -272,10 +279,66 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         }
     };
     const int pf_layer = (L > 1) ? 1 : 0;
-    if ((int)blockIdx.x < ntiles) prefetch(blockIdx.x);
+    // tiles of this workgroup: strided over the grid, or (IMGL) one contiguous range so that image changes are rare
+    const int tile_begin = IMGL ? (int)((long long)blockIdx.x * ntiles / (int)gridDim.x) : (int)blockIdx.x;
+    const int tile_end = IMGL ? (int)((long long)(blockIdx.x + 1) * ntiles / (int)gridDim.x) : ntiles;
+    const int tile_step = IMGL ? 1 : (int)gridDim.x;
+    if (tile_begin < tile_end) prefetch(tile_begin);
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- per-image layers: gradient flush and weight reload on an image change ---------------------------------
+    int cur_img = -1;
+    const size_t imgl_blk = IMGL ? (size_t)A.n_images * (size_t)(w * w + w) : 0;      // floats per image layer
+    auto imgl_flush = [&](int im) {
+#pragma unroll
+        for (int l = 1; l < LMAX; ++l) {
+            if (l >= Ld && l < L) {
+                using WG = WgradPlan<FB, FB>;
+                float* __restrict__ gW = A.d_imgl + (size_t)(l - Ld) * imgl_blk + (size_t)im * (size_t)(w * w);
+                float* __restrict__ gB = A.d_imgl + (size_t)(l - Ld) * imgl_blk + (size_t)A.n_images * (size_t)(w * w) + (size_t)im * w;
+                const int grp = wv % WG::GROUPS;
+                const int ob = (grp * WG::BPW) / FB, ib0 = (grp * WG::BPW) - ob * FB;
+#pragma unroll
+                for (int b = 0; b < WB; ++b) {
+                    if (b < WG::BPW) {
+                        const int i = 16 * (ib0 + b) + j;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int o = 16 * ob + 4 * q + t;
+                            if (o < w && i < w) atomicAdd(gW + o * w + i, wacc[l][b][t]);
+                            wacc[l][b][t] = 0.0f;
+                        }
+                    }
+                }
+                if (lane < w) atomicAdd(gB + lane, bacc[l]);
+                bacc[l] = 0.0f;
+            }
+        }
+    };
+    auto imgl_load = [&](int im) {
+        for (int l = Ld; l < L; ++l) {
+            const float* __restrict__ Wg = A.imgl + (size_t)(l - Ld) * imgl_blk + (size_t)im * (size_t)(w * w);
+            const float* __restrict__ Bg = A.imgl + (size_t)(l - Ld) * imgl_blk + (size_t)A.n_images * (size_t)(w * w) + (size_t)im * w;
+            float* dst = sW + (l - 1) * WP * PW;
+            for (int idx = tid; idx < WP * PW; idx += 512) {
+                const int o = idx / PW, i = idx - o * PW;
+                dst[idx] = (o < w && i < w) ? Wg[o * w + i] : 0.0f;
+            }
+            if (tid < WP) sB[l * WP + tid] = (tid < w) ? Bg[tid] : 0.0f;
+        }
+    };
+
+    for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
         const int gobs = tile * CL_TILE + CL_WOBS * wv + j;      // this lane's observation (all four k-groups)
+        if (IMGL) {
+            const int im = __builtin_amdgcn_readfirstlane(A.tile_img[tile]);
+            if (im != cur_img) {             // workgroup-uniform
+                lds_barrier();               // every wave is done with the previous image's matrices
+                if (MODE != 1 && cur_img >= 0) imgl_flush(cur_img);
+                imgl_load(im);
+                cur_img = im;
+                lds_barrier();
+            }
+        }
 
         // ================= forward =======================================================================
         float h0[KS1];                     // metadata^T as B operand: step t holds feature 4t + q
@@ -287,10 +350,14 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         float aim = 1.0f, zf0 = 0.0f, zf1 = 0.0f, et0 = 0.0f, et1 = 0.0f;
         const int gobs_e = tile * CL_TILE + CL_WOBS * wv + je;   // the observation this lane handles in the epilogue
         const unsigned zoff = 4u * (unsigned)rid * (unsigned)S;     // z_f / dz_f BYTE offset of this lane's reflection
-        const unsigned eoff = 4u * lane_obs_e * (unsigned)S;        // eta / ipred BYTE offset inside the tile
+        const unsigned eoff_t = 4u * lane_obs_e * (unsigned)S;      // eta / ipred BYTE offset inside the tile
         const int tile_u = opaque_uniform(tile);
-        const float* __restrict__ eta_t = A.eta ? A.eta + (size_t)tile_u * CL_TILE * S : nullptr;
-        float* __restrict__ ipred_t = A.ipred_out ? A.ipred_out + (size_t)tile_u * CL_TILE * S : nullptr;
+        // IMGL: the packed row -> the caller's row (eta / ipred_out / noise key are in the caller's order)
+        int rme = 0;
+        if (IMGL && MODE == 0 && rid >= 0) rme = A.row_map[gobs_e];
+        const unsigned eoff = IMGL ? 4u * (unsigned)rme * (unsigned)S : eoff_t;
+        const float* __restrict__ eta_t = A.eta ? (IMGL ? A.eta : A.eta + (size_t)tile_u * CL_TILE * S) : nullptr;
+        float* __restrict__ ipred_t = A.ipred_out ? (IMGL ? A.ipred_out : A.ipred_out + (size_t)tile_u * CL_TILE * S) : nullptr;
         if (MODE == 0 && rid >= 0) {
             if (A.use_img && img > 0) aim = ld_uo(A.img, 4u * (unsigned)(img - 1));
             if (qe < S) zf0 = ld_uo(A.z_f, zoff + 4u * qe);
@@ -369,10 +436,13 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 
         if (MODE == 1) {
             if (q == 0 && valid) {
-                A.loc_out[gobs] = o0;
-                A.sig_out[gobs] = sigma;
+                const int row = IMGL ? A.row_map[gobs] : gobs;
+                if (row >= 0) {
+                    A.loc_out[row] = o0;
+                    A.sig_out[row] = sigma;
+                }
             }
-            if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+            if (tile + tile_step < tile_end) prefetch(tile + tile_step);
             continue;
         }
 
@@ -394,7 +464,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     if (eta_t != nullptr) {
                         eta = (k == 0) ? et0 : ((k == 1) ? et1 : ld_uo(eta_t, eoff + 4u * s));
                     } else if ((k & 1) == 0) {       // one Philox block + Box-Muller pair serves samples s and s + 4
-                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + gobs_e), &eta, &eta_sin);
+                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + (IMGL ? rme : gobs_e)), &eta, &eta_sin);
                     } else {
                         eta = eta_sin;
                     }
@@ -446,8 +516,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             }
             STAMP(13);
         } else {
-            dloc = valid ? A.dO_ext[2 * (size_t)gobs] : 0.0f;
-            draw = valid ? A.dO_ext[2 * (size_t)gobs + 1] * dsig_draw : 0.0f;   // external grad is w.r.t. sigma
+            const int row = (IMGL && valid) ? A.row_map[gobs] : gobs;
+            const bool have = valid && row >= 0;
+            dloc = have ? A.dO_ext[2 * (size_t)row] : 0.0f;
+            draw = have ? A.dO_ext[2 * (size_t)row + 1] * dsig_draw : 0.0f;   // external grad is w.r.t. sigma
             if (q == 0) {
                 boacc0 += dloc; boacc1 += draw;
             }
@@ -496,7 +568,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             if (l < L) {
                 // next tile's inputs: issued two layers before the end of the backward pass -- early enough to cover the HBM
                 // latency, late enough that the registers of the upper layers' activations are free again
-                if (l == pf_layer && tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
+                if (l == pf_layer && tile + tile_step < tile_end) prefetch(tile + tile_step);
                 // dZ_l = dH_l * lrelu'(H_l)   (sign of the post-activation == sign of the pre-activation)
 #pragma unroll
                 for (int mb = 0; mb < FB; ++mb)
@@ -625,10 +697,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #endif
 
     if (MODE == 1) return;
+    if (IMGL && cur_img >= 0) imgl_flush(cur_img);
 
     // ================= flush the weight-gradient accumulators: LDS staging -> per-workgroup partial =========
     __syncthreads();
-    const int offWo = w * d + w + (L - 1) * (w * w + w);
+    const int offWo = w * d + w + (Ld - 1) * (w * w + w);
     const int Ptot = offWo + 2 * w + 2;
     for (int idx = tid; idx < Ptot; idx += 512) smem[idx] = 0.0f;
     __syncthreads();
@@ -642,7 +715,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         if (wv == turn) {
 #pragma unroll
             for (int l = 0; l < LMAX; ++l) {
-                if (l < L) {
+                if (l < Ld) {
                     const int IBn = (l == 0) ? IB1 : FB;
                     const int NBK = FB * IBn;
                     const int BPW = (NBK >= CL_NW) ? NBK / CL_NW : 1;
@@ -712,6 +785,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 // ---------------------------------------------------------------------------------------------------------
 // block = 32 consecutive elements x 8 chunks of the partial list; a thread sums its chunk (coalesced 128-B rows), the 8 chunk
 // sums are combined through LDS in chunk order => the result does not depend on scheduling
+#if !CL_IMGL
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int P,
                                                                float* __restrict__ out, const int* stop_flag) {
     if (stop_flag != nullptr && *stop_flag != 0) return;
@@ -733,10 +807,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
         out[i] += t;
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------
+#ifndef CL_IMGL
+#define CL_IMGL 0            // the file is compiled twice: -DCL_IMGL=0 (Dense-only scalers) and -DCL_IMGL=1 (per-image layers)
+#endif
+
 template <int WP, int DP, int LMAX, int MODE>
 static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SL = SmemLayout<WP, DP, LMAX>;
@@ -745,7 +824,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     size_t sm = sm_tiles;
     if (MODE != 1 && P * sizeof(float) > sm) sm = P * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE>;
+    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0)>;
     static size_t configured = 0;
     if (configured < sm) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -761,7 +840,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 // 256-register budget of a wave: w <= 16 -> up to 20 layers (the CLI default scaler is 20 x 10), w <= 32 -> 10, w <= 64 -> 5.
 template <int WP, int LMAX, int MODE>
 static int launch_dp(const cl_mlp_args& a, int grid, hipStream_t st) {
-    if (a.L > LMAX) return -2;
+    if (a.L + (CL_IMGL ? a.n_imgl : 0) > LMAX) return -2;
     const int dp = (a.d <= 8) ? 8 : (a.d <= 32 ? 32 : 64);
     if (dp == 8) return launch_one<WP, 8, LMAX, MODE>(a, grid, st);
     if (dp == 32) return launch_one<WP, 32, LMAX, MODE>(a, grid, st);
@@ -773,11 +852,21 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.L < 1 || a.w < 1 || a.d < 1) return -2;
     if (a.w > 64 || a.d > 64) return -2;
     if (a.w <= 16) return launch_dp<16, CL_MLP_LMAX_W16, MODE>(a, grid, st);
-    if (a.w <= 32) return (a.L <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
+    if (a.w <= 32) return (a.L + (CL_IMGL ? a.n_imgl : 0) <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }
 
+#if CL_IMGL
+int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (a.n_imgl < 1 || a.imgl == nullptr || a.tile_img == nullptr || a.row_map == nullptr || a.n_images < 1) return -1;
+    if (a.n_obs != a.n_pad || a.use_img) return -1;
+    if (mode != 1 && a.d_imgl == nullptr) return -1;
+    // eta / ipred_out are addressed with 32-bit byte offsets from their base in this variant
+    if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+#else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (a.n_imgl > 0) return cl_launch_mlp_imgl(a, mode, grid, st);
+#endif
     if (a.n_pad % CL_TILE != 0 || a.n_pad <= 0) return -1;
     // 32-bit byte offsets / buffer sizes inside the kernel: metadata image < 4 GiB, z_f < 4 GiB (shard further across GPUs otherwise)
     const unsigned long long meta_bytes = 4ull * (unsigned long long)((a.d + 3) & ~3) * (unsigned long long)a.n_pad;
@@ -793,8 +882,10 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     return -1;
 }
 
+#if !CL_IMGL
 int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st) {
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 31) / 32), dim3(256), 0, st, partials, nparts, P, out, stop_flag);
     return (int)hipGetLastError();
 }
+#endif

@@ -103,17 +103,22 @@ class FlatLayout:
     seg_owner: List[str]       # "q" | "scaler" | "likelihood" per tensor (for --freeze-*)
     n_ev11: int = 0            # 3 with the Evans-2011 error model
     n_dwr: int = 0             # number of ASUs with --optimize-double-wilson-r
+    n_imgl: int = 0            # floats of the per-image layers (NeuralImageScaler): K * M * (w*w + w)
 
     @property
     def n(self) -> int:
-        return 2 * self.R + self.P + self.n_img + self.n_ev11 + self.n_dwr
+        return 2 * self.R + self.P + self.n_img + self.n_imgl + self.n_ev11 + self.n_dwr
 
     @property
     def off_dwr(self) -> int:
-        return 2 * self.R + self.P + self.n_img + self.n_ev11
+        return 2 * self.R + self.P + self.n_img + self.n_imgl + self.n_ev11
 
     @property
     def off_ev11(self) -> int:
+        return 2 * self.R + self.P + self.n_img + self.n_imgl
+
+    @property
+    def off_imgl(self) -> int:
         return 2 * self.R + self.P + self.n_img
 
     @property
@@ -125,7 +130,8 @@ class FlatLayout:
         return 2 * self.R + self.P
 
 
-def make_layout(R: int, d: int, w: int, L: int, n_img: int, n_ev11: int = 0, n_dwr: int = 0) -> FlatLayout:
+def make_layout(R: int, d: int, w: int, L: int, n_img: int, n_ev11: int = 0, n_dwr: int = 0, imgl=None) -> FlatLayout:
+    """`imgl` = (K, M): K per-image layers over M images (NeuralImageScaler)."""
     seg, owner = [0, R, 2 * R], ["q", "q"]
     off, fan_in = 2 * R, d
     for _ in range(L):
@@ -137,22 +143,49 @@ def make_layout(R: int, d: int, w: int, L: int, n_img: int, n_ev11: int = 0, n_d
     P = off - 2 * R
     if n_img > 0:
         off += n_img; seg.append(off); owner.append("scaler")
+    n_imgl = 0
+    if imgl is not None:
+        K, M = imgl
+        for _ in range(K):               # ImageLayer kernel (M, w, w) and bias (M, w) (image.py:76-88)
+            off += M * w * w; seg.append(off); owner.append("scaler")
+            off += M * w; seg.append(off); owner.append("scaler")
+        n_imgl = K * M * (w * w + w)
     for _ in range(n_ev11):              # Sdfac, Sdadd, SdB: three scalar variables (mono.py:42-44)
         off += 1; seg.append(off); owner.append("likelihood")
     if n_dwr > 0:                        # the double-Wilson r vector (wilson.py:105-110)
         off += n_dwr; seg.append(off); owner.append("prior")
-    return FlatLayout(R, P, n_img, seg, owner, n_ev11, n_dwr)
+    return FlatLayout(R, P, n_img, seg, owner, n_ev11, n_dwr, n_imgl)
 
 
 # ------------------------------------------------------------------------------------------------------------
 # device image of one set of observations (the training shard, or a validation set)
 # ------------------------------------------------------------------------------------------------------------
+def pack_by_image(image_id: np.ndarray):
+    """Packed observation order of the per-image-layer kernel: rows grouped by image, every image padded to whole tiles.
+    Returns (pos, n_pad, tile_img, row_map): pos[i] = packed position of row i; row_map[p] = row of packed position p or -1."""
+    image_id = np.asarray(image_id).astype(np.int64)
+    order = np.argsort(image_id, kind="stable")
+    ids, counts = np.unique(image_id, return_counts=True)
+    tiles = (counts + TILE - 1) // TILE
+    base = np.concatenate([[0], np.cumsum(tiles)[:-1]]) * TILE          # first packed position of each image
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])              # first sorted row of each image
+    within = np.arange(len(image_id)) - np.repeat(first, counts)
+    pos = np.empty(len(image_id), dtype=np.int64)
+    pos[order] = np.repeat(base, counts) + within
+    n_pad = int(tiles.sum()) * TILE
+    row_map = np.full(n_pad, -1, dtype=np.int32)
+    row_map[pos] = np.arange(len(image_id), dtype=np.int32)
+    tile_img = np.repeat(ids, tiles).astype(np.int32)
+    return pos, n_pad, tile_img, row_map
+
+
 class ObsData:
     """refl_id / image_id int32 [N], meta_t fp32 [rows][n_pad], iobs / sig fp32 [N], optional harmonic_id + Laue work
-    buffers, and the per-launch workspace of the fused kernel (grid, gradient partials)."""
+    buffers, and the per-launch workspace of the fused kernel (grid, gradient partials).  With `pack_images` (per-image
+    layers) the arrays the fused kernel streams are in the packed order of `pack_by_image`."""
 
     def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None,
-                 laue_groups=None):
+                 laue_groups=None, pack_images: bool = False):
         refl_id = _np(BaseModel.get_refl_id(inputs)).reshape(-1).astype(np.int64)
         image_id = _np(BaseModel.get_image_id(inputs)).reshape(-1).astype(np.int64)
         metadata = _np(BaseModel.get_metadata(inputs)).astype(np.float32).reshape(len(refl_id), -1)
@@ -183,11 +216,27 @@ class ObsData:
         if n_images is not None and image_id.size and image_id.max() >= n_images:
             raise ValueError("image_id exceeds ImageScaler.max_images")
         self.d = int(metadata.shape[1])
-        self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
-        meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
-        meta_t[: self.d, : self.N] = metadata[sl].T
-        self.refl_id = torch.as_tensor(refl_id[sl].astype(np.int32), device=device)
-        self.image_id = torch.as_tensor(image_id[sl].astype(np.int32), device=device)
+        self.tile_img = self.row_map = None
+        rid_l, img_l = refl_id[sl].astype(np.int32), image_id[sl].astype(np.int32)
+        if pack_images:
+            pos, self.n_pad, tile_img, row_map = pack_by_image(img_l)
+            meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
+            meta_t[: self.d, pos] = metadata[sl].T
+            self.tile_img = torch.as_tensor(tile_img, device=device)
+            self.row_map = torch.as_tensor(row_map, device=device)
+            if not self.laue:           # the mono likelihood runs inside the fused kernel: its inputs are packed too
+                def packed(v, fill):
+                    out = np.full(self.n_pad, fill, dtype=v.dtype)
+                    out[pos] = v
+                    return out
+                rid_l, img_l = packed(rid_l, -1), packed(img_l, 0)
+                iobs_l, sig_l = packed(np.asarray(iobs_l), 0.0), packed(np.asarray(sig_l), 1.0)
+        else:
+            self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
+            meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
+            meta_t[: self.d, : self.N] = metadata[sl].T
+        self.refl_id = torch.as_tensor(rid_l, device=device)
+        self.image_id = torch.as_tensor(img_l, device=device)
         self.meta_t = torch.as_tensor(meta_t, device=device)
         self.iobs = torch.as_tensor(np.ascontiguousarray(iobs_l), device=device)
         self.sig = torch.as_tensor(np.ascontiguousarray(sig_l), device=device)
@@ -226,7 +275,7 @@ class ElboEngine:
         from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
         from careless_amd.models.priors.wilson import DoubleWilsonPrior, WilsonPrior
         from careless_amd.models.likelihoods.mono import LocationScaleLikelihood
-        from careless_amd.models.scaling.image import HybridImageScaler
+        from careless_amd.models.scaling.image import HybridImageScaler, NeuralImageScaler
         from careless_amd.models.scaling.nn import MetadataScaler
 
         q, prior, lik, scaler = model.surrogate_posterior, model.prior, model.likelihood, model.scaling_model
@@ -241,15 +290,18 @@ class ElboEngine:
                              "monochromatic inputs a careless_amd.models.likelihoods.mono one")
         if not isinstance(lik, (LocationScaleLikelihood, LaueBase)) or lik.kind not in ("normal", "studentt"):
             raise NotImplementedError(f"likelihood {type(lik).__name__} is not supported by the HIP engine yet")
+        imgl = None
         if isinstance(scaler, HybridImageScaler):
             mlp, img = scaler.mlp_scaler, scaler.image_scaler
+        elif isinstance(scaler, NeuralImageScaler):
+            mlp, img, imgl = scaler.metadata_scaler, None, scaler
         elif isinstance(scaler, MetadataScaler):
             mlp, img = scaler, None
         else:
             raise NotImplementedError(f"scaling model {type(scaler).__name__} is not supported by the HIP engine yet")
         if model.scale_prior is not None:
             raise NotImplementedError("scale_prior is never enabled by the reference CLI and is not supported")
-        self.q, self.prior, self.lik, self.mlp, self.img = q, prior, lik, mlp, img
+        self.q, self.prior, self.lik, self.mlp, self.img, self.imgl = q, prior, lik, mlp, img, imgl
 
         # ---- observations -> device layout (built after the layout is known, below) ---------------------------
         self.R = int(q.loc_raw.numel())
@@ -283,7 +335,14 @@ class ElboEngine:
         self.ev11 = bool(getattr(lik, "ev11", False))
         self.dw_trainable = self.double_wilson and prior.r_raw is not None
         n_dwr = int(prior.r_raw.numel()) if self.dw_trainable else 0
-        self.layout = make_layout(self.R, self.d, self.w, self.L, n_img, 3 if self.ev11 else 0, n_dwr)
+        if imgl is not None:
+            imgl.build(self.d)
+            max_l = int(self.lib.cl_mlp_max_layers(self.w))
+            if self.L + imgl.n_image_layers > max_l:
+                raise NotImplementedError(f"{self.L} Dense + {imgl.n_image_layers} image layers of width {self.w}: the HIP engine "
+                                          f"supports {max_l} hidden layers in total at this width")
+        self.layout = make_layout(self.R, self.d, self.w, self.L, n_img, 3 if self.ev11 else 0, n_dwr,
+                                  imgl=(imgl.n_image_layers, imgl.max_images) if imgl is not None else None)
         lay = self.layout
         assert lay.P == mlp.param_count(self.d) == int(self.lib.cl_mlp_param_count(self.d, self.w, self.L))
         self.params = torch.empty(lay.n, dtype=torch.float32, device=dev)
@@ -297,6 +356,9 @@ class ElboEngine:
         if n_img > 0:
             self.params[lay.off_img:lay.off_img + n_img] = img._scales.to(dev)
             img._scales = self.params[lay.off_img:lay.off_img + n_img]
+        if imgl is not None:
+            self.params[lay.off_imgl:lay.off_imgl + lay.n_imgl] = imgl.flat.to(dev)
+            imgl.flat = self.params[lay.off_imgl:lay.off_imgl + lay.n_imgl]
         if self.ev11:
             self.params[lay.off_ev11:lay.off_ev11 + 3] = lik.raw.to(dev)
             lik.raw = self.params[lay.off_ev11:lay.off_ev11 + 3]
@@ -315,7 +377,7 @@ class ElboEngine:
         if self.S < 1:
             raise ValueError("mc_sample_size must be >= 1")
         self.obs = ObsData(self.lib, inputs, self.shard.start, self.shard.stop, self.S, lay.P, dev, grid=grid, n_refl=self.R,
-                           n_images=(img.max_images if img is not None else None), laue_groups=self.laue_groups)
+                           n_images=self._max_images(), laue_groups=self.laue_groups, pack_images=imgl is not None)
         RS = self.R * self.S
         o_dz = 0
         o_g = (RS + 3) // 4 * 4
@@ -334,6 +396,11 @@ class ElboEngine:
         self.history_buf: Optional[torch.Tensor] = None
         self._keep = None
         self.refresh_config()
+
+    def _max_images(self):
+        if self.img is not None:
+            return self.img.max_images
+        return self.imgl.max_images if self.imgl is not None else None
 
     # the training shard's arrays under their old names
     N = property(lambda self: self.obs.N)
@@ -409,6 +476,12 @@ class ElboEngine:
         a.iobs = ptr(obs.iobs); a.sig = ptr(obs.sig)
         a.n_obs, a.n_pad = obs.N, obs.n_pad
         a.obs_offset = obs.start
+        if self.imgl is not None:
+            a.n_obs = obs.n_pad                         # packed: validity is per row (row_map / refl_id = -1)
+            a.imgl = self.params.data_ptr() + 4 * lay.off_imgl
+            a.d_imgl = self.grads.data_ptr() + 4 * lay.off_imgl
+            a.n_imgl, a.n_images = self.imgl.n_image_layers, self.imgl.max_images
+            a.tile_img, a.row_map = ptr(obs.tile_img), ptr(obs.row_map)
         a.mlp = self.params.data_ptr() + 4 * lay.off_mlp
         a.d, a.w, a.L = self.d, self.w, self.L
         a.leak = self.mlp.leakiness
@@ -490,7 +563,7 @@ class ElboEngine:
         if BaseModel.is_laue(inputs) != self.laue:
             raise ValueError("validation data and training data differ in kind (mono / Laue)")
         o = ObsData(self.lib, inputs, 0, None, self.S, self.layout.P, self.device, n_refl=self.R,
-                    n_images=(self.img.max_images if self.img is not None else None))
+                    n_images=self._max_images(), pack_images=self.imgl is not None)
         if o.d != self.d:
             raise ValueError("validation metadata width differs from the training data")
         return o
@@ -602,6 +675,12 @@ class ElboEngine:
             out.append(g[base + boff: base + boff + o])
         if lay.n_img > 0:
             out.append(g[lay.off_img: lay.off_img + lay.n_img])
+        if lay.n_imgl > 0:
+            K, M, w = self.imgl.n_image_layers, self.imgl.max_images, self.w
+            for k in range(K):
+                o = lay.off_imgl + k * M * (w * w + w)
+                out.append(g[o: o + M * w * w].view(M, w, w))
+                out.append(g[o + M * w * w: o + M * (w * w + w)].view(M, w))
         if lay.n_ev11 > 0:
             out.append(g[lay.off_ev11: lay.off_ev11 + lay.n_ev11])
         if lay.n_dwr > 0:
@@ -642,8 +721,9 @@ def tn_sample(q, n: int, seed=None, u_f=None) -> torch.Tensor:
     return z.view(R, n).t()
 
 
-def scaler_forward(mlp, metadata):
-    """loc, sigma of the scaler's Normal for every row of `metadata` via `cl_mlp_forward`."""
+def scaler_forward(mlp, metadata, imgl=None, image_id=None):
+    """loc, sigma of the scaler's Normal for every row of `metadata` via `cl_mlp_forward`; `imgl` + `image_id` add the
+    per-image layers of a `NeuralImageScaler`."""
     dev = require_gpu("MLPScaler.call")
     lib = _lib.get_lib()
     md = _np(metadata).astype(np.float32)
@@ -652,9 +732,22 @@ def scaler_forward(mlp, metadata):
     mlp.build(d)
     if mlp.flat.device != dev:
         mlp.flat = mlp.flat.to(dev)
-    n_pad = ((N + TILE - 1) // TILE) * TILE
-    meta_t = np.zeros((int(lib.cl_mlp_meta_rows(d)), n_pad), dtype=np.float32)
-    meta_t[:d, :N] = md.T
+    keep = []
+    if imgl is not None:
+        imgl.build(d)
+        if imgl.flat.device != dev:
+            imgl.flat = imgl.flat.to(dev)
+        ids = _np(image_id).reshape(-1).astype(np.int64)
+        if ids.size != N or (ids.size and (ids.min() < 0 or ids.max() >= imgl.max_images)):
+            raise ValueError("image_id does not match the metadata / exceeds max_images")
+        pos, n_pad, tile_img, row_map = pack_by_image(ids)
+        meta_t = np.zeros((int(lib.cl_mlp_meta_rows(d)), n_pad), dtype=np.float32)
+        meta_t[:d, pos] = md.T
+        keep = [torch.as_tensor(tile_img, device=dev), torch.as_tensor(row_map, device=dev)]
+    else:
+        n_pad = ((N + TILE - 1) // TILE) * TILE
+        meta_t = np.zeros((int(lib.cl_mlp_meta_rows(d)), n_pad), dtype=np.float32)
+        meta_t[:d, :N] = md.T
     meta_t = torch.as_tensor(meta_t, device=dev)
     loc = torch.empty(N, dtype=torch.float32, device=dev)
     sig = torch.empty(N, dtype=torch.float32, device=dev)
@@ -666,6 +759,10 @@ def scaler_forward(mlp, metadata):
     a.eps = mlp.epsilon
     a.S, a.R = 1, 1
     a.loc_out, a.sig_out = ptr(loc), ptr(sig)
+    if imgl is not None:
+        a.n_obs = n_pad
+        a.imgl, a.n_imgl, a.n_images = ptr(imgl.flat), imgl.n_image_layers, imgl.max_images
+        a.tile_img, a.row_map = ptr(keep[0]), ptr(keep[1])
     grid = min(max(1, int(lib.cl_mlp_default_grid())), n_pad // TILE)
     check(lib.cl_mlp_forward(C.byref(a), grid, _stream()), "cl_mlp_forward")
     return loc, sig

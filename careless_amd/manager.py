@@ -209,14 +209,17 @@ class DataManager:
                 istd = None
             else:
                 raise ValueError(f"Unsupported scale bijector type, {parser.scale_bijector}")
-            if parser.image_layers > 0:
-                raise NotImplementedError("--image-layers (NeuralImageScaler) is not supported by the HIP engine yet")
-            mlp_scaler = MLPScaler(parser.mlp_layers, mlp_width, epsilon=parser.epsilon, scale_bijector=bij, scale_multiplier=istd)
-            if parser.use_image_scales:
+            if parser.image_layers > 0:                     # manager.py:467-478
+                from careless_amd.models.scaling.image import NeuralImageScaler
+                n_images = int(np.max(BaseModel.get_image_id(self.inputs))) + 1
+                scaling_model = NeuralImageScaler(parser.image_layers, n_images, parser.mlp_layers, mlp_width,
+                                                  epsilon=parser.epsilon, scale_bijector=bij, scale_multiplier=istd)
+            elif parser.use_image_scales:
+                mlp_scaler = MLPScaler(parser.mlp_layers, mlp_width, epsilon=parser.epsilon, scale_bijector=bij, scale_multiplier=istd)
                 n_images = int(np.max(BaseModel.get_image_id(self.inputs))) + 1
                 scaling_model = HybridImageScaler(mlp_scaler, ImageScaler(n_images))
             else:
-                scaling_model = mlp_scaler
+                scaling_model = MLPScaler(parser.mlp_layers, mlp_width, epsilon=parser.epsilon, scale_bijector=bij, scale_multiplier=istd)
 
         model = VariationalMergingModel(surrogate_posterior, prior, likelihood, scaling_model,
                                         parser.mc_samples if mc_sample_size is None else mc_sample_size, kl_weight=parser.kl_weight)

@@ -125,6 +125,18 @@ typedef struct cl_mlp_args {
     /* Evans-2011 error model (--refine-uncertainties; careless/models/likelihoods/mono.py:39-73): NULL = off */
     const float* ev11;          /* [3] raw (pre-softplus) Sdfac, Sdadd, SdB                                   */
     float* d_ev11;              /* [3] += dL/d raw                                                             */
+    /* NeuralImageScaler (--image-layers K; careless/models/scaling/image.py:66-125): after the L Dense layers, K layers
+     * h <- LeakyReLU(W[image] h + b[image]) with one (w x w) matrix and bias per image.  n_imgl = 0 / NULL = off.
+     * Layout of imgl / d_imgl: K blocks of [ W: n_images x (w x w), row-major (out, in) | b: n_images x w ].
+     * The observation axis must then be PACKED: every 128-observation tile holds rows of ONE image (tile_img), rows of an
+     * image are padded to whole tiles with refl_id = -1, sig = 1, metadata 0; n_obs == n_pad.  row_map gives the caller's
+     * row of every packed row (-1: padding): eta / ipred_out / loc_out / sig_out / dO_ext and the noise key
+     * (obs_offset + row) stay in the caller's row order.                                                          */
+    const float* imgl;
+    float* d_imgl;              /* += dL/d(imgl)                                                               */
+    int n_imgl, n_images;
+    const int* tile_img;        /* [n_pad / CL_MLP_TILE] image of every tile                                   */
+    const int* row_map;         /* [n_pad]                                                                     */
 } cl_mlp_args;
 
 enum { CL_LIK_NORMAL_ = 0, CL_LIK_STUDENTT_ = 1 };

@@ -57,6 +57,7 @@ class ElboConfig:
     prior: str = "wilson"               # "wilson" | "double_wilson"
     ev11: bool = False                  # --refine-uncertainties: Evans-2011 error model (likelihoods/mono.py:39-73)
     optimize_dw_r: bool = False         # --optimize-double-wilson-r (priors/wilson.py:105-110)
+    image_layers: int = 0               # --image-layers: NeuralImageScaler (scaling/image.py:98-125); replaces the image scales
     # Adam (manager.py:494-501; args/optimizer.py)
     learning_rate: float = 1e-3
     beta_1: float = 0.9
@@ -276,11 +277,16 @@ def mlp_identity_init(d: int, width: int, n_layers: int, dtype=np.float32):
     return ws, bs
 
 
-def mlp_forward(metadata, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], leakiness: float):
-    """`MetadataScaler.call` (nn.py:92-103): L x Dense(w, LeakyReLU) then Dense(2, linear).  Returns (N, 2)."""
+def mlp_forward(metadata, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], leakiness: float,
+                image_id=None, imgl_w: Sequence[torch.Tensor] = (), imgl_b: Sequence[torch.Tensor] = ()):
+    """`MetadataScaler.call` (nn.py:92-103): L x Dense(w, LeakyReLU) then Dense(2, linear).  Returns (N, 2).
+    With `imgl_w` / `imgl_b` it is `NeuralImageScaler.call` (image.py:116-125): after the Dense stack, one
+    `ImageLayer` (image.py:90-96) per entry: act(matmul(w[image_id], h[..., None])[..., 0] + b[image_id])."""
     h = metadata
     for w, b in zip(weights[:-1], biases[:-1]):
         h = torch.nn.functional.leaky_relu(h @ w + b, negative_slope=leakiness)
+    for w, b in zip(imgl_w, imgl_b):
+        h = torch.nn.functional.leaky_relu(torch.einsum("noi,ni->no", w[image_id], h) + b[image_id], negative_slope=leakiness)
     return h @ weights[-1] + biases[-1]
 
 
@@ -336,6 +342,8 @@ class ElboParams:
     img_raw: Optional[torch.Tensor] = None   # (M-1,)
     dw_r_raw: Optional[torch.Tensor] = None  # (n_asu,) pre-sigmoid, only with --optimize-double-wilson-r
     ev11_raw: Optional[torch.Tensor] = None  # (3,) pre-softplus Sdfac, Sdadd, SdB (mono.py:42-44), only with cfg.ev11
+    imgl_w: Optional[List[torch.Tensor]] = None   # K x (M, w, w) per-image kernels, only with cfg.image_layers (image.py:76-82)
+    imgl_b: Optional[List[torch.Tensor]] = None   # K x (M, w)
 
     def tensors(self) -> List[torch.Tensor]:
         """Trainable tensors in the flat-buffer order the HIP engine uses."""
@@ -344,6 +352,8 @@ class ElboParams:
             out += [w, b]
         if self.img_raw is not None:
             out.append(self.img_raw)
+        for w, b in zip(self.imgl_w or [], self.imgl_b or []):
+            out += [w, b]
         if self.ev11_raw is not None:
             out.append(self.ev11_raw)
         if self.dw_r_raw is not None:
@@ -359,7 +369,9 @@ class ElboParams:
                 t = t.to(dtype)
             return t.requires_grad_(requires_grad)
         return ElboParams(c(self.q_loc_raw), c(self.q_scale_raw), [c(w) for w in self.mlp_w],
-                          [c(b) for b in self.mlp_b], c(self.img_raw), c(self.dw_r_raw), c(self.ev11_raw))
+                          [c(b) for b in self.mlp_b], c(self.img_raw), c(self.dw_r_raw), c(self.ev11_raw),
+                          None if self.imgl_w is None else [c(w) for w in self.imgl_w],
+                          None if self.imgl_b is None else [c(b) for b in self.imgl_b])
 
 
 @dataclass
@@ -396,7 +408,8 @@ def elbo_forward(p: ElboParams, x: ElboInputs, cfg: ElboConfig, u_f: torch.Tenso
     high = torch.as_tensor(cfg.high, dtype=loc.dtype)
     z_f = tn_sample(loc, scale, x.low, high, u_f)                              # variational.py:154
 
-    out = mlp_forward(x.metadata, p.mlp_w, p.mlp_b, cfg.leakiness)            # variational.py:156 -> nn.py:106-120
+    out = mlp_forward(x.metadata, p.mlp_w, p.mlp_b, cfg.leakiness,            # variational.py:156 -> nn.py:106-120
+                      x.image_id, p.imgl_w or (), p.imgl_b or ())             # --image-layers: image.py:116-125
     s_loc = out[:, 0]
     s_sig = scale_bijector(out[:, 1], cfg.scale_bijector, cfg.epsilon)
     z_scale = s_loc[None, :] + s_sig[None, :] * eta + cfg.scale_shift          # variational.py:157; tfb.Shift(istd) nn.py:84-87
@@ -591,6 +604,14 @@ def init_params(d: Dict, cfg: ElboConfig, n_layers: int, width: Optional[int], d
         with np.errstate(divide="ignore"):
             r0 = np.asarray(d["dw_r"], dtype=np.float64)
             dwr = (np.log(r0) - np.log1p(-r0)).astype(np.float32)
+    iw = ib = None
+    if getattr(cfg, "image_layers", 0) > 0:       # ImageLayer: eye per image, zero bias (image.py:73-88)
+        iw = [np.tile(np.eye(w, dtype=np.float32), (M, 1, 1)) for _ in range(cfg.image_layers)]
+        ib = [np.zeros((M, w), dtype=np.float32) for _ in range(cfg.image_layers)]
+        if perturb > 0.0:
+            iw = [(v + perturb * rng.normal(size=v.shape)).astype(np.float32) for v in iw]
+            ib = [(v + perturb * rng.normal(size=v.shape)).astype(np.float32) for v in ib]
     return ElboParams(t(a32), t(b32), [t(w_) for w_ in ws], [t(b_) for b_ in bs],
                       t(img) if img is not None else None, t(dwr) if dwr is not None else None,
-                      t(ev) if ev is not None else None)
+                      t(ev) if ev is not None else None,
+                      None if iw is None else [t(v) for v in iw], None if ib is None else [t(v) for v in ib])

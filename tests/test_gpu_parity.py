@@ -30,6 +30,13 @@ CASES = {
     "laue_2x32_normal_S3": dict(N=400, R=40, L=2, w=32, S=3, laue=True),
     "laue_5x64_studentt_S2_noimg": dict(N=700, R=64, L=5, w=64, S=2, laue=True, likelihood="studentt", dof=6.0, use_image_scales=False),
     "double_wilson_2x32_S3": dict(N=400, R=60, d0=5, L=2, w=32, S=3, double_wilson=True),
+    # --image-layers: NeuralImageScaler (per-image kernels after the Dense stack); images of very different sizes, > 1 tile
+    "image_layers1_2x32_S3": dict(N=700, R=40, d0=5, L=2, w=32, S=3, n_images=5, image_layers=1),
+    "image_layers2_3x64_S8_studentt": dict(N=1500, R=64, d0=5, posenc=True, L=3, w=64, S=8, n_images=7, image_layers=2,
+                                           likelihood="studentt", dof=16.0),
+    "image_layers2_4x10_softplus": dict(N=900, R=50, d0=5, L=4, w=10, S=2, n_images=6, image_layers=2, bijector="softplus",
+                                        shift=0.7),
+    "laue_image_layers1_2x32": dict(N=600, R=60, L=2, w=32, S=3, laue=True, n_images=4, image_layers=1),
     "double_wilson_trainable_r_S4": dict(N=400, R=60, d0=5, L=2, w=32, S=4, double_wilson=True, optimize_dw_r=True),
     "double_wilson_5x64_S8_studentt": dict(N=600, R=80, d0=5, L=5, w=64, S=8, double_wilson=True, likelihood="studentt", dof=8.0),
 }
@@ -53,6 +60,7 @@ def _assert_grads(g_hip, grads, prob):
     """Every gradient tensor within RTOL_GRAD (max-norm) of the fp64 oracle.  A LeakyReLU pre-activation that lies within
     fp32 rounding of zero takes the other branch in fp32 than in fp64, which moves the lower layers' gradients by O(1e-4) in ANY
     fp32 implementation (the reference's included); such a tensor must then agree with the oracle re-run in fp32 instead."""
+    assert len(g_hip) == len(grads)
     errs = [util.rel_err(a, b.numpy()) for a, b in zip(g_hip, grads)]
     if max(errs) < RTOL_GRAD:
         return
@@ -160,6 +168,64 @@ def test_philox_mode_matches_oracle_on_dumped_noise():
     assert abs(t["loss"] - float(out["loss"])) <= 1e-4 * abs(float(out["loss"]))
     errs = [util.rel_err(a.cpu().numpy(), b.numpy()) for a, b in zip(eng.grad_tensors(), grads)]
     assert max(errs) < RTOL_GRAD, errs
+
+
+def test_image_layers_philox_noise_is_keyed_by_the_callers_rows():
+    """--image-layers packs the observations by image inside the engine; the in-kernel noise must still be keyed by the caller's
+    row index (rows arrive in arbitrary image order here), so the dumped stream replayed through the oracle gives the same loss."""
+    from careless_amd.engine import debug_noise
+    kw = dict(N=500, R=40, d0=5, L=2, w=32, S=3, n_images=5, image_layers=1)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    perm = np.random.default_rng(3).permutation(kw["N"])
+    for k in ("refl_id", "image_id", "file_id", "metadata", "iobs", "sigiobs"):
+        data[k] = np.asarray(data[k])[perm]
+    x = O.inputs_from_numpy(data)
+    model = util.build_model(data, cfg, params, 2, 32)
+    model.seed = 77
+    ipred = model(util.reference_inputs(data)).cpu().numpy()
+    eng = model._engine
+    torch.cuda.synchronize()
+    u = debug_noise(77, 0, 3, 40, 0, kind=0).t().cpu().numpy()
+    e = debug_noise(77, 0, 3, 500, 0, kind=1).t().cpu().numpy()
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(out["loss"])) <= 1e-4 * abs(float(out["loss"]))
+    assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
+    errs = [util.rel_err(a.cpu().numpy(), b.numpy()) for a, b in zip(eng.grad_tensors(), grads)]
+    assert len(errs) == len(grads) and max(errs) < RTOL_GRAD, errs
+
+
+def test_image_layers_adam_trajectory_and_scaler_call():
+    kw = dict(N=600, R=48, d0=5, L=2, w=16, S=2, n_images=4, image_layers=2)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    steps = 10
+    rng = np.random.default_rng(11)
+    noises = [(rng.random((2, 48)).astype(np.float32), rng.normal(size=(2, 600)).astype(np.float32)) for _ in range(steps)]
+    model = util.build_model(data, cfg, params, 2, 16)
+    inputs = util.reference_inputs(data)
+    # scaler(inputs) before training: NeuralImageScaler.call (image.py:116-125)
+    dist = model.scaling_model(inputs)
+    o = O.mlp_forward(x.metadata, params.mlp_w, params.mlp_b, cfg.leakiness, x.image_id, params.imgl_w, params.imgl_b)
+    assert util.rel_err(dist.loc.cpu().numpy(), o[:, 0].numpy()) < 1e-5
+    assert util.rel_err(dist.scale.cpu().numpy(), O.scale_bijector(o[:, 1], "exp", cfg.epsilon).numpy()) < 1e-5
+    hist = model.train_model(inputs, steps, progress=False, noise=lambda i: noises[i])
+    p = params.clone()
+    st = O.AdamState.zeros_like(p.tensors())
+    ref = [O.train_step(p, x, cfg, st, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+           for u, e in noises]
+    for k in ("loss", "NLL", "F KLDiv", "Grad Norm"):
+        a = np.array(hist[k]); b = np.array([r[k] for r in ref])
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) < 2e-4, (k, a, b)
+    for a, b in zip(model.scaling_model.image_weights, [t for pair in zip(p.imgl_w, p.imgl_b) for t in pair]):
+        assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
+    # predictions through the trained model (prediction_mean_stddev -> scaler forward with image layers)
+    mean, std = model.scale_mean_stddev(inputs)
+    o = O.mlp_forward(x.metadata, p.mlp_w, p.mlp_b, cfg.leakiness, x.image_id, p.imgl_w, p.imgl_b)
+    assert util.rel_err(_np(mean).reshape(-1), o[:, 0].detach().numpy()) < 2e-4
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
 
 
 def test_noise_statistics_and_shard_independence():
@@ -313,7 +379,9 @@ def test_validation_nll_matches_oracle_scale():
 
 @pytest.mark.parametrize("kw", [dict(N=517, R=41, d0=5, L=2, w=32, S=3),
                                 dict(N=600, R=50, L=2, w=32, S=2, laue=True),
-                                dict(N=500, R=60, d0=5, L=2, w=32, S=2, double_wilson=True)], ids=["mono", "laue", "double_wilson"])
+                                dict(N=500, R=60, d0=5, L=2, w=32, S=2, double_wilson=True),
+                                dict(N=700, R=40, d0=5, L=2, w=32, S=2, n_images=5, image_layers=1)],
+                         ids=["mono", "laue", "double_wilson", "image_layers"])
 def test_rank_shards_sum_to_full_batch_on_gpu(kw):
     """Data-parallel decomposition on ONE GPU: the engines of rank 0 and rank 1 of a 2-rank world (all-reduce skipped) produce
     partial losses / gradients that add up to the single-rank result; in-kernel noise is keyed by global indices, so the shards

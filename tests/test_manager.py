@@ -52,8 +52,13 @@ def test_build_model_default_wiring():
     with pytest.raises(ValueError):                                  # reference tests/test_cli.py:92-110
         DataManager(inputs, data["centric"], data["multiplicity"], default_args(parents="None,0", dwr="0.,1.0"),
                     double_wilson=dict(reflids=np.zeros(30, int), root=np.ones(30, bool), asu_ids=np.zeros(30, int))).build_model()
-    with pytest.raises(NotImplementedError):
-        dm.build_model(default_args(image_layers=2))
+    m3 = dm.build_model(default_args(image_layers=2, mlp_layers=3, mlp_width=8))          # manager.py:467-478
+    from careless_amd.models.scaling.image import NeuralImageScaler
+    assert isinstance(m3.scaling_model, NeuralImageScaler)
+    assert (m3.scaling_model.n_image_layers, m3.scaling_model.max_images) == (2, int(data["image_id"].max()) + 1)
+    m3.scaling_model.build(5)
+    kern, bias = m3.scaling_model.image_weights[:2]                                        # identity per image, zero bias
+    assert tuple(kern.shape) == (m3.scaling_model.max_images, 8, 8) and bool((kern == np.eye(8, dtype=np.float32)).all()) and not bias.any()
 
 
 def test_wilson_prior_b_uses_resolution():

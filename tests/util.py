@@ -9,7 +9,10 @@ from oracle import elbo_oracle as O
 
 def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, likelihood="normal", dof=None,
                  bijector="exp", shift=0.0, use_image_scales=True, kl_weight=None, perturb=0.05, seed=7,
-                 outliers=False, double_wilson=False, laue=False, ev11=False, optimize_dw_r=False, **opt):
+                 outliers=False, double_wilson=False, laue=False, ev11=False, optimize_dw_r=False, image_layers=0, **opt):
+    if image_layers > 0:
+        use_image_scales = False        # NeuralImageScaler replaces the HybridImageScaler (manager.py:467-489)
+        opt["image_layers"] = image_layers
     if laue:
         data = O.make_synthetic_laue(N, R=R, n_images=n_images, seed=seed)
     elif double_wilson:
@@ -44,7 +47,7 @@ def build_model(data, cfg: O.ElboConfig, params: O.ElboParams, L, w):
     from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
     from careless_amd.models.merging.variational import VariationalMergingModel
     from careless_amd.models.priors.wilson import DoubleWilsonPrior, WilsonPrior
-    from careless_amd.models.scaling.image import HybridImageScaler, ImageScaler
+    from careless_amd.models.scaling.image import HybridImageScaler, ImageScaler, NeuralImageScaler
     from careless_amd.models.scaling.nn import MLPScaler
     from careless_amd.optimizers import Adam
 
@@ -65,9 +68,19 @@ def build_model(data, cfg: O.ElboConfig, params: O.ElboParams, L, w):
         lik.raw = torch.as_tensor(params.ev11_raw.numpy().astype(np.float32))
     else:
         lik = mod.NormalLikelihood() if cfg.likelihood == "normal" else mod.StudentTLikelihood(cfg.dof)
-    mlp = MLPScaler(L, w, leakiness=cfg.leakiness, epsilon=cfg.epsilon, scale_bijector=cfg.scale_bijector,
-                    scale_multiplier=(cfg.scale_shift if cfg.scale_shift else None))
     d = np.asarray(data["metadata"]).shape[1]
+    nis = None
+    if cfg.image_layers > 0:
+        nis = NeuralImageScaler(cfg.image_layers, int(data["n_images"]), L, w, leakiness=cfg.leakiness, epsilon=cfg.epsilon,
+                                scale_bijector=cfg.scale_bijector, scale_multiplier=(cfg.scale_shift if cfg.scale_shift else None))
+        nis.build(d)
+        mlp = nis.metadata_scaler
+        for dst, wt, b in zip(range(cfg.image_layers), params.imgl_w, params.imgl_b):
+            nis.image_weights[2 * dst].copy_(torch.as_tensor(wt.numpy().astype(np.float32)))
+            nis.image_weights[2 * dst + 1].copy_(torch.as_tensor(b.numpy().astype(np.float32)))
+    else:
+        mlp = MLPScaler(L, w, leakiness=cfg.leakiness, epsilon=cfg.epsilon, scale_bijector=cfg.scale_bijector,
+                        scale_multiplier=(cfg.scale_shift if cfg.scale_shift else None))
     mlp.build(d)
     ws = []
     for wt, b in zip(params.mlp_w, params.mlp_b):
@@ -77,6 +90,8 @@ def build_model(data, cfg: O.ElboConfig, params: O.ElboParams, L, w):
         img = ImageScaler(int(data["n_images"]))
         img._scales.copy_(torch.as_tensor(params.img_raw.numpy().astype(np.float32)))
         scaler = HybridImageScaler(mlp, img)
+    elif nis is not None:
+        scaler = nis
     else:
         scaler = mlp
     model = VariationalMergingModel(q, prior, lik, scaler, mc_sample_size=cfg.mc_samples, kl_weight=cfg.kl_weight)
