@@ -46,22 +46,28 @@ __global__ __launch_bounds__(256) void laue_predict_kernel(const cl_laue_args A)
 
 __global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride over the (slot, sample) pairs: the NLL ends in ONE double atomic per workgroup on one address (they
+    // serialise at ~12 ns each), so the grid is kept at a few workgroups per CU instead of one per 256 elements
+    const long long total = (long long)A.n_obs * A.S;
     double nll = 0.0;
     float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f;
-    if (p < (long long)A.n_obs * A.S) {
+    cl_ev11 ev = {1.0f, 0.0f, 0.0f};
+    float sg0 = 0.0f, sg1 = 0.0f, sg2 = 0.0f;
+    if (A.ev11 != nullptr) {
+        ev.sdfac = cl_softplus(A.ev11[0]); ev.sdadd = cl_softplus(A.ev11[1]); ev.sdb = cl_softplus(A.ev11[2]);
+        sg0 = cl_sigmoid(A.ev11[0]); sg1 = cl_sigmoid(A.ev11[1]); sg2 = cl_sigmoid(A.ev11[2]);
+    }
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(p / A.S);
         float dll, ll;
         if (A.ev11 != nullptr) {
-            cl_ev11 ev;
-            ev.sdfac = cl_softplus(A.ev11[0]); ev.sdadd = cl_softplus(A.ev11[1]); ev.sdb = cl_softplus(A.ev11[2]);
             float gf, gb, ga;
             ll = cl_lik_ev11(A.iconv[p], A.iobs[g], A.sig[g], A.lik_kind, A.dof, A.lik_const, ev, &dll, &gf, &gb, &ga);
-            g0 = -gf * A.w_ll * cl_sigmoid(A.ev11[0]); g1 = -ga * A.w_ll * cl_sigmoid(A.ev11[1]); g2 = -gb * A.w_ll * cl_sigmoid(A.ev11[2]);
+            g0 -= gf * A.w_ll * sg0; g1 -= ga * A.w_ll * sg1; g2 -= gb * A.w_ll * sg2;
         } else {
             ll = cl_lik_log_prob(A.iconv[p], A.iobs[g], A.sig[g], A.lik_kind, A.dof, A.lik_const, &dll);
         }
-        nll = -(double)ll * (double)A.w_ll;
+        nll -= (double)ll * (double)A.w_ll;
         A.iconv[p] = -dll * A.w_ll;                  // dNLL / d iconv[g][s]
     }
     __shared__ double sh[4];
@@ -79,28 +85,46 @@ __global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args
 __global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n_obs) return;
-    const int rid = A.refl_id[i], hid = A.harmonic_id[i];
-    float aim = 1.0f;
+    const bool act = i < A.n_obs;                    // no early return: the image-scale reduction below is wave-wide
     int im = 0;
-    if (A.use_img) { im = A.image_id[i]; if (im > 0) aim = A.img[im - 1]; }
-    const float loc = A.loc[i], sigma = A.sigma[i];
-    float dloc = 0.0f, dsig = 0.0f, da = 0.0f;
-    for (int s = 0; s < A.S; ++s) {
-        const float eta = laue_eta(A, i, s);
-        const float tq = loc + sigma * eta + A.shift;
-        const float zf = A.z_f[(size_t)rid * A.S + s];
-        const float gi = A.iconv[(size_t)hid * A.S + s];
-        const float dzs = gi * zf * zf;
-        atomicAdd(A.dz_f + (size_t)rid * A.S + s, gi * aim * tq * 2.0f * zf);
-        const float dt = dzs * aim;
-        dloc += dt;
-        dsig += dt * eta;
-        da += dzs * tq;
+    float da = 0.0f;
+    if (act) {
+        const int rid = A.refl_id[i], hid = A.harmonic_id[i];
+        float aim = 1.0f;
+        if (A.use_img) { im = A.image_id[i]; if (im > 0) aim = A.img[im - 1]; }
+        const float loc = A.loc[i], sigma = A.sigma[i];
+        float dloc = 0.0f, dsig = 0.0f;
+        for (int s = 0; s < A.S; ++s) {
+            const float eta = laue_eta(A, i, s);
+            const float tq = loc + sigma * eta + A.shift;
+            const float zf = A.z_f[(size_t)rid * A.S + s];
+            const float gi = A.iconv[(size_t)hid * A.S + s];
+            const float dzs = gi * zf * zf;
+            atomicAdd(A.dz_f + (size_t)rid * A.S + s, gi * aim * tq * 2.0f * zf);
+            const float dt = dzs * aim;
+            dloc += dt;
+            dsig += dt * eta;
+            da += dzs * tq;
+        }
+        A.dO[2 * (size_t)i] = dloc;
+        A.dO[2 * (size_t)i + 1] = dsig;
     }
-    A.dO[2 * (size_t)i] = dloc;
-    A.dO[2 * (size_t)i + 1] = dsig;
-    if (A.use_img && im > 0) atomicAdd(A.d_img + (im - 1), da);
+    if (A.use_img) {
+        // rows are (nearly) ordered by image, so a wave usually holds one image: 64 same-address atomics would serialise in the
+        // L2 atomic unit -- reduce in the wave and issue one
+        const int key = (act && im > 0) ? im : 0;    // 0: nothing to add (image 0 is pinned to 1, image.py:23-25)
+        int kmax = key;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
+        if (__all(key == kmax || key == 0)) {
+            float v = key ? da : 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if ((threadIdx.x & 63) == 0 && kmax > 0) atomicAdd(A.d_img + (kmax - 1), v);
+        } else if (key > 0) {
+            atomicAdd(A.d_img + (key - 1), da);
+        }
+    }
 }
 
 static int laue_check(const cl_laue_args& a) {
@@ -123,7 +147,9 @@ int cl_launch_laue_likelihood(const cl_laue_args& a, hipStream_t st) {
     if (a.iobs == nullptr || a.sig == nullptr || a.scalars == nullptr) return -1;
     const long long n = (long long)a.n_obs * a.S;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(laue_likelihood_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(laue_likelihood_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int cl_launch_laue_backward(const cl_laue_args& a, hipStream_t st) {

@@ -138,6 +138,13 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     constexpr int KS1 = DP / 4;          // MFMA k-steps of the first layer (4 metadata features per step)
     constexpr int IB1 = (DP + 15) / 16;  // 16-feature blocks of the metadata
     constexpr int PW = SL::PW, PW1 = SL::PW1, PB = CL_PB;
+    // Width <= 16: a layer has ONE 16x16 weight-gradient block and the plan below splits its 128-observation contraction into
+    // eight parts of 16 -- wave k contracts exactly the 16 columns of the staging tiles that wave k wrote itself.  The waves
+    // then never read each other's LDS data and the workgroup barriers of the backward pass reduce to wave-local ordering
+    // (layer 0 too when the metadata fits one block).  This is the geometry of the careless CLI default (20 layers x width d).
+    constexpr bool WLOC = (FB == 1);                 // hidden layers are wave-local
+    constexpr bool WLOC0 = WLOC && (IB1 == 1);       // ... and so is the first layer
+    static_assert(!WLOC || (WgradPlan<1, 1>::KPARTS == CL_NW && WgradPlan<1, 1>::GROUPS == 1), "wave-local wgrad plan");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const sW1 = smem + SL::oW1;
@@ -529,7 +536,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         // ================= backward =======================================================================
         // tile seam: every wave must be done reading the staging tiles of the previous tile's last wgrad
         STAMP(2);
-        lds_barrier();
+        if (WLOC0) wave_lds_sync(); else lds_barrier();
         STAMP(3);
         if (q == 0) { sDl[j] = dloc; sDs[j] = draw; }      // the dO tile for the Dense(2) wgrad (wave-private)
 
@@ -576,7 +583,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     for (int t = 0; t < 4; ++t) dH[mb][t] = (hs[l][mb][t] > 0.0f) ? dH[mb][t] : leak * dH[mb][t];
 
                 STAMP(5);
-                if (l < L - 1) lds_barrier();      // barrier A: the previous layer's wgrad reads are complete
+                // barrier A: the previous layer's wgrad reads are complete
+                if (l < L - 1) { if (WLOC) wave_lds_sync(); else lds_barrier(); }
                 STAMP(6);
 #pragma unroll
                 for (int mb = 0; mb < FB; ++mb)
@@ -629,7 +637,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     }
                 }
                 STAMP(7);
-                lds_barrier();                     // barrier B: staging tiles complete for all 128 observations
+                // barrier B: staging tiles complete for all 128 observations
+                if (WLOC && (l > 0 || WLOC0)) wave_lds_sync(); else lds_barrier();
                 STAMP(8);
 
                 // ---- wgrad: 16x16 blocks of dW_l^T[o][i] = sum_obs dZ[o][obs] H_in[i][obs] ---------------------

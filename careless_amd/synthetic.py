@@ -96,14 +96,11 @@ def make_synthetic_laue(N: int, R: Optional[int] = None, seed: int = 1234, n_ima
     group share image and observed intensity; Iobs / SigIobs live in slots [0,G) ordered by harmonic id and are padded with `pad`
     beyond (careless/io/formatter.py:617,637-640); metadata gets the wavelength as a sixth column."""
     rng = np.random.default_rng(seed)
-    sizes = []
-    tot = 0
-    while tot < N:
-        k = int(rng.choice([1, 2, 3], p=[0.8, 0.15, 0.05]))
-        k = min(k, N - tot)
-        sizes.append(k)
-        tot += k
-    G = len(sizes)
+    ks = rng.choice(np.array([1, 2, 3]), size=N, p=[0.8, 0.15, 0.05])       # more than enough groups; cut where the rows run out
+    cum = np.cumsum(ks)
+    G = int(np.searchsorted(cum, N, side="left")) + 1
+    sizes = ks[:G].copy()
+    sizes[-1] -= int(cum[G - 1]) - N
     hid = np.repeat(np.arange(G), sizes).astype(np.int64)
     d = make_synthetic(N, R=R, d0=5, seed=seed, n_images=n_images)
     # rows of one harmonic group come from one image

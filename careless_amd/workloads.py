@@ -10,19 +10,29 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
-from careless_amd.synthetic import make_synthetic
+from careless_amd.synthetic import make_synthetic, make_synthetic_double_wilson, make_synthetic_laue
 
 WORKLOADS: Dict[str, dict] = {
     # BASELINE.json configs[1]
     "mono_1M_normal_5x64_S1": dict(N=1_000_000, d0=5, posenc=False, L=5, w=64, S=1, dof=None, outliers=False),
     # BASELINE.json configs[2]: the configuration the headline metric is quoted on
     "mono_10M_studentt_posenc_5x64_S8": dict(N=10_000_000, d0=5, posenc=True, L=5, w=64, S=8, dof=16.0, outliers=True),
+    # BASELINE.json configs[3]: Laue harmonic deconvolution (quoted on 4 GPUs; runs on one)
+    "laue_5M_normal_5x64_S1": dict(N=5_000_000, d0=5, posenc=False, L=5, w=64, S=1, dof=None, outliers=False, kind="laue"),
+    # BASELINE.json configs[4]: two-ASU double-Wilson prior (quoted on 8 GPUs; runs on one)
+    "dw_50M_normal_5x64_S1": dict(N=50_000_000, d0=5, posenc=False, L=5, w=64, S=1, dof=None, outliers=False, kind="double_wilson"),
+    # the careless CLI defaults: 20 layers of the metadata width (args/scaling.py), Student-T off, mc-samples 1
+    "mono_10M_cli_default_20x5_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=5, S=1, dof=None, outliers=False),
+    # --image-layers 1 on the headline configuration (one Dense layer traded for a per-image layer)
+    "mono_10M_studentt_posenc_4x64_img1_S8": dict(N=10_000_000, d0=5, posenc=True, L=4, w=64, S=8, dof=16.0, outliers=True,
+                                                  image_layers=1),
 }
 
 
-def flops_per_obs(d: int, w: int, L: int) -> int:
-    """Algorithmic flops of the scaler per observation per step: 6 (d w + (L-1) w^2 + 2 w)  (SURVEY 8d)."""
-    return 6 * (d * w + (L - 1) * w * w + 2 * w)
+def flops_per_obs(d: int, w: int, L: int, image_layers: int = 0) -> int:
+    """Algorithmic flops of the scaler per observation per step: 6 (d w + (L-1) w^2 + 2 w)  (SURVEY 8d); a per-image layer
+    costs the same w x w product as a Dense layer."""
+    return 6 * (d * w + (L - 1 + image_layers) * w * w + 2 * w)
 
 
 def bytes_per_obs(d: int, S: int, image_scales: bool = True) -> int:
@@ -38,22 +48,34 @@ def reference_inputs(data) -> Tuple[np.ndarray, ...]:
 
 
 def build_model(data, L: int, w: int, S: int, dof: Optional[float] = None, image_scales: bool = True,
-                scale_bijector: str = "exp", epsilon: float = 1e-7, init_scale: float = 1.0, seed: int = 1234):
-    from careless_amd.models.likelihoods.mono import NormalLikelihood, StudentTLikelihood
+                scale_bijector: str = "exp", epsilon: float = 1e-7, init_scale: float = 1.0, seed: int = 1234,
+                kind: str = "mono", image_layers: int = 0):
     from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
     from careless_amd.models.merging.variational import VariationalMergingModel
-    from careless_amd.models.priors.wilson import WilsonPrior
-    from careless_amd.models.scaling.image import HybridImageScaler, ImageScaler
+    from careless_amd.models.priors.wilson import DoubleWilsonPrior, WilsonPrior
+    from careless_amd.models.scaling.image import HybridImageScaler, ImageScaler, NeuralImageScaler
     from careless_amd.models.scaling.nn import MLPScaler
     from careless_amd.optimizers import Adam
+    if kind == "laue":
+        from careless_amd.models.likelihoods.laue import NormalLikelihood, StudentTLikelihood
+    else:
+        from careless_amd.models.likelihoods.mono import NormalLikelihood, StudentTLikelihood
 
-    prior = WilsonPrior(data["centric"], data["multiplicity"], 1.0)
+    if kind == "double_wilson":
+        prior = DoubleWilsonPrior(data["centric"], data["multiplicity"], data["parent_ids"], data["root"], data["asu_ids"],
+                                  data["dw_r"], parents=[None, 0])
+    else:
+        prior = WilsonPrior(data["centric"], data["multiplicity"], 1.0)
     low = (1e-32 * ~np.asarray(data["centric"], dtype=bool)).astype(np.float32)          # manager.py:434
     q = TruncatedNormal.from_loc_and_scale(prior.mean(), prior.stddev() * init_scale, low, scale_shift=epsilon)
     lik = NormalLikelihood() if dof is None else StudentTLikelihood(dof)
     istd = float(np.asarray(data["iobs"]).std()) if scale_bijector == "softplus" else None  # manager.py:457
-    mlp = MLPScaler(L, w, epsilon=epsilon, scale_bijector=scale_bijector, scale_multiplier=istd)
-    scaler = HybridImageScaler(mlp, ImageScaler(int(data["n_images"]))) if image_scales else mlp
+    if image_layers > 0:                                                                   # manager.py:467-478
+        scaler = NeuralImageScaler(image_layers, int(data["n_images"]), L, w, epsilon=epsilon, scale_bijector=scale_bijector,
+                                   scale_multiplier=istd)
+    else:
+        mlp = MLPScaler(L, w, epsilon=epsilon, scale_bijector=scale_bijector, scale_multiplier=istd)
+        scaler = HybridImageScaler(mlp, ImageScaler(int(data["n_images"]))) if image_scales else mlp
     model = VariationalMergingModel(q, prior, lik, scaler, mc_sample_size=S)
     model.seed = seed
     model.compile(Adam(1e-3, 0.9, 0.99))                                                  # args/optimizer.py
@@ -65,9 +87,20 @@ def make_workload(name: str, N: Optional[int] = None, seed: int = 1234):
     spec = dict(WORKLOADS[name])
     if N is not None:
         spec["N"] = int(N)
-    data = make_synthetic(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
-    model = build_model(data, spec["L"], spec["w"], spec["S"], dof=spec["dof"])
+    kind = spec.setdefault("kind", "mono")
+    spec.setdefault("image_layers", 0)
+    if kind == "laue":
+        data = make_synthetic_laue(spec["N"], seed=seed)
+    elif kind == "double_wilson":
+        data = make_synthetic_double_wilson(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
+    else:
+        data = make_synthetic(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
+    model = build_model(data, spec["L"], spec["w"], spec["S"], dof=spec["dof"], kind=kind, image_layers=spec["image_layers"])
+    inputs = reference_inputs(data)
+    if kind == "laue":
+        col = lambda a, t: np.asarray(a).astype(t)[:, None]
+        inputs = inputs + (col(data["wavelength"], np.float32), col(data["harmonic_id"], np.int64))
     spec["d"] = int(np.asarray(data["metadata"]).shape[1])
     spec["R"] = int(data["n_refl"])
     spec["M"] = int(data["n_images"])
-    return model, reference_inputs(data), data, spec
+    return model, inputs, data, spec
