@@ -1,0 +1,167 @@
+"""Reciprocal-space bookkeeping from symmetry operators: resolution, canonical asymmetric-unit representative, centric flag,
+multiplicity epsilon and systematic absences.  Stands in for what the reference gets from gemmi / reciprocalspaceship in
+`careless/io/asu.py:5-143` (`ReciprocalASU`, `ReciprocalASUCollection`) and `careless/io/formatter.py:285-302`.
+
+The operators are the `SYMM` records of the MTZ header (all of them, centring translations included).  The ASU representative of
+a reflection is the lexicographically largest (h, k, l) of its orbit -- under the rotations only (anomalous: Friedel mates of
+acentric reflections stay separate) or under rotations and inversion (the default).  That is a valid asymmetric unit; it is not
+gemmi's choice, so merged reflections may be listed under a symmetry-equivalent index of the one the reference would print."""
+from __future__ import annotations
+
+import re
+from typing import List, Sequence
+
+import numpy as np
+
+
+def parse_symop(s: str):
+    """'X-Y, X, Z+1/2' -> (3x3 integer rotation acting on fractional coordinates, translation)."""
+    R = np.zeros((3, 3), dtype=np.int64)
+    t = np.zeros(3)
+    for i, part in enumerate(s.replace(" ", "").upper().split(",")):
+        for sign, num, den, ax in re.findall(r"([+-]?)(?:(\d+)/(\d+)|([XYZ]))", part):
+            sg = -1 if sign == "-" else 1
+            if ax:
+                R[i, "XYZ".index(ax)] += sg
+            else:
+                t[i] += sg * int(num) / int(den)
+    return R, t
+
+
+def reciprocal_metric(cell) -> np.ndarray:
+    a, b, c, al, be, ga = [float(v) for v in cell]
+    al, be, ga = np.deg2rad([al, be, ga])
+    G = np.array([[a * a, a * b * np.cos(ga), a * c * np.cos(be)],
+                  [a * b * np.cos(ga), b * b, b * c * np.cos(al)],
+                  [a * c * np.cos(be), b * c * np.cos(al), c * c]])
+    return np.linalg.inv(G)
+
+
+def inv_d2(hkl: np.ndarray, cell) -> np.ndarray:
+    """1 / d^2 of every Miller index (any crystal system)."""
+    h = np.asarray(hkl, dtype=np.float64)
+    return np.einsum("ni,ij,nj->n", h, reciprocal_metric(cell), h)
+
+
+def _key(h: np.ndarray) -> np.ndarray:
+    B = 1 << 20
+    return (h[..., 0] + B // 2) * B * B + (h[..., 1] + B // 2) * B + (h[..., 2] + B // 2)
+
+
+class SymmetryOps:
+    def __init__(self, symops: Sequence[str]):
+        parsed = [parse_symop(s) for s in symops]
+        self.R = np.stack([p[0] for p in parsed])         # (nops, 3, 3)
+        self.t = np.stack([p[1] for p in parsed])         # (nops, 3)
+
+    def orbit(self, hkl: np.ndarray) -> np.ndarray:
+        """(nops, N, 3): h' = h R for every operator (row-vector convention for reciprocal space)."""
+        return np.einsum("ni,oij->onj", np.asarray(hkl, dtype=np.int64), self.R)
+
+    def to_asu(self, hkl: np.ndarray, anomalous: bool = False) -> np.ndarray:
+        orb = self.orbit(hkl)
+        if not anomalous:
+            orb = np.concatenate([orb, -orb], axis=0)
+        best = np.argmax(_key(orb), axis=0)
+        return np.take_along_axis(orb, best[None, :, None], axis=0)[0]
+
+    def describe(self, hkl: np.ndarray):
+        """centric (N,) bool, epsilon (N,) int, absent (N,) bool."""
+        h = np.asarray(hkl, dtype=np.int64)
+        orb = self.orbit(h)
+        same = np.all(orb == h[None], axis=2)
+        eps = same.sum(0)
+        phase = np.einsum("ni,oi->on", h.astype(np.float64), self.t)
+        absent = np.any(same & (np.abs(phase - np.round(phase)) > 1e-6), axis=0)
+        centric = np.any(np.all(orb == -h[None], axis=2), axis=0)
+        return centric, eps, absent
+
+
+class ReciprocalASU:
+    """All unique reflections to `dmin` (reference careless/io/asu.py:5-83)."""
+
+    def __init__(self, cell, symops: Sequence[str], dmin: float, anomalous: bool = False, spacegroup_name: str = "P 1",
+                 spacegroup_number: int = 1):
+        self.cell, self.symops, self.dmin, self.anomalous = tuple(cell), list(symops), float(dmin), bool(anomalous)
+        self.spacegroup_name, self.spacegroup_number = spacegroup_name, int(spacegroup_number)
+        self.ops = SymmetryOps(symops)
+        s2max = 1.0 / (self.dmin * self.dmin) * (1.0 + 1e-6)
+        Gs = reciprocal_metric(cell)
+        # |h_i| <= sqrt(s2max * G_ii) with G the direct metric: bound of the index range
+        G = np.linalg.inv(Gs)
+        lim = [int(np.floor(np.sqrt(s2max * G[i, i]))) + 1 for i in range(3)]
+        ax = [np.arange(-m, m + 1) for m in lim]
+        g = np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1).reshape(-1, 3)
+        g = g[np.any(g != 0, axis=1)]
+        g = g[inv_d2(g, cell) <= s2max]
+        g = g[np.all(self.ops.to_asu(g, anomalous) == g, axis=1)]          # keep the representatives
+        centric, eps, absent = self.ops.describe(g)
+        g, centric, eps = g[~absent], centric[~absent], eps[~absent]
+        order = np.lexsort((g[:, 2], g[:, 1], g[:, 0]))
+        self.Hall = g[order]
+        self._centric, self._eps = centric[order], eps[order]
+        self._dHKL = (1.0 / np.sqrt(inv_d2(self.Hall, cell))).astype(np.float32)
+        k = _key(self.Hall)
+        self._sort = np.argsort(k)
+        self._keys = k[self._sort]
+
+    @property
+    def centric(self):
+        return self._centric
+
+    @property
+    def multiplicity(self):
+        return self._eps.astype(np.float32)
+
+    @property
+    def dHKL(self):
+        return self._dHKL
+
+    def __len__(self):
+        return len(self.Hall)
+
+    def to_refl_id(self, H: np.ndarray) -> np.ndarray:
+        """Reflection ids of Miller indices that are already ASU representatives; raises KeyError for anything else."""
+        k = _key(np.asarray(H, dtype=np.int64))
+        pos = np.searchsorted(self._keys, k)
+        pos = np.clip(pos, 0, len(self._keys) - 1)
+        if not np.all(self._keys[pos] == k):
+            raise KeyError("Miller index outside the reciprocal asymmetric unit (absent, beyond dmin, or not mapped to the ASU)")
+        return self._sort[pos].astype(np.int64)
+
+    def to_miller_index(self, refl_id):
+        return self.Hall[np.asarray(refl_id, dtype=np.int64)]
+
+
+class ReciprocalASUCollection:
+    """Several ASUs addressed by one contiguous reflection id (reference careless/io/asu.py:85-143)."""
+
+    def __init__(self, reciprocal_asus: List[ReciprocalASU]):
+        self.reciprocal_asus = list(reciprocal_asus)
+        sizes = [len(a) for a in self.reciprocal_asus]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.asu_ids = np.concatenate([np.full(n, i, dtype=np.int64) for i, n in enumerate(sizes)])
+        self.centric = np.concatenate([a.centric for a in self.reciprocal_asus])
+        self.multiplicity = np.concatenate([a.multiplicity for a in self.reciprocal_asus])
+        self.dHKL = np.concatenate([a.dHKL for a in self.reciprocal_asus])
+        self.Hall = np.concatenate([a.Hall for a in self.reciprocal_asus])
+
+    def __len__(self):
+        return len(self.reciprocal_asus)
+
+    def __iter__(self):
+        return iter(self.reciprocal_asus)
+
+    def to_refl_id(self, asu_ids, H) -> np.ndarray:
+        asu_ids = np.asarray(asu_ids, dtype=np.int64).reshape(-1)
+        H = np.asarray(H, dtype=np.int64)
+        out = np.empty(len(asu_ids), dtype=np.int64)
+        for i, a in enumerate(self.reciprocal_asus):
+            m = asu_ids == i
+            if m.any():
+                out[m] = a.to_refl_id(H[m]) + self.offsets[i]
+        return out
+
+    def to_asu_id_and_miller_index(self, refl_id):
+        refl_id = np.asarray(refl_id, dtype=np.int64).reshape(-1)
+        return self.asu_ids[refl_id], self.Hall[refl_id]

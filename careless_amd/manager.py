@@ -26,7 +26,7 @@ def default_args(**overrides) -> Namespace:
     ns = Namespace(
         type="mono",
         mc_samples=1, structure_factor_init_scale=1.0, epsilon=1e-7,                         # args/common.py
-        mlp_layers=20, mlp_width=None, image_layers=0, use_image_scales=True, scale_bijector="exp",   # args/scaling.py
+        mlp_layers=20, mlp_width=10, image_layers=0, use_image_scales=True, scale_bijector="exp",   # args/scaling.py
         iterations=10_000, learning_rate=1e-3, beta_1=0.9, beta_2=0.99,                      # args/optimizer.py
         clipnorm=None, clipvalue=None, global_clipnorm=None,
         studentt_likelihood_dof=None, refine_uncertainties=False,                            # args/likelihood.py
@@ -46,15 +46,22 @@ def default_args(**overrides) -> Namespace:
 class DataManager:
     """Data manipulation methods plus model construction (reference `DataManager`, array inputs)."""
 
-    def __init__(self, inputs, centric, multiplicity, parser: Optional[Namespace] = None, dHKL=None, double_wilson=None):
+    def __init__(self, inputs, centric, multiplicity=None, parser: Optional[Namespace] = None, dHKL=None, double_wilson=None):
         """
         inputs        : tuple in BaseModel.input_index order (numpy arrays, reference shapes / dtypes)
-        centric       : (R,) bool       -- `asu_collection.centric`
+        centric       : (R,) bool       -- `asu_collection.centric`; or a `careless_amd.io.asu.ReciprocalASUCollection`, which then
+                        also supplies multiplicity, dHKL and the double-Wilson parent lookup (the reference's call signature
+                        `DataManager(inputs, asu_collection, parser=parser)`, careless/careless.py:39)
         multiplicity  : (R,) float      -- `asu_collection.multiplicity`
         dHKL          : (R,) float, resolution of every reflection, only needed with --wilson-prior-b (manager.py:43-52)
         double_wilson : dict(reflids=, root=, asu_ids=) -- the parent lookup the reference derives with gemmi (priors/wilson.py:112-138)
         """
         self.inputs = tuple(inputs)
+        self.asu_collection = None
+        if hasattr(centric, "reciprocal_asus"):
+            self.asu_collection = rac = centric
+            centric, multiplicity = rac.centric, rac.multiplicity
+            dHKL = rac.dHKL if dHKL is None else dHKL
         self.centric = np.asarray(centric, dtype=bool)
         self.multiplicity = np.asarray(multiplicity, dtype=np.float32)
         self.parser = parser
@@ -181,6 +188,8 @@ class DataManager:
                 if r < 0:
                     from warnings import warn
                     warn(f"Supplied --double-wilson-r value {r} is negative")
+            if self.double_wilson is None and self.asu_collection is not None:
+                self.double_wilson = double_wilson_lookup(self.asu_collection, parents, parser.reindexing_ops)
             if self.double_wilson is None:
                 raise ValueError("the double-Wilson prior needs the parent lookup arrays (reflids, root, asu_ids)")
             dw = self.double_wilson
@@ -228,6 +237,37 @@ class DataManager:
                            clipvalue=parser.clipvalue, global_clipnorm=parser.global_clipnorm),
                       run_eagerly=getattr(parser, "run_eagerly", False))
         return model
+
+
+def double_wilson_lookup(rac, parents, reindexing_ops=None):
+    """reflids / root / asu_ids of `DoubleWilsonPrior` from an ASU collection (reference priors/wilson.py:112-138): every reflection
+    of a child ASU is re-indexed into the parent's setting (`--double-wilson-reindexing-ops`, ';'-separated, 'x,y,z' = identity),
+    mapped to the parent's ASU and looked up there; -1 = no such parent reflection (absent or beyond the resolution limit)."""
+    from careless_amd.io.asu import parse_symop
+    ops = None
+    if reindexing_ops is not None:
+        ops = [parse_symop(o)[0] for o in (reindexing_ops.split(";") if isinstance(reindexing_ops, str) else reindexing_ops)]
+    reflids, root = [], []
+    for child, parent in enumerate(parents):
+        casu = rac.reciprocal_asus[child]
+        if parent is None:
+            reflids.append(np.arange(len(casu), dtype=np.int64))           # as the reference: the ASU-local ids, unused for roots
+            root.append(np.ones(len(casu), dtype=bool))
+            continue
+        root.append(np.zeros(len(casu), dtype=bool))
+        pasu = rac.reciprocal_asus[parent]
+        h = casu.Hall
+        if ops is not None:
+            h = h @ ops[child]                                             # rs.utils.apply_to_hkl: h' = h R
+        h = pasu.ops.to_asu(h, pasu.anomalous)
+        ids = np.full(len(h), -1, dtype=np.int64)
+        from careless_amd.io.asu import _key
+        k = _key(h)
+        pos = np.clip(np.searchsorted(pasu._keys, k), 0, len(pasu._keys) - 1)
+        hit = pasu._keys[pos] == k
+        ids[hit] = pasu._sort[pos[hit]] + rac.offsets[parent]
+        reflids.append(ids)
+    return dict(reflids=np.concatenate(reflids), root=np.concatenate(root), asu_ids=rac.asu_ids)
 
 
 def merge_half_datasets(dm: DataManager, parser: Namespace, scaling_model, iterations: int, repeats: int = 1, progress=False):

@@ -1,0 +1,90 @@
+"""End-to-end runs of `careless_amd mono|poly` on the reference's fixture, modelled on the reference's tests/test_cli.py:36-228
+(same flag combinations, same assertions: output files exist and are readable, space group carried through, resolution cut kept)."""
+import os
+
+import numpy as np
+import pytest
+
+from careless_amd.io.asu import inv_d2
+from careless_amd.io.mtz import read_mtz
+from tests.mtz_fixture import PYP
+
+pytestmark = pytest.mark.gpu
+niter = 10
+
+
+def _run(flags, files, out, separate):
+    from careless_amd.careless import run_careless
+    from careless_amd.parser import parser
+    cmd = flags.split() + (["--separate-files"] if separate else []) + list(files) + [out]
+    args = parser.parse_args(cmd)
+    model, hist = run_careless(args)
+    assert len(hist["loss"]) == args.iterations and np.all(np.isfinite(hist["loss"]))
+    for i in range(len(files) if separate else 1):
+        f = out + f"_{i}.mtz"
+        assert os.path.exists(f)
+        ds, src = read_mtz(f), read_mtz(files[i])
+        assert ds.spacegroup_number == src.spacegroup_number and ds.symops == src.symops
+        assert len(ds) > 0 and np.all(np.isfinite(ds.columns["F"])) and np.all(ds.columns["SigF"] > 0) and np.all(ds.columns["N"] > 0)
+        if args.dmin is not None:
+            assert (1.0 / np.sqrt(inv_d2(ds.hkl(), ds.cell))).min() >= args.dmin
+        assert os.path.exists(out + f"_predictions_{i}.mtz")
+    for suffix in ("_history.csv", "_structure_factor", "_scale"):
+        assert os.path.exists(out + suffix)
+    return args, model, hist
+
+
+@pytest.mark.parametrize("mode", ["mono", "poly"])
+@pytest.mark.parametrize("ev11,dmin,anomalous,isigi,dof,separate", [(False, None, False, None, None, False), (True, 7.0, True, 1.0, 12.0, True),
+                                                                    (True, None, False, None, 12.0, False), (False, 7.0, True, None, None, True)])
+def test_twofile(tmp_path, mode, ev11, dmin, anomalous, isigi, dof, separate):
+    flags = f"{mode} --disable-gpu --iterations={niter} --disable-progress-bar --mlp-layers 4 dHKL,image_id"
+    flags += " --refine-uncertainties" if ev11 else ""
+    flags += f" --dmin={dmin}" if dmin is not None else ""
+    flags += " --anomalous" if anomalous else ""
+    flags += f" --isigi-cutoff={isigi}" if isigi is not None else ""
+    flags += f" --studentt-likelihood-dof={dof}" if dof is not None else ""
+    _run(flags, [PYP, PYP], str(tmp_path / "out"), separate)
+
+
+@pytest.mark.parametrize("mode", ["mono", "poly"])
+@pytest.mark.parametrize("optimize_r", [False, True])
+def test_double_wilson(tmp_path, mode, optimize_r):
+    flags = f"{mode} --iterations={niter} --disable-progress-bar --mlp-layers 3 dHKL,image_id --double-wilson-parents=None,0"
+    flags += " --optimize-double-wilson-r" if optimize_r else ""
+    _, model, hist = _run(flags + " --double-wilson-r=0.0,0.9", [PYP, PYP], str(tmp_path / "out"), True)
+    if optimize_r:
+        assert "rDW_1" in hist and abs(hist["rDW_1"][0] - 0.9) < 1e-6
+    with pytest.raises(ValueError):
+        _run(flags + " --double-wilson-r=0.0,1.0", [PYP, PYP], str(tmp_path / "out2"), True)
+
+
+def test_image_layers_crossvalidation_and_reloading(tmp_path):
+    out = str(tmp_path / "a")
+    flags = (f"mono --iterations={niter} --disable-progress-bar --mlp-layers 3 --mlp-width 8 --image-layers 2 --test-fraction 0.2 "
+             "--merge-half-datasets --half-dataset-repeats 2 --positional-encoding-keys X,Y dHKL,image_id,Hobs,Kobs,Lobs")
+    args, model, hist = _run(flags, [PYP], out, False)
+    assert "NLL_val" in hist and os.path.exists(out + "_xval_0.mtz")
+    x = read_mtz(out + "_xval_0.mtz")
+    assert set(np.unique(x.columns["half"])) == {0.0, 1.0} and set(np.unique(x.columns["repeat"])) == {0.0, 1.0}
+    p = read_mtz(out + "_predictions_0.mtz")
+    assert set(np.unique(p.columns["test"])) == {0.0, 1.0} and np.all(np.isfinite(p.columns["Ipred"]))
+    # second run: start from the saved weights, freeze the scales (reference careless.py:48-56)
+    out2 = str(tmp_path / "b")
+    flags2 = (f"mono --iterations=3 --disable-progress-bar --mlp-layers 3 --mlp-width 8 --image-layers 2 --scale-file {out}_scale "
+              f"--structure-factor-file {out}_structure_factor --freeze-scales --positional-encoding-keys X,Y dHKL,image_id,Hobs,Kobs,Lobs")
+    _, model2, _ = _run(flags2, [PYP], out2, False)
+    assert np.array_equal(model2.scaling_model.flat.cpu().numpy(), model.scaling_model.flat.cpu().numpy())   # frozen => unchanged
+
+
+def test_preformatted_npz_input(tmp_path):
+    from careless_amd.io.formats import save_inputs_npz
+    from careless_amd.io.formatter import MonoFormatter
+    inputs, rac = MonoFormatter(None, None, None, ["dHKL", "image_id"], False, False).format_files([PYP])
+    npz = str(tmp_path / "in.npz")
+    save_inputs_npz(npz, inputs, rac)
+    from careless_amd.careless import run_careless
+    from careless_amd.parser import parser
+    out = str(tmp_path / "o")
+    _, hist = run_careless(parser.parse_args(f"mono --iterations=5 --disable-progress-bar --mlp-layers 2 dHKL,image_id {npz} {out}".split()))
+    assert len(hist["loss"]) == 5 and read_mtz(out + "_0.mtz").spacegroup_number == 173

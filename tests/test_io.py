@@ -1,0 +1,197 @@
+"""On-disk formats and input formatting: MTZ round trip, reciprocal-ASU bookkeeping, mono / Laue formatters on the
+reference's own fixture `tests/data/pyp_off.mtz` (tests/golden/pyp_off.mtz), npz container, history CSV, command line.
+Modelled on the reference's tests/io/test_asu.py, tests/io/test_data_formatter.py (shape / dtype / consistency assertions)."""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+from careless_amd.io.asu import ReciprocalASU, ReciprocalASUCollection, SymmetryOps, inv_d2
+from careless_amd.io.formats import load_inputs_npz, save_inputs_npz, write_history_csv
+from careless_amd.io.formatter import LaueFormatter, MonoFormatter, expand_harmonics, standardize_metadata
+from careless_amd.io.mtz import read_mtz, write_mtz
+from careless_amd.models.base import BaseModel
+from tests import mtz_fixture
+
+PYP = mtz_fixture.PYP
+P212121 = ["X, Y, Z", "-X+1/2, -Y, Z+1/2", "-X, Y+1/2, -Z+1/2", "X+1/2, -Y+1/2, -Z"]
+C2 = ["X, Y, Z", "-X, Y, -Z", "X+1/2, Y+1/2, Z", "-X+1/2, Y+1/2, -Z"]
+
+
+def test_mtz_round_trip(tmp_path):
+    m = read_mtz(PYP)
+    assert (len(m), m.spacegroup_name, m.spacegroup_number, len(m.symops)) == (166, "P 63", 173, 6)
+    assert m.types["I"] == "J" and m.types["SigI"] == "Q" and m.types["BATCH"] == "B" and m.first_key_of_type("J") == "I"
+    out = str(tmp_path / "rt.mtz")
+    cols = dict(m.columns)
+    cols["I"] = cols["I"].copy(); cols["I"][3] = np.nan                    # missing value
+    write_mtz(out, cols, m.types, m.cell, m.symops, m.spacegroup_name, m.spacegroup_number)
+    m2 = read_mtz(out)
+    assert m2.keys() == m.keys() and m2.types == m.types and m2.symops == m.symops and m2.spacegroup_number == 173
+    assert np.allclose(m2.cell, m.cell) and all(np.array_equal(cols[k], m2.columns[k], equal_nan=True) for k in cols)
+    assert os.path.getsize(out) == 80 + 4 * 166 * 10 + 80 * sum(1 for _ in open(out, "rb").read()[80 + 4 * 1660:][::80])
+    with pytest.raises(ValueError):
+        write_mtz(out, {"I": [1.0]}, {"I": "J"}, m.cell)
+
+
+@pytest.mark.parametrize("anomalous", [True, False])
+@pytest.mark.parametrize("dmin", [10.0, 5.0])
+@pytest.mark.parametrize("cell,symops", [((66.9, 66.9, 40.95, 90, 90, 120), None), ((34.0, 45.0, 99.0, 90, 90, 90), P212121),
+                                         ((50.0, 60.0, 70.0, 90, 103.0, 90), C2)])
+def test_reciprocal_asu(dmin, anomalous, cell, symops):
+    symops = read_mtz(PYP).symops if symops is None else symops
+    asu = ReciprocalASU(cell, symops, dmin, anomalous)
+    ops = SymmetryOps(symops)
+    H = asu.Hall
+    assert len(H) > 0 and np.all(1.0 / np.sqrt(inv_d2(H, cell)) >= dmin * (1 - 1e-6)) and np.all(np.isfinite(asu.dHKL))
+    assert np.array_equal(asu.to_refl_id(H), np.arange(len(H))) and np.array_equal(asu.to_miller_index(np.arange(len(H))), H)
+    assert np.all(ops.to_asu(H, anomalous) == H)                           # representatives are fixed points of the mapping
+    centric, eps, absent = ops.describe(H)
+    assert not absent.any() and np.array_equal(centric, asu.centric) and np.array_equal(eps, asu.multiplicity)
+    # every reflection of the sphere maps onto exactly one listed representative, or is systematically absent
+    g = np.stack(np.meshgrid(*[np.arange(-21, 22)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    g = g[np.any(g != 0, 1)]
+    g = g[1.0 / np.sqrt(inv_d2(g, cell)) >= dmin]
+    _, _, ab = ops.describe(g)
+    ids = asu.to_refl_id(ops.to_asu(g[~ab], anomalous))
+    assert set(ids) == set(range(len(H)))
+    if not anomalous:                                                      # Friedel mates share an id
+        assert np.array_equal(asu.to_refl_id(ops.to_asu(-g[~ab], anomalous)), ids)
+    else:                                                                  # ... unless anomalous, where only centrics do
+        c = asu.centric[ids]
+        ids_m = asu.to_refl_id(ops.to_asu(-g[~ab], anomalous))
+        assert np.array_equal(ids_m[c], ids[c]) and np.all(ids_m[~c] != ids[~c])
+    with pytest.raises(KeyError):
+        asu.to_refl_id(np.array([[99, 99, 99]]))
+
+
+def test_asu_collection():
+    m = read_mtz(PYP)
+    a, b = ReciprocalASU(m.cell, m.symops, 5.0, False), ReciprocalASU(m.cell, m.symops, 10.0, True)
+    rac = ReciprocalASUCollection([a, b])
+    assert len(rac) == 2 and rac.reciprocal_asus[0] is a and len(rac.centric) == len(a) + len(b)
+    for i, asu in enumerate(rac):
+        rid = rac.to_refl_id(np.full(len(asu), i), asu.Hall)
+        assert np.array_equal(rid, np.arange(len(asu)) + rac.offsets[i])
+        ai, H = rac.to_asu_id_and_miller_index(rid)
+        assert np.all(ai == i) and np.array_equal(H, asu.Hall)
+
+
+def _check_inputs(inputs):
+    n = inputs[0].shape[0]
+    for v in inputs:                                                       # reference tests/io/test_data_formatter.py:46-52
+        assert v.ndim == 2 and v.dtype in (np.float32, np.int64) and v.shape[0] == n
+    return n
+
+
+@pytest.mark.parametrize("intensity_key,sigma_key,image_key", [("I", "SigI", "BATCH"), (None, None, None)])
+@pytest.mark.parametrize("separate,anomalous", [(True, True), (False, False)])
+@pytest.mark.parametrize("dmin,isigi", [(0.0, None), (7.0, 3.0)])
+@pytest.mark.parametrize("pe", [None, ["X", "Y"]])
+def test_mono_formatter(intensity_key, sigma_key, image_key, separate, anomalous, dmin, isigi, pe):
+    f = MonoFormatter(intensity_key, sigma_key, image_key, ["dHKL", "Hobs", "image_id"], separate, anomalous, dmin, isigi, pe, 3)
+    inputs, rac = f([read_mtz(PYP), read_mtz(PYP)])
+    n = _check_inputs(inputs)
+    assert len(inputs) == 6 and len(rac) == (2 if separate else 1)
+    md = BaseModel.get_metadata(inputs)
+    assert md.shape == (n, 3 + (12 if pe else 0)) and np.allclose(md[:, :3].mean(0), 0, atol=1e-4) and np.allclose(md[:, :3].std(0), 1, atol=1e-3)
+    assert BaseModel.get_refl_id(inputs).max() < len(rac.centric) and BaseModel.get_image_id(inputs).max() == 9      # 5 images x 2 files
+    if dmin == 0.0 and isigi is None:
+        assert n == 2 * 166
+        # the same grouping of observations as the test fixture's table-driven ASU mapping
+        fx = mtz_fixture.build_inputs()
+        rid = BaseModel.get_refl_id(inputs).reshape(-1)[:166]
+        if not anomalous:
+            assert len(np.unique(rid)) == 111
+            a, b = np.unique(rid, return_inverse=True)[1], np.unique(fx["refl_id"], return_inverse=True)[1]
+            assert len(set(zip(a.tolist(), b.tolist()))) == 111             # one-to-one between the two labellings
+            assert np.array_equal(rac.centric[rid], fx["centric"][fx["refl_id"]])
+            assert np.array_equal(rac.multiplicity[rid], fx["multiplicity"][fx["refl_id"]])
+
+
+@pytest.mark.parametrize("lam", [(None, None), (0.8, 1.5)])
+@pytest.mark.parametrize("dmin,isigi", [(None, None), (7.0, 3.0)])
+@pytest.mark.parametrize("separate,anomalous", [(True, True), (False, False)])
+def test_laue_formatter(lam, dmin, isigi, separate, anomalous):
+    f = LaueFormatter("Wavelength", None, None, None, ["dHKL", "Hobs", "image_id", "Wavelength"], separate, anomalous, lam[0], lam[1], dmin, isigi,
+                      ["X", "Y"], 3)
+    inputs, rac = f([read_mtz(PYP)])
+    n = _check_inputs(inputs)
+    assert len(inputs) == 8 and BaseModel.is_laue(inputs)
+    hid = BaseModel.get_harmonic_id(inputs).reshape(-1)
+    G = hid.max() + 1
+    assert np.array_equal(np.unique(hid), np.arange(G)) and G <= n
+    io, sg = BaseModel.get_intensities(inputs).reshape(-1), BaseModel.get_uncertainties(inputs).reshape(-1)
+    assert np.all(io[G:] == 1.0) and np.all(sg[G:] == 1.0)                 # padded slots (reference formatter.py:637-640)
+    # rows of one harmonic group sit on one image and are integer multiples of one primitive index
+    img = BaseModel.get_image_id(inputs).reshape(-1)
+    assert all(len(set(img[hid == g])) == 1 for g in range(min(G, 50)))
+    wl = BaseModel.get_wavelength(inputs).reshape(-1)
+    if lam[0] is not None:
+        assert wl.min() >= 0.8 and wl.max() <= 1.5
+
+
+def test_expand_harmonics_matches_definition():
+    m = read_mtz(PYP)
+    d = 1.0 / np.sqrt(inv_d2(m.hkl(), m.cell))
+    out = expand_harmonics(dict(m.columns), m.cell, dmin=4.0)
+    H = np.stack([out["H"], out["K"], out["L"]], 1).astype(int)
+    H0 = np.stack([out["H_0"], out["K_0"], out["L_0"]], 1).astype(int)
+    n = np.gcd.reduce(H, axis=1)
+    assert np.all(np.gcd.reduce(H0, axis=1) == 1) and np.array_equal(H, n[:, None] * H0)
+    assert np.all(1.0 / np.sqrt(inv_d2(H, m.cell)) >= 4.0 - 1e-6)
+    # every central ray lists n = 1 .. floor(d_0 / dmin); lambda_n = lambda_0 / n
+    key = np.stack([out["BATCH"], out["H_0"], out["K_0"], out["L_0"], out["I"]], 1)
+    _, inv = np.unique(key, axis=0, return_inverse=True)
+    for g in range(inv.max() + 1):
+        nn = np.sort(n[inv.reshape(-1) == g])
+        assert np.array_equal(nn, np.arange(1, len(nn) + 1))
+        w = out["Wavelength"][inv.reshape(-1) == g] * n[inv.reshape(-1) == g]
+        assert np.allclose(w, w[0], rtol=1e-5)
+
+
+def test_standardize_metadata_leaves_constant_columns():
+    x = np.array([[1.0, 5.0], [2.0, 5.0], [3.0, 5.0]], dtype=np.float32)
+    with pytest.warns(UserWarning):
+        y = standardize_metadata(x, ["a", "b"])
+    assert np.allclose(y[:, 0], [-1.2247, 0, 1.2247], atol=1e-3) and np.all(y[:, 1] == 5.0)
+
+
+def test_npz_container_and_history_csv(tmp_path):
+    f = MonoFormatter(None, None, None, ["dHKL", "image_id"], False, False)
+    inputs, rac = f.format_files([PYP])
+    p = str(tmp_path / "in.npz")
+    save_inputs_npz(p, inputs, rac)
+    inputs2, rac2 = load_inputs_npz(p)
+    assert len(inputs2) == len(inputs) and all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(inputs, inputs2))
+    assert np.array_equal(rac2.Hall, rac.Hall) and np.array_equal(rac2.centric, rac.centric)
+    c = str(tmp_path / "h.csv")
+    write_history_csv(c, {"loss": [3.0, 2.0], "NLL": [1.5, 1.0]})
+    assert open(c).read().splitlines() == ["step,loss,NLL", "0,3.0,1.5", "1,2.0,1.0"]
+    with pytest.raises(ValueError):
+        f.format_files(["x.stream"])
+
+
+def test_parser_matches_the_reference_flags():
+    from careless_amd.parser import parser
+    a = parser.parse_args(["mono", "dHKL,BATCH", "a.mtz", "b.mtz", "out"])
+    assert (a.type, a.metadata_keys, a.reflection_files, a.output_base) == ("mono", "dHKL,BATCH", ["a.mtz", "b.mtz"], "out")
+    assert (a.mlp_layers, a.mlp_width, a.iterations, a.mc_samples, a.use_image_scales, a.standardize_metadata, a.seed) == (20, 10, 10000, 1, True, True, 1234)
+    b = parser.parse_args(["poly", "--disable-image-scales", "--studentt-likelihood-dof", "16", "--double-wilson-r=0.,0.9",
+                           "--double-wilson-parents=None,0", "-l", "0.9", "1.2", "--image-layers", "2", "--jit-compile", "dHKL", "a.mtz", "o"])
+    assert (b.type, b.use_image_scales, b.studentt_likelihood_dof, b.dwr, b.parents, b.wavelength_range, b.image_layers,
+            b.wavelength_key) == ("poly", False, 16.0, "0.,0.9", "None,0", [0.9, 1.2], 2, "Wavelength")
+
+
+def test_double_wilson_lookup_from_asu_collection():
+    from careless_amd.manager import double_wilson_lookup
+    m = read_mtz(PYP)
+    a, b = ReciprocalASU(m.cell, m.symops, 6.0), ReciprocalASU(m.cell, m.symops, 8.0)
+    rac = ReciprocalASUCollection([a, b])
+    dw = double_wilson_lookup(rac, [None, 0], "x,y,z;x,y,z")
+    assert dw["root"][: len(a)].all() and not dw["root"][len(a):].any()
+    child = dw["reflids"][len(a):]
+    assert np.all(child >= 0) and np.array_equal(rac.Hall[child], b.Hall)          # the child's reflections exist in the bigger parent
+    dw2 = double_wilson_lookup(ReciprocalASUCollection([b, a]), [None, 0])
+    assert (dw2["reflids"][len(b):] == -1).sum() == len(a) - len(b)                # parent ends at 8 A: the rest is absent

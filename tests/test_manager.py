@@ -18,7 +18,7 @@ def _dm(laue=False, **flags):
 
 def test_default_flags_match_reference_cli():
     a = default_args()
-    assert (a.mc_samples, a.mlp_layers, a.mlp_width, a.image_layers, a.use_image_scales, a.scale_bijector) == (1, 20, None, 0, True, "exp")
+    assert (a.mc_samples, a.mlp_layers, a.mlp_width, a.image_layers, a.use_image_scales, a.scale_bijector) == (1, 20, 10, 0, True, "exp")
     assert (a.learning_rate, a.beta_1, a.beta_2, a.iterations, a.epsilon, a.seed) == (1e-3, 0.9, 0.99, 10000, 1e-7, 1234)
     assert a.studentt_likelihood_dof is None and a.kl_weight is None and a.clipnorm is None
     with pytest.raises(ValueError):
@@ -36,7 +36,7 @@ def test_build_model_default_wiring():
     assert np.array_equal(q.low.numpy(), (1e-32 * ~np.asarray(data["centric"])).astype(np.float32))
     assert isinstance(model.likelihood, NormalLikelihood) and isinstance(model.scaling_model, HybridImageScaler)
     mlp = model.scaling_model.mlp_scaler
-    assert (mlp.n_layers, mlp.width, mlp.scale_bijector, mlp.scale_multiplier) == (20, 5, "exp", None)    # mlp_width None -> d
+    assert (mlp.n_layers, mlp.width, mlp.scale_bijector, mlp.scale_multiplier) == (20, 10, "exp", None)   # the CLI defaults (args/scaling.py)
     assert model.scaling_model.image_scaler.max_images == int(data["image_id"].max()) + 1
     assert (model.optimizer.learning_rate, model.optimizer.beta_2, model.mc_sample_size) == (1e-3, 0.99, 1)
     m2 = dm.build_model(default_args(studentt_likelihood_dof=4.0, refine_uncertainties=True, scale_bijector="softplus",
