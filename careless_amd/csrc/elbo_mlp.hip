@@ -38,6 +38,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // compiler-level fence for memory operations: keeps hipcc from hoisting a whole layer of LDS operand reads
 // above the MFMAs that consume them
 #define CL_PIN() asm volatile("" ::: "memory")
+// Full scheduling fence.  Used to pin software-prefetched LDS operand reads ABOVE the MFMA group that runs while they are in
+// flight: a wave issues in order and an MFMA issue blocks until the matrix pipe accepts it, so reads placed after a group of
+// MFMAs only start when that group has drained; hipcc by itself keeps one operand buffer and emits exactly that order.
+#define CL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // Diagnostic build only (-DCL_STAMPS, scripts/stamps.py): per-wave cycle shares of the phases of a tile.  The shipped
 // library is built without it and executes no stamp.
@@ -396,15 +400,25 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         }
                     } else {
                         const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
+                        const float* pa0 = Wl + (16 * mb + j) * PW + 4 * q;
+                        const float* pa1 = Wl + (16 * (mb + MB1) + j) * PW + 4 * q;
+                        f32x4 a40 = *reinterpret_cast<const f32x4*>(pa0);
+                        f32x4 a41 = *reinterpret_cast<const f32x4*>(pa1);
 #pragma unroll
                         for (int kb = 0; kb < FB; ++kb) {
-                            const f32x4 a40 = *reinterpret_cast<const f32x4*>(Wl + (16 * mb + j) * PW + 16 * kb + 4 * q);
-                            const f32x4 a41 = *reinterpret_cast<const f32x4*>(Wl + (16 * (mb + MB1) + j) * PW + 16 * kb + 4 * q);
+                            f32x4 n40 = a40, n41 = a41;          // operands of the NEXT k-block, in flight under this block's MFMAs
+                            if (kb + 1 < FB) {
+                                n40 = *reinterpret_cast<const f32x4*>(pa0 + 16 * (kb + 1));
+                                n41 = *reinterpret_cast<const f32x4*>(pa1 + 16 * (kb + 1));
+                            }
+                            CL_SCHED_FENCE();
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 acc0 = mfma4(a40[t], hs[l > 0 ? l - 1 : 0][kb][t], acc0);
                                 if (MBS == 2) acc1 = mfma4(a41[t], hs[l > 0 ? l - 1 : 0][kb][t], acc1);
                             }
+                            CL_SCHED_FENCE();
+                            a40 = n40; a41 = n41;
                         }
                     }
                     CL_PIN();
@@ -623,14 +637,30 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     for (int mb = 0; mb < FB; mb += MBS) {
                         constexpr int MB1 = MBS - 1;
                         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                        // A operands (W rows 16 kb + 4 q + t, one ds_read_b32 per MFMA) of the next k-block are requested before
+                        // this block's MFMAs are issued (see CL_SCHED_FENCE)
+                        const float* wq = Wl + (4 * q) * PW + j + 16 * mb;
+                        float r0[4], r1[4];
 #pragma unroll
-                        for (int kb = 0; kb < FB; ++kb)
+                        for (int t = 0; t < 4; ++t) { r0[t] = wq[t * PW]; r1[t] = wq[t * PW + 16 * MB1]; }
+#pragma unroll
+                        for (int kb = 0; kb < FB; ++kb) {
+                            float n0[4], n1[4];
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                const float* wr = Wl + (16 * kb + 4 * q + t) * PW + j;
-                                acc0 = mfma4(wr[16 * mb], dH[kb][t], acc0);
-                                if (MBS == 2) acc1 = mfma4(wr[16 * (mb + MB1)], dH[kb][t], acc1);
+                                n0[t] = r0[t]; n1[t] = r1[t];
+                                if (kb + 1 < FB) { n0[t] = wq[(16 * (kb + 1) + t) * PW]; n1[t] = wq[(16 * (kb + 1) + t) * PW + 16 * MB1]; }
                             }
+                            CL_SCHED_FENCE();
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                acc0 = mfma4(r0[t], dH[kb][t], acc0);
+                                if (MBS == 2) acc1 = mfma4(r1[t], dH[kb][t], acc1);
+                            }
+                            CL_SCHED_FENCE();
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) { r0[t] = n0[t]; r1[t] = n1[t]; }
+                        }
                         dn[mb] = acc0;
                         if (MBS == 2) dn[mb + MB1] = acc1;
                         CL_PIN();
@@ -651,17 +681,26 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
                     static_assert(WG::BPW <= WB, "accumulator blocks");
                     f32x4 acc0 = wacc[l][0], acc1 = wacc[l][WB - 1];
-#pragma unroll 4
+                    // operands of the next 16 observations are requested before this step's MFMAs are issued (see CL_SCHED_FENCE)
+                    f32x4 a4 = *reinterpret_cast<const f32x4*>(pa);
+                    f32x4 b4 = *reinterpret_cast<const f32x4*>(pb);
+                    f32x4 c4 = (WG::BPW == 2) ? *reinterpret_cast<const f32x4*>(pb + 16 * PB) : b4;
+#pragma unroll
                     for (int g = 0; g < WG::KLEN / 16; ++g) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + 16 * g);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 16 * g);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) acc0 = mfma4(a4[t], b4[t], acc0);
-                        if (WG::BPW == 2) {
-                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(pb + 16 * PB + 16 * g);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) acc1 = mfma4(a4[t], c4[t], acc1);
+                        f32x4 na = a4, nb = b4, nc = c4;
+                        if (g + 1 < WG::KLEN / 16) {
+                            na = *reinterpret_cast<const f32x4*>(pa + 16 * (g + 1));
+                            nb = *reinterpret_cast<const f32x4*>(pb + 16 * (g + 1));
+                            if (WG::BPW == 2) nc = *reinterpret_cast<const f32x4*>(pb + 16 * PB + 16 * (g + 1));
                         }
+                        CL_SCHED_FENCE();
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc0 = mfma4(a4[t], b4[t], acc0);
+                            if (WG::BPW == 2) acc1 = mfma4(a4[t], c4[t], acc1);
+                        }
+                        CL_SCHED_FENCE();
+                        a4 = na; b4 = nb; c4 = nc;
                     }
                     wacc[l][0] = acc0;
                     if (WG::BPW == 2) wacc[l][WB - 1] = acc1;
@@ -673,17 +712,26 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
                     static_assert(WG::BPW <= WB, "accumulator blocks");
                     f32x4 acc0 = wacc[l][0], acc1 = wacc[l][WB - 1];
-#pragma unroll 4
+                    // operands of the next 16 observations are requested before this step's MFMAs are issued (see CL_SCHED_FENCE)
+                    f32x4 a4 = *reinterpret_cast<const f32x4*>(pa);
+                    f32x4 b4 = *reinterpret_cast<const f32x4*>(pb);
+                    f32x4 c4 = (WG::BPW == 2) ? *reinterpret_cast<const f32x4*>(pb + 16 * PB) : b4;
+#pragma unroll
                     for (int g = 0; g < WG::KLEN / 16; ++g) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pa + 16 * g);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 16 * g);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) acc0 = mfma4(a4[t], b4[t], acc0);
-                        if (WG::BPW == 2) {
-                            const f32x4 c4 = *reinterpret_cast<const f32x4*>(pb + 16 * PB + 16 * g);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) acc1 = mfma4(a4[t], c4[t], acc1);
+                        f32x4 na = a4, nb = b4, nc = c4;
+                        if (g + 1 < WG::KLEN / 16) {
+                            na = *reinterpret_cast<const f32x4*>(pa + 16 * (g + 1));
+                            nb = *reinterpret_cast<const f32x4*>(pb + 16 * (g + 1));
+                            if (WG::BPW == 2) nc = *reinterpret_cast<const f32x4*>(pb + 16 * PB + 16 * (g + 1));
                         }
+                        CL_SCHED_FENCE();
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc0 = mfma4(a4[t], b4[t], acc0);
+                            if (WG::BPW == 2) acc1 = mfma4(a4[t], c4[t], acc1);
+                        }
+                        CL_SCHED_FENCE();
+                        a4 = na; b4 = nb; c4 = nc;
                     }
                     wacc[l][0] = acc0;
                     if (WG::BPW == 2) wacc[l][WB - 1] = acc1;
