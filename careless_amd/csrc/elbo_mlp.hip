@@ -590,11 +590,14 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 // next tile's inputs: issued two layers before the end of the backward pass -- early enough to cover the HBM
                 // latency, late enough that the registers of the upper layers' activations are free again
                 if (l == pf_layer && tile + tile_step < tile_end) prefetch(tile + tile_step);
-                // dZ_l = dH_l * lrelu'(H_l)   (sign of the post-activation == sign of the pre-activation)
+                // dZ_l = dH_l * lrelu'(H_l)   (sign of the post-activation == sign of the pre-activation).  Only the top layer
+                // does it here: for the others it was done one step earlier, in the shadow of the wgrad operand reads (below)
+                if (l == L - 1) {
 #pragma unroll
-                for (int mb = 0; mb < FB; ++mb)
+                    for (int mb = 0; mb < FB; ++mb)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) dH[mb][t] = (hs[l][mb][t] > 0.0f) ? dH[mb][t] : leak * dH[mb][t];
+                        for (int t = 0; t < 4; ++t) dH[mb][t] = (hs[l][mb][t] > 0.0f) ? dH[mb][t] : leak * dH[mb][t];
+                }
 
                 STAMP(5);
                 // barrier A: the previous layer's wgrad reads are complete
@@ -617,39 +620,33 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
                     for (int t = 0; t < KS1; ++t) sH[(4 * t + q) * PB + CL_WOBS * wv + j] = h0s[t];
                 }
-                wave_lds_sync();
-                if (lane < WP) {                   // bias gradient: row sums of this wave's own columns of dZ
-                    float sb = 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x4 z4 = *reinterpret_cast<const f32x4*>(sZ + lane * PB + CL_WOBS * wv + 4 * e);
-                        sb += (z4[0] + z4[1]) + (z4[2] + z4[3]);
-                    }
-                    bacc[l] += sb;
-                }
                 // ---- dgrad: dH_{l-1} = W_l dZ_l.  Register + weight-image only, so it runs BEFORE barrier B and
                 //      overlaps the other waves' staging writes ---------------------------------------------------
                 f32x4 dn[FB];
                 if (l > 0) {
                     const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
                     constexpr int MBS = (FB >= 2) ? 2 : 1;
+                    constexpr int MB1 = MBS - 1;
+                    // A operands: W rows 16 kb + 4 q + t, one ds_read_b32 per MFMA.  Those of the next k-block (or of the next
+                    // pair of output blocks) are requested before this block's MFMAs are issued (see CL_SCHED_FENCE)
+                    const float* wq = Wl + (4 * q) * PW + j;
+                    float r0[4], r1[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { r0[t] = wq[t * PW]; r1[t] = wq[t * PW + 16 * MB1]; }
 #pragma unroll
                     for (int mb = 0; mb < FB; mb += MBS) {
-                        constexpr int MB1 = MBS - 1;
                         f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-                        // A operands (W rows 16 kb + 4 q + t, one ds_read_b32 per MFMA) of the next k-block are requested before
-                        // this block's MFMAs are issued (see CL_SCHED_FENCE)
-                        const float* wq = Wl + (4 * q) * PW + j + 16 * mb;
-                        float r0[4], r1[4];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) { r0[t] = wq[t * PW]; r1[t] = wq[t * PW + 16 * MB1]; }
 #pragma unroll
                         for (int kb = 0; kb < FB; ++kb) {
                             float n0[4], n1[4];
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 n0[t] = r0[t]; n1[t] = r1[t];
-                                if (kb + 1 < FB) { n0[t] = wq[(16 * (kb + 1) + t) * PW]; n1[t] = wq[(16 * (kb + 1) + t) * PW + 16 * MB1]; }
+                                if (kb + 1 < FB) {
+                                    n0[t] = wq[(16 * (kb + 1) + t) * PW + 16 * mb]; n1[t] = wq[(16 * (kb + 1) + t) * PW + 16 * (mb + MB1)];
+                                } else if (mb + MBS < FB) {
+                                    n0[t] = wq[t * PW + 16 * (mb + MBS)]; n1[t] = wq[t * PW + 16 * (mb + MBS + MB1)];
+                                }
                             }
                             CL_SCHED_FENCE();
 #pragma unroll
@@ -663,7 +660,6 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         }
                         dn[mb] = acc0;
                         if (MBS == 2) dn[mb + MB1] = acc1;
-                        CL_PIN();
                     }
                 }
                 STAMP(7);
@@ -685,6 +681,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     f32x4 a4 = *reinterpret_cast<const f32x4*>(pa);
                     f32x4 b4 = *reinterpret_cast<const f32x4*>(pb);
                     f32x4 c4 = (WG::BPW == 2) ? *reinterpret_cast<const f32x4*>(pb + 16 * PB) : b4;
+                    // bias gradient = row sums of this wave's own 16 columns of dZ: read here, summed under the first MFMA group
+                    f32x4 z4[4];
+                    const float* pz = sZ + (lane < WP ? lane : 0) * PB + CL_WOBS * wv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z4[e] = *reinterpret_cast<const f32x4*>(pz + 4 * e);
 #pragma unroll
                     for (int g = 0; g < WG::KLEN / 16; ++g) {
                         f32x4 na = a4, nb = b4, nc = c4;
@@ -700,6 +701,12 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             if (WG::BPW == 2) acc1 = mfma4(a4[t], c4[t], acc1);
                         }
                         CL_SCHED_FENCE();
+                        if (g == 0) {
+                            float sb = 0.0f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sb += (z4[e][0] + z4[e][1]) + (z4[e][2] + z4[e][3]);
+                            if (lane < WP) bacc[l] += sb;
+                        }
                         a4 = na; b4 = nb; c4 = nc;
                     }
                     wacc[l][0] = acc0;
@@ -716,6 +723,18 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     f32x4 a4 = *reinterpret_cast<const f32x4*>(pa);
                     f32x4 b4 = *reinterpret_cast<const f32x4*>(pb);
                     f32x4 c4 = (WG::BPW == 2) ? *reinterpret_cast<const f32x4*>(pb + 16 * PB) : b4;
+                    // bias gradient = row sums of this wave's own 16 columns of dZ: read here, summed under the first MFMA group
+                    f32x4 z4[4];
+                    const float* pz = sZ + (lane < WP ? lane : 0) * PB + CL_WOBS * wv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z4[e] = *reinterpret_cast<const f32x4*>(pz + 4 * e);
+                    // all waves left barrier B together and wait for these reads together: the VALU work of the NEXT layer step
+                    // (dH_{l-1} = dn, dZ_{l-1} = dH_{l-1} * lrelu'(H_{l-1})) goes here, under the LDS latency
+                    CL_SCHED_FENCE();
+#pragma unroll
+                    for (int mb = 0; mb < FB; ++mb)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) dH[mb][t] = (hs[l > 0 ? l - 1 : 0][mb][t] > 0.0f) ? dn[mb][t] : leak * dn[mb][t];
 #pragma unroll
                     for (int g = 0; g < WG::KLEN / 16; ++g) {
                         f32x4 na = a4, nb = b4, nc = c4;
@@ -731,16 +750,19 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             if (WG::BPW == 2) acc1 = mfma4(a4[t], c4[t], acc1);
                         }
                         CL_SCHED_FENCE();
+                        if (g == 0) {
+                            float sb = 0.0f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sb += (z4[e][0] + z4[e][1]) + (z4[e][2] + z4[e][3]);
+                            if (lane < WP) bacc[l] += sb;
+                        }
                         a4 = na; b4 = nb; c4 = nc;
                     }
                     wacc[l][0] = acc0;
                     if (WG::BPW == 2) wacc[l][WB - 1] = acc1;
                 }
                 STAMP(9);
-                if (l > 0) {
-#pragma unroll
-                    for (int mb = 0; mb < FB; ++mb) dH[mb] = dn[mb];
-                }
+
                 STAMP(10);
             }
         }
