@@ -603,17 +603,15 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 // barrier A: the previous layer's wgrad reads are complete
                 if (l < L - 1) { if (WLOC) wave_lds_sync(); else lds_barrier(); }
                 STAMP(6);
-#pragma unroll
-                for (int mb = 0; mb < FB; ++mb)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) sZ[(16 * mb + 4 * q + t) * PB + CL_WOBS * wv + j] = dH[mb][t];
-                if (l > 0) {
+                // staging writes of this wave's 16 columns: dZ_l into sZ and H_{l-1} into sH.  With a dgrad to run (l > 0) they
+                // are issued BETWEEN its MFMAs (both only read registers), so the LDS write phase costs no matrix-pipe time
+                float* const stz = sZ + (4 * q) * PB + CL_WOBS * wv + j;
+                float* const sth = sH + (4 * q) * PB + CL_WOBS * wv + j;
+                if (l == 0) {
 #pragma unroll
                     for (int mb = 0; mb < FB; ++mb)
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            sH[(16 * mb + 4 * q + t) * PB + CL_WOBS * wv + j] = hs[l > 0 ? l - 1 : 0][mb][t];
-                } else {
+                        for (int t = 0; t < 4; ++t) stz[(16 * mb + t) * PB] = dH[mb][t];
                     // the metadata tile is re-read (L2 hit) rather than kept in registers through the whole backward pass
                     float h0s[KS1];
                     load_meta(__builtin_amdgcn_readfirstlane(tile), h0s);
@@ -653,6 +651,20 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             for (int t = 0; t < 4; ++t) {
                                 acc0 = mfma4(r0[t], dH[kb][t], acc0);
                                 if (MBS == 2) acc1 = mfma4(r1[t], dH[kb][t], acc1);
+                            }
+                            {   // this group's share of the staging writes, interleaved with its MFMAs
+                                constexpr int IPG = 8 * MBS / FB;                  // write items per (pair, k-block) group
+                                const int gi = (mb / MBS) * FB + kb;
+#pragma unroll
+                                for (int e = IPG * gi; e < IPG * (gi + 1); ++e) {
+                                    if (e < 4 * FB) stz[(16 * (e / 4) + (e % 4)) * PB] = dH[(e / 4) % FB][e % 4];
+                                    else sth[(16 * ((e - 4 * FB) / 4) + (e % 4)) * PB] = hs[l > 0 ? l - 1 : 0][((e - 4 * FB) / 4) % FB][e % 4];
+                                }
+#pragma unroll
+                                for (int k = 0; k < IPG; ++k) {
+                                    __builtin_amdgcn_sched_group_barrier(0x008, (4 * MBS + IPG - 1) / IPG, 0);   // MFMA
+                                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                            // DS write
+                                }
                             }
                             CL_SCHED_FENCE();
 #pragma unroll
