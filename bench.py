@@ -79,6 +79,19 @@ def cpu_baseline(workload: str, n_sample: int):
                       f"fp32 PyTorch-CPU restatement of the reference graph (not TensorFlow), torch {torch.__version__}"}
 
 
+def traffic_bytes(workload: str, world: int):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json; collected with
+    scripts/pmc_passes.sh, separate --pmc runs); None for configurations that were not profiled."""
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        rec = json.load(open(os.path.join(here, "profiles", "traffic.json"))).get(workload)
+        if rec and rec.get("n_gpus") == world:
+            return rec["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -184,7 +197,7 @@ def main():
                        "parallelism": f"obs-shard x{world}" if world > 1 else "single",
                        "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
             "roofline": {"bound": "mfma", "kernel": "elbo_mlp_kernel (" + ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd") + ")", "achieved": achieved,
-                         "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": traffic_bytes(args.workload, world),
                          "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
                          "hbm_secondary": {"achieved_GBps": B * eng.N / (kern_ms * 1e-3) / 1e9, "bytes_per_obs": B}},
         }

@@ -402,23 +402,23 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         const float* Wl = sW + (l > 0 ? l - 1 : 0) * WP * PW;
                         const float* pa0 = Wl + (16 * mb + j) * PW + 4 * q;
                         const float* pa1 = Wl + (16 * (mb + MB1) + j) * PW + 4 * q;
-                        f32x4 a40 = *reinterpret_cast<const f32x4*>(pa0);
-                        f32x4 a41 = *reinterpret_cast<const f32x4*>(pa1);
+                        // two operand buffers used alternately (compile-time index after unrolling: no register copies)
+                        f32x4 oa[2], ob[2];
+                        oa[0] = *reinterpret_cast<const f32x4*>(pa0);
+                        ob[0] = *reinterpret_cast<const f32x4*>(pa1);
 #pragma unroll
                         for (int kb = 0; kb < FB; ++kb) {
-                            f32x4 n40 = a40, n41 = a41;          // operands of the NEXT k-block, in flight under this block's MFMAs
-                            if (kb + 1 < FB) {
-                                n40 = *reinterpret_cast<const f32x4*>(pa0 + 16 * (kb + 1));
-                                n41 = *reinterpret_cast<const f32x4*>(pa1 + 16 * (kb + 1));
+                            if (kb + 1 < FB) {       // operands of the NEXT k-block, in flight under this block's MFMAs
+                                oa[(kb + 1) & 1] = *reinterpret_cast<const f32x4*>(pa0 + 16 * (kb + 1));
+                                ob[(kb + 1) & 1] = *reinterpret_cast<const f32x4*>(pa1 + 16 * (kb + 1));
                             }
                             CL_SCHED_FENCE();
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                acc0 = mfma4(a40[t], hs[l > 0 ? l - 1 : 0][kb][t], acc0);
-                                if (MBS == 2) acc1 = mfma4(a41[t], hs[l > 0 ? l - 1 : 0][kb][t], acc1);
+                                acc0 = mfma4(oa[kb & 1][t], hs[l > 0 ? l - 1 : 0][kb][t], acc0);
+                                if (MBS == 2) acc1 = mfma4(ob[kb & 1][t], hs[l > 0 ? l - 1 : 0][kb][t], acc1);
                             }
                             CL_SCHED_FENCE();
-                            a40 = n40; a41 = n41;
                         }
                     }
                     CL_PIN();
