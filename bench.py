@@ -140,8 +140,8 @@ def main():
     # the dominant kernel is timed live with events on the stream it is launched on (torch's current stream)
     # the fused scaler kernel: one launch per step (mono), or forward + backward launches around the harmonic sums (Laue)
     timed_names = ("cl_elbo_mono_fwd_bwd", "cl_mlp_forward", "cl_mlp_backward_ext")
-    launches_per_step = 2 if spec.get("kind") == "laue" else 1
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps * launches_per_step)]
+    # (Laue: one launch on the single-pass path, forward + backward launches on the two-pass fallback)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps * 2)]
     slot = {"i": 0}
 
     def timed(fn):
@@ -173,7 +173,8 @@ def main():
     if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
-    kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.steps        # fused-kernel time per step
+    kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev[:slot["i"]]])) / args.steps        # fused-kernel time per step
+    launches_per_step = slot["i"] // args.steps
     hist = eng.read_history(steps_total)
     finite = bool(np.all(np.isfinite(hist["loss"]))) and len(hist["loss"]) == steps_total
 

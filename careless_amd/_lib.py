@@ -63,6 +63,7 @@ class MlpArgs(C.Structure):
         ("stop_flag", _vp),
         ("ev11", _vp), ("d_ev11", _vp),
         ("imgl", _vp), ("d_imgl", _vp), ("n_imgl", C.c_int), ("n_images", C.c_int), ("tile_img", _vp), ("row_map", _vp),
+        ("gmeta", _vp), ("tile_gmax", _vp), ("noise_row", _vp),
     ]
 
 

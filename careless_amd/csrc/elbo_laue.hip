@@ -143,8 +143,8 @@ int cl_launch_laue_predict(const cl_laue_args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 int cl_launch_laue_likelihood(const cl_laue_args& a, hipStream_t st) {
-    if (int e = laue_check(a)) return e;
-    if (a.iobs == nullptr || a.sig == nullptr || a.scalars == nullptr) return -1;
+    // needs the slot arrays only (it is also called on the padded slots alone by the single-pass path)
+    if (a.n_obs <= 0 || a.S <= 0 || a.iconv == nullptr || a.iobs == nullptr || a.sig == nullptr || a.scalars == nullptr) return -1;
     const long long n = (long long)a.n_obs * a.S;
     (void)hipGetLastError();
     long long blocks = (n + 255) / 256;

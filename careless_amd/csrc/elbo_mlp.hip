@@ -340,7 +340,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 
     for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
         const int gobs = tile * CL_TILE + CL_WOBS * wv + j;      // this lane's observation (all four k-groups)
-        if (IMGL) {
+        if (IMGL && A.n_imgl > 0) {
             const int im = __builtin_amdgcn_readfirstlane(A.tile_img[tile]);
             if (im != cur_img) {             // workgroup-uniform
                 lds_barrier();               // every wave is done with the previous image's matrices
@@ -365,7 +365,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         const int tile_u = opaque_uniform(tile);
         // IMGL: the packed row -> the caller's row (eta / ipred_out / noise key are in the caller's order)
         int rme = 0;
-        if (IMGL && MODE == 0 && rid >= 0) rme = A.row_map[gobs_e];
+        long long nkey = 0;                // noise key of this lane's row
+        if (IMGL && MODE == 0 && rid >= 0) {
+            rme = A.row_map[gobs_e];
+            nkey = (A.noise_row != nullptr) ? (long long)A.noise_row[gobs_e] : A.obs_offset + rme;
+        }
         const unsigned eoff = IMGL ? 4u * (unsigned)rme * (unsigned)S : eoff_t;
         const float* __restrict__ eta_t = A.eta ? (IMGL ? A.eta : A.eta + (size_t)tile_u * CL_TILE * S) : nullptr;
         float* __restrict__ ipred_t = A.ipred_out ? (IMGL ? A.ipred_out : A.ipred_out + (size_t)tile_u * CL_TILE * S) : nullptr;
@@ -475,7 +479,62 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             const float sige = __shfl(sigma, je);
             float pdl = 0.0f, pds = 0.0f, pda = 0.0f;
             STAMP(11);
-            if (rid >= 0) {
+            if (IMGL && A.gmeta != nullptr) {
+                // ---- single-pass Laue: the predictions of the rows of one harmonic group SUM before the likelihood
+                //      (ConvolvedLikelihood.convolve, careless/models/likelihoods/laue.py:20-34).  The members of a group sit in
+                //      consecutive rows of this wave; lane (row je, slot qe) collects the group's total with shuffles, every
+                //      member evaluates the same likelihood derivative, member 0 alone counts the group's log-likelihood.
+                const int gm = (rid >= 0) ? A.gmeta[gobs_e] : 0;
+                const int mem = gm & 0xff, cnt = gm >> 8;
+                const int lfirst = 4 * (je - mem) + qe;
+                const int gmax = __builtin_amdgcn_readfirstlane(A.tile_gmax[tile]);
+                const float inv_sg = 1.0f / sg;
+                const float log_sg = logf(sg);
+                float eta_sin = 0.0f;
+                const int K = (S + 3) >> 2;
+                for (int k = 0; k < K; ++k) {                     // wave-uniform trip count: all lanes take part in the shuffles
+                    const int s = qe + 4 * k;
+                    const bool act = (rid >= 0) && (s < S);
+                    float eta = 0.0f, zf = 0.0f;
+                    if (act) {
+                        if (eta_t != nullptr) {
+                            eta = (k == 0) ? et0 : ((k == 1) ? et1 : ld_uo(eta_t, eoff + 4u * s));
+                        } else if ((k & 1) == 0) {
+                            cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)nkey, &eta, &eta_sin);
+                        } else {
+                            eta = eta_sin;
+                        }
+                        zf = (k == 0) ? zf0 : ((k == 1) ? zf1 : ld_uo(A.z_f, zoff + 4u * s));
+                    }
+                    const float tq = o0e + sige * eta + A.shift;
+                    const float zs = aim * tq;
+                    const float ipred = act ? zs * zf * zf : 0.0f;
+                    if (act && ipred_t) *ptr_uo(ipred_t, eoff + 4u * s) = ipred;
+                    float tot = 0.0f;
+                    for (int mm = 0; mm < gmax; ++mm) {
+                        const float v = __shfl(ipred, (lfirst + 4 * mm) & 63);
+                        tot += (mm < cnt) ? v : 0.0f;
+                    }
+                    if (act) {
+                        float dll, ll;
+                        if (use_ev11) {
+                            float gf, gb, ga;
+                            ll = cl_lik_ev11(tot, io, sg, A.lik_kind, A.dof, A.lik_const, ev, &dll, &gf, &gb, &ga);
+                            if (mem == 0) { ev_g0 -= gf * A.w_ll; ev_g1 -= ga * A.w_ll; ev_g2 -= gb * A.w_ll; }
+                        } else {
+                            ll = cl_lik_log_prob2(tot, io, inv_sg, log_sg, A.lik_kind, A.dof, A.lik_const, &dll);
+                        }
+                        if (mem == 0) nll_acc -= ll * A.w_ll;
+                        const float gi = -dll * A.w_ll;                 // dNLL / d iconv = dNLL / d ipred of every member
+                        const float dzs = gi * zf * zf;
+                        atomicAdd(ptr_uo(A.dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
+                        const float dt = dzs * aim;
+                        pdl += dt;
+                        pds += dt * eta;
+                        pda += dzs * tq;
+                    }
+                }
+            } else if (rid >= 0) {
                 const float inv_sg = 1.0f / sg;
                 const float log_sg = logf(sg);
                 int k = 0;
@@ -485,7 +544,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     if (eta_t != nullptr) {
                         eta = (k == 0) ? et0 : ((k == 1) ? et1 : ld_uo(eta_t, eoff + 4u * s));
                     } else if ((k & 1) == 0) {       // one Philox block + Box-Muller pair serves samples s and s + 4
-                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + (IMGL ? rme : gobs_e)), &eta, &eta_sin);
+                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(IMGL ? nkey : A.obs_offset + gobs_e), &eta, &eta_sin);
                     } else {
                         eta = eta_sin;
                     }
@@ -949,14 +1008,15 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
 
 #if CL_IMGL
 int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
-    if (a.n_imgl < 1 || a.imgl == nullptr || a.tile_img == nullptr || a.row_map == nullptr || a.n_images < 1) return -1;
-    if (a.n_obs != a.n_pad || a.use_img) return -1;
-    if (mode != 1 && a.d_imgl == nullptr) return -1;
+    if (a.row_map == nullptr || a.n_obs != a.n_pad || a.n_imgl < 0) return -1;
+    if (a.n_imgl > 0 && (a.imgl == nullptr || a.tile_img == nullptr || a.n_images < 1 || a.use_img)) return -1;
+    if (a.n_imgl > 0 && mode != 1 && a.d_imgl == nullptr) return -1;
+    if (a.gmeta != nullptr && (a.tile_gmax == nullptr || mode != 0)) return -1;
     // eta / ipred_out are addressed with 32-bit byte offsets from their base in this variant
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
-    if (a.n_imgl > 0) return cl_launch_mlp_imgl(a, mode, grid, st);
+    if (a.n_imgl > 0 || a.row_map != nullptr) return cl_launch_mlp_imgl(a, mode, grid, st);   // packed layouts
 #endif
     if (a.n_pad % CL_TILE != 0 || a.n_pad <= 0) return -1;
     // 32-bit byte offsets / buffer sizes inside the kernel: metadata image < 4 GiB, z_f < 4 GiB (shard further across GPUs otherwise)

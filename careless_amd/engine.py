@@ -179,13 +179,70 @@ def pack_by_image(image_id: np.ndarray):
     return pos, n_pad, tile_img, row_map
 
 
+GRANULE = 16      # observations of one wave of the fused kernel
+
+
+def pack_laue(harmonic_id: np.ndarray, image_id: np.ndarray, by_image: bool):
+    """Packed order of the single-pass Laue kernel: the rows of a harmonic group are consecutive and inside one 16-row granule.
+    Groups are padded to the next power of two and laid out class by class (all groups of padded size p of an image are
+    contiguous, p rows apart), classes aligned to granules, images aligned to tiles when `by_image` (per-image layers).
+    Returns (pos, n_pad, gmeta, tile_gmax, row_map, tile_img) or None when a group has more than 16 rows."""
+    hid = np.asarray(harmonic_id).astype(np.int64)
+    img = np.asarray(image_id).astype(np.int64)
+    n = len(hid)
+    order = np.argsort(hid, kind="stable")
+    gid, first, size = np.unique(hid[order], return_index=True, return_counts=True)
+    if size.max() > GRANULE:
+        return None
+    member = np.arange(n) - np.repeat(first, size)                       # member index of every sorted row
+    gimg = img[order][first] if by_image else np.zeros(len(gid), dtype=np.int64)
+    cls = np.ones(len(gid), dtype=np.int64)
+    for p in (2, 4, 8, 16):
+        cls[size > p // 2] = p
+    # regions = (image, class) pairs in sorted order; groups ranked inside their region
+    key = gimg * 32 + cls
+    gorder = np.argsort(key, kind="stable")
+    rkey, rfirst, rcount = np.unique(key[gorder], return_index=True, return_counts=True)
+    rcls = rkey % 32
+    rimg = rkey // 32
+    rrows = -(-(rcount * rcls) // GRANULE) * GRANULE                     # rows of a region, aligned to granules
+    # image blocks aligned to tiles when the tiles must be single-image
+    if by_image:
+        ids, ifirst = np.unique(rimg, return_index=True)
+        irows = np.add.reduceat(rrows, ifirst)
+        irows = -(-irows // TILE) * TILE
+        ibase = np.concatenate([[0], np.cumsum(irows)[:-1]])
+        within = np.cumsum(rrows) - rrows - np.repeat((np.cumsum(rrows) - rrows)[ifirst], np.diff(np.concatenate([ifirst, [len(rimg)]])))
+        rbase = np.repeat(ibase, np.diff(np.concatenate([ifirst, [len(rimg)]]))) + within
+        n_pad = int(irows.sum())
+        tile_img = np.repeat(ids, irows // TILE).astype(np.int32)
+    else:
+        rbase = np.cumsum(rrows) - rrows
+        n_pad = int(-(-int(rrows.sum()) // TILE) * TILE)
+        tile_img = None
+    grank = np.empty(len(gid), dtype=np.int64)                           # rank of a group inside its region
+    grank[gorder] = np.arange(len(gid)) - np.repeat(rfirst, rcount)
+    gregion = np.empty(len(gid), dtype=np.int64)
+    gregion[gorder] = np.repeat(np.arange(len(rkey)), rcount)
+    gstart = rbase[gregion] + grank * cls                                # packed position of member 0
+    pos = np.empty(n, dtype=np.int64)
+    pos[order] = np.repeat(gstart, size) + member
+    gmeta = np.zeros(n_pad, dtype=np.int32)
+    gmeta[pos[order]] = (member | (np.repeat(size, size) << 8)).astype(np.int32)
+    row_map = np.full(n_pad, -1, dtype=np.int32)
+    row_map[pos] = np.arange(n, dtype=np.int32)
+    tile_gmax = np.zeros(n_pad // TILE, dtype=np.int32)
+    np.maximum.at(tile_gmax, pos[order] // TILE, np.repeat(size, size).astype(np.int32))
+    return pos, n_pad, gmeta, tile_gmax, row_map, tile_img
+
+
 class ObsData:
     """refl_id / image_id int32 [N], meta_t fp32 [rows][n_pad], iobs / sig fp32 [N], optional harmonic_id + Laue work
     buffers, and the per-launch workspace of the fused kernel (grid, gradient partials).  With `pack_images` (per-image
     layers) the arrays the fused kernel streams are in the packed order of `pack_by_image`."""
 
     def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None,
-                 laue_groups=None, pack_images: bool = False):
+                 laue_groups=None, pack_images: bool = False, laue_single_pass: bool = True):
         refl_id = _np(BaseModel.get_refl_id(inputs)).reshape(-1).astype(np.int64)
         image_id = _np(BaseModel.get_image_id(inputs)).reshape(-1).astype(np.int64)
         metadata = _np(BaseModel.get_metadata(inputs)).astype(np.float32).reshape(len(refl_id), -1)
@@ -216,9 +273,44 @@ class ObsData:
         if n_images is not None and image_id.size and image_id.max() >= n_images:
             raise ValueError("image_id exceeds ImageScaler.max_images")
         self.d = int(metadata.shape[1])
-        self.tile_img = self.row_map = None
+        self.tile_img = self.row_map = self.gmeta = self.tile_gmax = None
+        self.fused_laue = False
         rid_l, img_l = refl_id[sl].astype(np.int32), image_id[sl].astype(np.int32)
-        if pack_images:
+        lp = None
+        if self.laue:
+            hid_all0 = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1).astype(np.int64)
+            hl0 = hid_all0[sl] - (laue_groups[0] if (laue_groups is not None and self.rows is not None) else 0)
+            if laue_single_pass:
+                lp = pack_laue(hl0, img_l, by_image=pack_images)       # None: a group larger than a wave -> two-pass path
+        if lp is not None:
+            # single-pass Laue: everything the fused kernel streams is packed so that a harmonic group sits in one wave; the
+            # group's observed intensity is replicated on its member rows; the padded slots keep their own small arrays
+            pos, self.n_pad, gmeta, tile_gmax, row_map, tile_img = lp
+            G = int(hl0.max()) + 1
+            meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
+            meta_t[: self.d, pos] = metadata[sl].T
+
+            def packed(v, fill):
+                out = np.full(self.n_pad, fill, dtype=v.dtype)
+                out[pos] = v
+                return out
+            iobs_s, sig_s = np.asarray(iobs_l), np.asarray(sig_l)
+            self.pad_iobs = torch.as_tensor(np.ascontiguousarray(iobs_s[G:]), device=device)
+            self.pad_sig = torch.as_tensor(np.ascontiguousarray(sig_s[G:]), device=device)
+            self.pad_iconv = torch.zeros(max(1, (len(iobs_s) - G) * S), dtype=torch.float32, device=device)
+            rid_l, img_l = packed(rid_l, -1), packed(img_l, 0)
+            iobs_l, sig_l = packed(iobs_s[hl0], 0.0), packed(sig_s[hl0], 1.0)
+            self.gmeta = torch.as_tensor(gmeta, device=device)
+            self.tile_gmax = torch.as_tensor(tile_gmax, device=device)
+            self.row_map = torch.as_tensor(row_map, device=device)
+            self.tile_img = torch.as_tensor(tile_img, device=device) if tile_img is not None else None
+            self.noise_row = None
+            if self.rows is not None:                 # a shard of whole harmonic groups: rows are not a contiguous range
+                nr = np.full(self.n_pad, 0, dtype=np.int32)
+                nr[pos] = self.rows.astype(np.int32)
+                self.noise_row = torch.as_tensor(nr, device=device)
+            self.fused_laue = True
+        elif pack_images:
             pos, self.n_pad, tile_img, row_map = pack_by_image(img_l)
             meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
             meta_t[: self.d, pos] = metadata[sl].T
@@ -249,6 +341,7 @@ class ObsData:
             if self.rows is not None:
                 hl = hl - laue_groups[0]
                 self.row_index = torch.as_tensor(self.rows.astype(np.int64), device=device)
+        if self.laue and not self.fused_laue:
             self.harmonic_id = torch.as_tensor(hl.astype(np.int32), device=device)
             self.laue_loc = torch.empty(self.N, dtype=torch.float32, device=device)
             self.laue_sig = torch.empty(self.N, dtype=torch.float32, device=device)
@@ -377,7 +470,8 @@ class ElboEngine:
         if self.S < 1:
             raise ValueError("mc_sample_size must be >= 1")
         self.obs = ObsData(self.lib, inputs, self.shard.start, self.shard.stop, self.S, lay.P, dev, grid=grid, n_refl=self.R,
-                           n_images=self._max_images(), laue_groups=self.laue_groups, pack_images=imgl is not None)
+                           n_images=self._max_images(), laue_groups=self.laue_groups, pack_images=imgl is not None,
+                           laue_single_pass=not getattr(model, "laue_two_pass", False))
         RS = self.R * self.S
         o_dz = 0
         o_g = (RS + 3) // 4 * 4
@@ -476,12 +570,17 @@ class ElboEngine:
         a.iobs = ptr(obs.iobs); a.sig = ptr(obs.sig)
         a.n_obs, a.n_pad = obs.N, obs.n_pad
         a.obs_offset = obs.start
-        if self.imgl is not None:
+        if obs.row_map is not None:
             a.n_obs = obs.n_pad                         # packed: validity is per row (row_map / refl_id = -1)
+            a.row_map = ptr(obs.row_map)
+        if obs.fused_laue:
+            a.gmeta, a.tile_gmax = ptr(obs.gmeta), ptr(obs.tile_gmax)
+            a.noise_row = ptr(obs.noise_row)
+        if self.imgl is not None:
             a.imgl = self.params.data_ptr() + 4 * lay.off_imgl
             a.d_imgl = self.grads.data_ptr() + 4 * lay.off_imgl
             a.n_imgl, a.n_images = self.imgl.n_image_layers, self.imgl.max_images
-            a.tile_img, a.row_map = ptr(obs.tile_img), ptr(obs.row_map)
+            a.tile_img = ptr(obs.tile_img)
         a.mlp = self.params.data_ptr() + 4 * lay.off_mlp
         a.d, a.w, a.L = self.d, self.w, self.L
         a.leak = self.mlp.leakiness
@@ -539,7 +638,22 @@ class ElboEngine:
         """NLL of `obs` into scalars[NLL] and its gradient into dz_f / the flat gradient (scaler + image scales)."""
         lib, lay = self.lib, self.layout
         ma = self._mlp_args(step, eta, ipred_out, obs)
-        if self.laue:
+        if self.laue and obs.fused_laue:
+            # single pass: the harmonic group sums happen inside the fused kernel; the padded slots (no rows, iconv = 0,
+            # reference formatter.py:637-640 / laue.py:24) only add their constant -- and, with Ev11, its gradient
+            check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
+            npad = int(obs.pad_iobs.numel())
+            if npad > 0:
+                obs.pad_iconv.zero_()
+                la = LaueArgs()
+                la.iobs, la.sig, la.iconv = ptr(obs.pad_iobs), ptr(obs.pad_sig), ptr(obs.pad_iconv)
+                la.n_obs, la.S = npad, self.S
+                la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
+                la.w_ll = self.w_ll
+                la.scalars, la.stop_flag = ptr(self.scalars), ptr(self.stop_flag)
+                la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
+                check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
+        elif self.laue:
             self._laue_passes(ma, obs, step, eta, ipred_out, st)
         else:
             check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
@@ -563,7 +677,8 @@ class ElboEngine:
         if BaseModel.is_laue(inputs) != self.laue:
             raise ValueError("validation data and training data differ in kind (mono / Laue)")
         o = ObsData(self.lib, inputs, 0, None, self.S, self.layout.P, self.device, n_refl=self.R,
-                    n_images=self._max_images(), pack_images=self.imgl is not None)
+                    n_images=self._max_images(), pack_images=self.imgl is not None,
+                    laue_single_pass=not getattr(self.model, "laue_two_pass", False))
         if o.d != self.d:
             raise ValueError("validation metadata width differs from the training data")
         return o

@@ -135,8 +135,18 @@ typedef struct cl_mlp_args {
     const float* imgl;
     float* d_imgl;              /* += dL/d(imgl)                                                               */
     int n_imgl, n_images;
-    const int* tile_img;        /* [n_pad / CL_MLP_TILE] image of every tile                                   */
-    const int* row_map;         /* [n_pad]                                                                     */
+    const int* tile_img;        /* [n_pad / CL_MLP_TILE] image of every tile (only with n_imgl > 0)            */
+    const int* row_map;         /* [n_pad]; non-NULL selects the packed layout also without image layers      */
+    /* Single-pass Laue likelihood (careless/models/likelihoods/laue.py:9-47) inside cl_elbo_mono_fwd_bwd: packed layout in
+     * which the rows of one harmonic group are consecutive and never straddle a 16-row boundary (a wave's observations), so
+     * the group sum of the predictions is a lane reduction in the epilogue.  gmeta[row] = member index | (group size << 8);
+     * iobs / sig hold the GROUP's observed intensity on every member row; the group's likelihood is counted on member 0.
+     * tile_gmax[tile] = largest group size in the tile.  The padded slots [G, N) are the caller's job (cl_laue_likelihood on
+     * one zero slot with w_ll scaled by their number).  NULL = off.                                                   */
+    const int* gmeta;
+    const int* tile_gmax;
+    const int* noise_row;       /* optional [n_pad]: GLOBAL row of every packed row for the in-kernel noise key (shards that are
+                                 * not a contiguous row range); NULL = obs_offset + row_map[row]                        */
 } cl_mlp_args;
 
 enum { CL_LIK_NORMAL_ = 0, CL_LIK_STUDENTT_ = 1 };

@@ -37,20 +37,52 @@ CASES = {
     "image_layers2_4x10_softplus": dict(N=900, R=50, d0=5, L=4, w=10, S=2, n_images=6, image_layers=2, bijector="softplus",
                                         shift=0.7),
     "laue_image_layers1_2x32": dict(N=600, R=60, L=2, w=32, S=3, laue=True, n_images=4, image_layers=1),
+    # the two Laue code paths: single pass (group sums inside the fused kernel; the default) and two passes around the group sums
+    "laue_two_pass_2x32_S3": dict(N=400, R=40, L=2, w=32, S=3, laue=True, two_pass=True),
+    "laue_two_pass_ev11_studentt_S5": dict(N=500, R=40, L=2, w=32, S=5, laue=True, ev11=True, likelihood="studentt", dof=6.0, two_pass=True),
+    "laue_two_pass_image_layers1": dict(N=600, R=60, L=2, w=32, S=3, laue=True, n_images=4, image_layers=1, two_pass=True),
+    "laue_ev11_studentt_S5": dict(N=500, R=40, L=2, w=32, S=5, laue=True, ev11=True, likelihood="studentt", dof=6.0),
+    "laue_groups_up_to_12_rows_S6": dict(N=700, R=50, L=2, w=32, S=6, laue=True, regroup=4),
+    "laue_groups_over_16_rows_fall_back": dict(N=700, R=50, L=2, w=32, S=2, laue=True, regroup=16),
     "double_wilson_trainable_r_S4": dict(N=400, R=60, d0=5, L=2, w=32, S=4, double_wilson=True, optimize_dw_r=True),
     "double_wilson_5x64_S8_studentt": dict(N=600, R=80, d0=5, L=5, w=64, S=8, double_wilson=True, likelihood="studentt", dof=8.0),
 }
 
 
+def _regroup_laue(data, div):
+    """Merge every `div` consecutive harmonic groups into one (bigger groups than the generator makes)."""
+    hid = np.asarray(data["harmonic_id"]) // div
+    G = int(hid.max()) + 1
+    N = len(hid)
+    rng = np.random.default_rng(5)
+    iobs = np.ones(N, dtype=np.float32); sig = np.ones(N, dtype=np.float32)
+    iobs[:G] = (np.bincount(hid, weights=np.maximum(np.asarray(data["iobs"])[: len(hid)], 0.0), minlength=G)[:G] + rng.normal(size=G)).astype(np.float32)
+    sig[:G] = np.sqrt(np.abs(iobs[:G]) + 25.0)
+    data = dict(data)
+    data["harmonic_id"], data["iobs"], data["sigiobs"], data["n_groups"] = hid.astype(np.int64), iobs, sig, G
+    return data
+
+
 def _run_case(kw):
+    kw = dict(kw)
+    two_pass, regroup = kw.pop("two_pass", False), kw.pop("regroup", 0)
     L, w = kw["L"], kw["w"]
     data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    if regroup:
+        data = _regroup_laue(data, regroup)
+        x = O.inputs_from_numpy(data)
     out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64),
                                         torch.as_tensor(eta, dtype=torch.float64))
     model = util.build_model(data, cfg, params, L, w)
+    model.laue_two_pass = two_pass
     inputs = util.reference_inputs(data)
     ipred = model(inputs, u_f=u_f, eta=eta)
     eng = model._engine
+    if kw.get("laue"):
+        biggest = int(np.bincount(np.asarray(data["harmonic_id"])).max())
+        assert eng.obs.fused_laue == (not two_pass and biggest <= 16)    # groups of more than 16 rows fall back to two passes
+        if regroup:
+            assert (biggest > 16) == (regroup >= 16)
     torch.cuda.synchronize()
     terms = eng.loss_terms()
     return out, grads, ipred.cpu().numpy(), terms, [g.cpu().numpy() for g in eng.grad_tensors()], eng, (data, cfg, params, u_f, eta)
