@@ -341,6 +341,29 @@ def test_full_size_properties_1M():
     assert len(hist["loss"]) == 5 and all(np.isfinite(hist["loss"])) and hist["loss"][-1] < hist["loss"][0]
 
 
+def test_full_size_laue_single_pass_equals_two_pass():
+    """BASELINE configs[3] shape at 1 M rows: the two Laue implementations (group sums as lane reductions inside the fused kernel
+    vs. forward / group-sum / backward passes) draw the same in-kernel noise (keyed by the caller's rows) and must agree on the
+    loss and on every gradient -- a size-independent check that needs no oracle."""
+    from careless_amd.workloads import make_workload
+    from careless_amd.engine import ElboEngine
+    res = []
+    for two_pass in (False, True):
+        model, inputs, data, spec = make_workload("laue_5M_normal_5x64_S1", N=1_000_000)
+        model.laue_two_pass = two_pass
+        eng = ElboEngine(model, inputs, seed=5)
+        assert eng.obs.fused_laue == (not two_pass)
+        eng.forward_backward(2)
+        torch.cuda.synchronize()
+        res.append((eng.loss_terms(), eng.grads.clone()))
+    (ta, ga), (tb, gb) = res
+    assert abs(ta["nll"] - tb["nll"]) <= 1e-6 * abs(tb["nll"]) and ta["kl"] == tb["kl"]
+    lay = eng.layout
+    for lo, hi in zip(lay.seg_off[:-1], lay.seg_off[1:]):                      # per trainable tensor
+        a, b = ga[lo:hi], gb[lo:hi]
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6), (lo, hi)
+
+
 @pytest.mark.parametrize("clip", [dict(clipnorm=0.5), dict(clipvalue=0.01), dict(global_clipnorm=1.0)])
 def test_clipping_modes_match_oracle(clip):
     """tfk.optimizers.Adam(clipnorm= / clipvalue= / global_clipnorm=) (reference io/manager.py:494-501, tests/test_cli.py:196-208)"""
