@@ -28,6 +28,7 @@
 #include "cl_kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define CL_TILE CL_MLP_TILE
 #define CL_NW 8              // waves per workgroup
@@ -166,9 +167,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15;            // observation within the wave / MFMA row-or-column index
     const int q = lane >> 4;            // k-group of the MFMA step
-    float* const sS = smem + SL::oS + wv * CL_SCR;
-    float* const sDl = sS;              // per-wave dO tile: dL/dloc [16], dL/draw [16]
-    float* const sDs = sS + 16;
+    float* const sS = smem + SL::oS + wv * CL_SCR;      // per-wave dO tile: (dL/dloc, dL/draw) of the wave's 16 observations
 
     const int d = A.d, w = A.w;
     const int Ld = A.L;                              // Dense layers (parameters in A.mlp)
@@ -611,7 +610,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         STAMP(2);
         if (WLOC0) wave_lds_sync(); else lds_barrier();
         STAMP(3);
-        if (q == 0) { sDl[j] = dloc; sDs[j] = draw; }      // the dO tile for the Dense(2) wgrad (wave-private)
+        // the dO tile for the Dense(2) wgrad (wave-private), interleaved: (dL/dloc, dL/draw) of observation j at [2j, 2j+1]
+        if (q == 0) *reinterpret_cast<f32x2*>(sS + 2 * j) = f32x2{dloc, draw};
 
         f32x4 dH[FB];
 #pragma unroll
@@ -622,25 +622,25 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 for (int mb = 0; mb < FB; ++mb) {
                     const f32x4 w0 = *reinterpret_cast<const f32x4*>(sWo + 16 * mb + 4 * q);
                     const f32x4 w1 = *reinterpret_cast<const f32x4*>(sWo + WP + 16 * mb + 4 * q);
+                    dH[mb] = w0 * dloc + w1 * draw;                      // whole-vector form: packed fp32 math on aligned register pairs
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        dH[mb][t] = w0[t] * dloc + w1[t] * draw;
-                        sH[(16 * mb + 4 * q + t) * PB + CL_WOBS * wv + j] = hs[l][mb][t];
-                    }
+                    for (int t = 0; t < 4; ++t) sH[(16 * mb + 4 * q + t) * PB + CL_WOBS * wv + j] = hs[l][mb][t];
                 }
                 wave_lds_sync();
                 if (lane < WP) {
+                    // (dWo[0][i], dWo[1][i]) of feature i = lane as ONE packed accumulator: h * (dloc, draw) pairs straight from LDS
+                    f32x2 wo = {woacc0, woacc1};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const f32x4 h4 = *reinterpret_cast<const f32x4*>(sH + lane * PB + CL_WOBS * wv + 4 * e);
-                        const f32x4 d0 = *reinterpret_cast<const f32x4*>(sDl + 4 * e);
-                        const f32x4 d1 = *reinterpret_cast<const f32x4*>(sDs + 4 * e);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            woacc0 = fmaf(h4[t], d0[t], woacc0);
-                            woacc1 = fmaf(h4[t], d1[t], woacc1);
-                        }
+                        const f32x4 da = *reinterpret_cast<const f32x4*>(sS + 8 * e);          // observations 4e, 4e+1
+                        const f32x4 db = *reinterpret_cast<const f32x4*>(sS + 8 * e + 4);      // observations 4e+2, 4e+3
+                        wo += f32x2{da[0], da[1]} * h4[0];
+                        wo += f32x2{da[2], da[3]} * h4[1];
+                        wo += f32x2{db[0], db[1]} * h4[2];
+                        wo += f32x2{db[2], db[3]} * h4[3];
                     }
+                    woacc0 = wo[0]; woacc1 = wo[1];
                 }
                 wave_lds_sync();
                 STAMP(4);

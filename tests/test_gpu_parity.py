@@ -44,6 +44,8 @@ CASES = {
     "laue_ev11_studentt_S5": dict(N=500, R=40, L=2, w=32, S=5, laue=True, ev11=True, likelihood="studentt", dof=6.0),
     "laue_groups_up_to_12_rows_S6": dict(N=700, R=50, L=2, w=32, S=6, laue=True, regroup=4),
     "laue_groups_over_16_rows_fall_back": dict(N=700, R=50, L=2, w=32, S=2, laue=True, regroup=16),
+    "mono_rows_in_arbitrary_order_S5": dict(N=900, R=60, d0=5, L=3, w=64, S=5, n_images=9, shuffle_rows=True, likelihood="studentt", dof=4.0),
+    "mono_three_observations": dict(N=3, R=2, d0=5, L=2, w=32, S=2, n_images=1, use_image_scales=False),
     "double_wilson_trainable_r_S4": dict(N=400, R=60, d0=5, L=2, w=32, S=4, double_wilson=True, optimize_dw_r=True),
     "double_wilson_5x64_S8_studentt": dict(N=600, R=80, d0=5, L=5, w=64, S=8, double_wilson=True, likelihood="studentt", dof=8.0),
 }
@@ -65,11 +67,17 @@ def _regroup_laue(data, div):
 
 def _run_case(kw):
     kw = dict(kw)
-    two_pass, regroup = kw.pop("two_pass", False), kw.pop("regroup", 0)
+    two_pass, regroup, shuffle = kw.pop("two_pass", False), kw.pop("regroup", 0), kw.pop("shuffle_rows", False)
     L, w = kw["L"], kw["w"]
     data, cfg, params, x, u_f, eta = util.make_problem(**kw)
     if regroup:
         data = _regroup_laue(data, regroup)
+        x = O.inputs_from_numpy(data)
+    if shuffle:                                   # rows in arbitrary order: image ids unsorted inside a wave (per-lane atomics path)
+        perm = np.random.default_rng(2).permutation(kw["N"])
+        for k in ("refl_id", "image_id", "file_id", "metadata", "iobs", "sigiobs"):
+            data[k] = np.asarray(data[k])[perm]
+        eta = eta[:, perm]
         x = O.inputs_from_numpy(data)
     out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64),
                                         torch.as_tensor(eta, dtype=torch.float64))

@@ -249,3 +249,33 @@ def test_ev11_host_likelihood_matches_scipy():
     assert np.allclose(lk(inputs).log_prob(x), stats.norm.logpdf(x, data["iobs"], sc), rtol=1e-5, atol=1e-5)
     lt = StudentTEv11Likelihood(4.0)
     assert np.allclose(lt(inputs).log_prob(x), stats.t.logpdf(x, 4.0, data["iobs"], sc), rtol=1e-5, atol=1e-5)
+
+
+def test_pack_by_image_and_pack_laue_layouts():
+    """Host-side packing of the observation axis for the per-image-layer and single-pass Laue kernels (pure numpy)."""
+    from careless_amd.engine import GRANULE, TILE, pack_by_image, pack_laue
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 7, size=1000)
+    pos, n_pad, tile_img, row_map = pack_by_image(img)
+    assert n_pad % TILE == 0 and len(np.unique(pos)) == 1000 and np.all(tile_img[pos // TILE] == img)
+    assert np.all(row_map[pos] == np.arange(1000)) and (row_map >= 0).sum() == 1000
+    for by_image in (False, True):
+        sizes = rng.choice([1, 2, 3, 5, 16], p=[.7, .15, .05, .05, .05], size=300)
+        hid = np.repeat(np.arange(300), sizes)
+        gimg = np.sort(rng.integers(0, 4, size=300))
+        img = gimg[hid]
+        perm = rng.permutation(len(hid))
+        hid, img = hid[perm], img[perm]
+        pos, n_pad, gmeta, tile_gmax, row_map, tile_img = pack_laue(hid, img, by_image)
+        assert len(np.unique(pos)) == len(hid) and pos.max() < n_pad and n_pad % TILE == 0
+        for g in range(300):                       # members consecutive, inside one 16-row granule, member index / size recorded
+            p = np.sort(pos[hid == g])
+            assert np.all(np.diff(p) == 1) and p[0] // GRANULE == p[-1] // GRANULE
+            assert list(gmeta[p] & 0xff) == list(range(len(p))) and np.all(gmeta[p] >> 8 == len(p))
+        assert np.all(row_map[pos] == np.arange(len(hid))) and (gmeta[row_map < 0] == 0).all()
+        assert np.all(tile_gmax[pos // TILE] >= (gmeta[pos] >> 8)) and tile_gmax.max() == 16
+        if by_image:
+            assert np.all(tile_img[pos // TILE] == img)
+        else:
+            assert tile_img is None
+    assert pack_laue(np.zeros(17, int), np.zeros(17, int), False) is None      # a group larger than a wave: two-pass path
