@@ -54,13 +54,13 @@ int cl_elbo_mono_fwd_bwd(const cl_mlp_args* a, int grid, void* stream) {
 
 int cl_mlp_forward(const cl_mlp_args* a, int grid, void* stream) {
     if (int e = check_mlp(a)) return e;
-    if (a->loc_out == nullptr || a->sig_out == nullptr) return -1;
+    if (a->act_out == nullptr && (a->loc_out == nullptr || a->sig_out == nullptr)) return -1;
     return cl_launch_mlp(*a, 1, grid, (hipStream_t)stream);
 }
 
 int cl_mlp_backward_ext(const cl_mlp_args* a, int grid, void* stream) {
     if (int e = check_mlp(a)) return e;
-    if (a->dO_ext == nullptr || a->partials == nullptr) return -1;
+    if ((a->dO_ext == nullptr && a->dH_ext == nullptr) || a->partials == nullptr) return -1;
     return cl_launch_mlp(*a, 2, grid, (hipStream_t)stream);
 }
 

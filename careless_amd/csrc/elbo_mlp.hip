@@ -135,7 +135,10 @@ struct WgradPlan {
 // image (A.tile_img); a workgroup walks a CONTIGUOUS range of tiles, keeps the current image's matrices in the LDS slots
 // of layers [A.L, A.L + n_imgl) and its weight-gradient sums in the same register accumulators as any other layer, and
 // swaps both (atomicAdd of the sums into the image's gradient, reload) only when the image changes.
-template <int WP, int DP, int LMAX, int MODE, bool IMGL>
+// CHAIN: layer-block chaining for scalers deeper than LMAX (third compilation of this file): a block may have no Dense(2) head
+// (forward writes its last activations, A.act_out; backward starts from their gradient, A.dH_ext) and may return the gradient
+// w.r.t. its input (A.dX_out: the first layer gets a dgrad too).
+template <int WP, int DP, int LMAX, int MODE, bool IMGL, bool CHAIN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void elbo_mlp_kernel(const cl_mlp_args A) {
     using SL = SmemLayout<WP, DP, LMAX>;
@@ -173,6 +176,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     const int Ld = A.L;                              // Dense layers (parameters in A.mlp)
     const int L = IMGL ? A.L + A.n_imgl : A.L;       // all hidden layers (Dense + per-image)
     const float leak = A.leak;
+    const bool no_head = CHAIN && ((MODE == 1 && A.act_out != nullptr) || (MODE == 2 && A.dH_ext != nullptr));
 
     // ---- stage the weights (global W^T layout, see cl_kernels.h) into padded LDS images, zero-filled ---------
     {
@@ -198,9 +202,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         const float* __restrict__ Wo = P + w * d + w + (Ld - 1) * (w * w + w);
         for (int idx = tid; idx < 2 * WP; idx += 512) {
             const int c = idx / WP, i = idx - c * WP;
-            sWo[idx] = (i < w) ? Wo[c * w + i] : 0.0f;
+            sWo[idx] = (i < w && !no_head) ? Wo[c * w + i] : 0.0f;
         }
-        if (tid < 4) sBo[tid] = (tid < 2) ? Wo[2 * w + tid] : 0.0f;
+        if (tid < 4) sBo[tid] = (tid < 2 && !no_head) ? Wo[2 * w + tid] : 0.0f;
     }
     __syncthreads();
 
@@ -458,6 +462,24 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         float dsig_draw;
         const float sigma = cl_scale_bij(o1, A.bij_kind, A.eps, &dsig_draw);
 
+        if (MODE == 1 && no_head) {
+            // block of a chain: the last layer's activations, feature-major like the metadata (they ARE the next block's metadata)
+            if (valid) {
+#pragma unroll
+                for (int l = 0; l < LMAX; ++l)
+                    if (l == L - 1) {
+#pragma unroll
+                        for (int mb = 0; mb < FB; ++mb)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int f = 16 * mb + 4 * q + t;
+                                if (f < ((w + 3) & ~3)) A.act_out[(size_t)f * A.n_pad + gobs] = hs[l][mb][t];
+                            }
+                    }
+            }
+            if (tile + tile_step < tile_end) prefetch(tile + tile_step);
+            continue;
+        }
         if (MODE == 1) {
             if (q == 0 && valid) {
                 const int row = IMGL ? A.row_map[gobs] : gobs;
@@ -594,6 +616,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 boacc1 += draw;
             }
             STAMP(13);
+        } else if (no_head) {
+            dloc = 0.0f; draw = 0.0f;                     // head-less block of a chain: the gradient arrives as dH_ext below
         } else {
             const int row = (IMGL && valid) ? A.row_map[gobs] : gobs;
             const bool have = valid && row >= 0;
@@ -616,7 +640,16 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         f32x4 dH[FB];
 #pragma unroll
         for (int l = LMAX - 1; l >= 0; --l) {
-            if (l == L - 1) {
+            if (l == L - 1 && no_head) {
+                // head-less block of a chain: dL/dH_L comes from the next block (feature-major, like the metadata)
+#pragma unroll
+                for (int mb = 0; mb < FB; ++mb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int f = 16 * mb + 4 * q + t;
+                        dH[mb][t] = (valid && f < ((w + 3) & ~3)) ? A.dH_ext[(size_t)f * A.n_pad + gobs] : 0.0f;
+                    }
+            } else if (l == L - 1) {
                 // dH_L = W_o^T dO ; Dense(2) wgrad from the wave-private columns of the H staging tile
 #pragma unroll
                 for (int mb = 0; mb < FB; ++mb) {
@@ -676,6 +709,26 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     load_meta(__builtin_amdgcn_readfirstlane(tile), h0s);
 #pragma unroll
                     for (int t = 0; t < KS1; ++t) sH[(4 * t + q) * PB + CL_WOBS * wv + j] = h0s[t];
+                    if (CHAIN && A.dX_out != nullptr) {
+                        // block of a chain: the gradient w.r.t. this block's input, dX = W_1 dZ_0 (a dgrad for the first layer too),
+                        // written feature-major -- it is the dH_ext of the block before
+#pragma unroll
+                        for (int ib = 0; ib < IB1; ++ib) {
+                            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                            for (int kb = 0; kb < FB; ++kb)
+#pragma unroll
+                                for (int t = 0; t < 4; ++t)
+                                    acc = mfma4(sW1[(16 * kb + 4 * q + t) * PW1 + (16 * ib + j < DP ? 16 * ib + j : 0)], dH[kb][t], acc);
+                            if (valid) {
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    const int f = 16 * ib + 4 * q + t;
+                                    if (f < d4) A.dX_out[(size_t)f * A.n_pad + gobs] = acc[t];
+                                }
+                            }
+                        }
+                    }
                 }
                 // ---- dgrad: dH_{l-1} = W_l dZ_l.  Register + weight-image only, so it runs BEFORE barrier B and
                 //      overlaps the other waves' staging writes ---------------------------------------------------
@@ -852,7 +905,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     // ================= flush the weight-gradient accumulators: LDS staging -> per-workgroup partial =========
     __syncthreads();
     const int offWo = w * d + w + (Ld - 1) * (w * w + w);
-    const int Ptot = offWo + 2 * w + 2;
+    const int Ptot = no_head ? offWo : offWo + 2 * w + 2;
     for (int idx = tid; idx < Ptot; idx += 512) smem[idx] = 0.0f;
     __syncthreads();
     float bo0 = boacc0, bo1 = boacc1;
@@ -889,11 +942,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     if (lane < w) smem[offB + lane] += bacc[l];
                 }
             }
-            if (lane < w) {
+            if (lane < w && !no_head) {
                 smem[offWo + lane] += woacc0;
                 smem[offWo + w + lane] += woacc1;
             }
-            if (lane == 0) {
+            if (lane == 0 && !no_head) {
                 smem[offWo + 2 * w] += bo0;
                 smem[offWo + 2 * w + 1] += bo1;
             }
@@ -935,7 +988,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 // ---------------------------------------------------------------------------------------------------------
 // block = 32 consecutive elements x 8 chunks of the partial list; a thread sums its chunk (coalesced 128-B rows), the 8 chunk
 // sums are combined through LDS in chunk order => the result does not depend on scheduling
-#if !CL_IMGL
+#if !CL_IMGL && !CL_CHAIN
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int P,
                                                                float* __restrict__ out, const int* stop_flag) {
     if (stop_flag != nullptr && *stop_flag != 0) return;
@@ -963,7 +1016,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------------
 #ifndef CL_IMGL
-#define CL_IMGL 0            // the file is compiled twice: -DCL_IMGL=0 (Dense-only scalers) and -DCL_IMGL=1 (per-image layers)
+#define CL_IMGL 0            // the file is compiled three times: plain (-DCL_IMGL=0 -DCL_CHAIN=0), packed layouts / per-image layers
+#endif                       // (-DCL_IMGL=1) and layer-block chains (-DCL_CHAIN=1)
+#ifndef CL_CHAIN
+#define CL_CHAIN 0
 #endif
 
 template <int WP, int DP, int LMAX, int MODE>
@@ -974,7 +1030,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     size_t sm = sm_tiles;
     if (MODE != 1 && P * sizeof(float) > sm) sm = P * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0)>;
+    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0)>;
     static size_t configured = 0;
     if (configured < sm) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -1006,7 +1062,12 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }
 
-#if CL_IMGL
+#if CL_CHAIN
+int cl_launch_mlp_chain(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (a.row_map != nullptr || a.n_imgl > 0) return -2;                       // chains use the plain layout
+    if (a.act_out != nullptr && mode != 1) return -1;
+    if (a.dH_ext != nullptr && mode != 2) return -1;
+#elif CL_IMGL
 int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.row_map == nullptr || a.n_obs != a.n_pad || a.n_imgl < 0) return -1;
     if (a.n_imgl > 0 && (a.imgl == nullptr || a.tile_img == nullptr || a.n_images < 1 || a.use_img)) return -1;
@@ -1016,6 +1077,7 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
     if (a.n_imgl > 0 || a.row_map != nullptr) return cl_launch_mlp_imgl(a, mode, grid, st);   // packed layouts
 #endif
     if (a.n_pad % CL_TILE != 0 || a.n_pad <= 0) return -1;
@@ -1033,7 +1095,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     return -1;
 }
 
-#if !CL_IMGL
+#if !CL_IMGL && !CL_CHAIN
 int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st) {
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 31) / 32), dim3(256), 0, st, partials, nparts, P, out, stop_flag);

@@ -182,6 +182,33 @@ def pack_by_image(image_id: np.ndarray):
 GRANULE = 16      # observations of one wave of the fused kernel
 
 
+@dataclass
+class LayerBlock:
+    """One launch of a chained scaler: Dense layers [l0, l1) of the stack; the last block also carries the Dense(2) head."""
+    l0: int
+    l1: int
+    d_in: int          # width of the block's input: the metadata width for the first block, the hidden width for the others
+    off: int           # offset of the block's parameters inside the scaler's flat W^T layout
+    P: int             # number of parameters of the block (what its gradient partials hold)
+    final: bool
+
+
+def chain_plan(d: int, w: int, L: int, max_layers: int) -> List[LayerBlock]:
+    """Split a scaler of L Dense layers into the fewest, evenly sized blocks of at most `max_layers` layers (one block = one
+    launch of the fused kernel, include/careless_hip.h: act_out / dH_ext / dX_out)."""
+    K = -(-L // max_layers)
+    sizes = [L // K + (1 if i < L % K else 0) for i in range(K)]
+    off_of = lambda l: 0 if l == 0 else w * d + w + (l - 1) * (w * w + w)
+    blocks, l0 = [], 0
+    for k, n in enumerate(sizes):
+        l1 = l0 + n
+        final = k == K - 1
+        P = off_of(l1) - off_of(l0) + (2 * w + 2 if final else 0)
+        blocks.append(LayerBlock(l0, l1, d if k == 0 else w, off_of(l0), P, final))
+        l0 = l1
+    return blocks
+
+
 def pack_laue(harmonic_id: np.ndarray, image_id: np.ndarray, by_image: bool):
     """Packed order of the single-pass Laue kernel: the rows of a harmonic group are consecutive and inside one 16-row granule.
     Groups are padded to the next power of two and laid out class by class (all groups of padded size p of an image are
@@ -350,6 +377,13 @@ class ObsData:
         g = int(grid) if grid is not None else max(1, int(lib.cl_mlp_default_grid()))
         self.grid = min(g, self.n_pad // TILE)
         self.partials = torch.empty(self.grid * P, dtype=torch.float32, device=device)
+        self.chain_act = self.chain_dact = None       # activations / their gradients at the block boundaries of a chained scaler
+
+    def alloc_chain(self, lib, blocks, w, device):
+        rows = int(lib.cl_mlp_meta_rows(w))
+        n = len(blocks) - 1
+        self.chain_act = [torch.zeros(rows, self.n_pad, dtype=torch.float32, device=device) for _ in range(n)]
+        self.chain_dact = [torch.zeros(rows, self.n_pad, dtype=torch.float32, device=device) for _ in range(n)]
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -428,6 +462,13 @@ class ElboEngine:
         self.ev11 = bool(getattr(lik, "ev11", False))
         self.dw_trainable = self.double_wilson and prior.r_raw is not None
         n_dwr = int(prior.r_raw.numel()) if self.dw_trainable else 0
+        self.blocks = None
+        max_plain = int(self.lib.cl_mlp_max_layers(self.w))
+        if max_plain < 1:
+            raise NotImplementedError(f"scaler width {self.w}: the HIP engine supports hidden widths up to 64")
+        if imgl is None and self.L > max_plain:
+            # deeper than one launch holds in registers: a chain of layer blocks, activations exchanged through HBM
+            self.blocks = chain_plan(self.d, self.w, self.L, max_plain)
         if imgl is not None:
             imgl.build(self.d)
             max_l = int(self.lib.cl_mlp_max_layers(self.w))
@@ -471,7 +512,9 @@ class ElboEngine:
             raise ValueError("mc_sample_size must be >= 1")
         self.obs = ObsData(self.lib, inputs, self.shard.start, self.shard.stop, self.S, lay.P, dev, grid=grid, n_refl=self.R,
                            n_images=self._max_images(), laue_groups=self.laue_groups, pack_images=imgl is not None,
-                           laue_single_pass=not getattr(model, "laue_two_pass", False))
+                           laue_single_pass=not getattr(model, "laue_two_pass", False) and self.blocks is None)
+        if self.blocks is not None:
+            self.obs.alloc_chain(self.lib, self.blocks, self.w, dev)
         RS = self.R * self.S
         o_dz = 0
         o_g = (RS + 3) // 4 * 4
@@ -638,6 +681,8 @@ class ElboEngine:
         """NLL of `obs` into scalars[NLL] and its gradient into dz_f / the flat gradient (scaler + image scales)."""
         lib, lay = self.lib, self.layout
         ma = self._mlp_args(step, eta, ipred_out, obs)
+        if self.blocks is not None:
+            return self._data_term_chain(ma, obs, step, eta, ipred_out, st)
         if self.laue and obs.fused_laue:
             # single pass: the harmonic group sums happen inside the fused kernel; the padded slots (no rows, iconv = 0,
             # reference formatter.py:637-640 / laue.py:24) only add their constant -- and, with Ev11, its gradient
@@ -660,6 +705,42 @@ class ElboEngine:
         check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
                                      ptr(self.stop_flag), st), "cl_reduce_partials")
 
+    def _block_args(self, ma: MlpArgs, obs: ObsData, k: int) -> MlpArgs:
+        """Arguments of block k of the chain: its slice of the parameters, its input (metadata or the previous block's output)."""
+        lay, b = self.layout, self.blocks[k]
+        a = MlpArgs()
+        C.memmove(C.byref(a), C.byref(ma), C.sizeof(MlpArgs))
+        a.mlp = self.params.data_ptr() + 4 * (lay.off_mlp + b.off)
+        a.d, a.L = b.d_in, b.l1 - b.l0
+        a.meta_t = ptr(obs.meta_t) if k == 0 else ptr(obs.chain_act[k - 1])
+        return a
+
+    def _data_term_chain(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
+        """Scaler deeper than one launch: forward through the head-less blocks (activations to HBM), the last block does the
+        likelihood and its own backward (recomputing its forward), then the blocks are walked back, each recomputing its
+        forward from its stored input.  8 P_mm flops per observation instead of 6, plus 2 x 8 w bytes per block boundary."""
+        lib, lay, K = self.lib, self.layout, len(self.blocks)
+        gptr = lambda k: self.grads.data_ptr() + 4 * (lay.off_mlp + self.blocks[k].off)
+        for k in range(K - 1):
+            a = self._block_args(ma, obs, k)
+            a.act_out = ptr(obs.chain_act[k])
+            check(lib.cl_mlp_forward(C.byref(a), obs.grid, st), "cl_mlp_forward")
+        a = self._block_args(ma, obs, K - 1)
+        a.dX_out = ptr(obs.chain_dact[K - 2])
+        if self.laue:
+            self._laue_passes(a, obs, step, eta, ipred_out, st)
+        else:
+            check(lib.cl_elbo_mono_fwd_bwd(C.byref(a), obs.grid, st), "cl_elbo_mono_fwd_bwd")
+        check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, self.blocks[K - 1].P, gptr(K - 1), ptr(self.stop_flag), st),
+              "cl_reduce_partials")
+        for k in range(K - 2, -1, -1):
+            a = self._block_args(ma, obs, k)
+            a.dH_ext = ptr(obs.chain_dact[k])
+            a.dX_out = ptr(obs.chain_dact[k - 1]) if k > 0 else None
+            check(lib.cl_mlp_backward_ext(C.byref(a), obs.grid, st), "cl_mlp_backward_ext")
+            check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, self.blocks[k].P, gptr(k), ptr(self.stop_flag), st),
+                  "cl_reduce_partials")
+
     def evaluate_nll(self, obs: ObsData, key: int) -> float:
         """NLL of another observation set under the current parameters with fresh Monte-Carlo noise -- what
         `model.test_on_batch(validation_data)` reports as "NLL" (reference variational.py:257-260).  Uses the step workspace
@@ -678,9 +759,11 @@ class ElboEngine:
             raise ValueError("validation data and training data differ in kind (mono / Laue)")
         o = ObsData(self.lib, inputs, 0, None, self.S, self.layout.P, self.device, n_refl=self.R,
                     n_images=self._max_images(), pack_images=self.imgl is not None,
-                    laue_single_pass=not getattr(self.model, "laue_two_pass", False))
+                    laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None)
         if o.d != self.d:
             raise ValueError("validation metadata width differs from the training data")
+        if self.blocks is not None:
+            o.alloc_chain(self.lib, self.blocks, self.w, self.device)
         return o
 
     def _laue_passes(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
@@ -879,6 +962,25 @@ def scaler_forward(mlp, metadata, imgl=None, image_id=None):
         a.imgl, a.n_imgl, a.n_images = ptr(imgl.flat), imgl.n_image_layers, imgl.max_images
         a.tile_img, a.row_map = ptr(keep[0]), ptr(keep[1])
     grid = min(max(1, int(lib.cl_mlp_default_grid())), n_pad // TILE)
+    max_plain = int(lib.cl_mlp_max_layers(mlp.width))
+    if imgl is None and mlp.n_layers > max_plain:
+        # deeper than one launch: chain of layer blocks (see ElboEngine._data_term_chain)
+        blocks = chain_plan(d, mlp.width, mlp.n_layers, max_plain)
+        rows = int(lib.cl_mlp_meta_rows(mlp.width))
+        x = meta_t
+        for b in blocks:
+            a.mlp = mlp.flat.data_ptr() + 4 * b.off
+            a.d, a.L, a.meta_t = b.d_in, b.l1 - b.l0, ptr(x)
+            if not b.final:
+                y = torch.zeros(rows, n_pad, dtype=torch.float32, device=dev)
+                a.act_out = ptr(y)
+                check(lib.cl_mlp_forward(C.byref(a), grid, _stream()), "cl_mlp_forward")
+                keep.append(x)
+                x = y
+            else:
+                a.act_out = None
+                check(lib.cl_mlp_forward(C.byref(a), grid, _stream()), "cl_mlp_forward")
+        return loc, sig
     check(lib.cl_mlp_forward(C.byref(a), grid, _stream()), "cl_mlp_forward")
     return loc, sig
 

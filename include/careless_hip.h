@@ -147,6 +147,15 @@ typedef struct cl_mlp_args {
     const int* tile_gmax;
     const int* noise_row;       /* optional [n_pad]: GLOBAL row of every packed row for the in-kernel noise key (shards that are
                                  * not a contiguous row range); NULL = obs_offset + row_map[row]                        */
+    /* Scalers deeper than cl_mlp_max_layers(w) run as a CHAIN of layer blocks, each block one launch whose "metadata" is the
+     * previous block's output (same feature-major [cl_mlp_meta_rows(w)][n_pad] layout, d = w):
+     *   cl_mlp_forward      with act_out : `mlp` holds L Dense layers and NO Dense(2) head; writes the last layer's activations
+     *   cl_mlp_backward_ext with dH_ext  : same parameters; gradient w.r.t. those activations comes in (instead of dO_ext)
+     *   dX_out (any backward launch)     : also write dL/d(metadata) -- the dH_ext of the block before
+     * The scaler-gradient partials of a head-less block have cl_mlp_param_count(d, w, L) - 2 w - 2 entries.               */
+    float* act_out;             /* [cl_mlp_meta_rows(w)][n_pad]                                                        */
+    const float* dH_ext;        /* [cl_mlp_meta_rows(w)][n_pad]                                                        */
+    float* dX_out;              /* [cl_mlp_meta_rows(d)][n_pad]                                                        */
 } cl_mlp_args;
 
 enum { CL_LIK_NORMAL_ = 0, CL_LIK_STUDENTT_ = 1 };
@@ -154,7 +163,8 @@ enum { CL_BIJ_EXP_ = 0, CL_BIJ_SOFTPLUS_ = 1 };
 
 int cl_mlp_default_grid(void);                       /* workgroups of a persistent launch = CUs of the current device */
 size_t cl_mlp_param_count(int d, int w, int L);      /* P */
-int cl_mlp_max_layers(int w);                        /* deepest supported scaler of hidden width w (0: width unsupported) */
+int cl_mlp_max_layers(int w);                        /* Dense layers ONE launch holds at hidden width w (0: width unsupported); deeper
+                                                      * scalers are chained (act_out / dH_ext / dX_out)                          */
 int cl_mlp_meta_rows(int d);                         /* rows of meta_t: d rounded up to a multiple of 4 (one MFMA k-step) */
 int cl_elbo_mono_fwd_bwd(const cl_mlp_args* args, int grid, void* stream);
 int cl_mlp_forward(const cl_mlp_args* args, int grid, void* stream);

@@ -46,6 +46,12 @@ CASES = {
     "laue_groups_over_16_rows_fall_back": dict(N=700, R=50, L=2, w=32, S=2, laue=True, regroup=16),
     "mono_rows_in_arbitrary_order_S5": dict(N=900, R=60, d0=5, L=3, w=64, S=5, n_images=9, shuffle_rows=True, likelihood="studentt", dof=4.0),
     "mono_three_observations": dict(N=3, R=2, d0=5, L=2, w=32, S=2, n_images=1, use_image_scales=False),
+    # scalers deeper than one launch holds: chains of layer blocks (activations through HBM, forward recomputed per block)
+    "deep_12x64_studentt_S4": dict(N=700, R=50, d0=5, posenc=True, L=12, w=64, S=4, likelihood="studentt", dof=8.0),
+    "deep_25x10_softplus": dict(N=500, R=40, d0=5, L=25, w=10, S=2, bijector="softplus", shift=0.5),
+    "deep_11x32_noimg": dict(N=400, R=40, d0=5, L=11, w=32, S=3, use_image_scales=False),
+    "deep_laue_7x64": dict(N=500, R=50, L=7, w=64, S=2, laue=True, two_pass=True),
+    "deep_double_wilson_6x64": dict(N=400, R=60, d0=5, L=6, w=64, S=2, double_wilson=True),
     "double_wilson_trainable_r_S4": dict(N=400, R=60, d0=5, L=2, w=32, S=4, double_wilson=True, optimize_dw_r=True),
     "double_wilson_5x64_S8_studentt": dict(N=600, R=80, d0=5, L=5, w=64, S=8, double_wilson=True, likelihood="studentt", dof=8.0),
 }
@@ -266,6 +272,35 @@ def test_image_layers_adam_trajectory_and_scaler_call():
 
 def _np(t):
     return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def test_chained_deep_scaler_trajectory_validation_and_predictions():
+    """13 layers of width 32 = two launches per pass (10 is the most one launch holds): Adam trajectory against the oracle,
+    NLL_val, and the prediction path (`scaler(inputs)` chains its forward the same way)."""
+    kw = dict(N=500, R=40, d0=5, L=13, w=32, S=2)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    steps = 8
+    rng = np.random.default_rng(3)
+    noises = [(rng.random((2, 40)).astype(np.float32), rng.normal(size=(2, 500)).astype(np.float32)) for _ in range(steps)]
+    model = util.build_model(data, cfg, params, 13, 32)
+    inputs = util.reference_inputs(data)
+    hist = model.train_model(inputs, steps, progress=False, noise=lambda i: noises[i])
+    assert len(model._engine.blocks) == 2 and [b.l1 - b.l0 for b in model._engine.blocks] == [7, 6]
+    p = params.clone()
+    st = O.AdamState.zeros_like(p.tensors())
+    ref = [O.train_step(p, x, cfg, st, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+           for u, e in noises]
+    for k in ("loss", "NLL", "F KLDiv", "Grad Norm"):
+        a = np.array(hist[k]); b = np.array([r[k] for r in ref])
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) < 2e-4, (k, a, b)
+    mean, std = model.scale_mean_stddev(inputs)
+    o = O.mlp_forward(x.metadata, p.mlp_w, p.mlp_b, cfg.leakiness)
+    a_img = O.image_scales(p.img_raw)[x.image_id]
+    assert util.rel_err(_np(mean).reshape(-1), (a_img * o[:, 0]).detach().numpy()) < 2e-4
+    model2 = util.build_model(data, cfg, params, 13, 32)
+    tr, te = tuple(a[:400] for a in inputs), tuple(a[400:] for a in inputs)
+    h2 = model2.train_model(tr, 4, progress=False, validation_data=te, validation_frequency=2)
+    assert len(h2["NLL_val"]) == 4 and all(np.isfinite(h2["NLL_val"]))
 
 
 def test_noise_statistics_and_shard_independence():
