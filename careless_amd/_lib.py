@@ -107,6 +107,7 @@ EXPORTS = {
     "cl_mlp_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "cl_mlp_meta_rows": (C.c_int, [C.c_int]),
     "cl_mlp_max_layers": (C.c_int, [C.c_int]),
+    "cl_mlp_max_layers_imgl": (C.c_int, [C.c_int]),
     "cl_tn_forward": (C.c_int, [C.POINTER(TnArgs), _vp]),
     "cl_tn_backward": (C.c_int, [C.POINTER(TnArgs), _vp]),
     "cl_dw_prior_forward": (C.c_int, [C.POINTER(TnArgs), _vp]),

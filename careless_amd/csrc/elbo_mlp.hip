@@ -1057,7 +1057,7 @@ template <int MODE>
 static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.L < 1 || a.w < 1 || a.d < 1) return -2;
     if (a.w > 64 || a.d > 64) return -2;
-    if (a.w <= 16) return launch_dp<16, CL_MLP_LMAX_W16, MODE>(a, grid, st);
+    if (a.w <= 16) return launch_dp<16, (CL_IMGL ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16), MODE>(a, grid, st);
     if (a.w <= 32) return (a.L + (CL_IMGL ? a.n_imgl : 0) <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }

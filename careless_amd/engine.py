@@ -471,7 +471,7 @@ class ElboEngine:
             self.blocks = chain_plan(self.d, self.w, self.L, max_plain)
         if imgl is not None:
             imgl.build(self.d)
-            max_l = int(self.lib.cl_mlp_max_layers(self.w))
+            max_l = int(self.lib.cl_mlp_max_layers_imgl(self.w))
             if self.L + imgl.n_image_layers > max_l:
                 raise NotImplementedError(f"{self.L} Dense + {imgl.n_image_layers} image layers of width {self.w}: the HIP engine "
                                           f"supports {max_l} hidden layers in total at this width")

@@ -37,6 +37,7 @@ extern "C" {
 #define CL_MLP_TILE 128   /* observations per workgroup tile */
 /* deepest scaler the fused kernel is instantiated for, by hidden width (cl_mlp_max_layers) */
 #define CL_MLP_LMAX_W16 20 /* width <= 16 (the careless CLI default is 20 layers x width 10) */
+#define CL_MLP_LMAX_W16_IMGL 24 /* width <= 16 with per-image layers: Dense + image layers (the default 20 + --image-layers <= 4) */
 #define CL_MLP_LMAX_W32 10 /* width <= 32 */
 #define CL_MLP_LMAX_W64 5  /* width <= 64 */
 #define CL_HIST_STRIDE 8  /* doubles per history record: loss, F KLDiv, NLL, Grad Norm, skipped, 3 spare */
@@ -163,6 +164,7 @@ enum { CL_BIJ_EXP_ = 0, CL_BIJ_SOFTPLUS_ = 1 };
 
 int cl_mlp_default_grid(void);                       /* workgroups of a persistent launch = CUs of the current device */
 size_t cl_mlp_param_count(int d, int w, int L);      /* P */
+int cl_mlp_max_layers_imgl(int w);                   /* hidden layers (Dense + per-image) one launch holds with n_imgl > 0         */
 int cl_mlp_max_layers(int w);                        /* Dense layers ONE launch holds at hidden width w (0: width unsupported); deeper
                                                       * scalers are chained (act_out / dH_ext / dX_out)                          */
 int cl_mlp_meta_rows(int d);                         /* rows of meta_t: d rounded up to a multiple of 4 (one MFMA k-step) */

@@ -77,6 +77,16 @@ def test_image_layers_crossvalidation_and_reloading(tmp_path):
     assert np.array_equal(model2.scaling_model.flat.cpu().numpy(), model.scaling_model.flat.cpu().numpy())   # frozen => unchanged
 
 
+@pytest.mark.parametrize("scale_bijector", ["exp", "softplus"])
+@pytest.mark.parametrize("image_layers", [None, 2])
+def test_scale_bijector(tmp_path, scale_bijector, image_layers):
+    """reference tests/test_cli.py:211-228: default scaler (20 x 10), optionally with two per-image layers on top"""
+    flags = f"mono --disable-gpu --iterations={niter} --disable-progress-bar --scale-bijector={scale_bijector} dHKL,image_id"
+    if image_layers is not None:
+        flags = flags.replace("mono ", f"mono --image-layers={image_layers} ")
+    _run(flags, [PYP], str(tmp_path / "out"), False)
+
+
 def test_preformatted_npz_input(tmp_path):
     from careless_amd.io.formats import save_inputs_npz
     from careless_amd.io.formatter import MonoFormatter

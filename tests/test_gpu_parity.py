@@ -36,6 +36,7 @@ CASES = {
                                            likelihood="studentt", dof=16.0),
     "image_layers2_4x10_softplus": dict(N=900, R=50, d0=5, L=4, w=10, S=2, n_images=6, image_layers=2, bijector="softplus",
                                         shift=0.7),
+    "image_layers2_on_the_cli_default_20x10": dict(N=600, R=40, d0=5, L=20, w=10, S=2, n_images=4, image_layers=2),
     "laue_image_layers1_2x32": dict(N=600, R=60, L=2, w=32, S=3, laue=True, n_images=4, image_layers=1),
     # the two Laue code paths: single pass (group sums inside the fused kernel; the default) and two passes around the group sums
     "laue_two_pass_2x32_S3": dict(N=400, R=40, L=2, w=32, S=3, laue=True, two_pass=True),
