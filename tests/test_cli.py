@@ -87,6 +87,29 @@ def test_scale_bijector(tmp_path, scale_bijector, image_layers):
     _run(flags, [PYP], str(tmp_path / "out"), False)
 
 
+@pytest.mark.parametrize("extra", ["--freeze-structure-factors", "--freeze-scales", "--clipvalue=1.", "--clipnorm=1.", "--global-clipnorm=1.",
+                                   "--kl-weight=0.5", "--wilson-prior-b=20.", "--mc-samples=3 --studentt-likelihood-dof=8 --refine-uncertainties",
+                                   "--disable-image-scales --mlp-width=6 --mlp-layers=25", "--disable-metadata-standardization"])
+def test_flags_execute(tmp_path, extra):
+    """reference tests/test_cli.py:165-204 (freeze flags, clipping) and further flags of the path, default 20 x 10 scaler"""
+    _run(f"mono --disable-gpu --iterations={niter} --disable-progress-bar {extra} dHKL,image_id", [PYP], str(tmp_path / "out"), False)
+
+
+@pytest.mark.parametrize("which", ["scale", "structure_factor"])
+def test_weight_save_and_load(tmp_path, which):
+    """reference tests/test_cli.py:120-163"""
+    out = str(tmp_path / "out")
+    flags = f"mono --disable-gpu --iterations={niter} --disable-progress-bar dHKL,image_id"
+    _, model, _ = _run(flags, [PYP], out, False)
+    flag = f"--scale-file={out}_scale" if which == "scale" else f"--structure-factor-file={out}_structure_factor"
+    out2 = str(tmp_path / "out_reloaded")
+    from careless_amd.careless import run_careless
+    from careless_amd.parser import parser
+    args = parser.parse_args((flags.replace(f"--iterations={niter}", "--iterations=1") + f" {flag}").split() + [PYP, out2])
+    model2, hist2 = run_careless(args)
+    assert os.path.exists(out2 + "_0.mtz") and np.isfinite(hist2["loss"][0])
+
+
 def test_preformatted_npz_input(tmp_path):
     from careless_amd.io.formats import save_inputs_npz
     from careless_amd.io.formatter import MonoFormatter
