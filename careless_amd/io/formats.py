@@ -55,11 +55,44 @@ PREDICTION_TYPES = {"H": "H", "K": "H", "L": "H", "asu_id": "I", "image_id": "I"
                     "SigIobs": "Q", "Ipred": "J", "SigIpred": "Q", "Scale": "J", "SigScale": "Q", "repeat": "I", "half": "I"}
 
 
+ANOM_KEYS = ["F(+)", "SigF(+)", "F(-)", "SigF(-)", "I(+)", "SigI(+)", "I(-)", "SigI(-)", "N(+)", "N(-)"]   # the order PHENIX expects
+
+
+def unstack_anomalous(table: Dict[str, np.ndarray], asu: ReciprocalASU) -> Dict[str, np.ndarray]:
+    """One row per reflection of the NON-anomalous ASU with `X(+)` / `X(-)` columns (reciprocalspaceship's
+    `DataSet.unstack_anomalous`, used by reference manager.py:238-248).  A reflection of the anomalous ASU is a Friedel-plus
+    when it is also the representative of its orbit under rotations AND inversion; otherwise it is the minus mate of that
+    representative.  Centric reflections carry the same values in both columns; a missing mate gives NaN."""
+    H = np.stack([table["H"], table["K"], table["L"]], axis=1).astype(np.int64)
+    rep = asu.ops.to_asu(H, anomalous=False)
+    plus = np.all(rep == H, axis=1)
+    centric, _, _ = asu.ops.describe(H)
+    from careless_amd.io.asu import _key
+    keys = _key(rep)
+    uk, inv = np.unique(keys, return_inverse=True)
+    first = np.zeros(len(uk), dtype=np.int64)
+    first[inv] = np.arange(len(inv))
+    out = {"H": rep[first, 0], "K": rep[first, 1], "L": rep[first, 2]}
+    names = [k for k in table if k not in ("H", "K", "L")]
+    for k in names:
+        v = np.asarray(table[k], dtype=np.float32)
+        vp = np.full(len(uk), np.nan, dtype=np.float32)
+        vm = np.full(len(uk), np.nan, dtype=np.float32)
+        vp[inv[plus]] = v[plus]
+        vm[inv[~plus]] = v[~plus]
+        cm = np.zeros(len(uk), dtype=bool)
+        cm[inv[plus & centric]] = True
+        vm[cm] = vp[cm]
+        out[f"{k}(+)"], out[f"{k}(-)"] = vp, vm
+    order = [k for k in ANOM_KEYS if k in out] + [k for k in out if k not in ANOM_KEYS and k not in ("H", "K", "L")]
+    return {**{k: out[k] for k in ("H", "K", "L")}, **{k: out[k] for k in order}}
+
+
 def results_tables(results: Dict[str, np.ndarray], rac: ReciprocalASUCollection) -> List[Dict[str, np.ndarray]]:
-    """Split the per-reflection result arrays by ASU, attach Miller indices, drop unobserved reflections
-    (reference manager.py:205-236; anomalous data stay one row per Friedel mate)."""
+    """Split the per-reflection result arrays by ASU, attach Miller indices, drop unobserved reflections; anomalous ASUs are
+    unstacked into `F(+)`, `F(-)`, ... columns (reference manager.py:205-250)."""
     out = []
-    for i, _ in enumerate(rac):
+    for i, asu in enumerate(rac):
         m = (rac.asu_ids == i) & (np.asarray(results["N"]) > 0)
         t = {"H": rac.Hall[m, 0], "K": rac.Hall[m, 1], "L": rac.Hall[m, 2]}
         for k in ("F", "SigF", "I", "SigI", "N"):
@@ -67,12 +100,16 @@ def results_tables(results: Dict[str, np.ndarray], rac: ReciprocalASUCollection)
         for k in sorted(results):
             if k not in t and k != "observed":
                 t[k] = np.asarray(results[k])[m]
-        out.append(t)
+        out.append(unstack_anomalous(t, asu) if asu.anomalous else t)
     return out
 
 
 def write_table_mtz(path: str, table: Dict[str, np.ndarray], asu: ReciprocalASU, types: Optional[Dict[str, str]] = None):
     types = dict(RESULT_TYPES if types is None else types)
+    anom = {"F": "G", "SigF": "L", "I": "K", "SigI": "M", "N": "I"}     # MTZ types of Friedel-separated columns
     for k in table:
-        types.setdefault(k, "R")
+        if k in types:
+            continue
+        base = k[:-3] if k.endswith(("(+)", "(-)")) else None
+        types[k] = anom.get(base, "R") if base is not None else "R"
     write_mtz(path, table, types, asu.cell, asu.symops, getattr(asu, "spacegroup_name", "P 1"), getattr(asu, "spacegroup_number", 1))

@@ -25,7 +25,13 @@ def _run(flags, files, out, separate):
         assert os.path.exists(f)
         ds, src = read_mtz(f), read_mtz(files[i])
         assert ds.spacegroup_number == src.spacegroup_number and ds.symops == src.symops
-        assert len(ds) > 0 and np.all(np.isfinite(ds.columns["F"])) and np.all(ds.columns["SigF"] > 0) and np.all(ds.columns["N"] > 0)
+        if args.anomalous:                                   # reference tests/test_cli.py:49-50: Friedel mates in separate columns
+            assert "F(+)" in ds.columns and ds.types["F(+)"] == "G" and ds.keys()[3:13] == ["F(+)", "SigF(+)", "F(-)", "SigF(-)", "I(+)", "SigI(+)",
+                                                                                              "I(-)", "SigI(-)", "N(+)", "N(-)"]
+            f = np.concatenate([ds.columns["F(+)"], ds.columns["F(-)"]])
+            assert len(ds) > 0 and np.isfinite(f).any() and np.all(f[np.isfinite(f)] > 0)
+        else:
+            assert len(ds) > 0 and np.all(np.isfinite(ds.columns["F"])) and np.all(ds.columns["SigF"] > 0) and np.all(ds.columns["N"] > 0)
         if args.dmin is not None:
             assert (1.0 / np.sqrt(inv_d2(ds.hkl(), ds.cell))).min() >= args.dmin
         assert os.path.exists(out + f"_predictions_{i}.mtz")

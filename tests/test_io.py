@@ -195,3 +195,25 @@ def test_double_wilson_lookup_from_asu_collection():
     assert np.all(child >= 0) and np.array_equal(rac.Hall[child], b.Hall)          # the child's reflections exist in the bigger parent
     dw2 = double_wilson_lookup(ReciprocalASUCollection([b, a]), [None, 0])
     assert (dw2["reflids"][len(b):] == -1).sum() == len(a) - len(b)                # parent ends at 8 A: the rest is absent
+
+
+def test_anomalous_results_are_unstacked_into_friedel_columns():
+    """reference manager.py:238-248 (`unstack_anomalous` + PHENIX column order)"""
+    from careless_amd.io.formats import ANOM_KEYS, results_tables
+    m = read_mtz(PYP)
+    a = ReciprocalASU(m.cell, m.symops, 6.0, True)
+    rac = ReciprocalASUCollection([a])
+    n = len(a)
+    rng = np.random.default_rng(0)
+    res = {k: (rng.random(n) + 1).astype(np.float32) for k in ("F", "SigF", "I", "SigI", "loc")}
+    res["N"] = (rng.random(n) < 0.8).astype(np.float32) * 3
+    t = results_tables(res, rac)[0]
+    assert list(t.keys())[:13] == ["H", "K", "L"] + ANOM_KEYS and "loc(+)" in t
+    H = np.stack([t["H"], t["K"], t["L"]], 1)
+    assert np.all(a.ops.to_asu(H, False) == H) and len(np.unique(H, axis=0)) == len(H)       # rows = non-anomalous representatives
+    idp, idm = a.to_refl_id(a.ops.to_asu(H, True)), a.to_refl_id(a.ops.to_asu(-H, True))
+    for ids, col in ((idp, "F(+)"), (idm, "F(-)")):
+        seen = res["N"][ids] > 0
+        assert np.allclose(t[col][seen], res["F"][ids][seen]) and np.all(np.isnan(t[col][~seen]))
+    c = a.centric[idp]
+    assert np.array_equal(t["F(+)"][c], t["F(-)"][c], equal_nan=True)                         # centrics: both columns equal
