@@ -13,4 +13,5 @@ for d in "ABCD":
             if 'elbo_mlp' in r['Kernel_Name']:
                 acc[r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in acc.items(): print(d,k,len(v),sum(v)/len(v))
+print('# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request: double it (calibrated on this kernel\'s own access pattern with scripts/calib_fetch.sh: forward-only launch, 960 MB of metadata -> FETCH_SIZE 469117 KiB; WRITE_SIZE exact)')
 PY
