@@ -479,8 +479,10 @@ def test_validation_nll_matches_oracle_scale():
 @pytest.mark.parametrize("kw", [dict(N=517, R=41, d0=5, L=2, w=32, S=3),
                                 dict(N=600, R=50, L=2, w=32, S=2, laue=True),
                                 dict(N=500, R=60, d0=5, L=2, w=32, S=2, double_wilson=True),
-                                dict(N=700, R=40, d0=5, L=2, w=32, S=2, n_images=5, image_layers=1)],
-                         ids=["mono", "laue", "double_wilson", "image_layers"])
+                                dict(N=700, R=40, d0=5, L=2, w=32, S=2, n_images=5, image_layers=1),
+                                dict(N=600, R=40, d0=5, L=12, w=32, S=2),
+                                dict(N=600, R=50, L=2, w=32, S=2, laue=True, image_layers=1, n_images=4)],
+                         ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers"])
 def test_rank_shards_sum_to_full_batch_on_gpu(kw):
     """Data-parallel decomposition on ONE GPU: the engines of rank 0 and rank 1 of a 2-rank world (all-reduce skipped) produce
     partial losses / gradients that add up to the single-rank result; in-kernel noise is keyed by global indices, so the shards
