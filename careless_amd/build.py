@@ -16,6 +16,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcareless_hip.so")
 # (source, object stem, extra flags): elbo_mlp.hip is compiled twice -- Dense-only scalers and the per-image-layer variant
 UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=0"]), ("elbo_mlp.hip", "elbo_mlp_imgl", ["-DCL_IMGL=1"]),
+         ("elbo_mlp.hip", "elbo_mlp_packed", ["-DCL_IMGL=2"]),
          ("elbo_mlp.hip", "elbo_mlp_chain", ["-DCL_CHAIN=1"]),
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", [])]
 SOURCES = sorted({u[0] for u in UNITS})

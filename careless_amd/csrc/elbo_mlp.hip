@@ -138,7 +138,8 @@ struct WgradPlan {
 // CHAIN: layer-block chaining for scalers deeper than LMAX (third compilation of this file): a block may have no Dense(2) head
 // (forward writes its last activations, A.act_out; backward starts from their gradient, A.dH_ext) and may return the gradient
 // w.r.t. its input (A.dX_out: the first layer gets a dgrad too).
-template <int WP, int DP, int LMAX, int MODE, bool IMGL, bool CHAIN = false>
+// ILAY: the packed unit is compiled with (ILAY) and without the per-image-layer code: single-pass Laue only needs the packed layout
+template <int WP, int DP, int LMAX, int MODE, bool IMGL, bool CHAIN = false, bool ILAY = IMGL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void elbo_mlp_kernel(const cl_mlp_args A) {
     using SL = SmemLayout<WP, DP, LMAX>;
@@ -174,7 +175,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 
     const int d = A.d, w = A.w;
     const int Ld = A.L;                              // Dense layers (parameters in A.mlp)
-    const int L = IMGL ? A.L + A.n_imgl : A.L;       // all hidden layers (Dense + per-image)
+    const int L = ILAY ? A.L + A.n_imgl : A.L;       // all hidden layers (Dense + per-image)
     const float leak = A.leak;
     const bool no_head = CHAIN && ((MODE == 1 && A.act_out != nullptr) || (MODE == 2 && A.dH_ext != nullptr));
 
@@ -301,7 +302,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 
     // ---- per-image layers: gradient flush and weight reload on an image change ---------------------------------
     int cur_img = -1;
-    const size_t imgl_blk = IMGL ? (size_t)A.n_images * (size_t)(w * w + w) : 0;      // floats per image layer
+    const size_t imgl_blk = ILAY ? (size_t)A.n_images * (size_t)(w * w + w) : 0;      // floats per image layer
     auto imgl_flush = [&](int im) {
 #pragma unroll
         for (int l = 1; l < LMAX; ++l) {
@@ -343,7 +344,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 
     for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
         const int gobs = tile * CL_TILE + CL_WOBS * wv + j;      // this lane's observation (all four k-groups)
-        if (IMGL && A.n_imgl > 0) {
+        if (ILAY && A.n_imgl > 0) {
             const int im = __builtin_amdgcn_readfirstlane(A.tile_img[tile]);
             if (im != cur_img) {             // workgroup-uniform
                 lds_barrier();               // every wave is done with the previous image's matrices
@@ -900,7 +901,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #endif
 
     if (MODE == 1) return;
-    if (IMGL && cur_img >= 0) imgl_flush(cur_img);
+    if (ILAY && cur_img >= 0) imgl_flush(cur_img);
 
     // ================= flush the weight-gradient accumulators: LDS staging -> per-workgroup partial =========
     __syncthreads();
@@ -1030,7 +1031,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     size_t sm = sm_tiles;
     if (MODE != 1 && P * sizeof(float) > sm) sm = P * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0)>;
+    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0), (CL_IMGL == 1)>;
     static size_t configured = 0;
     if (configured < sm) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -1046,7 +1047,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 // 256-register budget of a wave: w <= 16 -> up to 20 layers (the CLI default scaler is 20 x 10), w <= 32 -> 10, w <= 64 -> 5.
 template <int WP, int LMAX, int MODE>
 static int launch_dp(const cl_mlp_args& a, int grid, hipStream_t st) {
-    if (a.L + (CL_IMGL ? a.n_imgl : 0) > LMAX) return -2;
+    if (a.L + (CL_IMGL == 1 ? a.n_imgl : 0) > LMAX) return -2;
     const int dp = (a.d <= 8) ? 8 : (a.d <= 32 ? 32 : 64);
     if (dp == 8) return launch_one<WP, 8, LMAX, MODE>(a, grid, st);
     if (dp == 32) return launch_one<WP, 32, LMAX, MODE>(a, grid, st);
@@ -1057,8 +1058,8 @@ template <int MODE>
 static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.L < 1 || a.w < 1 || a.d < 1) return -2;
     if (a.w > 64 || a.d > 64) return -2;
-    if (a.w <= 16) return launch_dp<16, (CL_IMGL ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16), MODE>(a, grid, st);
-    if (a.w <= 32) return (a.L + (CL_IMGL ? a.n_imgl : 0) <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
+    if (a.w <= 16) return launch_dp<16, (CL_IMGL == 1 ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16), MODE>(a, grid, st);
+    if (a.w <= 32) return (a.L + (CL_IMGL == 1 ? a.n_imgl : 0) <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }
 
@@ -1067,6 +1068,11 @@ int cl_launch_mlp_chain(const cl_mlp_args& a, int mode, int grid, hipStream_t st
     if (a.row_map != nullptr || a.n_imgl > 0) return -2;                       // chains use the plain layout
     if (a.act_out != nullptr && mode != 1) return -1;
     if (a.dH_ext != nullptr && mode != 2) return -1;
+#elif CL_IMGL == 2
+int cl_launch_mlp_packed(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (a.row_map == nullptr || a.n_obs != a.n_pad || a.n_imgl != 0) return -1;
+    if (a.gmeta != nullptr && (a.tile_gmax == nullptr || mode != 0)) return -1;
+    if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #elif CL_IMGL
 int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.row_map == nullptr || a.n_obs != a.n_pad || a.n_imgl < 0) return -1;
@@ -1078,7 +1084,8 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
-    if (a.n_imgl > 0 || a.row_map != nullptr) return cl_launch_mlp_imgl(a, mode, grid, st);   // packed layouts
+    if (a.n_imgl > 0) return cl_launch_mlp_imgl(a, mode, grid, st);            // packed layout + per-image layers
+    if (a.row_map != nullptr) return cl_launch_mlp_packed(a, mode, grid, st);    // packed layout (single-pass Laue)
 #endif
     if (a.n_pad % CL_TILE != 0 || a.n_pad <= 0) return -1;
     // 32-bit byte offsets / buffer sizes inside the kernel: metadata image < 4 GiB, z_f < 4 GiB (shard further across GPUs otherwise)
