@@ -21,7 +21,14 @@
 //     through two LDS tiles [feature][128 obs (+4)]; each wave then accumulates its own 16x16 blocks of dW_l^T over
 //     the whole tile, in registers, across ALL tiles of the kernel (no per-tile global traffic for weight grads);
 //   * per-workgroup weight-gradient partials are written once at kernel end; a tiny second kernel sums them in a
-//     fixed order (deterministic).
+//     fixed order (deterministic);
+//   * after every workgroup barrier the eight waves restart in lockstep, so a latency that one wave waits for is waited for
+//     by all of them: LDS operands are double-buffered by hand one MFMA group ahead (CL_SCHED_FENCE) and the post-barrier
+//     latency windows are filled with independent work (bias-gradient reads, the next layer's dZ, staging writes between the
+//     dgrad MFMAs) -- DESIGN.md section 4.1.
+// The file is compiled four times (build.py): plain; packed layout + per-image layers (-DCL_IMGL=1, NeuralImageScaler); packed
+// layout only (-DCL_IMGL=2, single-pass Laue: harmonic group sums as lane reductions in the epilogue); layer-block chains
+// (-DCL_CHAIN=1, scalers deeper than one launch holds).
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
 #include <hip/hip_runtime.h>
 #include "cl_math.h"
