@@ -205,7 +205,7 @@ def main():
         if args.sim_world > 1:
             out["diagnostic"] = f"rank 0 shard of a simulated {args.sim_world}-rank job: value is NOT a throughput of this workload"
             out["value"] = None
-        if not args.no_cpu_baseline and spec.get("kind", "mono") == "mono" and not spec.get("image_layers"):
+        if not args.no_cpu_baseline and world == 1 and spec.get("kind", "mono") == "mono" and not spec.get("image_layers"):
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
     if use_dist:
         dist.barrier()
