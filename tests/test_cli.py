@@ -9,6 +9,9 @@ from careless_amd.io.asu import inv_d2
 from careless_amd.io.mtz import read_mtz
 from tests.mtz_fixture import PYP
 
+ON = os.path.join(os.path.dirname(PYP), "pyp_2ms.mtz")             # the reference's second time point (tests/data/pyp_2ms.mtz)
+ON_P3 = os.path.join(os.path.dirname(PYP), "pyp_2ms_P3.mtz")       # ... re-indexed in P 3 (tests/data/pyp_2ms_P3.mtz)
+
 pytestmark = pytest.mark.gpu
 niter = 10
 
@@ -41,16 +44,20 @@ def _run(flags, files, out, separate):
 
 
 @pytest.mark.parametrize("mode", ["mono", "poly"])
+@pytest.mark.parametrize("change_sg", [False, True])
 @pytest.mark.parametrize("ev11,dmin,anomalous,isigi,dof,separate", [(False, None, False, None, None, False), (True, 7.0, True, 1.0, 12.0, True),
                                                                     (True, None, False, None, 12.0, False), (False, 7.0, True, None, None, True)])
-def test_twofile(tmp_path, mode, ev11, dmin, anomalous, isigi, dof, separate):
+def test_twofile(tmp_path, mode, change_sg, ev11, dmin, anomalous, isigi, dof, separate):
+    """reference tests/test_cli.py:63-90: the off / on pair, together or as separate outputs (then also with different space groups)"""
+    if change_sg and not separate:
+        pytest.skip("different space groups cannot be merged into one file (the reference skips this combination too)")
     flags = f"{mode} --disable-gpu --iterations={niter} --disable-progress-bar --mlp-layers 4 dHKL,image_id"
     flags += " --refine-uncertainties" if ev11 else ""
     flags += f" --dmin={dmin}" if dmin is not None else ""
     flags += " --anomalous" if anomalous else ""
     flags += f" --isigi-cutoff={isigi}" if isigi is not None else ""
     flags += f" --studentt-likelihood-dof={dof}" if dof is not None else ""
-    _run(flags, [PYP, PYP], str(tmp_path / "out"), separate)
+    _run(flags, [PYP, ON_P3 if change_sg else ON], str(tmp_path / "out"), separate)
 
 
 @pytest.mark.parametrize("mode", ["mono", "poly"])
@@ -58,11 +65,11 @@ def test_twofile(tmp_path, mode, ev11, dmin, anomalous, isigi, dof, separate):
 def test_double_wilson(tmp_path, mode, optimize_r):
     flags = f"{mode} --iterations={niter} --disable-progress-bar --mlp-layers 3 dHKL,image_id --double-wilson-parents=None,0"
     flags += " --optimize-double-wilson-r" if optimize_r else ""
-    _, model, hist = _run(flags + " --double-wilson-r=0.0,0.9", [PYP, PYP], str(tmp_path / "out"), True)
+    _, model, hist = _run(flags + " --double-wilson-r=0.0,0.9", [PYP, ON], str(tmp_path / "out"), True)
     if optimize_r:
         assert "rDW_1" in hist and abs(hist["rDW_1"][0] - 0.9) < 1e-6
     with pytest.raises(ValueError):
-        _run(flags + " --double-wilson-r=0.0,1.0", [PYP, PYP], str(tmp_path / "out2"), True)
+        _run(flags + " --double-wilson-r=0.0,1.0", [PYP, ON], str(tmp_path / "out2"), True)
 
 
 def test_image_layers_crossvalidation_and_reloading(tmp_path):
