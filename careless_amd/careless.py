@@ -12,9 +12,6 @@ def _format(parser):
     from careless_amd.io.formats import load_inputs_npz
     from careless_amd.io.formatter import LaueFormatter, MonoFormatter
     files = list(parser.reflection_files)
-    if getattr(parser, "spacegroups", None) is not None:
-        raise NotImplementedError("--spacegroups: overriding the space group needs a space-group table (gemmi); careless_amd takes the "
-                                  "symmetry operators from the reflection file header")
     if len(files) == 1 and files[0].endswith(".npz"):
         return load_inputs_npz(files[0])
     fmt = LaueFormatter.from_parser(parser) if parser.type == "poly" else MonoFormatter.from_parser(parser)

@@ -70,8 +70,29 @@ def expand_harmonics(cols: Dict[str, np.ndarray], cell, dmin: Optional[float] = 
     return out
 
 
+def parse_spacegroups(spec, n_files: int):
+    """`--spacegroups` (reference formatter.py:254-263): one entry or one per file.  Without a space-group table only the
+    triclinic group can be named (`1`, `P 1`, `P1`): every other symmetry has to come from the reflection file's own header."""
+    if spec is None:
+        return None
+    names = [v.strip() for v in str(spec).split(",")]
+    if len(names) == 1:
+        names = names * n_files
+    elif len(names) != n_files:
+        raise ValueError("Multiple values provided for --spacegroups=, but the number of provided values does not match the number of "
+                         "reflection files. Either provide a single spacegroup or one per reflection file as a comma-separated list. ")
+    out = []
+    for v in names:
+        if v.replace(" ", "").upper() not in ("1", "P1"):
+            raise NotImplementedError(f"--spacegroups={v}: naming a space group other than P 1 needs a space-group table (gemmi); "
+                                      "careless_amd takes the symmetry operators from the reflection file header")
+        out.append((["X, Y, Z"], "P 1", 1))
+    return out
+
+
 class DataFormatter:
     wavelength_key = None
+    spacegroups = None
 
     def __init__(self, intensity_key=None, uncertainty_key=None, image_key=None, metadata_keys=("dHKL",), separate_outputs=False,
                  anomalous=False, dmin=0.0, isigi_cutoff=None, positional_encoding_keys=None, encoding_bit_depth=5, standardize=True):
@@ -175,20 +196,33 @@ class DataFormatter:
         data, rac = self.get_data_and_asu_collection(list(datasets))
         return self.finalize(data, rac)
 
+    def load(self, filename: str, file_id: int) -> Mtz:
+        if str(filename).endswith(".mtz"):
+            ds = read_mtz(filename)
+        elif str(filename).endswith(".stream"):
+            from careless_amd.io.crystfel import read_crystfel
+            if self.spacegroups is None:
+                raise ValueError("Could not determine spacegroups. Please supply the --spacegroups flag")     # reference formatter.py:113
+            ds = read_crystfel(filename)
+        else:
+            raise ValueError(f"{filename}: reflection files are .mtz or .stream")
+        if self.spacegroups is not None:
+            ds.symops, ds.spacegroup_name, ds.spacegroup_number = self.spacegroups[file_id]
+        return ds
+
     def format_files(self, files):
-        for f in files:
-            if not str(f).endswith(".mtz"):
-                raise ValueError(f"{f}: only .mtz reflection files are read by careless_amd (CrystFEL streams need reciprocalspaceship)")
-        return self([read_mtz(f) for f in files])
+        return self([self.load(f, i) for i, f in enumerate(files)])
 
 
 class MonoFormatter(DataFormatter):
     @classmethod
     def from_parser(cls, parser):
         pe = parser.positional_encoding_keys.split(",") if parser.positional_encoding_keys is not None else None
-        return cls(parser.intensity_key, parser.uncertainty_key, parser.image_key, parser.metadata_keys.split(","), parser.separate_files,
-                   parser.anomalous, 0.0 if parser.dmin is None else parser.dmin, parser.isigi_cutoff, pe,
-                   parser.positional_encoding_frequencies, standardize=parser.standardize_metadata)
+        fmt = cls(parser.intensity_key, parser.uncertainty_key, parser.image_key, parser.metadata_keys.split(","), parser.separate_files,
+                  parser.anomalous, 0.0 if parser.dmin is None else parser.dmin, parser.isigi_cutoff, pe,
+                  parser.positional_encoding_frequencies, standardize=parser.standardize_metadata)
+        fmt.spacegroups = parse_spacegroups(getattr(parser, "spacegroups", None), len(parser.reflection_files))
+        return fmt
 
     def prep_dataset(self, mtz: Mtz):
         keys = self._guess_keys(mtz)
@@ -222,9 +256,11 @@ class LaueFormatter(DataFormatter):
         if parser.wavelength_range is not None:
             lmin, lmax = parser.wavelength_range
         pe = parser.positional_encoding_keys.split(",") if parser.positional_encoding_keys is not None else None
-        return cls(parser.wavelength_key, parser.intensity_key, parser.uncertainty_key, parser.image_key, parser.metadata_keys.split(","),
-                   parser.separate_files, parser.anomalous, lmin, lmax, parser.dmin, parser.isigi_cutoff, pe,
-                   parser.positional_encoding_frequencies, standardize=parser.standardize_metadata)
+        fmt = cls(parser.wavelength_key, parser.intensity_key, parser.uncertainty_key, parser.image_key, parser.metadata_keys.split(","),
+                  parser.separate_files, parser.anomalous, lmin, lmax, parser.dmin, parser.isigi_cutoff, pe,
+                  parser.positional_encoding_frequencies, standardize=parser.standardize_metadata)
+        fmt.spacegroups = parse_spacegroups(getattr(parser, "spacegroups", None), len(parser.reflection_files))
+        return fmt
 
     def prep_dataset(self, mtz: Mtz):
         keys = self._guess_keys(mtz)
@@ -239,6 +275,12 @@ class LaueFormatter(DataFormatter):
         keep = ~((cols[wk] < lam_min) | (cols[wk] > lam_max))
         cols = {k: v[keep] for k, v in cols.items()}
         return self._common_prep(cols, mtz, keys)
+
+    def format_files(self, files):
+        for f in files:
+            if str(f).endswith(".stream"):
+                raise ValueError("careless poly does not support .stream files. Use careless mono instead.")   # reference formatter.py:655-661
+        return super().format_files(files)
 
     def finalize(self, data, rac):
         data = dict(data)

@@ -123,6 +123,18 @@ def test_weight_save_and_load(tmp_path, which):
     assert os.path.exists(out2 + "_0.mtz") and np.isfinite(hist2["loss"][0])
 
 
+def test_crystfel(tmp_path):
+    """reference tests/test_cli.py:112-120"""
+    stream = os.path.join(os.path.dirname(PYP), "crystfel.stream")
+    from careless_amd.careless import run_careless
+    from careless_amd.parser import parser
+    out = str(tmp_path / "out")
+    _, hist = run_careless(parser.parse_args(f"mono --disable-gpu --iterations={niter} --disable-progress-bar --spacegroups=1 dHKL,image_id {stream} {out}".split()))
+    assert len(hist["loss"]) == niter and np.all(np.isfinite(hist["loss"])) and read_mtz(out + "_0.mtz").spacegroup_number == 1
+    with pytest.raises(ValueError):                                    # careless poly should fail with a clear error message
+        run_careless(parser.parse_args(f"poly --iterations={niter} --spacegroups=1 dHKL,image_id {stream} {out}".split()))
+
+
 def test_preformatted_npz_input(tmp_path):
     from careless_amd.io.formats import save_inputs_npz
     from careless_amd.io.formatter import MonoFormatter

@@ -217,3 +217,27 @@ def test_anomalous_results_are_unstacked_into_friedel_columns():
         assert np.allclose(t[col][seen], res["F"][ids][seen]) and np.all(np.isnan(t[col][~seen]))
     c = a.centric[idp]
     assert np.array_equal(t["F(+)"][c], t["F(-)"][c], equal_nan=True)                         # centrics: both columns equal
+
+
+def test_crystfel_stream_and_spacegroups_flag():
+    """reference tests/test_cli.py:112-120: a CrystFEL stream needs --spacegroups; `careless poly` rejects streams"""
+    from careless_amd.io.crystfel import read_crystfel
+    from careless_amd.io.formatter import parse_spacegroups
+    from careless_amd.parser import parser
+    stream = os.path.join(os.path.dirname(PYP), "crystfel.stream")
+    m = read_crystfel(stream)
+    assert len(m) == 618 and int(m.columns["BATCH"].max()) == 2 and m.cell == (79.2, 79.2, 38.0, 90.0, 90.0, 90.0)
+    assert m.types["I"] == "J" and m.types["BATCH"] == "B" and np.all(m.columns["SigI"] > 0)
+    a = parser.parse_args(["mono", "--spacegroups=1", "dHKL,image_id", stream, "out"])
+    inputs, rac = MonoFormatter.from_parser(a).format_files(a.reflection_files)
+    assert _check_inputs(inputs) == 618 and not rac.centric.any() and np.all(rac.multiplicity == 1.0)       # P 1
+    assert len(np.unique(BaseModel.get_image_id(inputs))) == 3
+    with pytest.raises(ValueError):                                   # no space group given
+        MonoFormatter.from_parser(parser.parse_args(["mono", "dHKL,image_id", stream, "out"])).format_files([stream])
+    with pytest.raises(ValueError):
+        LaueFormatter.from_parser(parser.parse_args(["poly", "--spacegroups=1", "dHKL,image_id", stream, "out"])).format_files([stream])
+    assert parse_spacegroups("P 1", 2) == [(["X, Y, Z"], "P 1", 1)] * 2
+    with pytest.raises(NotImplementedError):
+        parse_spacegroups("P 21 21 21", 1)
+    with pytest.raises(ValueError):
+        parse_spacegroups("1,1,1", 2)
