@@ -864,8 +864,15 @@ class ElboEngine:
 
     def grad_tensors(self) -> List[torch.Tensor]:
         """Gradients split per trainable tensor, in the oracle's order and Keras shapes
-        [q_loc_raw, q_scale_raw, W_0 (in,out), b_0, ..., W_o, b_o, image scales]."""
-        lay, g = self.layout, self.grads
+        [q_loc_raw, q_scale_raw, W_0 (in,out), b_0, ..., W_o, b_o, image scales, per-image layers, Ev11, double-Wilson r]."""
+        return self._split(self.grads)
+
+    def param_tensors(self) -> List[torch.Tensor]:
+        """The trainable tensors themselves, same order and shapes as `grad_tensors`."""
+        return self._split(self.params)
+
+    def _split(self, g: torch.Tensor) -> List[torch.Tensor]:
+        lay = self.layout
         out = [g[0:self.R], g[self.R:2 * self.R]]
         base = lay.off_mlp
         for off, o, i, boff in self.mlp.layer_slices(self.d):

@@ -26,7 +26,14 @@ CASES = {
     "mono_3x20_softplus_shift_noimg_S2": dict(N=160, R=20, d0=6, L=3, w=20, S=2, bijector="softplus", shift=3.5,
                                               use_image_scales=False),
     "mono_2x16_klweight_S4": dict(N=128, R=16, d0=5, L=2, w=16, S=4, kl_weight=0.5),
+    # cases added later (the four above are frozen as first generated); their files also carry every array of the problem
+    # (`data_*`: harmonic ids, double-Wilson parent lookup, ...) so the loader needs no generator
+    "laue_2x32_normal_S3": dict(N=200, R=24, L=2, w=32, S=3, laue=True),
+    "double_wilson_trainable_r_2x32_S3": dict(N=200, R=30, d0=5, L=2, w=32, S=3, double_wilson=True, optimize_dw_r=True),
+    "ev11_studentt_2x32_S4": dict(N=160, R=20, d0=5, L=2, w=32, S=4, ev11=True, likelihood="studentt", dof=8.0),
+    "image_layers2_2x16_S2": dict(N=300, R=24, d0=5, L=2, w=16, S=2, n_images=3, image_layers=2),
 }
+FROZEN = ("mono_2x32_normal_S3", "mono_5x64_studentt_posenc_S8", "mono_3x20_softplus_shift_noimg_S2", "mono_2x16_klweight_S4")
 STEPS = 6
 
 
@@ -54,6 +61,8 @@ def make(name, kw):
         traj_loss=np.array([h["loss"] for h in hist]), traj_gnorm=np.array([h["Grad Norm"] for h in hist]),
         traj_kl=np.array([h["F KLDiv"] for h in hist]), traj_nll=np.array([h["NLL"] for h in hist]),
     )
+    for k, v in data.items():                     # the whole problem (Laue / double-Wilson arrays included)
+        arrs[f"data_{k}"] = np.asarray(v)
     for i, t in enumerate(params.tensors()):
         arrs[f"param_{i:02d}"] = t.numpy().astype(np.float32)
     for i, g in enumerate(grads):
@@ -66,4 +75,6 @@ def make(name, kw):
 
 if __name__ == "__main__":
     for name, kw in CASES.items():
+        if name in FROZEN and "--all" not in sys.argv:
+            continue
         make(name, kw)
