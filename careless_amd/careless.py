@@ -70,6 +70,10 @@ def run_careless(parser):
     write_history_csv(parser.output_base + "_history.csv", history)
     model.surrogate_posterior.save_weights(parser.output_base + "_structure_factor")
     model.scaling_model.save_weights(parser.output_base + "_scale")
+    if getattr(parser, "save_data_manager", False):                 # reference careless.py:81-84
+        import pickle
+        with open(parser.output_base + "_data_manager.pickle", "wb") as out:
+            pickle.dump(dm, out)
 
     tables = _prediction_tables(dm, model, train, 0)
     if test is not None:

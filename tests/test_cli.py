@@ -135,6 +135,14 @@ def test_crystfel(tmp_path):
         run_careless(parser.parse_args(f"poly --iterations={niter} --spacegroups=1 dHKL,image_id {stream} {out}".split()))
 
 
+def test_save_data_manager(tmp_path):
+    import pickle
+    out = str(tmp_path / "out")
+    _run(f"mono --iterations=3 --disable-progress-bar --mlp-layers 2 --save-data-manager dHKL,image_id", [PYP], out, False)
+    dm = pickle.load(open(out + "_data_manager.pickle", "rb"))
+    assert len(dm.inputs) == 6 and len(dm.asu_collection.centric) == 485
+
+
 def test_preformatted_npz_input(tmp_path):
     from careless_amd.io.formats import save_inputs_npz
     from careless_amd.io.formatter import MonoFormatter
