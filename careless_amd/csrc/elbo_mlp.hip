@@ -189,9 +189,19 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     // ---- stage the weights (global W^T layout, see cl_kernels.h) into padded LDS images, zero-filled ---------
     {
         const float* __restrict__ P = A.mlp;
-        for (int idx = tid; idx < WP * PW1; idx += 512) {
-            const int o = idx / PW1, i = idx - o * PW1;
-            sW1[idx] = (o < w && i < d) ? P[o * d + i] : 0.0f;
+        for (int base = 0; base < WP * PW1; base += 8 * 512) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 512 + tid;
+                const int o = idx / PW1, i = idx - o * PW1;
+                v[u] = (idx < WP * PW1 && o < w && i < d) ? P[o * d + i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * 512 + tid;
+                if (idx < WP * PW1) sW1[idx] = v[u];
+            }
         }
         for (int idx = tid; idx < LMAX * WP; idx += 512) {
             const int l = idx / WP, o = idx - l * WP;
@@ -199,12 +209,24 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             if (l < Ld && o < w) v = (l == 0) ? P[w * d + o] : P[w * d + w + (l - 1) * (w * w + w) + w * w + o];
             sB[idx] = v;
         }
+        // eight independent loads in flight per thread (a plain loop waits for every load before issuing the next one, ~40
+        // serial round trips per launch: a fixed cost that matters once a GPU's shard is small)
         for (int l = 1; l < Ld; ++l) {
             const float* __restrict__ Wl = P + w * d + w + (l - 1) * (w * w + w);
             float* dst = sW + (l - 1) * WP * PW;
-            for (int idx = tid; idx < WP * PW; idx += 512) {
-                const int o = idx / PW, i = idx - o * PW;
-                dst[idx] = (o < w && i < w) ? Wl[o * w + i] : 0.0f;
+            for (int base = 0; base < WP * PW; base += 8 * 512) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 512 + tid;
+                    const int o = idx / PW, i = idx - o * PW;
+                    v[u] = (idx < WP * PW && o < w && i < w) ? Wl[o * w + i] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * 512 + tid;
+                    if (idx < WP * PW) dst[idx] = v[u];
+                }
             }
         }
         const float* __restrict__ Wo = P + w * d + w + (Ld - 1) * (w * w + w);
@@ -914,28 +936,31 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     __syncthreads();
     const int offWo = w * d + w + (Ld - 1) * (w * w + w);
     const int Ptot = no_head ? offWo : offWo + 2 * w + 2;
-    for (int idx = tid; idx < Ptot; idx += 512) smem[idx] = 0.0f;
-    __syncthreads();
     float bo0 = boacc0, bo1 = boacc1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         bo0 += __shfl_xor(bo0, off);
         bo1 += __shfl_xor(bo1, off);
     }
-    for (int turn = 0; turn < CL_NW; ++turn) {   // fixed order of the eight waves: deterministic sums
-        if (wv == turn) {
+    // (a) kernels.  A 16x16 block of dW_l^T is held by GROUPS waves when the layer has at least eight blocks (every element then has
+    //     exactly ONE owner: all waves store at once), or by KPARTS waves that split the observation axis (narrow layers): part 0
+    //     stores, the other parts add in part order.  Deterministic either way, and no wave waits for seven others in turn.
+    constexpr int NBK0 = FB * IB1, NBKH = FB * FB;
+    constexpr int KP0 = (NBK0 >= CL_NW) ? 1 : CL_NW / NBK0, KPH = (NBKH >= CL_NW) ? 1 : CL_NW / NBKH;
+    constexpr int NPASS = (KP0 > KPH) ? KP0 : KPH;
+    for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
-            for (int l = 0; l < LMAX; ++l) {
-                if (l < Ld) {
-                    const int IBn = (l == 0) ? IB1 : FB;
-                    const int NBK = FB * IBn;
-                    const int BPW = (NBK >= CL_NW) ? NBK / CL_NW : 1;
-                    const int GROUPS = NBK / BPW;
-                    const int grp = wv % GROUPS;
-                    const int ob = (grp * BPW) / IBn, ib0 = (grp * BPW) - ob * IBn;
-                    const int in_dim = (l == 0) ? d : w;
-                    const int offW = (l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w));
-                    const int offB = offW + w * in_dim;
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < Ld) {
+                const int IBn = (l == 0) ? IB1 : FB;
+                const int NBK = FB * IBn;
+                const int BPW = (NBK >= CL_NW) ? NBK / CL_NW : 1;
+                const int GROUPS = NBK / BPW;
+                const int grp = wv % GROUPS, kp = wv / GROUPS;
+                const int ob = (grp * BPW) / IBn, ib0 = (grp * BPW) - ob * IBn;
+                const int in_dim = (l == 0) ? d : w;
+                const int offW = (l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w));
+                if (kp == pass) {
 #pragma unroll
                     for (int b = 0; b < WB; ++b) {
                         if (b < BPW) {
@@ -943,24 +968,46 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 const int o = 16 * ob + 4 * q + t;
-                                if (o < w && i < in_dim) smem[offW + o * in_dim + i] += wacc[l][b][t];
+                                if (o < w && i < in_dim) {
+                                    float* dst = smem + offW + o * in_dim + i;
+                                    *dst = (pass == 0) ? wacc[l][b][t] : *dst + wacc[l][b][t];
+                                }
                             }
                         }
                     }
-                    if (lane < w) smem[offB + lane] += bacc[l];
                 }
-            }
-            if (lane < w && !no_head) {
-                smem[offWo + lane] += woacc0;
-                smem[offWo + w + lane] += woacc1;
-            }
-            if (lane == 0 && !no_head) {
-                smem[offWo + 2 * w] += bo0;
-                smem[offWo + 2 * w + 1] += bo1;
             }
         }
         __syncthreads();
     }
+    // (b) biases and the Dense(2) head: every wave holds a partial (its own 16 observations).  Each wave parks its values in a
+    //     private scratch row; one pass then adds the eight rows in wave order.
+    float* const scr = smem + ((Ptot + 3) & ~3);
+    constexpr int SCRW = LMAX * WP + 2 * WP + 2;
+    {
+        float* mine = scr + wv * SCRW;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l)
+            if (l < Ld && lane < WP) mine[l * WP + lane] = bacc[l];
+        if (lane < WP) { mine[LMAX * WP + lane] = woacc0; mine[LMAX * WP + WP + lane] = woacc1; }
+        if (lane == 0) { mine[LMAX * WP + 2 * WP] = bo0; mine[LMAX * WP + 2 * WP + 1] = bo1; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < SCRW; idx += 512) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < CL_NW; ++k) t += scr[k * SCRW + idx];
+        if (idx < LMAX * WP) {
+            const int l = idx / WP, o = idx - l * WP;
+            if (l < Ld && o < w) smem[((l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w))) + w * ((l == 0) ? d : w) + o] = t;
+        } else if (!no_head) {
+            const int r = idx - LMAX * WP;
+            if (r < WP) { if (r < w) smem[offWo + r] = t; }
+            else if (r < 2 * WP) { if (r - WP < w) smem[offWo + w + (r - WP)] = t; }
+            else smem[offWo + 2 * w + (r - 2 * WP)] = t;
+        }
+    }
+    __syncthreads();
     float* __restrict__ part = A.partials + (size_t)blockIdx.x * Ptot;
     for (int idx = tid; idx < Ptot; idx += 512) part[idx] = smem[idx];
 
@@ -1036,7 +1083,8 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     const size_t sm_tiles = (size_t)SL::total * sizeof(float);
     const size_t P = (size_t)a.w * a.d + a.w + (size_t)(a.L - 1) * (a.w * a.w + a.w) + 2 * a.w + 2;
     size_t sm = sm_tiles;
-    if (MODE != 1 && P * sizeof(float) > sm) sm = P * sizeof(float);
+    const size_t flush = (P + 4 + (size_t)CL_NW * (LMAX * WP + 2 * WP + 2)) * sizeof(float);      // gradient image + per-wave bias rows
+    if (MODE != 1 && flush > sm) sm = flush;
     if (sm > 160 * 1024) return -3;
     auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0), (CL_IMGL == 1)>;
     static size_t configured = 0;
