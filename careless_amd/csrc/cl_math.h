@@ -71,11 +71,18 @@ CL_HD float cl_u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.19209289550
 
 enum { CL_STREAM_QF = 1, CL_STREAM_SCALE = 2 };
 
-// uniform for the truncated-normal draw of reflection h, MC sample s
+// Uniforms for the truncated-normal draws of reflection idx: one Philox block serves the four MC samples 4k .. 4k+3
+// (component s & 3 of the block keyed by s >> 2), so a thread that walks s = 0, 1, 2, ... generates a block every 4th sample.
+CL_HD cl_u32x4 cl_noise_uniform_block(uint64_t seed, uint32_t step, uint32_t s_block, uint64_t idx) {
+    return cl_philox4x32<10>((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_QF << 28), s_block, step,
+                             (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+CL_HD float cl_noise_uniform_pick(const cl_u32x4& r, uint32_t s) {
+    const uint32_t c = s & 3u;
+    return cl_u01(c == 0 ? r.x : c == 1 ? r.y : c == 2 ? r.z : r.w);
+}
 CL_HD float cl_noise_uniform(uint64_t seed, uint32_t step, uint32_t s, uint64_t idx) {
-    const cl_u32x4 r = cl_philox4x32<10>((uint32_t)idx, (uint32_t)(idx >> 32) | ((uint32_t)CL_STREAM_QF << 28), s, step,
-                                        (uint32_t)seed, (uint32_t)(seed >> 32));
-    return cl_u01(r.x);
+    return cl_noise_uniform_pick(cl_noise_uniform_block(seed, step, s >> 2, idx), s);
 }
 
 // fast device forms of the transcendental pieces of the noise generator (1-ulp hardware approximations are ample for

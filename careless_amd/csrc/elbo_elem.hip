@@ -36,8 +36,11 @@ __device__ __forceinline__ void block_atomic_add_d(double v, double* dst) {
     }
 }
 
-__device__ __forceinline__ float tn_uniform(const cl_tn_args& A, int h, int s) {
-    return A.u_f ? A.u_f[(size_t)h * A.S + s] : cl_noise_uniform(A.seed, A.step, (uint32_t)s, (uint64_t)h);
+// uniform of (reflection h, sample s); `blk` caches the Philox block shared by samples 4k .. 4k+3 across loop iterations
+__device__ __forceinline__ float tn_uniform(const cl_tn_args& A, int h, int s, cl_u32x4& blk) {
+    if (A.u_f) return A.u_f[(size_t)h * A.S + s];
+    if ((s & 3) == 0) blk = cl_noise_uniform_block(A.seed, A.step, (uint32_t)s >> 2, (uint64_t)h);
+    return cl_noise_uniform_pick(blk, (uint32_t)s);
 }
 
 // correlation r of reflection h with its parent: fixed (dw_r) or sigmoid of the trainable per-ASU value
@@ -63,8 +66,9 @@ __global__ __launch_bounds__(256) void tn_forward_kernel(const cl_tn_args A) {
         const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
         const bool in_kl = (h >= A.kl_begin && h < A.kl_end);
         const bool dw_child = (A.prior_kind == CL_PRIOR_DOUBLE_WILSON_) && (A.root[h] == 0);
+        cl_u32x4 blk = {};
         for (int s = 0; s < A.S; ++s) {
-            const cl_tn_elem t = cl_tn_sample(a, b, low, A.high, A.eps, tn_uniform(A, h, s));
+            const cl_tn_elem t = cl_tn_sample(a, b, low, A.high, A.eps, tn_uniform(A, h, s, blk));
             A.z_f[(size_t)h * A.S + s] = t.z;
             if (in_kl) {
                 float dlp;
@@ -87,8 +91,9 @@ __global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
     const float wkl = in_kl ? A.w_kl * A.kl_grad_mult : 0.0f;
     const bool dw_child = (A.prior_kind == CL_PRIOR_DOUBLE_WILSON_) && (A.root[h] == 0);
     float gloc = 0.0f, gscale = 0.0f, loc = 0.0f, scale = 0.0f;
+    cl_u32x4 blk = {};
     for (int s = 0; s < A.S; ++s) {
-        const cl_tn_elem t = cl_tn_sample(a, b, low, A.high, A.eps, tn_uniform(A, h, s));
+        const cl_tn_elem t = cl_tn_sample(a, b, low, A.high, A.eps, tn_uniform(A, h, s, blk));
         loc = t.loc; scale = t.scale;
         float dq_dz, dq_dloc, dq_dscale, dp_dz;
         cl_tn_log_prob_grads(t, &dq_dz, &dq_dloc, &dq_dscale);
