@@ -3,9 +3,13 @@ multiplicity epsilon and systematic absences.  Stands in for what the reference 
 `careless/io/asu.py:5-143` (`ReciprocalASU`, `ReciprocalASUCollection`) and `careless/io/formatter.py:285-302`.
 
 The operators are the `SYMM` records of the MTZ header (all of them, centring translations included).  The ASU representative of
-a reflection is the lexicographically largest (h, k, l) of its orbit -- under the rotations only (anomalous: Friedel mates of
-acentric reflections stay separate) or under rotations and inversion (the default).  That is a valid asymmetric unit; it is not
-gemmi's choice, so merged reflections may be listed under a symmetry-equivalent index of the one the reference would print."""
+a reflection follows the CCP4 convention that gemmi / reciprocalspaceship use (`DataSet.hkl_to_asu`, reference
+`io/formatter.py:319,562`): one inequality set per Laue class in its reference setting (`_CCP4_ASU` below).  Which set applies is
+not looked up by space-group number but found by test: the set must select exactly one member of every orbit of a small index
+grid under the operators at hand.  For a setting none of the sets fits (e.g. monoclinic with unique axis c, where gemmi changes
+basis first) the representative is the lexicographically largest index of the orbit: a valid asymmetric unit, but then merged
+reflections may be listed under a symmetry mate of the index the reference prints.  Anomalous: an acentric reflection that reaches
+the ASU only through the inversion is a Friedel-minus and keeps the NEGATED representative, as `hkl_to_asu(anomalous=True)` does."""
 from __future__ import annotations
 
 import re
@@ -48,8 +52,27 @@ def _key(h: np.ndarray) -> np.ndarray:
     return (h[..., 0] + B // 2) * B * B + (h[..., 1] + B // 2) * B + (h[..., 2] + B // 2)
 
 
+# CCP4 reciprocal asymmetric units of the Laue classes in their reference settings (the `asuset` conventions; gemmi's
+# `ReciprocalAsu::is_in` evaluates the same conditions).  Order: -1, 2/m (unique b), mmm, 4/m and 6/m, 4/mmm and 6/mmm, -3,
+# -31m, -3m1, m-3, m-3m.
+_CCP4_ASU = (
+    lambda h, k, l: (l > 0) | ((l == 0) & ((h > 0) | ((h == 0) & (k >= 0)))),
+    lambda h, k, l: (k >= 0) & ((l > 0) | ((l == 0) & (h >= 0))),
+    lambda h, k, l: (h >= 0) & (k >= 0) & (l >= 0),
+    lambda h, k, l: (l >= 0) & (((h >= 0) & (k > 0)) | ((h == 0) & (k == 0))),
+    lambda h, k, l: (h >= k) & (k >= 0) & (l >= 0),
+    lambda h, k, l: ((h >= 0) & (k > 0)) | ((h == 0) & (k == 0) & (l >= 0)),
+    lambda h, k, l: (h >= k) & (k >= 0) & ((k > 0) | (l >= 0)),
+    lambda h, k, l: (h >= k) & (k >= 0) & ((h > k) | (l >= 0)),
+    lambda h, k, l: (h >= 0) & (((l >= h) & (k > h)) | ((l == h) & (k == h))),
+    lambda h, k, l: (k >= l) & (l >= h) & (h >= 0),
+)
+_UNSET = object()
+
+
 class SymmetryOps:
     def __init__(self, symops: Sequence[str]):
+        self._case = _UNSET
         parsed = [parse_symop(s) for s in symops]
         self.R = np.stack([p[0] for p in parsed])         # (nops, 3, 3)
         self.t = np.stack([p[1] for p in parsed])         # (nops, 3)
@@ -58,12 +81,40 @@ class SymmetryOps:
         """(nops, N, 3): h' = h R for every operator (row-vector convention for reciprocal space)."""
         return np.einsum("ni,oij->onj", np.asarray(hkl, dtype=np.int64), self.R)
 
+    def asu_case(self):
+        """Index into `_CCP4_ASU` of the inequality set that is an asymmetric unit for these operators, or None."""
+        if self._case is _UNSET:
+            ax = np.arange(-3, 4)
+            g = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), axis=-1).reshape(-1, 3)
+            orb = self.orbit(g)
+            orb = np.concatenate([orb, -orb], axis=0)                      # (2 nops, N, 3)
+            k = _key(orb)
+            self._case = None
+            for i, inside in enumerate(_CCP4_ASU):
+                sel = inside(orb[..., 0], orb[..., 1], orb[..., 2])
+                if not sel.any(axis=0).all():
+                    continue
+                lo = np.where(sel, k, np.iinfo(np.int64).max).min(axis=0)
+                hi = np.where(sel, k, np.iinfo(np.int64).min).max(axis=0)
+                if np.all(lo == hi):                                       # one DISTINCT member of every orbit
+                    self._case = i
+                    break
+        return self._case
+
     def to_asu(self, hkl: np.ndarray, anomalous: bool = False) -> np.ndarray:
-        orb = self.orbit(hkl)
-        if not anomalous:
-            orb = np.concatenate([orb, -orb], axis=0)
-        best = np.argmax(_key(orb), axis=0)
-        return np.take_along_axis(orb, best[None, :, None], axis=0)[0]
+        rot = self.orbit(hkl)
+        orb = np.concatenate([rot, -rot], axis=0)
+        case = self.asu_case()
+        if case is None:
+            best = np.argmax(_key(orb), axis=0)
+        else:
+            best = np.argmax(_CCP4_ASU[case](orb[..., 0], orb[..., 1], orb[..., 2]), axis=0)   # first member inside
+        rep = np.take_along_axis(orb, best[None, :, None], axis=0)[0]
+        if anomalous:
+            # Friedel-minus: the representative is not among the rotation images (so the reflection is acentric)
+            minus = ~np.any(np.all(rot == rep[None], axis=2), axis=0)
+            rep = np.where(minus[:, None], -rep, rep)
+        return rep
 
     def describe(self, hkl: np.ndarray):
         """centric (N,) bool, epsilon (N,) int, absent (N,) bool."""

@@ -4,7 +4,7 @@ Restates what `MonoFormatter` / `LaueFormatter` do (reference careless/io/format
 by `careless_amd.io.mtz` -- resolution cut, systematic absences, observed Miller indices as metadata, mapping to the reciprocal
 ASU, key guessing by MTZ column type, I/sigma cut, harmonic expansion for Laue data (reference careless/utils/laue.py:9-81),
 image / harmonic group ids, 1/d^2, z-scoring, positional encoding, padded per-group intensities -- without reciprocalspaceship
-or gemmi: the symmetry comes from the operators in the file header (`careless_amd.io.asu`).  CrystFEL `.stream` input is not read."""
+or gemmi: the symmetry comes from the operators in the file header (`careless_amd.io.asu`).  CrystFEL `.stream` files go through `careless_amd.io.crystfel`."""
 from __future__ import annotations
 
 import warnings

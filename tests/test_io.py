@@ -66,6 +66,58 @@ def test_reciprocal_asu(dmin, anomalous, cell, symops):
         asu.to_refl_id(np.array([[99, 99, 99]]))
 
 
+_LAUE_SETTINGS = {   # generators in the reference setting -> index of the CCP4 inequality set gemmi assigns to that Laue class
+    "P 1": (["x,y,z"], 0), "P 1 2 1": (["x,y,z", "-x,y,-z"], 1), "P 2 2 2": (["x,y,z", "-x,-y,z", "-x,y,-z"], 2),
+    "P 4": (["x,y,z", "-y,x,z"], 3), "P 4 2 2": (["x,y,z", "-y,x,z", "-x,y,-z"], 4), "P 3": (["x,y,z", "-y,x-y,z"], 5),
+    "P 3 1 2": (["x,y,z", "-y,x-y,z", "-y,-x,-z"], 6), "P 3 2 1": (["x,y,z", "-y,x-y,z", "y,x,-z"], 7),
+    "P 6": (["x,y,z", "x-y,x,z"], 3), "P 6 2 2": (["x,y,z", "x-y,x,z", "y,x,-z"], 4),
+    "P 2 3": (["x,y,z", "-x,-y,z", "-x,y,-z", "z,x,y"], 8), "P 4 3 2": (["x,y,z", "-x,-y,z", "-x,y,-z", "z,x,y", "y,x,-z"], 9),
+    "P 1 1 2": (["x,y,z", "-x,-y,z"], None),          # non-reference setting: no CCP4 set applies as it stands
+}
+
+
+def _close_group(generators):
+    from careless_amd.io.asu import parse_symop
+    mats = {tuple(parse_symop(g)[0].ravel()) for g in generators}
+    while True:
+        more = {tuple((np.array(a).reshape(3, 3) @ np.array(b).reshape(3, 3)).ravel()) for a in mats for b in mats} | mats
+        if len(more) == len(mats):
+            break
+        mats = more
+    xyz = "xyz"
+    def row(r):
+        return "".join(("+" if c > 0 else "-") + xyz[j] for j, c in enumerate(r) if c).lstrip("+")
+    return [",".join(row(np.array(m).reshape(3, 3)[i]) for i in range(3)) for m in sorted(mats)]
+
+
+@pytest.mark.parametrize("name", sorted(_LAUE_SETTINGS))
+def test_asu_representative_follows_the_ccp4_convention(name):
+    """reference io/formatter.py:319 maps with rs `hkl_to_asu` = gemmi's CCP4 inequality sets; ours must pick the same one."""
+    gens, case = _LAUE_SETTINGS[name]
+    ops = SymmetryOps(_close_group(gens))
+    assert ops.asu_case() == case
+    g = np.stack(np.meshgrid(*[np.arange(-6, 7)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    rep = ops.to_asu(g)
+    assert np.array_equal(ops.to_asu(rep), rep) and np.array_equal(ops.to_asu(-g), rep)          # idempotent, Friedel-blind
+    orbit = np.concatenate([ops.orbit(g), -ops.orbit(g)])
+    assert np.all(np.any(np.all(orbit == rep[None], axis=2), axis=0))                            # a member of the orbit
+    anom = ops.to_asu(g, anomalous=True)
+    centric = ops.describe(g)[0]
+    minus = np.any(anom != rep, axis=1)
+    assert np.array_equal(anom[minus], -rep[minus]) and not (minus & centric).any()
+    assert np.array_equal(np.any(ops.to_asu(-g, anomalous=True) != anom, axis=1), ~centric & np.any(g != 0, axis=1))
+
+
+def test_fixture_indices_written_by_the_reference_toolchain_are_asu_representatives():
+    """The reference's MTZ fixtures were written by reciprocalspaceship with H, K, L already in gemmi's ASU (M/ISYM column
+    present): P 63 (Laue class 6/m) and P 3 (-3).  Every row must be a fixed point of our mapping."""
+    for f in (mtz_fixture.PYP, mtz_fixture.PYP.replace("pyp_off", "pyp_2ms"), mtz_fixture.PYP.replace("pyp_off", "pyp_2ms_P3")):
+        m = read_mtz(f)
+        assert "M/ISYM" in m.columns
+        H = np.stack([m.columns[k] for k in "HKL"], 1).astype(np.int64)
+        assert np.array_equal(SymmetryOps(m.symops).to_asu(H), H)
+
+
 def test_asu_collection():
     m = read_mtz(PYP)
     a, b = ReciprocalASU(m.cell, m.symops, 5.0, False), ReciprocalASU(m.cell, m.symops, 10.0, True)
