@@ -26,12 +26,12 @@ int cl_mlp_default_grid(void) {
 
 int cl_mlp_max_layers(int w) {
     if (w < 1 || w > 64) return 0;
-    return w <= 16 ? CL_MLP_LMAX_W16 : (w <= 32 ? CL_MLP_LMAX_W32 : CL_MLP_LMAX_W64);
+    return w <= 15 ? CL_MLP_LMAX_W16 : (w <= 32 ? CL_MLP_LMAX_W32 : CL_MLP_LMAX_W64);
 }
 
 int cl_mlp_max_layers_imgl(int w) {
     if (w < 1 || w > 64) return 0;
-    return w <= 16 ? CL_MLP_LMAX_W16_IMGL : (w <= 32 ? CL_MLP_LMAX_W32 : CL_MLP_LMAX_W64);
+    return w <= 15 ? CL_MLP_LMAX_W16_IMGL : (w <= 32 ? CL_MLP_LMAX_W32 : CL_MLP_LMAX_W64);
 }
 
 int cl_mlp_meta_rows(int d) { return d < 1 ? 0 : ((d + 3) & ~3); }

@@ -37,6 +37,12 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CL_BIAS_ONE
+#define CL_BIAS_ONE 1
+#endif
+#ifndef CL_PF_NEXT
+#define CL_PF_NEXT 1
+#endif
 #define CL_TILE CL_MLP_TILE
 #define CL_NW 8              // waves per workgroup
 #define CL_WOBS 16           // observations per wave in forward / dgrad
@@ -133,6 +139,25 @@ struct WgradPlan {
     static_assert(BPW <= 2, "at most two accumulator blocks per wave and layer");
 };
 
+// Width <= 15 (the WP = 16 instance): the eight waves of a workgroup all accumulate the SAME 16x16 block of every layer's dW^T (each over its own 16
+// observations), so the accumulators alone are 4 registers x LMAX per wave, next to 4 x LMAX registers of activations: the
+// 20-layer instance (the CLI default) spilled ~80 registers to scratch and was bound by that traffic.  The accumulators of the
+// top NACC layers therefore live in LDS instead: one private 1-KiB slot per (layer, wave), lane-major float4, read before and
+// written after that layer's four wgrad MFMAs.  NACC is whatever the LDS left over by the weight images and staging tiles holds.
+template <int WP, int DP, int LMAX, int MODE, bool ILAY>
+struct AccPlan {
+    using SL = SmemLayout<WP, DP, LMAX>;
+    static constexpr int FLUSH = ((WP * DP + WP + (LMAX - 1) * (WP * WP + WP) + 2 * WP + 2 + 3) & ~3) + 4 +
+                                 CL_NW * (LMAX * WP + 2 * WP + 2);                         // floats the gradient flush may touch
+    static constexpr int OFF = ((SL::total > FLUSH ? SL::total : FLUSH) + 3) & ~3;           // start of the accumulator slots
+    static constexpr int SLOT = CL_NW * 256;                                                // floats per layer
+    static constexpr int ROOM = (160 * 1024 / 4 - OFF) / SLOT;
+    static constexpr bool ON = (WP == 16) && (MODE != 1) && (LMAX > 10);
+    static constexpr int NACC = ON ? (ROOM < LMAX - 1 ? (ROOM > 0 ? ROOM : 0) : LMAX - 1) : 0;
+    static constexpr int LREG = LMAX - NACC;                                                // layers < LREG keep register accumulators
+    static constexpr int total = OFF + NACC * SLOT;
+};
+
 }  // namespace
 
 // MODE 0: full ELBO step (mono likelihood in the epilogue);  MODE 1: forward only (loc, sigma per observation);
@@ -154,7 +179,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     constexpr int KS1 = DP / 4;          // MFMA k-steps of the first layer (4 metadata features per step)
     constexpr int IB1 = (DP + 15) / 16;  // 16-feature blocks of the metadata
     constexpr int PW = SL::PW, PW1 = SL::PW1, PB = CL_PB;
-    // Width <= 16: a layer has ONE 16x16 weight-gradient block and the plan below splits its 128-observation contraction into
+    // Width <= 15: a layer has ONE 16x16 weight-gradient block and the plan below splits its 128-observation contraction into
     // eight parts of 16 -- wave k contracts exactly the 16 columns of the staging tiles that wave k wrote itself.  The waves
     // then never read each other's LDS data and the workgroup barriers of the backward pass reduce to wave-local ordering
     // (layer 0 too when the metadata fits one block).  This is the geometry of the careless CLI default (20 layers x width d).
@@ -173,12 +198,22 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;   // a previous step hit a non-finite gradient norm
 
+    // Narrow kernel (w <= 15): padded feature 15 of every hidden activation is held at 1.0 (bias image 1.0 on a zero weight row, and
+    // LeakyReLU(1) = 1), and nothing reads it: the next layer's weight column 15 is zero padding.  Column 15 of a layer's dW^T
+    // accumulator is then sum_obs dZ[o][obs] * 1 = the BIAS gradient, for free inside the wgrad MFMAs: no LMAX bias registers, no
+    // re-read of the dZ tile (a third of this kernel's LDS traffic), no row sums.  Layer 0 (metadata input) keeps its own sum.
+    constexpr bool BONE = WLOC && (CL_BIAS_ONE != 0);
+    using AP = AccPlan<WP, DP, LMAX, MODE, ILAY>;
+    constexpr int LREG = AP::LREG;       // layers >= LREG accumulate their weight gradient in LDS (narrow kernel only)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15;            // observation within the wave / MFMA row-or-column index
     const int q = lane >> 4;            // k-group of the MFMA step
     float* const sS = smem + SL::oS + wv * CL_SCR;      // per-wave dO tile: (dL/dloc, dL/draw) of the wave's 16 observations
+    // this lane's float4 of the LDS-resident dW^T accumulator of layer l (l >= LREG)
+    f32x4* const sAcc = reinterpret_cast<f32x4*>(smem + AP::OFF) + wv * 64 + lane;
+    auto acc_slot = [&](int l) -> f32x4& { return sAcc[(l >= LREG ? l - LREG : 0) * (CL_NW * 64)]; };
 
     const int d = A.d, w = A.w;
     const int Ld = A.L;                              // Dense layers (parameters in A.mlp)
@@ -207,6 +242,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             const int l = idx / WP, o = idx - l * WP;
             float v = 0.0f;
             if (l < Ld && o < w) v = (l == 0) ? P[w * d + o] : P[w * d + w + (l - 1) * (w * w + w) + w * w + o];
+            if (BONE && o == 15) v = 1.0f;
             sB[idx] = v;
         }
         // eight independent loads in flight per thread (a plain loop waits for every load before issuing the next one, ~40
@@ -249,6 +285,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         for (int b = 0; b < WB; ++b)
 #pragma unroll
             for (int t = 0; t < 4; ++t) wacc[l][b][t] = 0.0f;
+    }
+    if (AP::NACC > 0) {
+#pragma unroll
+        for (int l = LREG; l < LMAX; ++l) acc_slot(l) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     float woacc0 = 0.0f, woacc1 = 0.0f, boacc0 = 0.0f, boacc1 = 0.0f;
     float nll_acc = 0.0f;
@@ -345,15 +385,19 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 for (int b = 0; b < WB; ++b) {
                     if (b < WG::BPW) {
                         const int i = 16 * (ib0 + b) + j;
+                        const bool in_lds = (AP::NACC > 0) && (l >= LREG);
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const int o = 16 * ob + 4 * q + t;
-                            if (o < w && i < w) atomicAdd(gW + o * w + i, wacc[l][b][t]);
-                            wacc[l][b][t] = 0.0f;
+                            const float g = in_lds ? acc_slot(l)[t] : wacc[l < LREG ? l : 0][b][t];
+                            if (o < w && i < w) atomicAdd(gW + o * w + i, g);
+                            if (BONE && o < w && i == 15) atomicAdd(gB + o, g);
+                            if (!in_lds) wacc[l < LREG ? l : 0][b][t] = 0.0f;
                         }
+                        if (in_lds) acc_slot(l) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                     }
                 }
-                if (lane < w) atomicAdd(gB + lane, bacc[l]);
+                if (!BONE && lane < w) atomicAdd(gB + lane, bacc[l]);
                 bacc[l] = 0.0f;
             }
         }
@@ -367,7 +411,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 const int o = idx / PW, i = idx - o * PW;
                 dst[idx] = (o < w && i < w) ? Wg[o * w + i] : 0.0f;
             }
-            if (tid < WP) sB[l * WP + tid] = (tid < w) ? Bg[tid] : 0.0f;
+            if (tid < WP) sB[l * WP + tid] = (tid < w) ? Bg[tid] : ((BONE && tid == 15) ? 1.0f : 0.0f);
         }
     };
 
@@ -418,6 +462,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         STAMP_VM(0);
         f32x4 hs[LMAX][FB];                // post-activation H_l^T: block fb, reg t = feature 16fb + 4q + t, obs j
         float o0 = 0.0f, o1 = 0.0f;
+        // Width <= 15: a layer is ONE chain of four dependent MFMAs, so there is no k-block loop to prefetch inside; the weight
+        // operand and the bias of the NEXT layer are requested before this layer's MFMAs instead (CL_PF_NEXT)
+        constexpr bool PFN = (FB == 1) && (CL_PF_NEXT != 0);
+        f32x4 pfw = {0.0f, 0.0f, 0.0f, 0.0f}, pfb = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
             if (l < L) {
@@ -427,8 +475,13 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
                 for (int mb = 0; mb < FB; mb += MBS) {
                     constexpr int MB1 = MBS - 1;           // offset of the second block of the pair (0: no second block)
-                    f32x4 acc0 = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * mb + 4 * q);         // bias
+                    f32x4 acc0 = (PFN && l > 0) ? pfb : *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * mb + 4 * q);         // bias
                     f32x4 acc1 = *reinterpret_cast<const f32x4*>(sB + l * WP + 16 * (mb + MB1) + 4 * q);
+                    f32x4 nxw = pfw, nxb = pfb;
+                    if (PFN && l + 1 < LMAX) {
+                        nxw = *reinterpret_cast<const f32x4*>(sW + l * WP * PW + j * PW + 4 * q);
+                        nxb = *reinterpret_cast<const f32x4*>(sB + (l + 1) * WP + 4 * q);
+                    }
                     if (l == 0) {
 #pragma unroll
                         for (int t = 0; t < KS1; ++t) {
@@ -441,7 +494,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         const float* pa1 = Wl + (16 * (mb + MB1) + j) * PW + 4 * q;
                         // two operand buffers used alternately (compile-time index after unrolling: no register copies)
                         f32x4 oa[2], ob[2];
-                        oa[0] = *reinterpret_cast<const f32x4*>(pa0);
+                        oa[0] = PFN ? pfw : *reinterpret_cast<const f32x4*>(pa0);
                         ob[0] = *reinterpret_cast<const f32x4*>(pa1);
 #pragma unroll
                         for (int kb = 0; kb < FB; ++kb) {
@@ -459,6 +512,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         }
                     }
                     CL_PIN();
+                    if (PFN) { pfw = nxw; pfb = nxb; }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         hs[l][mb][t] = fmaxf(acc0[t], leak * acc0[t]);
@@ -503,7 +557,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 const int f = 16 * mb + 4 * q + t;
-                                if (f < ((w + 3) & ~3)) A.act_out[(size_t)f * A.n_pad + gobs] = hs[l][mb][t];
+                                if (f < ((w + 3) & ~3)) A.act_out[(size_t)f * A.n_pad + gobs] = (BONE && f >= w) ? 0.0f : hs[l][mb][t];
                             }
                     }
             }
@@ -872,16 +926,21 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const float* pa = sZ + (16 * ob + j) * PB + kp * WG::KLEN + 4 * q;
                     const float* pb = sH + (16 * ib0 + j) * PB + kp * WG::KLEN + 4 * q;
                     static_assert(WG::BPW <= WB, "accumulator blocks");
-                    f32x4 acc0 = wacc[l][0], acc1 = wacc[l][WB - 1];
+                    const bool acc_lds = (AP::NACC > 0) && (l >= LREG);               // compile-time after unrolling
+                    f32x4 acc0 = acc_lds ? acc_slot(l) : wacc[l < LREG ? l : 0][0];
+                    f32x4 acc1 = wacc[l < LREG ? l : 0][WB - 1];
                     // operands of the next 16 observations are requested before this step's MFMAs are issued (see CL_SCHED_FENCE)
                     f32x4 a4 = *reinterpret_cast<const f32x4*>(pa);
                     f32x4 b4 = *reinterpret_cast<const f32x4*>(pb);
                     f32x4 c4 = (WG::BPW == 2) ? *reinterpret_cast<const f32x4*>(pb + 16 * PB) : b4;
                     // bias gradient = row sums of this wave's own 16 columns of dZ: read here, summed under the first MFMA group
+                    // (narrow kernel: it is column 15 of the accumulator instead, see BONE)
                     f32x4 z4[4];
                     const float* pz = sZ + (lane < WP ? lane : 0) * PB + CL_WOBS * wv;
+                    if (!BONE) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) z4[e] = *reinterpret_cast<const f32x4*>(pz + 4 * e);
+                        for (int e = 0; e < 4; ++e) z4[e] = *reinterpret_cast<const f32x4*>(pz + 4 * e);
+                    }
                     // all waves left barrier B together and wait for these reads together: the VALU work of the NEXT layer step
                     // (dH_{l-1} = dn, dZ_{l-1} = dH_{l-1} * lrelu'(H_{l-1})) goes here, under the LDS latency
                     CL_SCHED_FENCE();
@@ -904,7 +963,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             if (WG::BPW == 2) acc1 = mfma4(a4[t], c4[t], acc1);
                         }
                         CL_SCHED_FENCE();
-                        if (g == 0) {
+                        if (g == 0 && !BONE) {
                             float sb = 0.0f;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) sb += (z4[e][0] + z4[e][1]) + (z4[e][2] + z4[e][3]);
@@ -912,8 +971,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         }
                         a4 = na; b4 = nb; c4 = nc;
                     }
-                    wacc[l][0] = acc0;
-                    if (WG::BPW == 2) wacc[l][WB - 1] = acc1;
+                    if (acc_lds) acc_slot(l) = acc0; else wacc[l < LREG ? l : 0][0] = acc0;
+                    if (WG::BPW == 2) wacc[l < LREG ? l : 0][WB - 1] = acc1;
                 }
                 STAMP(9);
 
@@ -970,7 +1029,13 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                                 const int o = 16 * ob + 4 * q + t;
                                 if (o < w && i < in_dim) {
                                     float* dst = smem + offW + o * in_dim + i;
-                                    *dst = (pass == 0) ? wacc[l][b][t] : *dst + wacc[l][b][t];
+                                    const float g = (AP::NACC > 0 && l >= LREG) ? acc_slot(l)[t] : wacc[l < LREG ? l : 0][b][t];
+                                    *dst = (pass == 0) ? g : *dst + g;
+                                }
+                                if (BONE && l > 0 && o < w && i == 15) {          // the bias gradient rides in column 15
+                                    float* dst = smem + offW + w * in_dim + o;
+                                    const float g = (AP::NACC > 0 && l >= LREG) ? acc_slot(l)[t] : wacc[l < LREG ? l : 0][b][t];
+                                    *dst = (pass == 0) ? g : *dst + g;
                                 }
                             }
                         }
@@ -988,7 +1053,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         float* mine = scr + wv * SCRW;
 #pragma unroll
         for (int l = 0; l < LMAX; ++l)
-            if (l < Ld && lane < WP) mine[l * WP + lane] = bacc[l];
+            if (l < Ld && lane < WP) mine[l * WP + lane] = (BONE && l > 0) ? 0.0f : bacc[l];
         if (lane < WP) { mine[LMAX * WP + lane] = woacc0; mine[LMAX * WP + WP + lane] = woacc1; }
         if (lane == 0) { mine[LMAX * WP + 2 * WP] = bo0; mine[LMAX * WP + 2 * WP + 1] = bo1; }
     }
@@ -999,7 +1064,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         for (int k = 0; k < CL_NW; ++k) t += scr[k * SCRW + idx];
         if (idx < LMAX * WP) {
             const int l = idx / WP, o = idx - l * WP;
-            if (l < Ld && o < w) smem[((l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w))) + w * ((l == 0) ? d : w) + o] = t;
+            if (l < Ld && o < w && !(BONE && l > 0))
+                smem[((l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w))) + w * ((l == 0) ? d : w) + o] = t;
         } else if (!no_head) {
             const int r = idx - LMAX * WP;
             if (r < WP) { if (r < w) smem[offWo + r] = t; }
@@ -1085,6 +1151,8 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     size_t sm = sm_tiles;
     const size_t flush = (P + 4 + (size_t)CL_NW * (LMAX * WP + 2 * WP + 2)) * sizeof(float);      // gradient image + per-wave bias rows
     if (MODE != 1 && flush > sm) sm = flush;
+    using AP = AccPlan<WP, DP, LMAX, MODE, (CL_IMGL == 1)>;
+    if (AP::NACC > 0) sm = (size_t)AP::total * sizeof(float);                                       // + LDS-resident accumulators
     if (sm > 160 * 1024) return -3;
     auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0), (CL_IMGL == 1)>;
     static size_t configured = 0;
@@ -1099,7 +1167,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 }
 
 // Instantiated geometries: the padded width WP fixes how many layers of activations + weight-gradient blocks fit in the
-// 256-register budget of a wave: w <= 16 -> up to 20 layers (the CLI default scaler is 20 x 10), w <= 32 -> 10, w <= 64 -> 5.
+// 256-register budget of a wave: w <= 15 -> up to 20 layers (the CLI default scaler is 20 x 10), w <= 32 -> 10, w <= 64 -> 5.
 template <int WP, int LMAX, int MODE>
 static int launch_dp(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.L + (CL_IMGL == 1 ? a.n_imgl : 0) > LMAX) return -2;
@@ -1113,7 +1181,7 @@ template <int MODE>
 static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.L < 1 || a.w < 1 || a.d < 1) return -2;
     if (a.w > 64 || a.d > 64) return -2;
-    if (a.w <= 16) return launch_dp<16, (CL_IMGL == 1 ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16), MODE>(a, grid, st);
+    if (a.w <= 15) return launch_dp<16, (CL_IMGL == 1 ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16), MODE>(a, grid, st);
     if (a.w <= 32) return (a.L + (CL_IMGL == 1 ? a.n_imgl : 0) <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }

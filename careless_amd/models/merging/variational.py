@@ -63,7 +63,8 @@ class VariationalMergingModel(BaseModel):
                 n = int(np.asarray(BaseModel.get_refl_id(inputs).shape)[0])
                 rank, world, pg = self._dist
                 shard = make_shard(n, int(self.surrogate_posterior.loc_raw.numel()), rank, world)
-            self._engine = ElboEngine(self, inputs, seed=self.seed, shard=shard, process_group=pg)
+            self._engine = ElboEngine(self, inputs, seed=self.seed, shard=shard, process_group=pg,
+                                      grid=getattr(self, "kernel_grid", None))   # None: one persistent workgroup per CU
             self._engine_inputs = inputs
         else:
             self._engine.refresh_config()

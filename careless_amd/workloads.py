@@ -23,6 +23,8 @@ WORKLOADS: Dict[str, dict] = {
     "dw_50M_normal_5x64_S1": dict(N=50_000_000, d0=5, posenc=False, L=5, w=64, S=1, dof=None, outliers=False, kind="double_wilson"),
     # the careless CLI defaults: --mlp-layers 20 --mlp-width 10 (args/scaling.py), Normal likelihood, mc-samples 1
     "mono_10M_cli_default_20x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False),
+    # half the default depth (register-pressure experiments on the narrow kernel)
+    "mono_10M_10x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=10, w=10, S=1, dof=None, outliers=False),
     # --image-layers 1 on the headline configuration (one Dense layer traded for a per-image layer)
     "mono_10M_studentt_posenc_4x64_img1_S8": dict(N=10_000_000, d0=5, posenc=True, L=4, w=64, S=8, dof=16.0, outliers=True,
                                                   image_layers=1),

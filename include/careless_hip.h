@@ -36,8 +36,10 @@ extern "C" {
 
 #define CL_MLP_TILE 128   /* observations per workgroup tile */
 /* deepest scaler the fused kernel is instantiated for, by hidden width (cl_mlp_max_layers) */
-#define CL_MLP_LMAX_W16 20 /* width <= 16 (the careless CLI default is 20 layers x width 10) */
-#define CL_MLP_LMAX_W16_IMGL 24 /* width <= 16 with per-image layers: Dense + image layers (the default 20 + --image-layers <= 4) */
+#ifndef CL_MLP_LMAX_W16
+#define CL_MLP_LMAX_W16 20
+#endif /* width <= 15 (the careless CLI default is 20 layers x width 10); padded feature 15 carries the bias gradient */
+#define CL_MLP_LMAX_W16_IMGL 24 /* width <= 15 with per-image layers: Dense + image layers (the default 20 + --image-layers <= 4) */
 #define CL_MLP_LMAX_W32 10 /* width <= 32 */
 #define CL_MLP_LMAX_W64 5  /* width <= 64 */
 #define CL_HIST_STRIDE 8  /* doubles per history record: loss, F KLDiv, NLL, Grad Norm, skipped, 3 spare */

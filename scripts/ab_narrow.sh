@@ -1,0 +1,5 @@
+# A/B experimental libraries on a narrow-scaler workload (one device, one gpurun call): bash scripts/ab_narrow.sh WORKLOAD variant...
+wl=$1; shift
+for r in 1 2; do for v in "$@"; do
+  CARELESS_HIP_LIB=$PWD/careless_amd/lib/exp_$v.so python bench.py --workload $wl --steps 15 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('exp_$v', d['config']['workload'], '%.3f ms'%d['ms_per_step'], '%.4g refl/s'%d['value'], 'loss', d['config']['final_loss'])"
+done; done

@@ -22,6 +22,11 @@ CASES = {
     "mlp1x64_d40_S1": dict(N=200, R=17, d0=40, L=1, w=64, S=1),
     "mlp4x48_klweight_S4": dict(N=640, R=100, d0=5, L=4, w=48, S=4, kl_weight=0.5, likelihood="studentt", dof=12.0),
     "cli_default_20x10_S1": dict(N=500, R=50, d0=5, L=20, w=10, S=1, perturb=0.02),
+    # few persistent workgroups -> each walks several tiles: accumulators (registers, and LDS slots for the upper layers of the
+    # narrow kernel) carry over from tile to tile
+    "cli_default_20x10_six_tiles_per_workgroup": dict(N=1500, R=60, d0=5, L=20, w=10, S=2, perturb=0.02, grid=2),
+    "mlp5x64_five_tiles_per_workgroup": dict(N=1900, R=64, d0=5, L=5, w=64, S=2, grid=3),
+    "mlp14x15_d21_S3": dict(N=700, R=30, d0=5, posenc=True, L=14, w=15, S=3, perturb=0.02, grid=2),
     "mlp8x24_S2_studentt": dict(N=300, R=30, d0=5, L=8, w=24, S=2, likelihood="studentt", dof=4.0, perturb=0.03),
     "mlp12x16_d21_S3": dict(N=260, R=30, d0=5, posenc=True, L=12, w=16, S=3, perturb=0.02),
     "ev11_normal_2x32_S3": dict(N=400, R=40, d0=5, L=2, w=32, S=3, ev11=True),
@@ -75,6 +80,7 @@ def _regroup_laue(data, div):
 def _run_case(kw):
     kw = dict(kw)
     two_pass, regroup, shuffle = kw.pop("two_pass", False), kw.pop("regroup", 0), kw.pop("shuffle_rows", False)
+    grid = kw.pop("grid", None)
     L, w = kw["L"], kw["w"]
     data, cfg, params, x, u_f, eta = util.make_problem(**kw)
     if regroup:
@@ -90,6 +96,7 @@ def _run_case(kw):
                                         torch.as_tensor(eta, dtype=torch.float64))
     model = util.build_model(data, cfg, params, L, w)
     model.laue_two_pass = two_pass
+    model.kernel_grid = grid
     inputs = util.reference_inputs(data)
     ipred = model(inputs, u_f=u_f, eta=eta)
     eng = model._engine
