@@ -37,6 +37,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CL_ACC_WP
+#define CL_ACC_WP 16   /* widest instance with LDS-resident accumulators (32: measured -0.8 % on a 10 x 32 scaler) */
+#endif
 #ifndef CL_BIAS_ONE
 #define CL_BIAS_ONE 1
 #endif
@@ -152,7 +155,7 @@ struct AccPlan {
     static constexpr int OFF = ((SL::total > FLUSH ? SL::total : FLUSH) + 3) & ~3;           // start of the accumulator slots
     static constexpr int SLOT = CL_NW * 256;                                                // floats per layer
     static constexpr int ROOM = (160 * 1024 / 4 - OFF) / SLOT;
-    static constexpr bool ON = (WP == 16) && (MODE != 1) && (LMAX > 10);
+    static constexpr bool ON = (WP <= CL_ACC_WP) && (MODE != 1) && (LMAX > 5);
     static constexpr int NACC = ON ? (ROOM < LMAX - 1 ? (ROOM > 0 ? ROOM : 0) : LMAX - 1) : 0;
     static constexpr int LREG = LMAX - NACC;                                                // layers < LREG keep register accumulators
     static constexpr int total = OFF + NACC * SLOT;
