@@ -1,14 +1,16 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 # usage: bash scripts/pmc_passes.sh [workload]   (PMC passes over the fused kernel of one bench workload; default = the bench line)
+T=${1:-bench}
 B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ${1:+--workload $1}"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/pmcA -- $B > gpurun_out/pmcA.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcB -- $B > gpurun_out/pmcB.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcC -- $B > gpurun_out/pmcC.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d gpurun_out/pmcD -- $B > gpurun_out/pmcD.log 2>&1
-python3 - <<'PY'
-import csv,glob,collections
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/pmcA_$T -- $B > gpurun_out/pmcA.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmcB_$T -- $B > gpurun_out/pmcB.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcC_$T -- $B > gpurun_out/pmcC.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_EA0_ATOMIC_sum --output-format csv -d gpurun_out/pmcD_$T -- $B > gpurun_out/pmcD.log 2>&1
+python3 - $T <<'PY'
+import csv,glob,collections,sys
+T=sys.argv[1]
 for d in "ABCD":
-    for f in glob.glob(f"gpurun_out/pmc{d}/*/*counter_collection.csv"):
+    for f in glob.glob(f"gpurun_out/pmc{d}_{T}/*/*counter_collection.csv"):
         acc=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if 'elbo_mlp' in r['Kernel_Name']:
