@@ -31,6 +31,7 @@
 // (-DCL_CHAIN=1, scalers deeper than one launch holds).
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "cl_math.h"
 #include "cl_kernels.h"
 
@@ -1158,11 +1159,14 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (AP::NACC > 0) sm = (size_t)AP::total * sizeof(float);                                       // + LDS-resident accumulators
     if (sm > 160 * 1024) return -3;
     auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0), (CL_IMGL == 1)>;
-    static size_t configured = 0;
-    if (configured < sm) {
+    // largest dynamic-LDS size this instance has been configured for (one process drives one device; host threads may race here:
+    // setting the attribute twice is harmless, publishing a size that was not set is not, hence set first, then raise the mark)
+    static std::atomic<size_t> configured{0};
+    size_t have = configured.load(std::memory_order_acquire);
+    if (have < sm) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) return (int)e;
-        configured = sm;
+        while (have < sm && !configured.compare_exchange_weak(have, sm, std::memory_order_release, std::memory_order_acquire)) {}
     }
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), sm, st, a);

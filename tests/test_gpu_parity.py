@@ -47,6 +47,8 @@ CASES = {
     "laue_two_pass_2x32_S3": dict(N=400, R=40, L=2, w=32, S=3, laue=True, two_pass=True),
     "laue_two_pass_ev11_studentt_S5": dict(N=500, R=40, L=2, w=32, S=5, laue=True, ev11=True, likelihood="studentt", dof=6.0, two_pass=True),
     "laue_two_pass_image_layers1": dict(N=600, R=60, L=2, w=32, S=3, laue=True, n_images=4, image_layers=1, two_pass=True),
+    "laue_two_pass_narrow_12x10": dict(N=600, R=40, L=12, w=10, S=2, laue=True, two_pass=True, perturb=0.02),
+    "laue_single_pass_narrow_20x10": dict(N=900, R=40, L=20, w=10, S=3, laue=True, perturb=0.02, grid=2),
     "laue_ev11_studentt_S5": dict(N=500, R=40, L=2, w=32, S=5, laue=True, ev11=True, likelihood="studentt", dof=6.0),
     "laue_groups_up_to_12_rows_S6": dict(N=700, R=50, L=2, w=32, S=6, laue=True, regroup=4),
     "laue_groups_over_16_rows_fall_back": dict(N=700, R=50, L=2, w=32, S=2, laue=True, regroup=16),
