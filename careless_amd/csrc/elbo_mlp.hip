@@ -38,6 +38,15 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CL_ASM_MAX
+#define CL_ASM_MAX 1
+#endif
+#ifndef CL_OPAQUE_L
+#define CL_OPAQUE_L 1
+#endif
+#ifndef CL_WPIPE
+#define CL_WPIPE 1
+#endif
 #ifndef CL_ACC_WP
 #define CL_ACC_WP 16   /* widest instance with LDS-resident accumulators (32: measured -0.8 % on a 10 x 32 scaler) */
 #endif
@@ -109,6 +118,18 @@ __device__ __forceinline__ int opaque_uniform(int v) {
     v = __builtin_amdgcn_readfirstlane(v);
     asm volatile("" : "+s"(v));
     return v;
+}
+
+// LeakyReLU as max(x, leak x) with a bare v_max_f32: fmaxf() makes hipcc canonicalise x first (a second v_max per element)
+__device__ __forceinline__ float lrelu(float x, float leak) {
+#if CL_ASM_MAX
+    const float m = leak * x;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
+    return r;
+#else
+    return fmaxf(x, leak * x);
+#endif
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -420,6 +441,14 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     };
 
     for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
+#if CL_OPAQUE_L
+        // the layer count, made opaque once per tile: otherwise hipcc hoists every `l == L - 1` / `l < L` test of the unrolled layer
+        // loops out of the tile loop, runs out of SGPRs, parks the masks in VGPR lanes and pays v_readlane / v_writelane round trips
+        // (plus bool -> VGPR -> bool conversions) inside every layer
+        const int Lt = opaque_uniform(L);
+#else
+        const int Lt = L;
+#endif
         const int gobs = tile * CL_TILE + CL_WOBS * wv + j;      // this lane's observation (all four k-groups)
         if (ILAY && A.n_imgl > 0) {
             const int im = __builtin_amdgcn_readfirstlane(A.tile_img[tile]);
@@ -472,7 +501,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         f32x4 pfw = {0.0f, 0.0f, 0.0f, 0.0f}, pfb = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
-            if (l < L) {
+            if (l < Lt) {
                 // two output blocks at a time (when the layer has them): two independent accumulator chains keep the MFMA
                 // pipe at its issue rate (one 16x16x4 chain is paced by the 40-cycle dependent latency, not the 32-cycle issue)
                 constexpr int MBS = (FB >= 2) ? 2 : 1;
@@ -519,11 +548,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     if (PFN) { pfw = nxw; pfb = nxb; }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        hs[l][mb][t] = fmaxf(acc0[t], leak * acc0[t]);
-                        if (MBS == 2) hs[l][mb + MB1][t] = fmaxf(acc1[t], leak * acc1[t]);
+                        hs[l][mb][t] = lrelu(acc0[t], leak);
+                        if (MBS == 2) hs[l][mb + MB1][t] = lrelu(acc1[t], leak);
                     }
                 }
-                if (l == L - 1) {
+                if (l == Lt - 1) {
                     // final Dense(2): every k-group holds a quarter of the features of observation j
 #pragma unroll
                     for (int mb = 0; mb < FB; ++mb) {
@@ -555,7 +584,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             if (valid) {
 #pragma unroll
                 for (int l = 0; l < LMAX; ++l)
-                    if (l == L - 1) {
+                    if (l == Lt - 1) {
 #pragma unroll
                         for (int mb = 0; mb < FB; ++mb)
 #pragma unroll
@@ -726,9 +755,19 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         if (q == 0) *reinterpret_cast<f32x2*>(sS + 2 * j) = f32x2{dloc, draw};
 
         f32x4 dH[FB];
+        // Narrow kernel (WPIPE): a layer step is two chains of four dependent MFMAs (dgrad, wgrad), each behind an LDS round trip,
+        // and with two waves per SIMD that latency IS the run time.  The wgrad of layer l is therefore issued one iteration late:
+        // its operand reads are requested right after the layer's staging writes (one wave's LDS operations execute in order, and
+        // the wave only reads the 16 columns it wrote itself, so no wait is needed in between, nor before the next layer's writes),
+        // and its MFMAs run interleaved with the dgrad MFMAs of layer l-1, when the operands have long arrived.  The weight
+        // operands of the dgrad are requested one iteration ahead as well.  With no wgrad pending (top layer) the operands are
+        // zero and the MFMAs add exactly 0 to an accumulator, so the pipeline needs no branches.
+        constexpr bool WPIPE = WLOC && (CL_WPIPE != 0);
+        f32x4 pa4 = {0.0f, 0.0f, 0.0f, 0.0f}, pb4 = {0.0f, 0.0f, 0.0f, 0.0f}, pacc = {0.0f, 0.0f, 0.0f, 0.0f};
+        float r0w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int l = LMAX - 1; l >= 0; --l) {
-            if (l == L - 1 && no_head) {
+            if (l == Lt - 1 && no_head) {
                 // head-less block of a chain: dL/dH_L comes from the next block (feature-major, like the metadata)
 #pragma unroll
                 for (int mb = 0; mb < FB; ++mb)
@@ -737,7 +776,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         const int f = 16 * mb + 4 * q + t;
                         dH[mb][t] = (valid && f < ((w + 3) & ~3)) ? A.dH_ext[(size_t)f * A.n_pad + gobs] : 0.0f;
                     }
-            } else if (l == L - 1) {
+            } else if (l == Lt - 1) {
                 // dH_L = W_o^T dO ; Dense(2) wgrad from the wave-private columns of the H staging tile
 #pragma unroll
                 for (int mb = 0; mb < FB; ++mb) {
@@ -766,13 +805,13 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 wave_lds_sync();
                 STAMP(4);
             }
-            if (l < L) {
+            if (l < Lt) {
                 // next tile's inputs: issued two layers before the end of the backward pass -- early enough to cover the HBM
                 // latency, late enough that the registers of the upper layers' activations are free again
                 if (l == pf_layer && tile + tile_step < tile_end) prefetch(tile + tile_step);
                 // dZ_l = dH_l * lrelu'(H_l)   (sign of the post-activation == sign of the pre-activation).  Only the top layer
                 // does it here: for the others it was done one step earlier, in the shadow of the wgrad operand reads (below)
-                if (l == L - 1) {
+                if (l == Lt - 1) {
 #pragma unroll
                     for (int mb = 0; mb < FB; ++mb)
 #pragma unroll
@@ -780,8 +819,55 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 }
 
                 STAMP(5);
+                // accumulator of the pending wgrad (layer l+1): registers, or the LDS slot read when its operands were requested
+                const int LP = (l + 1 < LMAX) ? l + 1 : LMAX - 1;               // (compile-time after unrolling)
+                const bool LP_LDS = (AP::NACC > 0) && (LP >= LREG);
+              if (WPIPE && l > 0) {
+                const float* wq = sW + (l > 0 ? l - 1 : 0) * WP * PW + (4 * q) * PW + j;
+                if (l == Lt - 1) {                                  // top layer: nothing was requested ahead
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) r0w[t] = wq[t * PW];
+                }
+                float rn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (l >= 2) {                                      // weight operands of the next iteration (layer l-1)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) rn[t] = (wq - WP * PW)[t * PW];
+                }
+                float* const stz = sZ + (4 * q) * PB + CL_WOBS * wv + j;
+                float* const sth = sH + (4 * q) * PB + CL_WOBS * wv + j;
+                f32x4 accd = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 accw = LP_LDS ? pacc : wacc[LP < LREG ? LP : 0][0];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    accd = mfma4(r0w[t], dH[0][t], accd);                              // dgrad of layer l
+                    if (l + 1 < LMAX) accw = mfma4(pa4[t], pb4[t], accw);              // wgrad of layer l+1 (operands from last iteration)
+                    stz[t * PB] = dH[0][t];                                            // staging: dZ_l and H_{l-1}, this wave's columns
+                    sth[t * PB] = hs[l > 0 ? l - 1 : 0][0][t];
+                }
+                if (l + 1 < LMAX) { if (LP_LDS) acc_slot(LP) = accw; else wacc[LP < LREG ? LP : 0][0] = accw; }
+                CL_PIN();
+                // operands (and LDS accumulator) of this layer's wgrad: consumed one iteration from now
+                pa4 = *reinterpret_cast<const f32x4*>(sZ + j * PB + CL_WOBS * wv + 4 * q);
+                pb4 = *reinterpret_cast<const f32x4*>(sH + j * PB + CL_WOBS * wv + 4 * q);
+                if ((AP::NACC > 0) && (l >= LREG)) pacc = acc_slot(l);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    dH[0][t] = (hs[l > 0 ? l - 1 : 0][0][t] > 0.0f) ? accd[t] : leak * accd[t];
+                    r0w[t] = rn[t];
+                }
+                STAMP(9);
+              } else {
+                if (WPIPE && LMAX > 1) {
+                    // layer 0 takes the staged path below; first retire the pending wgrad of layer 1 (zero operands if Lt == 1)
+                    f32x4 accw = LP_LDS ? pacc : wacc[LP < LREG ? LP : 0][0];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) accw = mfma4(pa4[t], pb4[t], accw);
+                    if (LP_LDS) acc_slot(LP) = accw; else wacc[LP < LREG ? LP : 0][0] = accw;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { pa4[t] = 0.0f; pb4[t] = 0.0f; }
+                }
                 // barrier A: the previous layer's wgrad reads are complete
-                if (l < L - 1) { if (WLOC) wave_lds_sync(); else lds_barrier(); }
+                if (l < Lt - 1) { if (WLOC) wave_lds_sync(); else lds_barrier(); }
                 STAMP(6);
                 // staging writes of this wave's 16 columns: dZ_l into sZ and H_{l-1} into sH.  With a dgrad to run (l > 0) they
                 // are issued BETWEEN its MFMAs (both only read registers), so the LDS write phase costs no matrix-pipe time
@@ -979,6 +1065,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     if (WG::BPW == 2) wacc[l < LREG ? l : 0][WB - 1] = acc1;
                 }
                 STAMP(9);
+              }
 
                 STAMP(10);
             }
