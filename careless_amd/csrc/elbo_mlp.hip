@@ -764,7 +764,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         // zero and the MFMAs add exactly 0 to an accumulator, so the pipeline needs no branches.
         constexpr bool WPIPE = WLOC && (CL_WPIPE != 0);
         f32x4 pa4 = {0.0f, 0.0f, 0.0f, 0.0f}, pb4 = {0.0f, 0.0f, 0.0f, 0.0f}, pacc = {0.0f, 0.0f, 0.0f, 0.0f};
-        float r0w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        float r0w[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
         for (int l = LMAX - 1; l >= 0; --l) {
             if (l == Lt - 1 && no_head) {
@@ -824,14 +824,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 const bool LP_LDS = (AP::NACC > 0) && (LP >= LREG);
               if (WPIPE && l > 0) {
                 const float* wq = sW + (l > 0 ? l - 1 : 0) * WP * PW + (4 * q) * PW + j;
-                if (l == Lt - 1) {                                  // top layer: nothing was requested ahead
+                float (&rw)[4] = r0w[l & 1];                       // weight operands of this layer (two buffers, by layer parity)
+                if (l == Lt - 1) {                                 // top layer: nothing was requested ahead
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) r0w[t] = wq[t * PW];
-                }
-                float rn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (l >= 2) {                                      // weight operands of the next iteration (layer l-1)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) rn[t] = (wq - WP * PW)[t * PW];
+                    for (int t = 0; t < 4; ++t) rw[t] = wq[t * PW];
                 }
                 float* const stz = sZ + (4 * q) * PB + CL_WOBS * wv + j;
                 float* const sth = sH + (4 * q) * PB + CL_WOBS * wv + j;
@@ -839,22 +835,26 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 f32x4 accw = LP_LDS ? pacc : wacc[LP < LREG ? LP : 0][0];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    accd = mfma4(r0w[t], dH[0][t], accd);                              // dgrad of layer l
+                    accd = mfma4(rw[t], dH[0][t], accd);                               // dgrad of layer l
                     if (l + 1 < LMAX) accw = mfma4(pa4[t], pb4[t], accw);              // wgrad of layer l+1 (operands from last iteration)
                     stz[t * PB] = dH[0][t];                                            // staging: dZ_l and H_{l-1}, this wave's columns
                     sth[t * PB] = hs[l > 0 ? l - 1 : 0][0][t];
                 }
                 if (l + 1 < LMAX) { if (LP_LDS) acc_slot(LP) = accw; else wacc[LP < LREG ? LP : 0][0] = accw; }
-                CL_PIN();
-                // operands (and LDS accumulator) of this layer's wgrad: consumed one iteration from now
+                CL_SCHED_FENCE();
+                // requested now, consumed one iteration from now: the operands (and LDS accumulator) of this layer's wgrad and the
+                // weight operands of the next dgrad.  Issued AFTER this iteration's MFMAs: the wait in front of those covers every
+                // LDS operation in flight (the counter is in order), so anything requested before them would be waited for at once
                 pa4 = *reinterpret_cast<const f32x4*>(sZ + j * PB + CL_WOBS * wv + 4 * q);
                 pb4 = *reinterpret_cast<const f32x4*>(sH + j * PB + CL_WOBS * wv + 4 * q);
                 if ((AP::NACC > 0) && (l >= LREG)) pacc = acc_slot(l);
+                if (l >= 2) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    dH[0][t] = (hs[l > 0 ? l - 1 : 0][0][t] > 0.0f) ? accd[t] : leak * accd[t];
-                    r0w[t] = rn[t];
+                    for (int t = 0; t < 4; ++t) r0w[(l - 1) & 1][t] = (wq - WP * PW)[t * PW];
                 }
+                CL_SCHED_FENCE();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dH[0][t] = (hs[l > 0 ? l - 1 : 0][0][t] > 0.0f) ? accd[t] : leak * accd[t];
                 STAMP(9);
               } else {
                 if (WPIPE && LMAX > 1) {
