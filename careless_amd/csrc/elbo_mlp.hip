@@ -38,6 +38,12 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef CL_META_RANGE
+#define CL_META_RANGE 2   /* largest KS1 (metadata k-steps) that takes the branch-free metadata prefetch */
+#endif
+#ifndef CL_META_OPAQUE
+#define CL_META_OPAQUE 1
+#endif
 #ifndef CL_ASM_MAX
 #define CL_ASM_MAX 1
 #endif
@@ -361,11 +367,19 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     const int row4_b = 16 * A.n_pad;                            // bytes between feature groups (4 rows)
     auto load_meta = [&](int tile, float (&dst)[KS1]) {
         const int soff = tile * (CL_TILE * 4);
+        const int d4m = CL_META_OPAQUE ? opaque_uniform(d4) : d4;
 #pragma unroll
         for (int t = 0; t < KS1; ++t) {
-            dst[t] = 0.0f;
-            if (4 * t < d4)                                     // wave-uniform
-                dst[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_meta, (int)lane_meta_b, soff + t * row4_b, 0));
+            // the feature-group offset goes into the per-lane offset, which the hardware range-checks against the 4 d4 n_pad bytes of
+            // the descriptor: groups past the padded metadata rows return 0 without a branch (a `4 t < d4` test per load costs a
+            // spilled SGPR mask and a descriptor reload each -- ~100 v_readlane per tile at the end of the backward pass)
+            if (KS1 <= CL_META_RANGE) {      // (d <= 8 instance; with eight loads the unconditional form costs registers: -9 % on cfg3)
+                dst[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_meta, (int)(lane_meta_b + (unsigned)(t * row4_b)), soff, 0));
+            } else {
+                dst[t] = 0.0f;
+                if (4 * t < d4m)                                // wave-uniform
+                    dst[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_meta, (int)lane_meta_b, soff + t * row4_b, 0));
+            }
         }
     };
     const int nb_obs = 4 * A.n_obs;
