@@ -101,7 +101,12 @@ class SymmetryOps:
                     break
         return self._case
 
+    _CHUNK = 1 << 18          # rows mapped at a time: the orbit of a chunk is (2 nops, chunk, 3) int64, ~600 MB for 48 operators
+
     def to_asu(self, hkl: np.ndarray, anomalous: bool = False) -> np.ndarray:
+        hkl = np.asarray(hkl, dtype=np.int64)
+        if len(hkl) > self._CHUNK:
+            return np.concatenate([self.to_asu(hkl[i:i + self._CHUNK], anomalous) for i in range(0, len(hkl), self._CHUNK)])
         rot = self.orbit(hkl)
         orb = np.concatenate([rot, -rot], axis=0)
         case = self.asu_case()
@@ -119,6 +124,9 @@ class SymmetryOps:
     def describe(self, hkl: np.ndarray):
         """centric (N,) bool, epsilon (N,) int, absent (N,) bool."""
         h = np.asarray(hkl, dtype=np.int64)
+        if len(h) > self._CHUNK:
+            parts = [self.describe(h[i:i + self._CHUNK]) for i in range(0, len(h), self._CHUNK)]
+            return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
         orb = self.orbit(h)
         same = np.all(orb == h[None], axis=2)
         eps = same.sum(0)
