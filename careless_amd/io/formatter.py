@@ -71,8 +71,10 @@ def expand_harmonics(cols: Dict[str, np.ndarray], cell, dmin: Optional[float] = 
 
 
 def parse_spacegroups(spec, n_files: int):
-    """`--spacegroups` (reference formatter.py:254-263): one entry or one per file.  Without a space-group table only the
-    triclinic group can be named (`1`, `P 1`, `P1`): every other symmetry has to come from the reflection file's own header."""
+    """`--spacegroups` (reference formatter.py:254-263): one entry or one per file, by number or Hermann-Mauguin name.  The
+    operators come from the built-in table of the 65 chiral space groups (`careless_amd.io.spacegroups`); other groups and
+    non-reference settings raise NotImplementedError (a reflection file's own header is always honoured)."""
+    from careless_amd.io.spacegroups import lookup
     if spec is None:
         return None
     names = [v.strip() for v in str(spec).split(",")]
@@ -81,13 +83,7 @@ def parse_spacegroups(spec, n_files: int):
     elif len(names) != n_files:
         raise ValueError("Multiple values provided for --spacegroups=, but the number of provided values does not match the number of "
                          "reflection files. Either provide a single spacegroup or one per reflection file as a comma-separated list. ")
-    out = []
-    for v in names:
-        if v.replace(" ", "").upper() not in ("1", "P1"):
-            raise NotImplementedError(f"--spacegroups={v}: naming a space group other than P 1 needs a space-group table (gemmi); "
-                                      "careless_amd takes the symmetry operators from the reflection file header")
-        out.append((["X, Y, Z"], "P 1", 1))
-    return out
+    return [lookup(v) for v in names]
 
 
 class DataFormatter:

@@ -60,6 +60,26 @@ def test_twofile(tmp_path, mode, change_sg, ev11, dmin, anomalous, isigi, dof, s
     _run(flags, [PYP, ON_P3 if change_sg else ON], str(tmp_path / "out"), separate)
 
 
+def test_spacegroups_flag_overrides_the_file_header(tmp_path):
+    """`--spacegroups` with one name per file (reference formatter.py:254-263, 301-302: the file's space group is replaced before
+    the indices are mapped to the asymmetric unit): naming P 3 for the P 63 file gives what a copy of that file with a P 3 header gives"""
+    from careless_amd.careless import run_careless
+    from careless_amd.io.mtz import write_mtz
+    from careless_amd.io.spacegroups import lookup
+    from careless_amd.parser import parser
+    flags = f"mono --iterations={niter} --disable-progress-bar --mlp-layers 3 --separate-files dHKL,image_id"
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    src, copy = read_mtz(ON), str(tmp_path / "on_as_p3.mtz")
+    ops, name, number = lookup("P 3")
+    write_mtz(copy, src.columns, src.types, src.cell, ops, name, number)
+    run_careless(parser.parse_args(flags.split() + [PYP, copy, a]))
+    run_careless(parser.parse_args(flags.split() + ["--spacegroups=P 63,P 3", PYP, ON, b]))
+    for i in range(2):
+        x, y = read_mtz(a + f"_{i}.mtz"), read_mtz(b + f"_{i}.mtz")
+        assert x.spacegroup_number == y.spacegroup_number == (173, 143)[i] and np.array_equal(x.hkl(), y.hkl())
+        assert np.allclose(x.columns["F"], y.columns["F"], rtol=1e-5) and np.array_equal(x.columns["N"], y.columns["N"])
+
+
 @pytest.mark.parametrize("mode", ["mono", "poly"])
 @pytest.mark.parametrize("optimize_r", [False, True])
 def test_double_wilson(tmp_path, mode, optimize_r):

@@ -289,7 +289,51 @@ def test_crystfel_stream_and_spacegroups_flag():
     with pytest.raises(ValueError):
         LaueFormatter.from_parser(parser.parse_args(["poly", "--spacegroups=1", "dHKL,image_id", stream, "out"])).format_files([stream])
     assert parse_spacegroups("P 1", 2) == [(["X, Y, Z"], "P 1", 1)] * 2
+    assert [g[1:] for g in parse_spacegroups("P 21 21 21,96", 2)] == [("P 21 21 21", 19), ("P 43 21 2", 96)]
     with pytest.raises(NotImplementedError):
-        parse_spacegroups("P 21 21 21", 1)
+        parse_spacegroups("P n m a", 1)                                # not a chiral group: not in the table
     with pytest.raises(ValueError):
         parse_spacegroups("1,1,1", 2)
+
+
+def test_spacegroup_table():
+    """`--spacegroups` by name or number (reference formatter.py:254-263 uses gemmi.SpaceGroup): every entry of the built-in table
+    closes to its group order, maps to the CCP4 asymmetric unit gemmi assigns to its number, reproduces the operator sets of the
+    reference's own MTZ fixtures and the textbook reflection conditions."""
+    from careless_amd.io import spacegroups as sg
+    ccp4 = lambda n: (0 if n <= 2 else 1 if n <= 15 else 2 if n <= 74 else 3 if n <= 88 else 4 if n <= 142 else 5 if n <= 148 else
+                      {149: 6, 150: 7, 151: 6, 152: 7, 153: 6, 154: 7, 155: 7}[n] if n <= 155 else
+                      3 if n <= 176 else 4 if n <= 194 else 8 if n <= 206 else 9)
+    assert len(sg._TABLE) == 65
+    for n, (name, _, order) in sg._TABLE.items():
+        ops = sg.operators(n)                                          # raises if the closure has the wrong size
+        assert len(ops) == order and ops[0] == "X, Y, Z" and sg.lookup(name)[2] == n and sg.lookup(str(n))[1] == name
+        assert SymmetryOps(ops).asu_case() == ccp4(n), name
+    key = lambda ops: sorted((tuple(SymmetryOps([o]).R[0].ravel()), tuple(np.round(SymmetryOps([o]).t[0] % 1, 6))) for o in ops)
+    for f in (mtz_fixture.PYP, mtz_fixture.PYP.replace("pyp_off", "pyp_2ms_P3")):
+        m = read_mtz(f)
+        assert key(sg.operators(m.spacegroup_number)) == key(m.symops) and sg.lookup(m.spacegroup_name)[2] == m.spacegroup_number
+    assert sg.lookup("P212121")[2] == sg.lookup("p 21 21 21")[2] == 19 and sg.lookup("P 21")[2] == 4 and sg.lookup("H 3 2")[2] == 155
+    g = np.stack(np.meshgrid(*[np.arange(-7, 8)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    h, k, l = g.T
+    conditions = {                      # International Tables A: a reflection is ABSENT when the condition below is violated
+        19: ((k == 0) & (l == 0) & (h % 2 != 0)) | ((h == 0) & (l == 0) & (k % 2 != 0)) | ((h == 0) & (k == 0) & (l % 2 != 0)),
+        4: (h == 0) & (l == 0) & (k % 2 != 0),
+        5: (h + k) % 2 != 0,
+        23: (h + k + l) % 2 != 0,
+        22: ((h + k) % 2 != 0) | ((h + l) % 2 != 0) | ((k + l) % 2 != 0),
+        92: ((h == 0) & (k == 0) & (l % 4 != 0)) | ((k == 0) & (l == 0) & (h % 2 != 0)) | ((h == 0) & (l == 0) & (k % 2 != 0)),
+        96: ((h == 0) & (k == 0) & (l % 4 != 0)) | ((k == 0) & (l == 0) & (h % 2 != 0)) | ((h == 0) & (l == 0) & (k % 2 != 0)),
+        152: (h == 0) & (k == 0) & (l % 3 != 0),
+        146: (-h + k + l) % 3 != 0,
+        178: (h == 0) & (k == 0) & (l % 6 != 0),
+        180: (h == 0) & (k == 0) & (l % 3 != 0),
+        173: (h == 0) & (k == 0) & (l % 2 != 0),
+        198: ((k == 0) & (l == 0) & (h % 2 != 0)) | ((h == 0) & (l == 0) & (k % 2 != 0)) | ((h == 0) & (k == 0) & (l % 2 != 0)),
+        213: ((k == 0) & (l == 0) & (h % 4 != 0)) | ((h == 0) & (l == 0) & (k % 4 != 0)) | ((h == 0) & (k == 0) & (l % 4 != 0)),
+        98: ((h + k + l) % 2 != 0) | ((h == 0) & (k == 0) & (l % 4 != 0)),
+        210: ((h + k) % 2 != 0) | ((h + l) % 2 != 0) | ((k + l) % 2 != 0) | ((k == 0) & (l == 0) & (h % 4 != 0))
+             | ((h == 0) & (l == 0) & (k % 4 != 0)) | ((h == 0) & (k == 0) & (l % 4 != 0)),
+    }
+    for n, absent in conditions.items():
+        assert np.array_equal(SymmetryOps(sg.operators(n)).describe(g)[2], absent), sg._TABLE[n][0]
