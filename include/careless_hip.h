@@ -39,7 +39,9 @@ extern "C" {
 #ifndef CL_MLP_LMAX_W16
 #define CL_MLP_LMAX_W16 20
 #endif /* width <= 15 (the careless CLI default is 20 layers x width 10); padded feature 15 carries the bias gradient */
-#define CL_MLP_LMAX_W16_IMGL 24 /* width <= 15 with per-image layers: Dense + image layers (the default 20 + --image-layers <= 4) */
+#ifndef CL_MLP_LMAX_W16_IMGL
+#define CL_MLP_LMAX_W16_IMGL 24
+#endif /* width <= 15 with per-image layers: Dense + image layers (the default 20 + --image-layers <= 4) */
 #define CL_MLP_LMAX_W32 10 /* width <= 32 */
 #define CL_MLP_LMAX_W64 5  /* width <= 64 */
 #define CL_HIST_STRIDE 8  /* doubles per history record: loss, F KLDiv, NLL, Grad Norm, skipped, 3 spare */
