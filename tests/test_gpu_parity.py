@@ -27,6 +27,8 @@ CASES = {
     "cli_default_20x10_six_tiles_per_workgroup": dict(N=1500, R=60, d0=5, L=20, w=10, S=2, perturb=0.02, grid=2),
     "mlp5x64_five_tiles_per_workgroup": dict(N=1900, R=64, d0=5, L=5, w=64, S=2, grid=3),
     "mlp14x15_d21_S3": dict(N=700, R=30, d0=5, posenc=True, L=14, w=15, S=3, perturb=0.02, grid=2),
+    "mlp2x32_S12_studentt": dict(N=300, R=40, d0=5, L=2, w=32, S=12, likelihood="studentt", dof=8.0),       # more than 8 MC samples
+    "laue_2x32_S11": dict(N=400, R=40, L=2, w=32, S=11, laue=True),
     "mlp8x24_S2_studentt": dict(N=300, R=30, d0=5, L=8, w=24, S=2, likelihood="studentt", dof=4.0, perturb=0.03),
     "mlp12x16_d21_S3": dict(N=260, R=30, d0=5, posenc=True, L=12, w=16, S=3, perturb=0.02),
     "ev11_normal_2x32_S3": dict(N=400, R=40, d0=5, L=2, w=32, S=3, ev11=True),
