@@ -50,6 +50,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CL_OPAQUE_L
 #define CL_OPAQUE_L 1
 #endif
+#ifndef CL_KPERM
+#define CL_KPERM 1
+#endif
 #ifndef CL_WPIPE
 #define CL_WPIPE 1
 #endif
@@ -202,7 +205,8 @@ struct AccPlan {
 // (forward writes its last activations, A.act_out; backward starts from their gradient, A.dH_ext) and may return the gradient
 // w.r.t. its input (A.dX_out: the first layer gets a dgrad too).
 // ILAY: the packed unit is compiled with (ILAY) and without the per-image-layer code: single-pass Laue only needs the packed layout
-template <int WP, int DP, int LMAX, int MODE, bool IMGL, bool CHAIN = false, bool ILAY = IMGL>
+// KS: narrow kernel only -- number of 4-feature MFMA steps the hidden width needs (2, 3 or 4; see KPERM)
+template <int WP, int DP, int LMAX, int MODE, bool IMGL, bool CHAIN = false, bool ILAY = IMGL, int KS = 4>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void elbo_mlp_kernel(const cl_mlp_args A) {
     using SL = SmemLayout<WP, DP, LMAX>;
@@ -234,6 +238,12 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     // accumulator is then sum_obs dZ[o][obs] * 1 = the BIAS gradient, for free inside the wgrad MFMAs: no LMAX bias registers, no
     // re-read of the dZ tile (a third of this kernel's LDS traffic), no row sums.  Layer 0 (metadata input) keeps its own sum.
     constexpr bool BONE = WLOC && (CL_BIAS_ONE != 0);
+    // Narrow kernel: hidden feature f lives in accumulator row ("slot") 4 (f & 3) + (f >> 2) instead of row f (an involution; every
+    // LDS image and the gradient flush use it consistently).  MFMA step t of a layer then contracts the features 4t .. 4t+3 rather
+    // than {t, 4+t, 8+t, 12+t}, so for a width-w layer only ceil(w / 4) of the four forward and dgrad steps have anything to
+    // multiply: the CLI default (w = 10) runs 3 + 3 + 4 MFMAs per layer instead of 12.  Slot 15 stays feature 15 (the bias ones).
+    constexpr bool KPERM = WLOC && (CL_KPERM != 0);
+    auto sl = [](int f) { return (KPERM && f < 16) ? (((f & 3) << 2) | (f >> 2)) : f; };
     using AP = AccPlan<WP, DP, LMAX, MODE, ILAY>;
     constexpr int LREG = AP::LREG;       // layers >= LREG accumulate their weight gradient in LDS (narrow kernel only)
     const int tid = threadIdx.x;
@@ -261,7 +271,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             for (int u = 0; u < 8; ++u) {
                 const int idx = base + u * 512 + tid;
                 const int o = idx / PW1, i = idx - o * PW1;
-                v[u] = (idx < WP * PW1 && o < w && i < d) ? P[o * d + i] : 0.0f;
+                v[u] = (idx < WP * PW1 && sl(o) < w && i < d) ? P[sl(o) * d + i] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -272,7 +282,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         for (int idx = tid; idx < LMAX * WP; idx += 512) {
             const int l = idx / WP, o = idx - l * WP;
             float v = 0.0f;
-            if (l < Ld && o < w) v = (l == 0) ? P[w * d + o] : P[w * d + w + (l - 1) * (w * w + w) + w * w + o];
+            if (l < Ld && sl(o) < w) v = (l == 0) ? P[w * d + sl(o)] : P[w * d + w + (l - 1) * (w * w + w) + w * w + sl(o)];
             if (BONE && o == 15) v = 1.0f;
             sB[idx] = v;
         }
@@ -287,7 +297,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 for (int u = 0; u < 8; ++u) {
                     const int idx = base + u * 512 + tid;
                     const int o = idx / PW, i = idx - o * PW;
-                    v[u] = (idx < WP * PW && o < w && i < w) ? Wl[o * w + i] : 0.0f;
+                    v[u] = (idx < WP * PW && sl(o) < w && i < WP && sl(i) < w) ? Wl[sl(o) * w + sl(i)] : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -299,7 +309,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         const float* __restrict__ Wo = P + w * d + w + (Ld - 1) * (w * w + w);
         for (int idx = tid; idx < 2 * WP; idx += 512) {
             const int c = idx / WP, i = idx - c * WP;
-            sWo[idx] = (i < w && !no_head) ? Wo[c * w + i] : 0.0f;
+            sWo[idx] = (sl(i) < w && !no_head) ? Wo[c * w + sl(i)] : 0.0f;
         }
         if (tid < 4) sBo[tid] = (tid < 2 && !no_head) ? Wo[2 * w + tid] : 0.0f;
     }
@@ -331,6 +341,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 
     const int ntiles = A.n_pad / CL_TILE;
     const int S = A.S;
+    // MFMA steps of a hidden layer's forward / dgrad that hold real features: a template parameter, because a run-time test around
+    // single MFMAs costs more than the skipped ones save (-8 % against +10 %)
+    constexpr int ks = KPERM ? KS : 4;     // MFMA steps of a hidden layer's forward / dgrad that hold real features
 #ifdef CL_STAMPS
     unsigned long long st_acc[CL_NPH];
 #pragma unroll
@@ -429,8 +442,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         for (int t = 0; t < 4; ++t) {
                             const int o = 16 * ob + 4 * q + t;
                             const float g = in_lds ? acc_slot(l)[t] : wacc[l < LREG ? l : 0][b][t];
-                            if (o < w && i < w) atomicAdd(gW + o * w + i, g);
-                            if (BONE && o < w && i == 15) atomicAdd(gB + o, g);
+                            if (sl(o) < w && sl(i) < w) atomicAdd(gW + sl(o) * w + sl(i), g);
+                            if (BONE && sl(o) < w && i == 15) atomicAdd(gB + sl(o), g);
                             if (!in_lds) wacc[l < LREG ? l : 0][b][t] = 0.0f;
                         }
                         if (in_lds) acc_slot(l) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -448,9 +461,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             float* dst = sW + (l - 1) * WP * PW;
             for (int idx = tid; idx < WP * PW; idx += 512) {
                 const int o = idx / PW, i = idx - o * PW;
-                dst[idx] = (o < w && i < w) ? Wg[o * w + i] : 0.0f;
+                dst[idx] = (sl(o) < w && i < WP && sl(i) < w) ? Wg[sl(o) * w + sl(i)] : 0.0f;
             }
-            if (tid < WP) sB[l * WP + tid] = (tid < w) ? Bg[tid] : ((BONE && tid == 15) ? 1.0f : 0.0f);
+            if (tid < WP) sB[l * WP + tid] = (sl(tid) < w) ? Bg[sl(tid)] : ((BONE && tid == 15) ? 1.0f : 0.0f);
         }
     };
 
@@ -552,7 +565,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             CL_SCHED_FENCE();
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                acc0 = mfma4(oa[kb & 1][t], hs[l > 0 ? l - 1 : 0][kb][t], acc0);
+                                if (!KPERM || t < ks) acc0 = mfma4(oa[kb & 1][t], hs[l > 0 ? l - 1 : 0][kb][t], acc0);
                                 if (MBS == 2) acc1 = mfma4(ob[kb & 1][t], hs[l > 0 ? l - 1 : 0][kb][t], acc1);
                             }
                             CL_SCHED_FENCE();
@@ -603,7 +616,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         for (int mb = 0; mb < FB; ++mb)
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                const int f = 16 * mb + 4 * q + t;
+                                const int f = sl(16 * mb + 4 * q + t);
                                 if (f < ((w + 3) & ~3)) A.act_out[(size_t)f * A.n_pad + gobs] = (BONE && f >= w) ? 0.0f : hs[l][mb][t];
                             }
                     }
@@ -787,7 +800,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 for (int mb = 0; mb < FB; ++mb)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int f = 16 * mb + 4 * q + t;
+                        const int f = sl(16 * mb + 4 * q + t);
                         dH[mb][t] = (valid && f < ((w + 3) & ~3)) ? A.dH_ext[(size_t)f * A.n_pad + gobs] : 0.0f;
                     }
             } else if (l == Lt - 1) {
@@ -849,7 +862,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 f32x4 accw = LP_LDS ? pacc : wacc[LP < LREG ? LP : 0][0];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    accd = mfma4(rw[t], dH[0][t], accd);                               // dgrad of layer l
+                    if (!KPERM || t < ks) accd = mfma4(rw[t], dH[0][t], accd);         // dgrad of layer l (steps with features < w only)
                     if (l + 1 < LMAX) accw = mfma4(pa4[t], pb4[t], accw);              // wgrad of layer l+1 (operands from last iteration)
                     stz[t * PB] = dH[0][t];                                            // staging: dZ_l and H_{l-1}, this wave's columns
                     sth[t * PB] = hs[l > 0 ? l - 1 : 0][0][t];
@@ -1128,16 +1141,17 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
                     for (int b = 0; b < WB; ++b) {
                         if (b < BPW) {
-                            const int i = 16 * (ib0 + b) + j;
+                            const int islot = 16 * (ib0 + b) + j;
+                            const int i = (l == 0) ? islot : sl(islot);        // input feature: metadata column, or hidden feature of a slot
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                const int o = 16 * ob + 4 * q + t;
+                                const int o = sl(16 * ob + 4 * q + t);
                                 if (o < w && i < in_dim) {
                                     float* dst = smem + offW + o * in_dim + i;
                                     const float g = (AP::NACC > 0 && l >= LREG) ? acc_slot(l)[t] : wacc[l < LREG ? l : 0][b][t];
                                     *dst = (pass == 0) ? g : *dst + g;
                                 }
-                                if (BONE && l > 0 && o < w && i == 15) {          // the bias gradient rides in column 15
+                                if (BONE && l > 0 && o < w && islot == 15) {      // the bias gradient rides in column (slot) 15
                                     float* dst = smem + offW + w * in_dim + o;
                                     const float g = (AP::NACC > 0 && l >= LREG) ? acc_slot(l)[t] : wacc[l < LREG ? l : 0][b][t];
                                     *dst = (pass == 0) ? g : *dst + g;
@@ -1168,13 +1182,13 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
         for (int k = 0; k < CL_NW; ++k) t += scr[k * SCRW + idx];
         if (idx < LMAX * WP) {
-            const int l = idx / WP, o = idx - l * WP;
+            const int l = idx / WP, o = sl(idx - l * WP);           // row (slot) of the scratch image -> hidden feature
             if (l < Ld && o < w && !(BONE && l > 0))
                 smem[((l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w))) + w * ((l == 0) ? d : w) + o] = t;
         } else if (!no_head) {
             const int r = idx - LMAX * WP;
-            if (r < WP) { if (r < w) smem[offWo + r] = t; }
-            else if (r < 2 * WP) { if (r - WP < w) smem[offWo + w + (r - WP)] = t; }
+            if (r < WP) { if (sl(r) < w) smem[offWo + sl(r)] = t; }
+            else if (r < 2 * WP) { if (sl(r - WP) < w) smem[offWo + w + sl(r - WP)] = t; }
             else smem[offWo + 2 * w + (r - 2 * WP)] = t;
         }
     }
@@ -1248,7 +1262,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 #define CL_CHAIN 0
 #endif
 
-template <int WP, int DP, int LMAX, int MODE>
+template <int WP, int DP, int LMAX, int MODE, int KS = 4>
 static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SL = SmemLayout<WP, DP, LMAX>;
     const size_t sm_tiles = (size_t)SL::total * sizeof(float);
@@ -1259,7 +1273,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     using AP = AccPlan<WP, DP, LMAX, MODE, (CL_IMGL == 1)>;
     if (AP::NACC > 0) sm = (size_t)AP::total * sizeof(float);                                       // + LDS-resident accumulators
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0), (CL_IMGL == 1)>;
+    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0), (CL_IMGL == 1), KS>;
     // largest dynamic-LDS size this instance has been configured for (one process drives one device; host threads may race here:
     // setting the attribute twice is harmless, publishing a size that was not set is not, hence set first, then raise the mark)
     static std::atomic<size_t> configured{0};
@@ -1276,20 +1290,26 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 
 // Instantiated geometries: the padded width WP fixes how many layers of activations + weight-gradient blocks fit in the
 // 256-register budget of a wave: w <= 15 -> up to 20 layers (the CLI default scaler is 20 x 10), w <= 32 -> 10, w <= 64 -> 5.
-template <int WP, int LMAX, int MODE>
+template <int WP, int LMAX, int MODE, int KS = 4>
 static int launch_dp(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.L + (CL_IMGL == 1 ? a.n_imgl : 0) > LMAX) return -2;
     const int dp = (a.d <= 8) ? 8 : (a.d <= 32 ? 32 : 64);
-    if (dp == 8) return launch_one<WP, 8, LMAX, MODE>(a, grid, st);
-    if (dp == 32) return launch_one<WP, 32, LMAX, MODE>(a, grid, st);
-    return launch_one<WP, 64, LMAX, MODE>(a, grid, st);
+    if (dp == 8) return launch_one<WP, 8, LMAX, MODE, KS>(a, grid, st);
+    if (dp == 32) return launch_one<WP, 32, LMAX, MODE, KS>(a, grid, st);
+    return launch_one<WP, 64, LMAX, MODE, KS>(a, grid, st);
 }
 
 template <int MODE>
 static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.L < 1 || a.w < 1 || a.d < 1) return -2;
     if (a.w > 64 || a.d > 64) return -2;
-    if (a.w <= 15) return launch_dp<16, (CL_IMGL == 1 ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16), MODE>(a, grid, st);
+    if (a.w <= 15) {
+        // the narrow instance comes in three step counts (hidden width <= 8, <= 12, <= 15); the forward-only launch keeps all four
+        constexpr int L16 = (CL_IMGL == 1 ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16);
+        if (MODE != 1 && CL_KPERM && a.w <= 8) return launch_dp<16, L16, MODE, 2>(a, grid, st);
+        if (MODE != 1 && CL_KPERM && a.w <= 12) return launch_dp<16, L16, MODE, 3>(a, grid, st);
+        return launch_dp<16, L16, MODE, 4>(a, grid, st);
+    }
     if (a.w <= 32) return (a.L + (CL_IMGL == 1 ? a.n_imgl : 0) <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }

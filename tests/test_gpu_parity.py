@@ -29,6 +29,12 @@ CASES = {
     "mlp14x15_d21_S3": dict(N=700, R=30, d0=5, posenc=True, L=14, w=15, S=3, perturb=0.02, grid=2),
     "mlp2x32_S12_studentt": dict(N=300, R=40, d0=5, L=2, w=32, S=12, likelihood="studentt", dof=8.0),       # more than 8 MC samples
     "laue_2x32_S11": dict(N=400, R=40, L=2, w=32, S=11, laue=True),
+    # narrow instance, all three MFMA-step counts (hidden width <= 8 / <= 12 / <= 15)
+    "mlp9x7_d6_S2": dict(N=700, R=40, d0=6, L=9, w=7, S=2, perturb=0.03, grid=2),
+    "mlp7x12_S3_studentt": dict(N=500, R=40, d0=5, L=7, w=12, S=3, likelihood="studentt", dof=6.0, perturb=0.03),
+    "mlp5x13_softplus": dict(N=400, R=30, d0=5, L=5, w=13, S=2, bijector="softplus", shift=1.5, perturb=0.03),
+    "image_layers2_3x8": dict(N=800, R=40, d0=5, L=3, w=8, S=2, n_images=5, image_layers=2, perturb=0.03),
+    "laue_two_pass_narrow_8x5": dict(N=500, R=40, L=8, w=5, S=2, laue=True, two_pass=True, perturb=0.03),
     "mlp8x24_S2_studentt": dict(N=300, R=30, d0=5, L=8, w=24, S=2, likelihood="studentt", dof=4.0, perturb=0.03),
     "mlp12x16_d21_S3": dict(N=260, R=30, d0=5, posenc=True, L=12, w=16, S=3, perturb=0.02),
     "ev11_normal_2x32_S3": dict(N=400, R=40, d0=5, L=2, w=32, S=3, ev11=True),
