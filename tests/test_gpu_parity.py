@@ -167,13 +167,16 @@ def test_refl_gather_is_bit_exact():
     assert np.array_equal(ipred, expect * np.float32(1.0))
 
 
-def test_adam_trajectory_matches_oracle():
-    kw = dict(N=384, R=48, d0=5, L=2, w=32, S=2)
+@pytest.mark.parametrize("L,w", [(2, 32), (20, 10)], ids=["2x32", "cli_default_20x10"])
+def test_adam_trajectory_matches_oracle(L, w):
+    """20 Adam steps on injected noise: history and final parameters follow the oracle; also for the CLI-default geometry, which
+    runs on the narrow instance (permuted features, LDS-resident accumulators, bias gradient in column 15)"""
+    kw = dict(N=384, R=48, d0=5, L=L, w=w, S=2)
     data, cfg, params, x, u_f0, eta0 = util.make_problem(**kw)
     steps = 20
     rng = np.random.default_rng(11)
     noises = [(rng.random((2, 48)).astype(np.float32), rng.normal(size=(2, 384)).astype(np.float32)) for _ in range(steps)]
-    model = util.build_model(data, cfg, params, 2, 32)
+    model = util.build_model(data, cfg, params, L, w)
     hist = model.train_model(util.reference_inputs(data), steps, progress=False, noise=lambda i: noises[i])
     p = params.clone()
     st = O.AdamState.zeros_like(p.tensors())
