@@ -502,8 +502,9 @@ def test_validation_nll_matches_oracle_scale():
                                 dict(N=500, R=60, d0=5, L=2, w=32, S=2, double_wilson=True),
                                 dict(N=700, R=40, d0=5, L=2, w=32, S=2, n_images=5, image_layers=1),
                                 dict(N=600, R=40, d0=5, L=12, w=32, S=2),
-                                dict(N=600, R=50, L=2, w=32, S=2, laue=True, image_layers=1, n_images=4)],
-                         ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers"])
+                                dict(N=600, R=50, L=2, w=32, S=2, laue=True, image_layers=1, n_images=4),
+                                dict(N=900, R=40, d0=5, L=20, w=10, S=2, perturb=0.02)],
+                         ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers", "cli_default_20x10"])
 def test_rank_shards_sum_to_full_batch_on_gpu(kw):
     """Data-parallel decomposition on ONE GPU: the engines of rank 0 and rank 1 of a 2-rank world (all-reduce skipped) produce
     partial losses / gradients that add up to the single-rank result; in-kernel noise is keyed by global indices, so the shards
@@ -531,3 +532,32 @@ def test_rank_shards_sum_to_full_batch_on_gpu(kw):
         nll += t["nll"]; kl += t["kl"]
     assert abs(nll - t_full["nll"]) <= 1e-5 * abs(t_full["nll"]) and abs(kl - t_full["kl"]) <= 1e-5 * max(abs(t_full["kl"]), 1.0)
     assert util.rel_err(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 2e-5
+
+
+def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch():
+    """1 M observations on the careless CLI's default scaler (20 x 10: the narrow kernel instance), in-kernel noise: the eight
+    rank shards of an 8-GPU job, run one after the other on this GPU without the all-reduce, add up to the single-GPU step --
+    a size-independent property (every workgroup walks dozens of tiles, the accumulators carry over in registers and LDS)."""
+    from careless_amd.engine import ElboEngine, make_shard
+    from careless_amd.workloads import make_workload
+    model, inputs, data, spec = make_workload("mono_10M_cli_default_20x10_S1", N=1_000_000)
+    n, r = 1_000_000, int(model.surrogate_posterior.loc_raw.numel())
+    full = ElboEngine(model, inputs, seed=7)
+    full.forward_backward(1)
+    torch.cuda.synchronize()
+    g_full, t_full = full.grads.clone(), full.loss_terms()
+    g_sum, nll, kl = torch.zeros_like(g_full), 0.0, 0.0
+    for rank in range(8):
+        eng = ElboEngine(model, inputs, seed=7, shard=make_shard(n, r, rank, 8))
+        eng.local_only = True
+        eng.forward_backward(1)
+        torch.cuda.synchronize()
+        g_sum += eng.grads
+        t = eng.loss_terms()
+        nll += t["nll"]; kl += t["kl"]
+        del eng
+    assert abs(nll - t_full["nll"]) <= 1e-6 * abs(t_full["nll"]) and abs(kl - t_full["kl"]) <= 1e-6 * max(abs(t_full["kl"]), 1.0)
+    lay = full.layout
+    for lo, hi in zip(lay.seg_off[:-1], lay.seg_off[1:]):                      # per trainable tensor (fp32 atomics: summation order only)
+        a, b = g_sum[lo:hi], g_full[lo:hi]
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6), (lo, hi)
