@@ -289,7 +289,11 @@ int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, d
 int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
     if (a.n <= 0) return -1;
     int grid = (a.n + 255) / 256;
-    if (grid > 256) grid = 256;   // two same-address fp64 atomics per workgroup (fused gradient norm): 18.5 -> 15.6 us against 512
+    // two same-address fp64 atomics per workgroup (fused gradient norm), ~12 ns each and serialised: few workgroups for the usual
+    // ~1e6 parameters (18.5 -> 15.6 us against 512), more when the vector is long enough for streaming to dominate (per-image
+    // layers: 4e7 parameters)
+    const int cap = (a.n >= (1 << 22)) ? 1024 : 256;
+    if (grid > cap) grid = cap;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, a);
     return (int)hipGetLastError();
