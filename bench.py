@@ -7,7 +7,12 @@ One "step" = one full-batch ELBO step (forward + backward + gradient norm + Adam
 workload -- what the reference runs per iteration of `train_model` (careless/models/merging/variational.py:255-256).
 Workload at every N: BASELINE.json configs[2] (10 M observations, Student-T likelihood, positional-encoding metadata,
 5x64 scaler, mc-samples 8), observations sharded over the ranks (strong scaling), one all-reduce of the flat gradient.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line (rank 0).
+
+Ranks: one process per GPU.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks exist already
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment).  A bare `python bench.py --gpus N` starts them itself: the parent
+process -- which never touches the GPU, before or after -- spawns N fresh children with that environment, relays rank 0's
+JSON line and exits non-zero if any rank fails or if the world that came up is not N.
 """
 from __future__ import annotations
 
@@ -19,25 +24,102 @@ import time
 
 import numpy as np
 
+HEADLINE = "mono_10M_studentt_posenc_5x64_S8"
+# BASELINE.json quotes configs[3] on 4 GPUs and configs[4] on 8: measured after the headline line when that many ranks are up
+EXTRA_AT = {4: "laue_5M_normal_5x64_S1", 8: "dw_50M_normal_5x64_S1"}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="mono_10M_studentt_posenc_5x64_S8")
+    ap.add_argument("--workload", default=HEADLINE)
     ap.add_argument("--nobs", type=int, default=None, help="override the number of observations (debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gradient all-reduce even with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank "
                                                       "control flow on a single-GPU box)")
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="observations of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline at the workload's full size, 5 timed steps (SURVEY 8d; "
+                                                            "takes minutes and tens of GB of host memory)")
+    ap.add_argument("--extra", default="auto", help="'auto': with 4 (8) ranks also time the Laue (double-Wilson) configuration "
+                                                    "BASELINE.json quotes on 4 (8) GPUs and report it under 'extra_configs'; 'none'; or a workload name")
     ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: run rank 0's shard of a W-rank job on this one GPU "
                                                              "(per-rank step time of the strong-scaling runs; not a bench line)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(workload: str, n_sample: int):
+# ----------------------------------------------------------------------------------------------------------------------------
+# launcher: parent of the N rank processes (no torch.cuda / HIP call in this process, ever)
+# ----------------------------------------------------------------------------------------------------------------------------
+def launch(args, argv, script=None) -> int:
+    """`script`: the program every rank runs (this file; the launcher's unit test passes a CPU stand-in)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        # rank 0's stdout carries the JSON line; the other ranks' stdout goes to our stderr so nothing can interleave with it
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        time.sleep(0.2)
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = (r, p.returncode)
+    if failed is not None:                       # the others may be waiting for the dead rank inside a collective
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}", file=sys.stderr)
+        return 1
+    reader.join(timeout=30)
+    out = None
+    for ln in lines:
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                out = json.loads(ln)
+            except ValueError:
+                pass
+    if out is None:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    if out.get("n_gpus") != n or out.get("ranks_seen") != n:
+        print(f"bench.py: asked for {n} ranks, the job saw {out.get('ranks_seen')}", file=sys.stderr)
+        return 1
+    print(json.dumps(out), flush=True)
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(workload: str, n_sample: int, steps: int, full: bool = False):
     """The oracle (fp32 PyTorch-CPU restatement of the reference graph -- NOT TensorFlow) timed on this box's host
     cores on a bounded sample of the same workload.  Reported beside the GPU number, never the thing shipped."""
     import torch
@@ -48,34 +130,54 @@ def cpu_baseline(workload: str, n_sample: int):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    data = O.make_synthetic(n_sample, d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"])
-    cfg = O.ElboConfig(mc_samples=spec["S"], likelihood="normal" if spec["dof"] is None else "studentt", dof=spec["dof"])
     dt = torch.float32
-    x = O.inputs_from_numpy(data, dtype=dt)
-    p = O.init_params(data, cfg, spec["L"], spec["w"], dtype=dt)
-    st = O.AdamState.zeros_like(p.tensors())
-    g = torch.Generator().manual_seed(0)
-    R, S = int(data["n_refl"]), spec["S"]
-    def one_step():
-        u = torch.rand(S, R, generator=g, dtype=dt).clamp(1e-6, 1 - 1e-6)
-        eta = torch.randn(S, n_sample, generator=g, dtype=dt)
-        t0 = time.perf_counter()
-        O.train_step(p, x, cfg, st, u, eta)
-        return time.perf_counter() - t0
+    cfg = O.ElboConfig(mc_samples=spec["S"], likelihood="normal" if spec["dof"] is None else "studentt", dof=spec["dof"])
+    S = spec["S"]
 
-    # be fair to the CPU: more threads than physical cores (or than the cgroup grants) only slows torch down, so try
-    # a few thread counts on one step each and keep the fastest for the timed run
+    def problem(n):
+        data = O.make_synthetic(n, d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"])
+        x = O.inputs_from_numpy(data, dtype=dt)
+        p = O.init_params(data, cfg, spec["L"], spec["w"], dtype=dt)
+        st = O.AdamState.zeros_like(p.tensors())
+        g = torch.Generator().manual_seed(0)
+        R = int(data["n_refl"])
+
+        def one_step():
+            u = torch.rand(S, R, generator=g, dtype=dt).clamp(1e-6, 1 - 1e-6)
+            eta = torch.randn(S, n, generator=g, dtype=dt)
+            t0 = time.perf_counter()
+            O.train_step(p, x, cfg, st, u, eta)
+            return time.perf_counter() - t0
+        return one_step
+
+    # thread count: more torch threads than physical cores (or than the cgroup grants) only slows the CPU path down.  Picked
+    # on a small separate problem, outside the timed run
+    probe = problem(100_000)
     best, cores = None, avail
     for nt in sorted({avail, min(avail, 64), min(avail, 32), min(avail, 16)}, reverse=True):
         torch.set_num_threads(nt)
-        one_step()
-        tt = one_step()
+        probe()
+        tt = probe()
         if best is None or tt < best:
             best, cores = tt, nt
+    del probe
     torch.set_num_threads(cores)
-    t = float(np.median([one_step() for _ in range(3)]))
-    return {"value": n_sample / t, "unit": "reflections/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} observations of the same workload, median of 3 steps after warm-up, {cores} torch threads (best of a small sweep), "
+    if full:
+        n_sample, steps = spec["N"], max(5, steps)
+        # autograd keeps ~(2 L w + 14 S) fp32 values per observation alive; stay inside the host's free memory
+        per_obs = 4 * (3 * spec["L"] * spec["w"] + 24 * S)
+        try:
+            free = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
+            n_sample = int(min(n_sample, 0.6 * free / per_obs))
+        except Exception:
+            pass
+    step = problem(n_sample)
+    step()                                            # warm-up (allocator, thread pool)
+    times = [step() for _ in range(steps)]
+    t = float(np.median(times))
+    return {"value": n_sample / t, "unit": "reflections/s", "cores": cores, "kind": "port", "seconds_per_step": t, "n_obs": n_sample,
+            "sample": f"{n_sample} observations of the same workload ({'full size' if n_sample == spec['N'] else 'bounded sample'}), median of "
+                      f"{steps} steps after one warm-up step, {cores} torch threads (picked on a separate 100k problem), "
                       f"fp32 PyTorch-CPU restatement of the reference graph (not TensorFlow), torch {torch.__version__}"}
 
 
@@ -92,40 +194,22 @@ def traffic_bytes(workload: str, world: int):
     return None
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
+# ----------------------------------------------------------------------------------------------------------------------------
+# one timed workload on the ranks that are up
+# ----------------------------------------------------------------------------------------------------------------------------
+def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     import torch
     import torch.distributed as dist
-    from careless_amd.workloads import flops_per_obs, bytes_per_obs, make_workload
+    from careless_amd.workloads import bytes_per_obs, flops_per_obs, make_workload
 
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        # RCCL writes its NCCL_DEBUG chatter (version banner, warnings) to stdout through C stdio, where it interleaves with
-        # the JSON line: send it to a file instead
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
-    model, inputs, data, spec = make_workload(args.workload, N=args.nobs)
+    model, inputs, data, spec = make_workload(name, N=nobs)
     if args.sim_world > 1:
         model.set_data_parallel(0, args.sim_world)
     elif use_dist:
         model.set_data_parallel(rank, world)
     eng = model.engine(inputs)
     eng.force_allreduce = bool(args.force_dist)
-    steps_total = args.warmup + args.steps
+    steps_total = warmup + steps
     eng.alloc_history(steps_total)
 
     def sync():
@@ -134,14 +218,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         eng.train_step(i)
     sync()
-    # the dominant kernel is timed live with events on the stream it is launched on (torch's current stream)
-    # the fused scaler kernel: one launch per step (mono), or forward + backward launches around the harmonic sums (Laue)
+    # the dominant kernel is timed live with events on the stream it is launched on (torch's current stream):
+    # the fused scaler kernel, one launch per step (mono, single-pass Laue), or forward + backward launches around the
+    # harmonic sums (two-pass Laue fallback)
     timed_names = ("cl_elbo_mono_fwd_bwd", "cl_mlp_forward", "cl_mlp_backward_ext")
-    # (Laue: one launch on the single-pass path, forward + backward launches on the two-pass fallback)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps * 2)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps * 2)]
     slot = {"i": 0}
 
     def timed(fn):
@@ -164,49 +248,108 @@ def main():
     real_lib = eng.lib
     eng.lib = _LibProxy(real_lib)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.train_step(args.warmup + i)
+    for i in range(steps):
+        eng.train_step(warmup + i)
     sync()
     t1 = time.perf_counter()
     eng.lib = real_lib
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    per_rank = torch.tensor([float(eng.N)], dtype=torch.float64, device="cuda")
+    obs_per_rank = [int(eng.N)]
     if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(gathered, per_rank)
+        obs_per_rank = [int(g.item()) for g in gathered]
     elapsed = float(elapsed.item())
-    kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev[:slot["i"]]])) / args.steps        # fused-kernel time per step
-    launches_per_step = slot["i"] // args.steps
+    kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev[:slot["i"]]])) / steps        # fused-kernel time per step
+    launches_per_step = slot["i"] // steps
     hist = eng.read_history(steps_total)
     finite = bool(np.all(np.isfinite(hist["loss"]))) and len(hist["loss"]) == steps_total
+    if rank != 0:
+        return None
+    N = spec["N"]
+    ms = 1e3 * elapsed / steps
+    F = flops_per_obs(spec["d"], spec["w"], spec["L"], spec.get("image_layers", 0))
+    B = bytes_per_obs(spec["d"], spec["S"])
+    achieved = F * eng.N / (kern_ms * 1e-3) / 1e12
+    achieved_step = F * eng.N / (ms * 1e-3) / 1e12         # SURVEY 8d defines `achieved` on the whole step time
+    return {
+        "value": N / (elapsed / steps), "ms_per_step": ms, "spec": spec,
+        "config": {"workload": name, "n_obs": N, "n_refl": spec["R"], "n_images": spec["M"],
+                   "metadata_width": spec["d"], "mlp": f"{spec['L']}x{spec['w']}", "mc_samples": spec["S"],
+                   "likelihood": "normal" if spec["dof"] is None else f"studentt(dof={spec['dof']})",
+                   "prior": "double-wilson (2 ASUs, r=0.9)" if spec.get("kind") == "double_wilson" else "wilson",
+                   "kind": spec.get("kind", "mono"), "image_scales": spec.get("image_layers", 0) == 0,
+                   "image_layers": spec.get("image_layers", 0), "noise": "in-kernel philox",
+                   "parallelism": f"obs-shard x{world}" if world > 1 else "single",
+                   "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
+        "roofline": {"bound": "mfma", "kernel": "elbo_mlp_kernel (" + ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd") + ")",
+                     "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                     "traffic": traffic_bytes(name, world), "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
+                     "achieved_on_step_time": achieved_step, "frac_on_step_time": achieved_step / 157.3,
+                     "hbm_secondary": {"achieved_GBps": B * eng.N / (kern_ms * 1e-3) / 1e9, "bytes_per_obs": B}},
+        "obs_per_rank": obs_per_rank,
+    }
+
+
+def worker(args) -> int:
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    ndev = torch.cuda.device_count()
+    use_dist = world > 1 or args.force_dist
+    if world > 1 and args.backend == "nccl" and ndev < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, found {ndev} (--backend gloo rehearses the control flow on fewer)")
+    torch.cuda.set_device(local_rank % max(1, ndev))
+    if use_dist:
+        # RCCL writes its NCCL_DEBUG chatter (version banner, warnings) to stdout through C stdio, where it would interleave
+        # with the JSON line: send it to a file instead
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/rccl_bench_%h_%p.log")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    ranks_seen = dist.get_world_size() if use_dist else 1
+
+    res = run_workload(args, args.workload, args.nobs, args.steps, args.warmup, rank, world, use_dist)
+    extra_name = EXTRA_AT.get(world) if args.extra == "auto" else (None if args.extra == "none" else args.extra)
+    if args.workload != HEADLINE or args.nobs is not None or args.sim_world > 1:
+        extra_name = extra_name if args.extra not in ("auto", "none") else None
+    extras = {}
+    if extra_name:
+        try:                                    # never lose the headline line to the extra configuration
+            ex = run_workload(args, extra_name, None, min(args.steps, 10), min(args.warmup, 2), rank, world, use_dist)
+            if ex is not None:
+                extras[extra_name] = {"value": ex["value"], "unit": "reflections/s", "n_gpus": world, "ms_per_step": ex["ms_per_step"],
+                                      "config": ex["config"], "roofline": ex["roofline"], "obs_per_rank": ex["obs_per_rank"]}
+        except Exception as e:                   # noqa: BLE001
+            extras[extra_name] = {"error": repr(e)}
 
     out = None
     if rank == 0:
-        N = spec["N"]
-        ms = 1e3 * elapsed / args.steps
-        F = flops_per_obs(spec["d"], spec["w"], spec["L"], spec.get("image_layers", 0))
-        B = bytes_per_obs(spec["d"], spec["S"])
-        achieved = F * eng.N / (kern_ms * 1e-3) / 1e12
-        out = {
-            "metric": "reflections/sec per ELBO step", "value": N / (elapsed / args.steps), "unit": "reflections/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "n_obs": N, "n_refl": spec["R"], "n_images": spec["M"],
-                       "metadata_width": spec["d"], "mlp": f"{spec['L']}x{spec['w']}", "mc_samples": spec["S"],
-                       "likelihood": "normal" if spec["dof"] is None else f"studentt(dof={spec['dof']})",
-                       "prior": "double-wilson (2 ASUs, r=0.9)" if spec.get("kind") == "double_wilson" else "wilson",
-                       "kind": spec.get("kind", "mono"), "image_scales": spec.get("image_layers", 0) == 0,
-                       "image_layers": spec.get("image_layers", 0), "noise": "in-kernel philox",
-                       "parallelism": f"obs-shard x{world}" if world > 1 else "single",
-                       "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
-            "roofline": {"bound": "mfma", "kernel": "elbo_mlp_kernel (" + ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd") + ")", "achieved": achieved,
-                         "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": traffic_bytes(args.workload, world),
-                         "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
-                         "hbm_secondary": {"achieved_GBps": B * eng.N / (kern_ms * 1e-3) / 1e9, "bytes_per_obs": B}},
-        }
+        spec = res.pop("spec")
+        out = {"metric": "reflections/sec per ELBO step", "value": res["value"], "unit": "reflections/s",
+               "n_gpus": world, "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None),
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": res["config"], "roofline": res["roofline"], "obs_per_rank": res["obs_per_rank"]}
+        if extras:
+            out["extra_configs"] = extras
         if args.sim_world > 1:
             out["diagnostic"] = f"rank 0 shard of a simulated {args.sim_world}-rank job: value is NOT a throughput of this workload"
             out["value"] = None
         if not args.no_cpu_baseline and world == 1 and spec.get("kind", "mono") == "mono" and not spec.get("image_layers"):
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample if args.nobs is None else min(args.cpu_sample, args.nobs),
+                                               args.cpu_steps, args.cpu_full)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -218,7 +361,17 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)          # the ONE JSON line, last on stdout
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    have_ranks = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not have_ranks:
+        return launch(args, argv)
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

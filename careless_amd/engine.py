@@ -10,7 +10,7 @@ Step schedule (all on one HIP stream, no host synchronisation):
 
 HBM layout owned by the engine (see include/careless_hip.h):
     params / m / v / grads : one flat fp32 vector  [ q_loc_raw (R) | q_scale_raw (R) | scaler W^T layout (P) | image scales (M-1) ]
-    workspace              : [ dz_f (R*S) | grads (n) + 4 | scalars (4 doubles) | per-tensor norms ]  -- one memset per step
+    workspace              : [ dz_f (R*S) | grads (n) | scalars (4 doubles) | per-tensor norms ]  -- one memset per step
     observation shard      : refl_id i32, image_id i32, meta_t [d][n_pad], iobs, sig   (immutable)
 PyTorch is used for device memory, streams and torch.distributed only.
 """
@@ -68,7 +68,15 @@ def make_shard(n_obs: int, n_refl: int, rank: int = 0, world: int = 1) -> Shard:
     is counted exactly once after the gradient all-reduce."""
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} outside world of size {world}")
+    from careless_amd.distributed import check_world
+    check_world(n_obs, world)
     per = (n_obs + world - 1) // world
+    if (world - 1) * per >= n_obs:          # ceil-sized chunks would leave the last ranks empty: floor-sized, remainder spread
+        base, extra = divmod(n_obs, world)
+        start = rank * base + min(rank, extra)
+        stop = start + base + (1 if rank < extra else 0)
+        rper = (n_refl + world - 1) // world
+        return Shard(rank, world, start, stop, min(rank * rper, n_refl), min((rank + 1) * rper, n_refl))
     start, stop = min(rank * per, n_obs), min((rank + 1) * per, n_obs)
     rper = (n_refl + world - 1) // world
     return Shard(rank, world, start, stop, min(rank * rper, n_refl), min((rank + 1) * rper, n_refl))
@@ -85,6 +93,8 @@ def laue_group_shard(harmonic_id: np.ndarray, rank: int, world: int):
     cum = np.concatenate([[0], np.cumsum(counts)])
     bounds = [int(np.searchsorted(cum, N * r / world, side="left")) for r in range(world)] + [G]
     bounds = np.clip(bounds, 0, G)
+    if G < world or np.any(np.diff(bounds) <= 0):      # same test on every rank: all raise together, none waits in the collective
+        raise ValueError(f"cannot shard {G} harmonic groups over {world} ranks: every rank needs at least one whole group")
     g0, g1 = int(bounds[rank]), int(bounds[rank + 1])
     pads = [int(cum[bounds[r + 1]] - cum[bounds[r]]) - int(bounds[r + 1] - bounds[r]) for r in range(world)]
     pad0 = G + int(sum(pads[:rank]))
@@ -523,8 +533,7 @@ class ElboEngine:
         tot = o_seg + 2 * self.nseg
         self.ws = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.dz_f = self.ws[o_dz:o_dz + RS]
-        self.grads_ext = self.ws[o_g:o_g + lay.n + 4]   # gradient + [nll, kl] tail for the all-reduce
-        self.grads = self.grads_ext[: lay.n]
+        self.grads = self.ws[o_g:o_g + lay.n]
         self.scalars = self.ws[o_sc:o_sc + 8].view(torch.float64)
         self.seg_sq = self.ws[o_seg:o_seg + 2 * self.nseg].view(torch.float64)
         self.z_f = torch.empty(RS, dtype=torch.float32, device=dev)
@@ -634,7 +643,7 @@ class ElboEngine:
         a.lik_kind, a.dof, a.lik_const = self.lik_kind, self.dof, self.lik_const
         a.bij_kind, a.eps = self.bij_kind, self.mlp.epsilon
         a.shift = self.mlp.scale_multiplier or 0.0
-        a.w_ll = self.w_ll
+        a.w_ll = self._w_ll(obs)
         a.eta = ptr(eta)
         a.seed, a.step = self.seed, step & 0xFFFFFFFF
         a.dz_f = ptr(self.dz_f)
@@ -648,18 +657,24 @@ class ElboEngine:
             a.d_ev11 = self.grads.data_ptr() + 4 * lay.off_ev11
         return a
 
-    def _noise_to_device(self, u_f, eta):
+    def _w_ll(self, obs: ObsData) -> float:
+        """Weight of one log-likelihood term: sum / S, or with `kl_weight` the mean over the S x N terms of the observation set
+        the model is called on (reference variational.py:172-177) -- the validation set's own N for `NLL_val` (:257-260)."""
+        return 1.0 / self.S if self.model.kl_weight is None else 1.0 / (self.S * obs.N_total)
+
+    def _noise_to_device(self, u_f, eta, obs: Optional[ObsData] = None):
         """Injected noise arrives in the reference's (S, R) / (S, N_total) orientation; device layout is [R][S] / [N][S]."""
+        obs = self.obs if obs is None else obs
         du = de = None
         if u_f is not None:
             u = torch.as_tensor(_np(u_f), dtype=torch.float32).reshape(self.S, self.R)
             du = u.t().contiguous().to(self.device)
         if eta is not None:
-            e = torch.as_tensor(_np(eta), dtype=torch.float32).reshape(self.S, self.N_total)
-            if self.obs.rows is not None:
-                de = e[:, torch.as_tensor(self.obs.rows)].t().contiguous().to(self.device)
+            e = torch.as_tensor(_np(eta), dtype=torch.float32).reshape(self.S, obs.N_total)
+            if obs.rows is not None:
+                de = e[:, torch.as_tensor(obs.rows)].t().contiguous().to(self.device)
             else:
-                de = e[:, self.shard.start:self.shard.stop].t().contiguous().to(self.device)
+                de = e[:, obs.start:obs.start + obs.N].t().contiguous().to(self.device)
         return du, de
 
     # ------------------------------------------------------------------------------------------------------
@@ -694,7 +709,7 @@ class ElboEngine:
                 la.iobs, la.sig, la.iconv = ptr(obs.pad_iobs), ptr(obs.pad_sig), ptr(obs.pad_iconv)
                 la.n_obs, la.S = npad, self.S
                 la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
-                la.w_ll = self.w_ll
+                la.w_ll = ma.w_ll
                 la.scalars, la.stop_flag = ptr(self.scalars), ptr(self.stop_flag)
                 la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
                 check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
@@ -741,15 +756,16 @@ class ElboEngine:
             check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, self.blocks[k].P, gptr(k), ptr(self.stop_flag), st),
                   "cl_reduce_partials")
 
-    def evaluate_nll(self, obs: ObsData, key: int) -> float:
+    def evaluate_nll(self, obs: ObsData, key: int, u_f=None, eta=None) -> float:
         """NLL of another observation set under the current parameters with fresh Monte-Carlo noise -- what
-        `model.test_on_batch(validation_data)` reports as "NLL" (reference variational.py:257-260).  Uses the step workspace
-        (call it between steps); synchronises."""
+        `model.test_on_batch(validation_data)` reports as "NLL" (reference variational.py:257-260).  `u_f` (S, R) / `eta`
+        (S, N_val) inject the noise (parity tests).  Uses the step workspace (call it between steps); synchronises."""
         lib, st = self.lib, _stream()
+        u_f, eta = self._noise_to_device(u_f, eta, obs)
         self.ws.zero_()
-        tn = self._tn_args(key, None)
+        tn = self._tn_args(key, u_f)
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
-        self._data_term(obs, key, None, None, st)
+        self._data_term(obs, key, eta, None, st)
         torch.cuda.synchronize()
         return float(self.scalars[0].item())
 
@@ -780,7 +796,7 @@ class ElboEngine:
         la.img, la.use_img = ma.img, ma.use_img
         la.z_f, la.R, la.S = ptr(self.z_f), self.R, self.S
         la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
-        la.shift, la.w_ll = ma.shift, self.w_ll
+        la.shift, la.w_ll = ma.shift, ma.w_ll
         la.eta = ptr(eta)
         la.seed, la.step = self.seed, step & 0xFFFFFFFF
         la.iconv, la.dz_f, la.d_img, la.dO = ptr(obs.laue_iconv), ptr(self.dz_f), ma.d_img, ptr(obs.laue_dO)
@@ -795,7 +811,7 @@ class ElboEngine:
 
     def _allreduce(self):
         from careless_amd.distributed import allreduce_flat_
-        allreduce_flat_(self.grads_ext, self.scalars, self.layout.n, self.process_group)
+        allreduce_flat_(self.grads, self.process_group)
 
     def optimizer_step(self, step_index: int):
         lib, st, opt = self.lib, _stream(), self.opt
@@ -829,6 +845,7 @@ class ElboEngine:
     def alloc_history(self, steps: int):
         self.history_buf = torch.zeros(max(1, steps) * _lib.CL_HIST_STRIDE, dtype=torch.float64, device=self.device)
         self.stop_flag.zero_()
+        self._hist_reduced = False
         self.rdw_hist = (torch.zeros(max(1, steps), self.layout.n_dwr, dtype=torch.float32, device=self.device)
                          if self.dw_trainable else None)
 
@@ -844,6 +861,11 @@ class ElboEngine:
         """Synchronise and convert the device history to the reference's dict of lists (variational.py:262-268).
         Steps after the first non-finite gradient norm were skipped on the device and are dropped, which reproduces
         the reference's early `break` (:271-274)."""
+        if self.shard.world > 1 and not getattr(self, "local_only", False) and not self._hist_reduced:
+            self._hist_reduced = True
+            # the records hold this rank's partial NLL / KL: summed over the ranks once, in fp64 (careless_amd/distributed.py)
+            from careless_amd.distributed import allreduce_history_
+            allreduce_history_(self.history_buf, _lib.CL_HIST_STRIDE, self.kl_mult, self.process_group)
         h = self.history_buf.view(-1, _lib.CL_HIST_STRIDE)[:steps].cpu().numpy()
         keep = h[:, 4] == 0.0
         h = h[keep]

@@ -23,13 +23,9 @@ class ConvolvedLikelihood:
     def convolve(self, value):
         """value: (n_predictions,) or (b, n_predictions); duplicates sum, untouched slots stay 0 (scatter_nd)."""
         value = np.asarray(value.detach().cpu() if hasattr(value, "detach") else value)
-        out = np.zeros_like(value)
-        if value.ndim == 1:
-            np.add.at(out, self.harmonic_id, value)
-        else:
-            for b in range(value.shape[0]):
-                np.add.at(out[b], self.harmonic_id, value[b])
-        return out
+        rows = value.reshape(-1, value.shape[-1])
+        out = np.stack([np.bincount(self.harmonic_id, weights=r, minlength=r.shape[0]) for r in rows])
+        return out.reshape(value.shape).astype(value.dtype if value.dtype.kind == "f" else np.float64)
 
     def mean(self, *args, **kwargs):
         return self.distribution.mean(*args, **kwargs)

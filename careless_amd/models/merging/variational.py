@@ -82,11 +82,12 @@ class VariationalMergingModel(BaseModel):
     # -- training ------------------------------------------------------------------------------------------
     def train_model(self, data, steps, message=None, format_string="{:0.2e}", validation_data=None,
                     validation_frequency=10, progress=True, use_custom_train_step=True, jit_compile=None,
-                    reduce_retracing=False, noise=None):
+                    reduce_retracing=False, noise=None, validation_noise=None):
         """Full-batch ELBO optimisation for `steps` iterations (reference variational.py:226-275).
 
         `noise`: optional callable step -> (u_f (S,R), eta (S,N)) injecting the Monte-Carlo noise (parity tests);
-        by default the kernels draw it with the counter-based generator keyed by (seed, iteration)."""
+        by default the kernels draw it with the counter-based generator keyed by (seed, iteration).
+        `validation_noise`: the same for the validation pass, eta of shape (S, N_validation)."""
         eng = self.engine(data)
         eng.alloc_history(steps)
         val_obs, val_scale, nll_val, val_hist = None, 1.0, float("nan"), []
@@ -110,7 +111,8 @@ class VariationalMergingModel(BaseModel):
             eng.train_step(i, u_f, eta)
             if val_obs is not None:
                 if i % validation_frequency == 0:             # the stale value is re-logged in between (:257-260)
-                    nll_val = val_scale * eng.evaluate_nll(val_obs, (eng.t & 0x3FFFFFFF) | 0x40000000)
+                    vu, ve = validation_noise(i) if validation_noise is not None else (None, None)
+                    nll_val = val_scale * eng.evaluate_nll(val_obs, (eng.t & 0x3FFFFFFF) | 0x40000000, vu, ve)
                 val_hist.append(nll_val)
             done = i + 1
             if bar is not None:
@@ -127,16 +129,29 @@ class VariationalMergingModel(BaseModel):
         return history
 
     # -- output-step helpers ---------------------------------------------------------------------------------
+    def _convolved(self, inputs):
+        """The likelihood's `convolve` for Laue data, None for monochromatic data (reference variational.py:70-76, 111-119)."""
+        from careless_amd.models.likelihoods.laue import LaueBase
+        if isinstance(self.likelihood, LaueBase):
+            return self.likelihood(inputs).convolve
+        return None
+
     def scale_mean_stddev(self, inputs):
-        """Moments of the posterior scale of every observation (reference variational.py:47-78)."""
+        """Moments of the posterior scale of every observation (reference variational.py:47-78).  Laue data: the moments of the
+        rows of a harmonic group are summed into the group's slot (means add, variances add), slots without rows stay 0."""
         dist = self.scaling_model(inputs)
-        return dist.mean().cpu().numpy(), dist.stddev().cpu().numpy()
+        mean, stddev = dist.mean().cpu().numpy(), dist.stddev().cpu().numpy()
+        convolve = self._convolved(inputs)
+        if convolve is not None:
+            mean = convolve(mean)
+            stddev = np.sqrt(convolve(stddev * stddev))
+        return mean, stddev
 
     def prediction_mean_stddev(self, inputs):
-        """E[I] and sd[I] of every observation under the current model (reference variational.py:80-121)."""
-        refl_id = torch.as_tensor(np.asarray(
-            self.get_refl_id(inputs).cpu() if torch.is_tensor(self.get_refl_id(inputs)) else self.get_refl_id(inputs)
-        ).reshape(-1).astype(np.int64))
+        """E[I] and sd[I] of every observation under the current model (reference variational.py:80-121); for Laue data
+        per harmonic slot: `iexp` and `ivar` of the member rows are summed before the square root (:113-119)."""
+        rid = self.get_refl_id(inputs)
+        refl_id = torch.as_tensor(np.asarray(rid.cpu() if torch.is_tensor(rid) else rid).reshape(-1).astype(np.int64))
         q = self.surrogate_posterior
         dist = self.scaling_model(inputs)
         smean, sstd = dist.mean().double().cpu(), dist.stddev().double().cpu()
@@ -144,5 +159,9 @@ class VariationalMergingModel(BaseModel):
         iexp = smean * f2[refl_id]
         f4 = torch.as_tensor(np.asarray(q.moment_4(method="scipy"), dtype=np.float64))
         s2 = smean ** 2 + sstd ** 2
-        ivar = f4[refl_id] * s2 - iexp * iexp
-        return iexp.numpy().astype(np.float32), np.sqrt(ivar.numpy()).astype(np.float32)
+        ivar = f4[refl_id] * s2 - iexp * iexp              # var(I) = <F^4><Sigma^2> - <I>^2
+        iexp, ivar = iexp.numpy(), ivar.numpy()
+        convolve = self._convolved(inputs)
+        if convolve is not None:
+            iexp, ivar = convolve(iexp), convolve(ivar)
+        return iexp.astype(np.float32), np.sqrt(ivar).astype(np.float32)

@@ -529,6 +529,76 @@ def train_step(p: ElboParams, x: ElboInputs, cfg: ElboConfig, st: AdamState, u_f
 
 
 # --------------------------------------------------------------------------------------------------
+# the output step right after the path  (variational.py:47-121, io/manager.py:188-236)
+# --------------------------------------------------------------------------------------------------
+def _scale_moments(p: ElboParams, x: ElboInputs, cfg: ElboConfig):
+    """mean / stddev of `scaling_model(inputs)`: Normal(loc, sigma) shifted by istd (tfb.Shift, nn.py:84-87) and, with image
+    scales, scaled by a = w[image_id] (tfb.Scale, image.py:60-63) => mean a (loc + shift), stddev |a| sigma [3P]."""
+    out = mlp_forward(x.metadata, p.mlp_w, p.mlp_b, cfg.leakiness, x.image_id, p.imgl_w or (), p.imgl_b or ())
+    mean = out[:, 0] + cfg.scale_shift
+    sd = scale_bijector(out[:, 1], cfg.scale_bijector, cfg.epsilon)
+    if cfg.use_image_scales:
+        a = image_scales(p.img_raw)[x.image_id]
+        mean, sd = a * mean, a.abs() * sd
+    return mean, sd
+
+
+def scale_mean_stddev(p: ElboParams, x: ElboInputs, cfg: ElboConfig):
+    """`VariationalMergingModel.scale_mean_stddev` (variational.py:47-78); Laue: mean and variance convolved (:70-76)."""
+    with torch.no_grad():
+        mean, sd = _scale_moments(p, x, cfg)
+        if cfg.laue:
+            mean = laue_convolve(mean, x.harmonic_id)
+            sd = torch.sqrt(laue_convolve(sd * sd, x.harmonic_id))
+    return mean, sd
+
+
+def prediction_mean_stddev(p: ElboParams, x: ElboInputs, cfg: ElboConfig):
+    """`VariationalMergingModel.prediction_mean_stddev` (variational.py:80-121): <I> = <Sigma><F^2>,
+    var(I) = <F^4><Sigma^2> - <I>^2, <F^4> from `moment_4(method='scipy')` = scipy.stats.truncnorm.moment(4)
+    (surrogate_posteriors.py:75-83; high = inf, :85), Laue: both convolved before the square root (:113-119)."""
+    from scipy.stats import truncnorm
+    with torch.no_grad():
+        loc, scale = tn_loc_scale(p.q_loc_raw, p.q_scale_raw, cfg.epsilon)
+        high = torch.as_tensor(cfg.high, dtype=loc.dtype)
+        smean, ssd = _scale_moments(p, x, cfg)
+        f2 = tn_mean(loc, scale, x.low, high) ** 2 + tn_variance(loc, scale, x.low, high)
+        iexp = smean * f2[x.refl_id]
+        a = ((x.low - loc) / scale).numpy()
+        f4 = torch.as_tensor(truncnorm.moment(4, a, np.inf, loc.numpy(), scale.numpy()))
+        s2 = smean ** 2 + ssd ** 2
+        ivar = f4[x.refl_id] * s2 - iexp * iexp
+        if cfg.laue:
+            iexp, ivar = laue_convolve(iexp, x.harmonic_id), laue_convolve(ivar, x.harmonic_id)
+    return iexp, torch.sqrt(ivar)
+
+
+def merged_results(p: ElboParams, x: ElboInputs, cfg: ElboConfig, max_intensity_snr: float = 1e-5):
+    """`DataManager.get_results` numerics (io/manager.py:188-197): F, SigF = TN mean / stddev, I = SigF^2 + F^2,
+    SigI = sqrt(max((I snr)^2, <F^4> - I^2))."""
+    from scipy.stats import truncnorm
+    with torch.no_grad():
+        loc, scale = tn_loc_scale(p.q_loc_raw, p.q_scale_raw, cfg.epsilon)
+        high = torch.as_tensor(cfg.high, dtype=loc.dtype)
+        F = tn_mean(loc, scale, x.low, high)
+        SigF = torch.sqrt(tn_variance(loc, scale, x.low, high))
+        I = SigF * SigF + F * F
+        a = ((x.low - loc) / scale).numpy()
+        f4 = torch.as_tensor(truncnorm.moment(4, a, np.inf, loc.numpy(), scale.numpy()))
+        SigI = torch.sqrt(torch.maximum((I * max_intensity_snr) ** 2, f4 - I * I))
+    return dict(F=F, SigF=SigF, I=I, SigI=SigI)
+
+
+def validation_nll(p: ElboParams, x_val: ElboInputs, cfg: ElboConfig, u_f, eta, n_train: int):
+    """What `train_model` logs as NLL_val (variational.py:248-260): the "NLL" metric of `test_on_batch(validation_data)`
+    -- `call` on the validation tuple, so with `kl_weight` the mean runs over the VALIDATION observations (:175-177) --
+    times len(train) / len(validation)."""
+    with torch.no_grad():
+        out = elbo_forward(p, x_val, cfg, u_f, eta)
+    return float(out["nll"]) * n_train / int(x_val.refl_id.shape[0])
+
+
+# --------------------------------------------------------------------------------------------------
 # synthetic problems: the deterministic generator of SURVEY 8(d) lives in careless_amd/synthetic.py (plain numpy,
 # no compute path) so that bench.py can build its workload without touching the oracle; re-exported here.
 # --------------------------------------------------------------------------------------------------

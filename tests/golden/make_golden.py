@@ -9,6 +9,7 @@ same file can be replayed through the real reference if a machine with TensorFlo
 
     python tests/golden/make_golden.py
 """
+import json
 import os
 import sys
 
@@ -20,19 +21,7 @@ sys.path.insert(0, ROOT)
 from oracle import elbo_oracle as O  # noqa: E402
 from tests import util  # noqa: E402
 
-CASES = {
-    "mono_2x32_normal_S3": dict(N=256, R=32, d0=5, L=2, w=32, S=3),
-    "mono_5x64_studentt_posenc_S8": dict(N=96, R=12, d0=5, posenc=True, L=5, w=64, S=8, likelihood="studentt", dof=4.0),
-    "mono_3x20_softplus_shift_noimg_S2": dict(N=160, R=20, d0=6, L=3, w=20, S=2, bijector="softplus", shift=3.5,
-                                              use_image_scales=False),
-    "mono_2x16_klweight_S4": dict(N=128, R=16, d0=5, L=2, w=16, S=4, kl_weight=0.5),
-    # cases added later (the four above are frozen as first generated); their files also carry every array of the problem
-    # (`data_*`: harmonic ids, double-Wilson parent lookup, ...) so the loader needs no generator
-    "laue_2x32_normal_S3": dict(N=200, R=24, L=2, w=32, S=3, laue=True),
-    "double_wilson_trainable_r_2x32_S3": dict(N=200, R=30, d0=5, L=2, w=32, S=3, double_wilson=True, optimize_dw_r=True),
-    "ev11_studentt_2x32_S4": dict(N=160, R=20, d0=5, L=2, w=32, S=4, ev11=True, likelihood="studentt", dof=8.0),
-    "image_layers2_2x16_S2": dict(N=300, R=24, d0=5, L=2, w=16, S=2, n_images=3, image_layers=2),
-}
+CASES = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cases.json")))     # shared with scripts/replay_golden_in_reference.py
 FROZEN = ("mono_2x32_normal_S3", "mono_5x64_studentt_posenc_S8", "mono_3x20_softplus_shift_noimg_S2", "mono_2x16_klweight_S4")
 STEPS = 6
 

@@ -22,7 +22,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
-    from careless_amd.distributed import allreduce_flat_
+    from careless_amd.distributed import allreduce_flat_, allreduce_history_
+    from careless_amd._lib import CL_HIST_STRIDE
     from careless_amd.engine import make_shard
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -39,12 +40,16 @@ def _worker(rank, world, port, q):
     u, e = torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta[:, sl], dtype=torch.float64)
     out, grads = O.elbo_value_and_grads(params, xs, cfg, u, e, kl_mask=kl_mask)
     flat = torch.cat([g.reshape(-1) for g in grads]).to(torch.float32)
-    n = flat.numel()
-    ext = torch.cat([flat, torch.zeros(4)])
-    scalars = torch.tensor([float(out["nll"]), float(out["kl"]), 0.0, 0.0], dtype=torch.float64)
-    allreduce_flat_(ext, scalars, n)
+    allreduce_flat_(flat)
+    # the loss terms travel once, in fp64, with the history (three steps' worth of records here; the second one "skipped")
+    stride = CL_HIST_STRIDE
+    hist = torch.zeros(3 * stride, dtype=torch.float64)
+    for i in range(3):
+        hist[i * stride + 1], hist[i * stride + 2] = float(out["kl"]) * (i + 1), float(out["nll"]) * (i + 1)
+    hist[stride + 4] = 1.0
+    allreduce_history_(hist, stride, 0.5)
     if rank == 0:
-        q.put((ext[:n].numpy(), scalars.numpy()))
+        q.put((flat.numpy(), hist.view(3, stride).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +62,7 @@ def test_two_rank_shards_sum_to_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, scalars = q.get(timeout=180)
+    got, hist = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -67,5 +72,27 @@ def test_two_rank_shards_sum_to_full_batch():
                                         torch.as_tensor(eta, dtype=torch.float64))
     full = torch.cat([g.reshape(-1) for g in grads]).numpy()
     assert np.allclose(got, full, rtol=2e-5, atol=1e-6 * np.abs(full).max())
-    assert np.isclose(scalars[0], float(out["nll"]), rtol=1e-6)
-    assert np.isclose(scalars[1], float(out["kl"]), rtol=1e-6)
+    nll, kl = float(out["nll"]), float(out["kl"])
+    for i in (0, 2):                                  # fp64 end to end: the shard sums reproduce the full batch to 1e-12
+        assert np.isclose(hist[i, 2], nll * (i + 1), rtol=1e-12) and np.isclose(hist[i, 1], kl * (i + 1), rtol=1e-12)
+        assert np.isclose(hist[i, 0], (nll + 0.5 * kl) * (i + 1), rtol=1e-12)
+    assert hist[1, 0] == 0.0 and hist[1, 4] == 1.0      # a skipped record keeps its (zero) loss; the flag column is not summed
+
+
+def test_make_shard_never_hands_out_an_empty_range():
+    """Every rank of a data-parallel job owns at least one observation (an idle rank would meet the others only inside the
+    collective); impossible splits raise on every rank alike."""
+    import pytest
+    from careless_amd.engine import laue_group_shard, make_shard
+    for n, world in [(10, 4), (9, 4), (5, 4), (4, 4), (1000003, 8), (17, 16)]:
+        sh = [make_shard(n, 7, r, world) for r in range(world)]
+        assert sh[0].start == 0 and sh[-1].stop == n and all(a.stop == b.start for a, b in zip(sh, sh[1:]))
+        assert all(s.stop > s.start for s in sh)
+        assert sh[0].kl_begin == 0 and sh[-1].kl_end == 7 and all(a.kl_end == b.kl_begin for a, b in zip(sh, sh[1:]))
+    with pytest.raises(ValueError):
+        make_shard(3, 7, 0, 4)
+    hid = np.repeat(np.arange(5), [3, 1, 2, 1, 1])
+    parts = [laue_group_shard(hid, r, 2) for r in range(2)]
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == 5
+    with pytest.raises(ValueError):
+        laue_group_shard(np.zeros(8, dtype=np.int64), 0, 2)          # one group cannot be split over two ranks

@@ -114,9 +114,11 @@ def test_build_model_trains_and_merges_half_datasets():
         assert len(hist["loss"]) == 6 and all(np.isfinite(hist["loss"])) and len(hist["NLL_val"]) == 6
         res = dm.get_results(model.surrogate_posterior, inputs=train)
         assert np.all(np.isfinite(res["F"])) and np.all(res["SigF"] > 0)
-        if not laue:
-            pred = dm.get_predictions(model, inputs=train)
-            assert np.all(np.isfinite(pred["Ipred"])) and np.all(pred["SigIpred"] >= 0) and len(pred["Scale"]) == len(train[0])
+        pred = dm.get_predictions(model, inputs=train)
+        assert np.all(np.isfinite(pred["Ipred"])) and np.all(pred["SigIpred"] >= 0) and len(pred["Scale"]) == len(train[0])
+        if laue:                                   # per harmonic slot (variational.py:70-76, 113-119): slots without rows hold 0
+            G = int(BaseModel.get_harmonic_id(train).max()) + 1
+            assert np.all(pred["Ipred"][:G] > 0) and not pred["Ipred"][G:].any() and not pred["SigScale"][G:].any()
         flat0 = model.scaling_model.mlp_scaler.flat.clone()
         halves = merge_half_datasets(dm, dm.parser, model.scaling_model, iterations=4, repeats=1)
         assert len(halves) == 2 and all(np.all(np.isfinite(r["F"])) for _, _, r in halves)

@@ -212,3 +212,45 @@ def test_positional_encoding_layout():
     ang = np.stack([np.pi * p[:, 0], 2 * np.pi * p[:, 0], np.pi * p[:, 1], 2 * np.pi * p[:, 1]], axis=1)
     assert pe.shape == (3, 8)
     assert np.allclose(pe, np.concatenate([np.cos(ang), np.sin(ang)], axis=1))
+
+
+def test_output_step_restatement_vs_monte_carlo_moments():
+    """oracle `prediction_mean_stddev` / `scale_mean_stddev` (reference variational.py:47-121): the closed-form moments of
+    I = Sigma * F^2 per observation -- and their per-harmonic-slot sums for Laue data -- agree with the sample moments of the
+    oracle's own forward pass (`elbo_forward`'s ipred, which follows variational.py:154-167 + laue.py:20-25 independently)."""
+    from tests import util
+    for laue in (False, True):
+        S = 20000
+        data, cfg, params, x, _, _ = util.make_problem(N=60, R=12, d0=5, L=2, w=16, S=S, laue=laue, perturb=0.02, seed=3)
+        rng = np.random.default_rng(0)
+        u = torch.as_tensor(rng.random((S, 12))); eta = torch.as_tensor(rng.normal(size=(S, 60)))
+        ipred = O.elbo_forward(params, x, cfg, u, eta)["ipred"]
+        if laue:
+            ipred = O.laue_convolve(ipred, x.harmonic_id)
+        ie, isd = O.prediction_mean_stddev(params, x, cfg)
+        m, sd = ipred.mean(0), ipred.std(0)
+        assert bool(((m - ie).abs() <= 5.0 * isd / math.sqrt(S) + 1e-12).all()), ((m - ie).abs() * math.sqrt(S) / isd).max()
+        assert torch.allclose(sd, isd, rtol=0.1, atol=1e-9)       # heavy-tailed (I ~ F^2): the sample sd converges slowly
+        if laue:
+            G = int(x.harmonic_id.max()) + 1
+            assert G < 60 and not ie[G:].any() and not isd[G:].any()
+            sm, ssd = O.scale_mean_stddev(params, x, cfg)
+            cfg1 = O.ElboConfig(**{**cfg.__dict__, "laue": False})
+            sm1, ssd1 = O.scale_mean_stddev(params, x, cfg1)
+            assert torch.allclose(sm, torch.zeros(60, dtype=sm.dtype).index_add(0, x.harmonic_id, sm1))
+            assert torch.allclose(ssd ** 2, torch.zeros(60, dtype=sm.dtype).index_add(0, x.harmonic_id, ssd1 ** 2))
+
+
+def test_merged_results_follow_the_reference_floor_on_sigi():
+    """`get_results` numerics (io/manager.py:188-197): I = SigF^2 + F^2, SigI^2 = max((I * 1e-5)^2, <F^4> - I^2); F, SigF vs scipy"""
+    from tests import util
+    data, cfg, params, x, _, _ = util.make_problem(N=60, R=12, d0=5, L=2, w=16, S=1)
+    r = O.merged_results(params, x, cfg)
+    loc, scale = O.tn_loc_scale(params.q_loc_raw, params.q_scale_raw, cfg.epsilon)
+    a = ((x.low - loc) / scale).numpy()
+    assert np.allclose(r["F"].numpy(), stats.truncnorm.mean(a, np.inf, loc.numpy(), scale.numpy()), rtol=1e-9)
+    assert np.allclose(r["SigF"].numpy(), stats.truncnorm.std(a, np.inf, loc.numpy(), scale.numpy()), rtol=1e-7)
+    assert torch.allclose(r["I"], r["F"] ** 2 + r["SigF"] ** 2)
+    assert bool((r["SigI"] >= 1e-5 * r["I"]).all())
+    hi = O.merged_results(params, x, cfg, max_intensity_snr=10.0)       # a huge floor takes over
+    assert torch.allclose(hi["SigI"], 10.0 * hi["I"])

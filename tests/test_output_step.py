@@ -1,0 +1,146 @@
+"""The output step right after the ELBO path against its oracle restatement: `get_predictions` (Ipred, SigIpred, Scale, SigScale;
+reference io/manager.py:89-161 -> models/merging/variational.py:47-121, Laue rows convolved per harmonic slot :70-76, :113-119),
+`get_results` (F, SigF, I, SigI; manager.py:188-197) and `NLL_val` (variational.py:248-260).  Tolerance 1e-4 (north_star: merged
+amplitudes within 1e-4 relative)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import elbo_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "mono_2x32": dict(N=500, R=40, d0=5, L=2, w=32, S=2),
+    "mono_softplus_shift_noimg": dict(N=400, R=50, d0=6, L=3, w=20, S=1, bijector="softplus", shift=3.5, use_image_scales=False),
+    "mono_cli_default_20x10": dict(N=600, R=50, d0=5, L=20, w=10, S=1, perturb=0.02),
+    "laue_2x32": dict(N=600, R=50, L=2, w=32, S=2, laue=True),
+    "laue_groups_up_to_12_rows": dict(N=700, R=50, L=2, w=32, S=1, laue=True, regroup=4),
+    "laue_rows_shuffled_softplus": dict(N=500, R=40, L=2, w=32, S=1, laue=True, bijector="softplus", shift=1.5, shuffle=True),
+    "image_layers2_3x8": dict(N=800, R=40, d0=5, L=3, w=8, S=1, n_images=5, image_layers=2, perturb=0.03),
+    "laue_image_layers1": dict(N=600, R=60, L=2, w=32, S=1, laue=True, n_images=4, image_layers=1),
+    "deep_12x64": dict(N=500, R=40, d0=5, L=12, w=64, S=1),
+}
+
+
+def _close(a, b, tol=1e-4):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * np.max(np.abs(b))))) < tol
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_predictions_and_results_match_oracle(name):
+    from careless_amd import results
+    from tests.test_gpu_parity import _regroup_laue
+    kw = dict(CASES[name])
+    regroup, shuffle = kw.pop("regroup", 0), kw.pop("shuffle", False)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    if regroup:
+        data = _regroup_laue(data, regroup)
+    if shuffle:                                  # rows of a harmonic group are not adjacent in real files
+        perm = np.random.default_rng(3).permutation(kw["N"])
+        for k in ("refl_id", "image_id", "file_id", "metadata", "wavelength", "harmonic_id"):
+            data[k] = np.asarray(data[k])[perm]
+    x = O.inputs_from_numpy(data)
+    model = util.build_model(data, cfg, params, kw["L"], kw["w"])
+    inputs = util.reference_inputs(data)
+    pred = results.get_predictions(model, inputs)
+    ie, isd = O.prediction_mean_stddev(params, x, cfg)
+    sm, ssd = O.scale_mean_stddev(params, x, cfg)
+    for k, ref in (("Ipred", ie), ("SigIpred", isd), ("Scale", sm), ("SigScale", ssd)):
+        assert len(pred[k]) == kw["N"] and _close(pred[k], ref.numpy()), k
+    if kw.get("laue"):
+        G = int(np.asarray(data["harmonic_id"]).max()) + 1
+        assert G < kw["N"] and not pred["Ipred"][G:].any() and not pred["Scale"][G:].any()     # slots without rows (scatter_nd zeros)
+        if regroup:
+            assert int(np.bincount(np.asarray(data["harmonic_id"])).max()) > 4
+    res = results.get_results(model.surrogate_posterior, inputs)
+    ref = O.merged_results(params, x, cfg)
+    for k in ("F", "SigF", "I", "SigI"):
+        assert _close(res[k], ref[k].numpy()), k
+    assert np.array_equal(res["N"], np.bincount(np.asarray(data["refl_id"]), minlength=kw["R"]))
+
+
+@pytest.mark.parametrize("kw", [dict(N=400, R=40, d0=5, L=2, w=32, S=4),
+                                dict(N=400, R=40, d0=5, L=2, w=32, S=3, kl_weight=0.5, likelihood="studentt", dof=8.0),
+                                dict(N=480, R=40, L=2, w=32, S=2, laue=True)], ids=["sum", "kl_weight_mean", "laue"])
+def test_validation_nll_matches_oracle_on_injected_noise(kw):
+    """NLL_val = len(train) / len(validation) * NLL(validation) with the parameters AFTER the step, every `validation_frequency`
+    steps and stale in between (variational.py:248-260); with --kl-weight the mean runs over the validation set's own size."""
+    from careless_amd.manager import DataManager, default_args
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    inputs = util.reference_inputs(data)
+    N, R, S = kw["N"], kw["R"], kw["S"]
+    if kw.get("laue"):                                         # the reference's own split keeps harmonic groups whole (manager.py:299-343)
+        np.random.seed(4)
+        dm = DataManager(inputs, data["centric"], data["multiplicity"], default_args(type="poly"))
+        train, test = dm.split_data_by_refl(0.3)
+    else:
+        train, test = tuple(a[:300] for a in inputs), tuple(a[300:] for a in inputs)
+    n_tr, n_te = len(train[0]), len(test[0])
+
+    def as_inputs(t):
+        d = dict(data)
+        d.update(refl_id=t[0][:, 0], image_id=t[1][:, 0], metadata=t[3], iobs=t[4][:, 0], sigiobs=t[5][:, 0])
+        if kw.get("laue"):
+            d.update(harmonic_id=t[7][:, 0])
+        return O.inputs_from_numpy(d)
+    x_tr, x_te = as_inputs(train), as_inputs(test)
+    steps, freq = 5, 2
+    rng = np.random.default_rng(12)
+    noises = [(rng.random((S, R)).astype(np.float32), rng.normal(size=(S, n_tr)).astype(np.float32)) for _ in range(steps)]
+    vnoises = [(rng.random((S, R)).astype(np.float32), rng.normal(size=(S, n_te)).astype(np.float32)) for _ in range(steps)]
+    model = util.build_model(data, cfg, params, kw["L"], kw["w"])
+    hist = model.train_model(train, steps, progress=False, validation_data=test, validation_frequency=freq,
+                             noise=lambda i: noises[i], validation_noise=lambda i: vnoises[i])
+    p = params.clone()
+    st = O.AdamState.zeros_like(p.tensors())
+    t64 = lambda a: torch.as_tensor(a, dtype=torch.float64)
+    ref, last = [], None
+    for i in range(steps):
+        O.train_step(p, x_tr, cfg, st, t64(noises[i][0]), t64(noises[i][1]))
+        if i % freq == 0:
+            last = O.validation_nll(p, x_te, cfg, t64(vnoises[i][0]), t64(vnoises[i][1]), n_tr)
+        ref.append(last)
+    assert np.allclose(hist["NLL_val"], ref, rtol=1e-4), (hist["NLL_val"], ref)
+    assert hist["NLL_val"][0] == hist["NLL_val"][1] != hist["NLL_val"][2]
+
+
+def test_poly_cli_prediction_file_holds_the_per_group_sums(tmp_path):
+    """`careless poly`: <out>_predictions_0.mtz has one row per harmonic group whose Ipred / Scale are the SUMS over the group's rows
+    and whose SigIpred / SigScale are the root of the summed variances (reference variational.py:70-76, 113-119; manager.py:135-153)."""
+    from careless_amd.careless import run_careless
+    from careless_amd.io.formatter import LaueFormatter
+    from careless_amd.io.mtz import read_mtz
+    from careless_amd.models.base import BaseModel
+    from careless_amd.parser import parser
+    from tests.mtz_fixture import PYP
+    out = str(tmp_path / "out")
+    args = parser.parse_args(f"poly --iterations=8 --disable-progress-bar --mlp-layers 3 dHKL,image_id {PYP} {out}".split())
+    model, hist = run_careless(args)
+    inputs, _ = LaueFormatter.from_parser(args).format_files([PYP])
+    hid = np.asarray(BaseModel.get_harmonic_id(inputs)).reshape(-1)
+    rid = np.asarray(BaseModel.get_refl_id(inputs)).reshape(-1)
+    G, N = int(hid.max()) + 1, len(hid)
+    assert G < N, "the fixture must expand to at least one multi-harmonic group"
+    q = model.surrogate_posterior
+    dist = model.scaling_model(inputs)
+    smean, ssd = dist.mean().double().cpu().numpy(), dist.stddev().double().cpu().numpy()
+    F, SigF = q.mean().double().cpu().numpy(), q.stddev().double().cpu().numpy()
+    f4 = np.asarray(q.moment_4(method="scipy"), dtype=np.float64)
+    iexp = smean * (F * F + SigF * SigF)[rid]
+    ivar = f4[rid] * (smean ** 2 + ssd ** 2) - iexp ** 2
+    tab = read_mtz(out + "_predictions_0.mtz")
+    assert len(tab) == G
+    sums = lambda v: np.bincount(hid, weights=v, minlength=G)[:G]
+    assert np.allclose(tab.columns["Ipred"], sums(iexp), rtol=1e-4)
+    assert np.allclose(tab.columns["SigIpred"], np.sqrt(sums(ivar)), rtol=1e-4)
+    assert np.allclose(tab.columns["Scale"], sums(smean), rtol=1e-4)
+    assert np.allclose(tab.columns["SigScale"], np.sqrt(sums(ssd ** 2)), rtol=1e-4)
+    assert np.array_equal(tab.columns["Iobs"], np.asarray(BaseModel.get_intensities(inputs)).reshape(-1)[:G])
+    multi = np.bincount(hid, minlength=G) > 1
+    assert multi.any() and not np.allclose(tab.columns["Ipred"][multi], iexp[np.unique(hid, return_index=True)[1]][multi], rtol=1e-3)
