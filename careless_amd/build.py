@@ -18,6 +18,7 @@ LIB = os.path.join(LIBDIR, "libcareless_hip.so")
 UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=0"]), ("elbo_mlp.hip", "elbo_mlp_imgl", ["-DCL_IMGL=1"]),
          ("elbo_mlp.hip", "elbo_mlp_packed", ["-DCL_IMGL=2"]),
          ("elbo_mlp.hip", "elbo_mlp_chain", ["-DCL_CHAIN=1"]),
+         ("elbo_narrow.hip", "elbo_narrow", ["-fno-slp-vectorize"]),     # (packed fp32 math costs more than it saves beside MFMAs)
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", [])]
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["cl_math.h", "cl_kernels.h", os.path.join("..", "..", "include", "careless_hip.h")]

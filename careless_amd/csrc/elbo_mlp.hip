@@ -32,6 +32,7 @@
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdlib>
 #include "cl_math.h"
 #include "cl_kernels.h"
 
@@ -1345,6 +1346,14 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     const int ntiles = a.n_pad / CL_TILE;
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) return -1;
+#if !CL_IMGL && !CL_CHAIN
+    // hidden width <= 15 (the careless CLI default): the full step runs on the one-wave-per-SIMD kernel of elbo_narrow.hip
+    // (CARELESS_HIP_NARROW=0 keeps the eight-wave instance below: A/B measurements)
+    if (mode == 0 && cl_narrow_supports(a)) {
+        static const bool narrow_on = [] { const char* e = getenv("CARELESS_HIP_NARROW"); return !(e != nullptr && e[0] == '0'); }();
+        if (narrow_on) return cl_launch_narrow(a, grid, st);
+    }
+#endif
     switch (mode) {
         case 0: return launch_mode<0>(a, grid, st);
         case 1: return launch_mode<1>(a, grid, st);
