@@ -20,6 +20,15 @@
 #define CL_HD inline
 #endif
 
+// Placed inside the EXPENSIVE arm of a branch on a wave-uniform kind / flag: an (empty) side effect hipcc cannot speculate, so the
+// arm stays behind a real scalar branch.  Without it hipcc if-converts e.g. `kind == exp ? exp(x) : softplus(x)` into straight-line
+// code that evaluates BOTH arms in every lane (the accurate log1p alone is ~80 vector instructions per call).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CL_KEEP_BRANCH() asm volatile("")
+#else
+#define CL_KEEP_BRANCH()
+#endif
+
 #define CL_LOG_2PI_F 1.8378770664093453f
 #define CL_INV_SQRT2_F 0.70710678118654752f
 #define CL_INV_SQRT_2PI_F 0.3989422804014327f
@@ -236,6 +245,7 @@ CL_HD float cl_scale_bij(float raw, int kind, float eps, float* dsig_draw) {
         *dsig_draw = ex;
         return ex + eps;
     }
+    CL_KEEP_BRANCH();
     *dsig_draw = cl_sigmoid(raw);
     return cl_softplus(raw) + eps;
 }
@@ -271,6 +281,7 @@ CL_HD float cl_lik_log_prob2(float ipred, float iobs, float inv_sig, float log_s
         *dll = -y * inv_sig;
         return -0.5f * y * y - 0.5f * CL_LOG_2PI_F - log_sig;
     }
+    CL_KEEP_BRANCH();
     const float y2 = y * y;
     *dll = -(dof + 1.0f) * y / (dof + y2) * inv_sig;
     return -0.5f * (dof + 1.0f) * cl_log1p_pos(y2 / dof) - log_sig + lik_const;

@@ -34,6 +34,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CL_NARROW_STAGGER
 #define CL_NARROW_STAGGER 0     /* x 127 x 64 cycles of start delay for the second wave of every SIMD (measured: no effect) */
 #endif
+#ifndef CL_NARROW_PRIO
+#define CL_NARROW_PRIO 0
+#endif
+#ifndef CL_NARROW_BFI
+#define CL_NARROW_BFI 0     /* 1: multiply + sign mask + bit select instead of compare + conditional move (measured slower: hipcc emits 5 ops) */
+#endif
 #ifndef CL_NARROW_WAVES
 #define CL_NARROW_WAVES 8      /* waves per workgroup: 8 = two per SIMD (G = 2 groups per wave), 4 = one per SIMD with 512 registers */
 #endif
@@ -54,19 +60,56 @@ __device__ __forceinline__ float lrelu(float x, float leak) {
     return r;
 }
 
+// dZ = dH * lrelu'(h): dH where h > 0, leak dH otherwise (h == 0 takes the leak branch, like `h > 0 ? ... : ...`; -0.0 cannot
+// occur: h = max(x, leak x)).  Written as multiply + sign mask + bit select: beside fp32 MFMAs a compare / conditional-move pair
+// costs ~50 % more issue time than a shift / bit-field-insert pair (scripts/probe/coissue_probe.hip).
+__device__ __forceinline__ float lrelu_bwd(float h, float dh, float leak) {
+#if CL_NARROW_BFI
+    const float p = leak * dh;
+    const int pos = __builtin_bit_cast(int, -h) >> 31;             // all ones where h > 0 (h is never -0.0 / NaN-free path aside)
+    return __builtin_bit_cast(float, (__builtin_bit_cast(int, dh) & pos) | (__builtin_bit_cast(int, p) & ~pos));
+#else
+    return (h > 0.0f) ? dh : leak * dh;
+#endif
+}
+
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int opaque_uniform(int v) {
     v = __builtin_amdgcn_readfirstlane(v);
     asm volatile("" : "+s"(v));
     return v;
 }
-// a wave-uniform test whose outcome the optimiser cannot relate to its operands.  Inside `if (l == Lt - 1) { ... hs[l] ... }` hipcc
-// otherwise replaces the unrolled layer number l by the run-time value Lt - 1, finds the twenty blocks identical, merges them into
-// one that indexes `hs` at run time -- and the activations land in scratch memory
-__device__ __forceinline__ bool opaque_flag(bool c) {
-    int v = __builtin_amdgcn_readfirstlane(c ? 1 : 0);
-    asm volatile("" : "+s"(v));
-    return v != 0;
+// "Is layer l the top layer?" as a bit test on an opaque SGPR mask (1 << (L - 1)).  Written as `l == Lt - 1` hipcc replaces the
+// unrolled layer number l inside the guarded block by the run-time value Lt - 1, finds the twenty blocks identical, merges them
+// into one that indexes `hs` at run time -- and the activations land in scratch memory.
+__device__ __forceinline__ unsigned top_layer_mask(int L) {
+    unsigned m = 1u << (unsigned)(__builtin_amdgcn_readfirstlane(L) - 1);
+    asm volatile("" : "+s"(m));
+    return m;
+}
+// The kernel arguments, re-read from the kernarg segment behind an opaque pointer.  hipcc loads every field of the by-value argument
+// struct at kernel entry and keeps it in SGPRs for the whole kernel (> 100 SGPRs: it then parks them in VGPR lanes and pays
+// v_readlane / v_writelane in the per-tile code); fields that only the epilogue and the prefetch use are instead loaded there,
+// once per tile, by scalar loads that cannot be hoisted.
+typedef const __attribute__((address_space(4))) cl_mlp_args* cl_args_p;
+__device__ __forceinline__ cl_args_p kernargs_again() {
+    cl_args_p p = (cl_args_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// sum over the 64 lanes of a wave (returned in every lane's copy of a scalar): four DPP butterfly steps inside the 16-lane rows,
+// then the rows through row_bcast -- six VALU instructions and no LDS round trip (a shuffle loop is 6 x ds_bpermute + adds)
+__device__ __forceinline__ float wave_sum(float v) {
+#define NDPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xF, false))
+    v += NDPP(v, 0xB1, 0xF);        // quad_perm [1,0,3,2]
+    v += NDPP(v, 0x4E, 0xF);        // quad_perm [2,3,0,1]
+    v += NDPP(v, 0x141, 0xF);       // row_half_mirror
+    v += NDPP(v, 0x140, 0xF);       // row_mirror: every lane now holds its row's sum
+    v += NDPP(v, 0x142, 0xA);       // row_bcast15 into rows 1 and 3
+    v += NDPP(v, 0x143, 0xC);       // row_bcast31 into rows 2 and 3: lane 63 holds the total
+#undef NDPP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 template <class T>
 __device__ __forceinline__ T ld_uo(const T* base, unsigned byte_off) {       // (wave-uniform pointer)[32-bit per-lane byte offset]
@@ -98,8 +141,8 @@ struct NSmem {
     static constexpr int PBW = 16 * G + 4;                    // pitch of a per-wave staging tile [16 slots][16 G observations]
     static constexpr int oW = 0;                              // NL layer images + G head images, [16][NPW] each
     static constexpr int oB = oW + (NL + G) * 16 * NPW;       // (NL + 1) x 16 bias images
-    static constexpr int oT = oB + (NL + 1) * 16;             // per wave: sZ, sH, sD
-    static constexpr int TW = 3 * 16 * PBW;
+    static constexpr int oT = oB + (NL + 1) * 16;             // per wave: sZ [16 rows], sH [16 rows], sD [3 rows: dloc, draw, zeros]
+    static constexpr int TW = (2 * 16 + 3) * PBW;
     static constexpr int oA = (oT + NWAVES * TW + 3) & ~3;    // LDS-resident weight-gradient accumulators: [layer - LREG][wave][lane] float4
     static constexpr int SLOT = NWAVES * 256;                 // floats per layer
     static constexpr int ROOM = (160 * 1024 / 4 - oA) / SLOT;
@@ -122,6 +165,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
     constexpr int LREG = SM::LREG;
     constexpr int PBW = SM::PBW;
     constexpr int WT = 16 * G;                        // observations of one wave tile
+    static_assert(CL_MLP_TILE % WT == 0, "a wave tile must not straddle the end of the padded observation axis");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const sW = smem + SM::oW;
     float* const sB = smem + SM::oB;
@@ -173,16 +217,15 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         }
         // staging tiles: rows that are never written hold their constants (zero; row 15 of the input tile = the ones)
         for (int idx = tid; idx < NWAVES * SM::TW; idx += NT) {
-            const int r = idx % SM::TW;
-            const int tile = r / (16 * PBW), row = (r - tile * 16 * PBW) / PBW;
-            smem[SM::oT + idx] = (tile == 1 && row == 15) ? 1.0f : 0.0f;
+            const int row = (idx % SM::TW) / PBW;                       // 0-15 sZ, 16-31 sH, 32-34 sD
+            smem[SM::oT + idx] = (row == 16 + 15) ? 1.0f : 0.0f;
         }
         for (int idx = tid; idx < SM::NACC * SM::SLOT; idx += NT) smem[SM::oA + idx] = 0.0f;
     }
     __syncthreads();
 
     float* const sZ = smem + SM::oT + wv * SM::TW;     // dZ_l                          [slot][observation]
-    float* const sD = sZ + 2 * 16 * PBW;               // rows 0, 1: dL/dloc, dL/draw   (sH = sZ + 16 PBW: the layer's input)
+    float* const sD = sZ + 2 * 16 * PBW;               // rows 0, 1: dL/dloc, dL/draw; row 2: zeros   (sH = sZ + 16 PBW: the layer's input)
 
     // ---- accumulators that live across all tiles of this wave ----------------------------------------------------------
     f32x4 wacc[LREG];                   // dW_l^T of layer l < LREG; the upper layers' live in LDS (acc_slot)
@@ -197,43 +240,47 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
     const bool use_ev11 = A.ev11 != nullptr;
     if (use_ev11) { ev.sdfac = cl_softplus(A.ev11[0]); ev.sdadd = cl_softplus(A.ev11[1]); ev.sdb = cl_softplus(A.ev11[2]); }
 
-    const int S = A.S;
     const int n_wt = (A.n_obs + WT - 1) / WT;                        // wave tiles
     const int wt_step = (int)gridDim.x * NWAVES;
-    const unsigned n_pad_u = (unsigned)A.n_pad;
-    const int last_obs = A.n_obs - 1;
+    // loop-invariant per-lane byte offsets of the metadata loads (one per group; the row / tile part is wave-uniform)
+    unsigned meta_off[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) meta_off[g] = 4u * ((unsigned)q * (unsigned)A.n_pad + (unsigned)(16 * g + j));
 
-    // per-observation inputs of a wave tile, loaded one tile ahead (plain loads, every address clamped into its array)
+    // per-observation inputs of a wave tile, loaded one tile ahead (plain loads; a wave tile never leaves the padded metadata rows
+    // because 16 G divides CL_MLP_TILE, the per-observation arrays are clamped to their last element)
     float xn[G][KS];
     int ridn = -1, imgn = 0;
     float ion = 0.0f, sgn = 1.0f;
-    auto prefetch = [&](int wt_in) {
+    auto prefetch = [&](int wt_in, cl_args_p E) {
         const int wt = uniform(wt_in);
         const int base = wt * WT;
+        const unsigned n_pad_u = (unsigned)E->n_pad;
+        const int last_obs = E->n_obs - 1;
+        const float* __restrict__ mt = E->meta_t + base;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int col = min(base + 16 * g + j, last_obs);
-            const unsigned off = 4u * ((unsigned)q * n_pad_u + (unsigned)col);
+        for (int t = 0; t < KS; ++t) {
+            // k-steps past the rows of meta_t (cl_mlp_meta_rows) re-read step 0 and are zeroed: no branch, every address valid
+            const bool have = t < ks1;                                   // wave-uniform
+            const float* row = mt + (have ? (size_t)(4 * t) * n_pad_u : (size_t)0);
 #pragma unroll
-            for (int t = 0; t < KS; ++t) {
-                // k-steps past the rows of meta_t (cl_mlp_meta_rows) re-read step 0 and are zeroed: no branch, every address valid
-                const bool have = t < ks1;                                   // wave-uniform
-                const float v = ld_uo(A.meta_t + (have ? (size_t)(4 * t) * n_pad_u : (size_t)0), off);
+            for (int g = 0; g < G; ++g) {
+                const float v = ld_uo(row, meta_off[g]);
                 xn[g][t] = have ? v : 0.0f;
             }
         }
         const int o = base + lane;
         const bool ok = lane < WT && o <= last_obs;
-        const unsigned ob = 4u * (unsigned)(ok ? o : last_obs);
-        const int rr = ld_uo(A.refl_id, ob);
+        const unsigned ob = 4u * (unsigned)min(o, last_obs);
+        const int rr = ld_uo(E->refl_id, ob);
         ridn = ok ? rr : -1;
-        ion = ld_uo(A.iobs, ob);
-        const float ss = ld_uo(A.sig, ob);
+        ion = ld_uo(E->iobs, ob);
+        const float ss = ld_uo(E->sig, ob);
         sgn = ok ? ss : 1.0f;
-        imgn = A.use_img ? ld_uo(A.image_id, ob) : 0;
+        imgn = E->use_img ? ld_uo(E->image_id, ob) : 0;
     };
     const int wt_begin = (int)blockIdx.x * NWAVES + wv;
-    if (wt_begin < n_wt) prefetch(wt_begin);
+    if (wt_begin < n_wt) prefetch(wt_begin, kernargs_again());
 #if CL_NARROW_STAGGER
     // Two waves per SIMD run the same program with no barrier between them: started together they would stay in lockstep and
     // reach their latency-bound phases (epilogue, tile prologue) at the same time, leaving the matrix pipe idle.  The second wave
@@ -244,11 +291,16 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
     }
 #endif
 
+#if CL_NARROW_PRIO
+    // static priority for the younger half (the second wave of every SIMD loses the arbitration otherwise)
+    if (NWAVES > 4 && wv >= NWAVES / 2) __builtin_amdgcn_s_setprio(CL_NARROW_PRIO);
+#endif
     const float* const wrow = sW + j * NPW + 4 * q;        // forward A operands: image row j, slots 4q .. 4q+3 (one ds_read_b128)
     const float* const wcol = sW + (4 * q) * NPW + j;      // dgrad A operands: image rows 4q + t, column j
     float* const stw = sZ + (4 * q) * PBW + j;             // staging writes: rows 4q + t, this lane's observation column (+ 16 g)
     const float* const strd = sZ + j * PBW + 4 * q;        // staging reads: row j, observations 4q .. 4q+3 (+ 16 g): one ds_read_b128
     constexpr int TH = 16 * PBW;                           // offset of the input tile (sH) from sZ
+    const float* const strdD = sD + (j < 2 ? j : 2) * PBW + 4 * q;   // head wgrad A operand: row j of [dloc; draw; 0; 0; ...]
 
 #ifdef CL_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -257,6 +309,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
 #endif
     for (int wt = wt_begin; wt < n_wt; wt += wt_step) {
         const int Lt = opaque_uniform(L);
+        const unsigned topm = top_layer_mask(L);
         float x0[G][KS];
 #pragma unroll
         for (int g = 0; g < G; ++g)
@@ -264,21 +317,20 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
             for (int t = 0; t < KS; ++t) x0[g][t] = (4 * t + q == 15) ? 1.0f : xn[g][t];     // metadata slot 15 = the ones (KS = 4)
         const int rid = ridn, img = imgn;
         const float io = ion, sg = sgn;
-        const long long gobs = (long long)wt * WT + lane;            // this lane's observation in the epilogue (lane = observation)
-        const unsigned zoff = 4u * (unsigned)(rid < 0 ? 0 : rid) * (unsigned)S;
-        float aim = 1.0f;
-        if (rid >= 0 && A.use_img && img > 0) aim = ld_uo(A.img, 4u * (unsigned)(img - 1));
-        float zf0 = 0.0f;
-        if (rid >= 0) zf0 = ld_uo(A.z_f, zoff);                      // sample 0's gather: its latency hides under the forward pass
-
+        float aim = 1.0f, zf0 = 0.0f;
+        {
+            // gathers that depend on the prefetched ids: issued now, consumed in the epilogue
+            cl_args_p E0 = kernargs_again();
+            if (rid >= 0) {
+                if (E0->use_img && img > 0) aim = ld_uo(E0->img, 4u * (unsigned)(img - 1));
+                zf0 = ld_uo(E0->z_f, 4u * (unsigned)rid * (unsigned)E0->S);       // sample 0
+            }
+        }
         NSTAMP(0);
         // ================= forward ==========================================================================================
-        // Software pipeline over the groups: the LeakyReLU of group g runs between the MFMAs of group g+1; that of the last
-        // group is deferred into the next layer's first slot (`carry` = its raw pre-activations) -- or, on the top layer, done
-        // at once.  `top` = the top layer's activations (the head's input), copied out where the depth puts them.
+        // `top` = the top layer's activations (the head's input), copied out where the depth puts them.
         float hs[NL][G][KS];
         float top[G][KS];
-        f32x4 carry = {0.0f, 0.0f, 0.0f, 0.0f};
         f32x4 wfn = *reinterpret_cast<const f32x4*>(wrow), biasn = *reinterpret_cast<const f32x4*>(sB + 4 * q);
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -289,30 +341,23 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     biasn = *reinterpret_cast<const f32x4*>(sB + (l + 1 < NL ? l + 1 : 0) * 16 + 4 * q);
                 }
                 f32x4 acc[G];
+                // the groups' MFMA chains interleaved step by step (dependent MFMAs of one chain are G issue slots apart), then the
+                // LeakyReLUs of all groups: the wave's vector phase runs beside its SIMD partner's MFMAs
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
+                for (int t = 0; t < KS; ++t) {
 #pragma unroll
-                    for (int t = 0; t < KS; ++t) {
-                        NFENCE();
+                    for (int g = 0; g < G; ++g) {
                         const float b = (l == 0) ? x0[g][t] : hs[l > 0 ? l - 1 : 0][g][t];
                         acc[g] = mfma4(wf[t], b, t == 0 ? bias : acc[g]);
-                        NFENCE();
-                        // fillers: the LeakyReLU of the group before.  Its chain issued its last MFMA one slot ago and the result
-                        // needs ~40 cycles more, so nothing of it goes behind this slot's first MFMA
-#define NARROW_FILL(e)                                                                                   \
-    if ((e) < KS && (KS == 1 ? 0 : 1 + (e) * (KS - 1) / KS) == t) {                                      \
-        if (g > 0) hs[l][g - 1][(e) < KS ? (e) : 0] = lrelu(acc[g - 1][(e) < KS ? (e) : 0], leak);        \
-        else if (l > 0) hs[l > 0 ? l - 1 : 0][G - 1][(e) < KS ? (e) : 0] = lrelu(carry[(e) < KS ? (e) : 0], leak); \
-    }
-                        NARROW_FILL(0) NARROW_FILL(1) NARROW_FILL(2) NARROW_FILL(3)
-#undef NARROW_FILL
                     }
                 }
                 NFENCE();
-                carry = acc[G - 1];
-                if (opaque_flag(l == Lt - 1)) {
 #pragma unroll
-                    for (int t = 0; t < KS; ++t) hs[l][G - 1][t] = lrelu(carry[t], leak);
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int t = 0; t < KS; ++t) hs[l][g][t] = lrelu(acc[g][t], leak);
+                NFENCE();
+                if (topm & (1u << l)) {
 #pragma unroll
                     for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -336,15 +381,25 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         acc_h += acc_h2;
 
         // ================= epilogue: lane = observation; sample, predict, likelihood, dL/d(loc, raw) ==========================
+        cl_args_p E = kernargs_again();              // the epilogue's and the prefetch's arguments, loaded here (see kernargs_again)
+        const int S = E->S;
+        const float w_ll = E->w_ll;
+        const long long gobs = (long long)wt * WT + lane;            // this lane's observation (lane = observation)
+        const unsigned zoff = 4u * (unsigned)(rid < 0 ? 0 : rid) * (unsigned)S;
         const float o0 = acc_h[0];
         float dsig_draw;
-        const float sigma = cl_scale_bij(acc_h[1], A.bij_kind, A.eps, &dsig_draw);
+        const float sigma = cl_scale_bij(acc_h[1], E->bij_kind, E->eps, &dsig_draw);
         float pdl = 0.0f, pds = 0.0f, pda = 0.0f;
         if (rid >= 0) {
-            const float inv_sg = 1.0f / sg;
-            const float log_sg = logf(sg);
-            const float* __restrict__ eta_p = A.eta ? A.eta + (size_t)gobs * S : nullptr;
-            float* __restrict__ ipred_p = A.ipred_out ? A.ipred_out + (size_t)gobs * S : nullptr;
+            // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
+            const float inv_sg = cl_fast_rcp(sg);
+            const float log_sg = cl_fast_log(sg);
+            const float* __restrict__ eta_p = E->eta ? E->eta + (size_t)gobs * S : nullptr;
+            float* __restrict__ ipred_p = E->ipred_out ? E->ipred_out + (size_t)gobs * S : nullptr;
+            const float* __restrict__ zf_p = E->z_f;
+            float* __restrict__ dzf_p = E->dz_f;
+            const int lik_kind = E->lik_kind;
+            const float dof = E->dof, lik_const = E->lik_const, shift = E->shift;
             float esin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int s = 0; s < S; ++s) {
                 float eta;
@@ -352,46 +407,44 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     eta = eta_p[s];
                 } else if (((s >> 2) & 1) == 0) {        // one Philox block + Box-Muller pair serves samples s and s + 4
                     float sn;
-                    cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(A.obs_offset + gobs), &eta, &sn);
+                    cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)(E->obs_offset + gobs), &eta, &sn);
                     const int kk = s & 3;
                     if (kk == 0) esin[0] = sn; else if (kk == 1) esin[1] = sn; else if (kk == 2) esin[2] = sn; else esin[3] = sn;
                 } else {
                     const int kk = s & 3;
                     eta = (kk == 0) ? esin[0] : (kk == 1) ? esin[1] : (kk == 2) ? esin[2] : esin[3];
                 }
-                const float zf = (s == 0) ? zf0 : ld_uo(A.z_f, zoff + 4u * s);
-                const float tq = o0 + sigma * eta + A.shift;
+                const float zf = (s == 0) ? zf0 : ld_uo(zf_p, zoff + 4u * s);
+                const float tq = o0 + sigma * eta + shift;
                 const float zs = aim * tq;
                 const float ipred = zs * zf * zf;
                 if (ipred_p) ipred_p[s] = ipred;
                 float dll, ll;
                 if (use_ev11) {
                     float gf, gb, ga;
-                    ll = cl_lik_ev11(ipred, io, sg, A.lik_kind, A.dof, A.lik_const, ev, &dll, &gf, &gb, &ga);
-                    ev_g0 -= gf * A.w_ll; ev_g1 -= ga * A.w_ll; ev_g2 -= gb * A.w_ll;     // order: Sdfac, Sdadd, SdB
+                    ll = cl_lik_ev11(ipred, io, sg, lik_kind, dof, lik_const, ev, &dll, &gf, &gb, &ga);
+                    ev_g0 -= gf * w_ll; ev_g1 -= ga * w_ll; ev_g2 -= gb * w_ll;     // order: Sdfac, Sdadd, SdB
                 } else {
-                    ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, A.lik_kind, A.dof, A.lik_const, &dll);
+                    ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, lik_kind, dof, lik_const, &dll);
                 }
-                nll_acc -= ll * A.w_ll;
-                const float gi = -dll * A.w_ll;                 // dNLL / d ipred
+                nll_acc -= ll * w_ll;
+                const float gi = -dll * w_ll;                 // dNLL / d ipred
                 const float dzs = gi * zf * zf;
-                atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(A.dz_f) + zoff + 4u * s), gi * zs * 2.0f * zf);
+                atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
                 const float dt = dzs * aim;
                 pdl += dt;
                 pds += dt * eta;
                 pda += dzs * tq;
             }
         }
-        if (A.use_img) {
+        if (E->use_img) {
             // image ids are sorted: the observations of a wave tile almost always share one image -> ONE atomic per wave
             const int img0 = uniform(img);
             if (__all(img == img0 || rid < 0)) {
-                float v = (rid >= 0) ? pda : 0.0f;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off);
-                if (lane == 0 && img0 > 0) atomicAdd(A.d_img + (img0 - 1), v);
+                const float v = wave_sum((rid >= 0) ? pda : 0.0f);
+                if (lane == 0 && img0 > 0) atomicAdd(E->d_img + (img0 - 1), v);
             } else if (rid >= 0 && img > 0) {
-                atomicAdd(A.d_img + (img - 1), pda);
+                atomicAdd(E->d_img + (img - 1), pda);
             }
         }
         const float dloc = pdl, draw = pds * dsig_draw;              // zero for padding observations
@@ -402,7 +455,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
 
         NSTAMP(2);
         // next tile's inputs: their latency hides under the backward pass
-        if (wt + wt_step < n_wt) prefetch(wt + wt_step);
+        if (wt + wt_step < n_wt) prefetch(wt + wt_step, E);
         NSTAMP(3);
 
         // ================= backward =========================================================================================
@@ -420,7 +473,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         for (int g = 0; g < G; ++g) {
 #pragma unroll
             for (int t = 0; t < KS; ++t) (stw + TH)[t * PBW + 16 * g] = top[g][t];
-            pa[g] = *reinterpret_cast<const f32x4*>(strd + 2 * TH + 16 * g);        // sD
+            pa[g] = *reinterpret_cast<const f32x4*>(strdD + 16 * g);                // sD (rows >= 2 of the head's "dZ" are zero)
             pb[g] = *reinterpret_cast<const f32x4*>(strd + TH + 16 * g);            // sH
         }
 #pragma unroll
@@ -436,39 +489,37 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) wacc_h = mfma4(pa[g][t], pb[g][t], wacc_h);
 #pragma unroll
-        for (int t = 0; t < KS; ++t) dz[t] = (top[0][t] > 0.0f) ? dH[0][t] : leak * dH[0][t];
+        for (int t = 0; t < KS; ++t) dz[t] = lrelu_bwd(top[0][t], dH[0][t], leak);
         // the top layer has no pending weight gradient: zero operands, its MFMAs add exactly 0 to an accumulator
 #pragma unroll
         for (int g = 0; g < G; ++g) { pa[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; pb[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-        // LDS-resident accumulator of the pending weight gradient, requested one layer ahead
-        f32x4 pacc = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (SM::NACC > 0) pacc = acc_slot(Lt < NL ? Lt : NL - 1);                      // (run-time slot; unused when Lt < LREG or Lt == NL)
+        // Requested one layer ahead, into TWO buffers used alternately by layer parity (a single carried buffer costs a register
+        // copy per element and layer where the skipped-layer paths join): the LDS-resident accumulator of the pending weight
+        // gradient and the dgrad weight operands.  The depth decides which parity the top layer has, so both start out equal.
+        f32x4 paccb[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        if (SM::NACC > 0) { paccb[0] = acc_slot(Lt < NL ? Lt : NL - 1); paccb[1] = paccb[0]; }     // (run-time slot; unused when Lt < LREG or Lt == NL)
 
         NSTAMP(4);
-        float wdn[KS];                      // dgrad weight operands of the layer that comes next
+        float wdb[2][KS];
         {
             const int lt1 = Lt > 1 ? Lt - 1 : 1;
 #pragma unroll
-            for (int t = 0; t < KS; ++t) wdn[t] = wcol[lt1 * 16 * NPW + t * NPW];
+            for (int t = 0; t < KS; ++t) { wdb[0][t] = wcol[lt1 * 16 * NPW + t * NPW]; wdb[1][t] = wdb[0][t]; }
         }
 #pragma unroll
         for (int l = NL - 1; l >= 0; --l) {
             if (l < Lt) {
-                float wd[KS];
-#pragma unroll
-                for (int t = 0; t < KS; ++t) wd[t] = wdn[t];
+                float (&wd)[KS] = wdb[l & 1];
                 if (l > 1) {
 #pragma unroll
-                    for (int t = 0; t < KS; ++t) wdn[t] = wcol[(l > 1 ? l - 1 : 1) * 16 * NPW + t * NPW];
+                    for (int t = 0; t < KS; ++t) wdb[(l - 1) & 1][t] = wcol[(l > 1 ? l - 1 : 1) * 16 * NPW + t * NPW];
                 }
                 // accumulator of the pending weight gradient (layer l+1; above the top layer: the head's, which receives zeros)
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int lp = l + 1;
                 const bool lp_head = lp >= NL;                       // compile-time after unrolling
                 const bool lp_lds = !lp_head && lp >= LREG;
-                f32x4 wa = lp_head ? wacc_h : (lp_lds ? pacc : wacc[lp < LREG ? lp : 0]);
-                if (SM::NACC > 0 && l >= LREG) pacc = acc_slot(l);                      // next layer's slot, in flight under this layer's MFMAs
+                f32x4 wa = lp_head ? wacc_h : (lp_lds ? paccb[lp & 1] : wacc[lp < LREG ? lp : 0]);
+                if (SM::NACC > 0 && l >= LREG) paccb[l & 1] = acc_slot(l);              // next layer's slot, in flight under this layer's MFMAs
                 f32x4 dHn[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
@@ -492,7 +543,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     if (g + 1 < G) {
 #pragma unroll
                         for (int t = 0; t < KS; ++t)
-                            dzn[t] = (hs[l][g + 1 < G ? g + 1 : 0][t] > 0.0f) ? dH[g + 1 < G ? g + 1 : 0][t] : leak * dH[g + 1 < G ? g + 1 : 0][t];
+                            dzn[t] = lrelu_bwd(hs[l][g + 1 < G ? g + 1 : 0][t], dH[g + 1 < G ? g + 1 : 0][t], leak);
                     }
                     NFENCE();
                     wa = mfma4(pa[g][3], pb[g][3], wa);
@@ -506,7 +557,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                         for (int t = 0; t < KS; ++t) dz[t] = dzn[t];
                     } else if (l > 0) {          // group 0 of the layer below
 #pragma unroll
-                        for (int t = 0; t < KS; ++t) dz[t] = (hs[l > 0 ? l - 1 : 0][0][t] > 0.0f) ? dHn[0][t] : leak * dHn[0][t];
+                        for (int t = 0; t < KS; ++t) dz[t] = lrelu_bwd(hs[l > 0 ? l - 1 : 0][0][t], dHn[0][t], leak);
                     }
                 }
                 if (lp_head) wacc_h = wa;
@@ -626,7 +677,7 @@ int cl_launch_narrow(const cl_mlp_args& a, int grid, hipStream_t st) {
     const int m = a.w > a.d ? a.w : a.d;               // the metadata layer takes the same number of k-steps as the hidden ones
 #if CL_NARROW_WAVES == 4
     if (m <= 8) return launch_narrow_one<4, 2, 4>(a, grid, st);
-    if (m <= 12) return launch_narrow_one<3, 3, 4>(a, grid, st);
+    if (m <= 12) return launch_narrow_one<2, 3, 4>(a, grid, st);
     return launch_narrow_one<2, 4, 4>(a, grid, st);
 #else
     if (m <= 8) return launch_narrow_one<2, 2, 8>(a, grid, st);
