@@ -25,3 +25,19 @@ int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, 
 int cl_launch_laue_predict(const cl_laue_args& a, hipStream_t st);
 int cl_launch_laue_likelihood(const cl_laue_args& a, hipStream_t st);
 int cl_launch_laue_backward(const cl_laue_args& a, hipStream_t st);
+
+// The kernel arguments, re-read from the kernarg segment behind an opaque pointer.  hipcc loads every field of a by-value argument
+// struct at kernel entry and keeps it in SGPRs for the whole kernel (more than the ~100 there are: it then parks them in VGPR lanes
+// and pays v_readlane / v_writelane in the per-tile code); fields that only one phase of a tile uses are loaded there instead, by
+// scalar loads that cannot be hoisted.  Only valid in kernels whose single parameter is a `cl_mlp_args` by value.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) cl_mlp_args* cl_args_p;
+__device__ __forceinline__ cl_args_p kernargs_again() {
+    cl_args_p p = (cl_args_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#else
+typedef const cl_mlp_args* cl_args_p;                                        // (host pass over the kernel bodies: never executed)
+__host__ __device__ inline cl_args_p kernargs_again() { return nullptr; }
+#endif

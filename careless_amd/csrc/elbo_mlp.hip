@@ -63,6 +63,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CL_BIAS_ONE
 #define CL_BIAS_ONE 1
 #endif
+#ifndef CL_FAST_SG
+#define CL_FAST_SG 0     /* 1: hardware rcp / log for 1/sigma, log sigma in the epilogue (measured: no gain on the 64-wide instances) */
+#endif
+#ifndef CL_VOL_STAGE
+#define CL_VOL_STAGE 0
+#endif
+#if CL_VOL_STAGE
+#define CL_STAGE_Q volatile
+#else
+#define CL_STAGE_Q
+#endif
 #ifndef CL_PF_NEXT
 #define CL_PF_NEXT 1
 #endif
@@ -497,6 +508,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         const float io = ion, sg = sgn;
         // gathers that depend on the prefetched ids: issued now, consumed in the epilogue (latency hides under forward)
         float aim = 1.0f, zf0 = 0.0f, zf1 = 0.0f, et0 = 0.0f, et1 = 0.0f;
+        cl_args_p E0 = kernargs_again();     // arguments of the gathers below, re-read here (see kernargs_again, cl_kernels.h)
         const int gobs_e = tile * CL_TILE + CL_WOBS * wv + je;   // the observation this lane handles in the epilogue
         const unsigned zoff = 4u * (unsigned)rid * (unsigned)S;     // z_f / dz_f BYTE offset of this lane's reflection
         const unsigned eoff_t = 4u * lane_obs_e * (unsigned)S;      // eta / ipred BYTE offset inside the tile
@@ -505,16 +517,16 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         int rme = 0;
         long long nkey = 0;                // noise key of this lane's row
         if (IMGL && MODE == 0 && rid >= 0) {
-            rme = A.row_map[gobs_e];
-            nkey = (A.noise_row != nullptr) ? (long long)A.noise_row[gobs_e] : A.obs_offset + rme;
+            rme = E0->row_map[gobs_e];
+            nkey = (E0->noise_row != nullptr) ? (long long)E0->noise_row[gobs_e] : E0->obs_offset + rme;
         }
         const unsigned eoff = IMGL ? 4u * (unsigned)rme * (unsigned)S : eoff_t;
-        const float* __restrict__ eta_t = A.eta ? (IMGL ? A.eta : A.eta + (size_t)tile_u * CL_TILE * S) : nullptr;
-        float* __restrict__ ipred_t = A.ipred_out ? (IMGL ? A.ipred_out : A.ipred_out + (size_t)tile_u * CL_TILE * S) : nullptr;
+        const float* __restrict__ eta_t = E0->eta ? (IMGL ? E0->eta : E0->eta + (size_t)tile_u * CL_TILE * S) : nullptr;
+        float* __restrict__ ipred_t = E0->ipred_out ? (IMGL ? E0->ipred_out : E0->ipred_out + (size_t)tile_u * CL_TILE * S) : nullptr;
         if (MODE == 0 && rid >= 0) {
-            if (A.use_img && img > 0) aim = ld_uo(A.img, 4u * (unsigned)(img - 1));
-            if (qe < S) zf0 = ld_uo(A.z_f, zoff + 4u * qe);
-            if (qe + 4 < S) zf1 = ld_uo(A.z_f, zoff + 4u * (qe + 4));
+            if (E0->use_img && img > 0) aim = ld_uo(E0->img, 4u * (unsigned)(img - 1));
+            if (qe < S) zf0 = ld_uo(E0->z_f, zoff + 4u * qe);
+            if (qe + 4 < S) zf1 = ld_uo(E0->z_f, zoff + 4u * (qe + 4));
             if (eta_t != nullptr) {
                 if (qe < S) et0 = ld_uo(eta_t, eoff + 4u * qe);
                 if (qe + 4 < S) et1 = ld_uo(eta_t, eoff + 4u * (qe + 4));
@@ -638,6 +650,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         }
 
         // ================= epilogue: sample, predict, likelihood, dL/dO =====================================
+        cl_args_p E = kernargs_again();      // the epilogue's arguments are loaded here, once per tile, not held in SGPRs across the tile
         float dloc, draw;
         if (MODE == 0) {
             // move the scaler outputs from the MFMA lane map (observation lane&15) to the epilogue lane map (lane>>2)
@@ -645,17 +658,18 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             const float sige = __shfl(sigma, je);
             float pdl = 0.0f, pds = 0.0f, pda = 0.0f;
             STAMP(11);
-            if (IMGL && A.gmeta != nullptr) {
+            if (IMGL && E->gmeta != nullptr) {
                 // ---- single-pass Laue: the predictions of the rows of one harmonic group SUM before the likelihood
                 //      (ConvolvedLikelihood.convolve, careless/models/likelihoods/laue.py:20-34).  The members of a group sit in
                 //      consecutive rows of this wave; lane (row je, slot qe) collects the group's total with shuffles, every
                 //      member evaluates the same likelihood derivative, member 0 alone counts the group's log-likelihood.
-                const int gm = (rid >= 0) ? A.gmeta[gobs_e] : 0;
+                const int gm = (rid >= 0) ? E->gmeta[gobs_e] : 0;
                 const int mem = gm & 0xff, cnt = gm >> 8;
                 const int lfirst = 4 * (je - mem) + qe;
-                const int gmax = __builtin_amdgcn_readfirstlane(A.tile_gmax[tile]);
-                const float inv_sg = 1.0f / sg;
-                const float log_sg = logf(sg);
+                const int gmax = __builtin_amdgcn_readfirstlane(E->tile_gmax[tile]);
+                // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
+                const float inv_sg = CL_FAST_SG ? cl_fast_rcp(sg) : 1.0f / sg;
+                const float log_sg = CL_FAST_SG ? cl_fast_log(sg) : logf(sg);
                 float eta_sin = 0.0f;
                 const int K = (S + 3) >> 2;
                 for (int k = 0; k < K; ++k) {                     // wave-uniform trip count: all lanes take part in the shuffles
@@ -666,13 +680,13 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         if (eta_t != nullptr) {
                             eta = (k == 0) ? et0 : ((k == 1) ? et1 : ld_uo(eta_t, eoff + 4u * s));
                         } else if ((k & 1) == 0) {
-                            cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)nkey, &eta, &eta_sin);
+                            cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)nkey, &eta, &eta_sin);
                         } else {
                             eta = eta_sin;
                         }
-                        zf = (k == 0) ? zf0 : ((k == 1) ? zf1 : ld_uo(A.z_f, zoff + 4u * s));
+                        zf = (k == 0) ? zf0 : ((k == 1) ? zf1 : ld_uo(E->z_f, zoff + 4u * s));
                     }
-                    const float tq = o0e + sige * eta + A.shift;
+                    const float tq = o0e + sige * eta + E->shift;
                     const float zs = aim * tq;
                     const float ipred = act ? zs * zf * zf : 0.0f;
                     if (act && ipred_t) *ptr_uo(ipred_t, eoff + 4u * s) = ipred;
@@ -685,15 +699,15 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         float dll, ll;
                         if (use_ev11) {
                             float gf, gb, ga;
-                            ll = cl_lik_ev11(tot, io, sg, A.lik_kind, A.dof, A.lik_const, ev, &dll, &gf, &gb, &ga);
-                            if (mem == 0) { ev_g0 -= gf * A.w_ll; ev_g1 -= ga * A.w_ll; ev_g2 -= gb * A.w_ll; }
+                            ll = cl_lik_ev11(tot, io, sg, E->lik_kind, E->dof, E->lik_const, ev, &dll, &gf, &gb, &ga);
+                            if (mem == 0) { ev_g0 -= gf * E->w_ll; ev_g1 -= ga * E->w_ll; ev_g2 -= gb * E->w_ll; }
                         } else {
-                            ll = cl_lik_log_prob2(tot, io, inv_sg, log_sg, A.lik_kind, A.dof, A.lik_const, &dll);
+                            ll = cl_lik_log_prob2(tot, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
                         }
-                        if (mem == 0) nll_acc -= ll * A.w_ll;
-                        const float gi = -dll * A.w_ll;                 // dNLL / d iconv = dNLL / d ipred of every member
+                        if (mem == 0) nll_acc -= ll * E->w_ll;
+                        const float gi = -dll * E->w_ll;                 // dNLL / d iconv = dNLL / d ipred of every member
                         const float dzs = gi * zf * zf;
-                        atomicAdd(ptr_uo(A.dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
+                        atomicAdd(ptr_uo(E->dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
                         const float dt = dzs * aim;
                         pdl += dt;
                         pds += dt * eta;
@@ -701,8 +715,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     }
                 }
             } else if (rid >= 0) {
-                const float inv_sg = 1.0f / sg;
-                const float log_sg = logf(sg);
+                // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
+                const float inv_sg = CL_FAST_SG ? cl_fast_rcp(sg) : 1.0f / sg;
+                const float log_sg = CL_FAST_SG ? cl_fast_log(sg) : logf(sg);
                 int k = 0;
                 float eta_sin = 0.0f;
                 for (int s = qe; s < S; s += 4, ++k) {
@@ -710,27 +725,27 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     if (eta_t != nullptr) {
                         eta = (k == 0) ? et0 : ((k == 1) ? et1 : ld_uo(eta_t, eoff + 4u * s));
                     } else if ((k & 1) == 0) {       // one Philox block + Box-Muller pair serves samples s and s + 4
-                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(IMGL ? nkey : A.obs_offset + gobs_e), &eta, &eta_sin);
+                        cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)(IMGL ? nkey : E->obs_offset + gobs_e), &eta, &eta_sin);
                     } else {
                         eta = eta_sin;
                     }
-                    const float zf = (k == 0) ? zf0 : ((k == 1) ? zf1 : ld_uo(A.z_f, zoff + 4u * s));
-                    const float tq = o0e + sige * eta + A.shift;
+                    const float zf = (k == 0) ? zf0 : ((k == 1) ? zf1 : ld_uo(E->z_f, zoff + 4u * s));
+                    const float tq = o0e + sige * eta + E->shift;
                     const float zs = aim * tq;
                     const float ipred = zs * zf * zf;
                     if (ipred_t) *ptr_uo(ipred_t, eoff + 4u * s) = ipred;
                     float dll, ll;
                     if (use_ev11) {
                         float gf, gb, ga;
-                        ll = cl_lik_ev11(ipred, io, sg, A.lik_kind, A.dof, A.lik_const, ev, &dll, &gf, &gb, &ga);
-                        ev_g0 -= gf * A.w_ll; ev_g1 -= ga * A.w_ll; ev_g2 -= gb * A.w_ll;     // order: Sdfac, Sdadd, SdB
+                        ll = cl_lik_ev11(ipred, io, sg, E->lik_kind, E->dof, E->lik_const, ev, &dll, &gf, &gb, &ga);
+                        ev_g0 -= gf * E->w_ll; ev_g1 -= ga * E->w_ll; ev_g2 -= gb * E->w_ll;     // order: Sdfac, Sdadd, SdB
                     } else {
-                        ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, A.lik_kind, A.dof, A.lik_const, &dll);
+                        ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
                     }
-                    nll_acc -= ll * A.w_ll;
-                    const float gi = -dll * A.w_ll;                 // dNLL / d ipred
+                    nll_acc -= ll * E->w_ll;
+                    const float gi = -dll * E->w_ll;                 // dNLL / d ipred
                     const float dzs = gi * zf * zf;
-                    atomicAdd(ptr_uo(A.dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
+                    atomicAdd(ptr_uo(E->dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
                     const float dt = dzs * aim;
                     pdl += dt;
                     pds += dt * eta;
@@ -740,7 +755,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             pdl += __shfl_xor(pdl, 1); pds += __shfl_xor(pds, 1); pda += __shfl_xor(pda, 1);
             pdl += __shfl_xor(pdl, 2); pds += __shfl_xor(pds, 2); pda += __shfl_xor(pda, 2);
             STAMP(12);
-            if (A.use_img) {
+            if (E->use_img) {
                 // image ids are sorted, so the 16 observations of a wave almost always share one image: reduce in the
                 // wave and issue ONE atomic instead of 16 same-address ones (which serialise in the L2 atomic unit)
                 const int img0 = __builtin_amdgcn_readfirstlane(img);
@@ -748,9 +763,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     float v = (qe == 0 && rid >= 0) ? pda : 0.0f;
 #pragma unroll
                     for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off);
-                    if (lane == 0 && img0 > 0) atomicAdd(ptr_uo(A.d_img, 4u * (unsigned)(img0 - 1)), v);
+                    if (lane == 0 && img0 > 0) atomicAdd(ptr_uo(E->d_img, 4u * (unsigned)(img0 - 1)), v);
                 } else if (qe == 0 && rid >= 0 && img > 0) {
-                    atomicAdd(ptr_uo(A.d_img, 4u * (unsigned)(img - 1)), pda);
+                    atomicAdd(ptr_uo(E->d_img, 4u * (unsigned)(img - 1)), pda);
                 }
             }
             // back to the MFMA lane map: lane (j, q) needs dL/dloc and dL/dsigma of observation j, held by lanes 4j..4j+3
@@ -764,10 +779,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         } else if (no_head) {
             dloc = 0.0f; draw = 0.0f;                     // head-less block of a chain: the gradient arrives as dH_ext below
         } else {
-            const int row = (IMGL && valid) ? A.row_map[gobs] : gobs;
+            const int row = (IMGL && valid) ? E->row_map[gobs] : gobs;
             const bool have = valid && row >= 0;
-            dloc = have ? A.dO_ext[2 * (size_t)row] : 0.0f;
-            draw = have ? A.dO_ext[2 * (size_t)row + 1] * dsig_draw : 0.0f;   // external grad is w.r.t. sigma
+            dloc = have ? E->dO_ext[2 * (size_t)row] : 0.0f;
+            draw = have ? E->dO_ext[2 * (size_t)row + 1] * dsig_draw : 0.0f;   // external grad is w.r.t. sigma
             if (q == 0) {
                 boacc0 += dloc; boacc1 += draw;
             }
@@ -971,8 +986,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                                 const int gi = (mb / MBS) * FB + kb;
 #pragma unroll
                                 for (int e = IPG * gi; e < IPG * (gi + 1); ++e) {
-                                    if (e < 4 * FB) stz[(16 * (e / 4) + (e % 4)) * PB] = dH[(e / 4) % FB][e % 4];
-                                    else sth[(16 * ((e - 4 * FB) / 4) + (e % 4)) * PB] = hs[l > 0 ? l - 1 : 0][((e - 4 * FB) / 4) % FB][e % 4];
+                                    // (CL_VOL_STAGE: volatile stores are not merged into ds_write2_b32, whose 8-bit offsets cost a
+                                    // v_add_u32 of the base per pair -- a vector instruction beside the MFMAs -- where single
+                                    // ds_write_b32 take the whole offset as an immediate)
+                                    if (e < 4 * FB) *(CL_STAGE_Q float*)&stz[(16 * (e / 4) + (e % 4)) * PB] = dH[(e / 4) % FB][e % 4];
+                                    else *(CL_STAGE_Q float*)&sth[(16 * ((e - 4 * FB) / 4) + (e % 4)) * PB] = hs[l > 0 ? l - 1 : 0][((e - 4 * FB) / 4) % FB][e % 4];
                                 }
 #pragma unroll
                                 for (int k = 0; k < IPG; ++k) {

@@ -87,17 +87,6 @@ __device__ __forceinline__ unsigned top_layer_mask(int L) {
     asm volatile("" : "+s"(m));
     return m;
 }
-// The kernel arguments, re-read from the kernarg segment behind an opaque pointer.  hipcc loads every field of the by-value argument
-// struct at kernel entry and keeps it in SGPRs for the whole kernel (> 100 SGPRs: it then parks them in VGPR lanes and pays
-// v_readlane / v_writelane in the per-tile code); fields that only the epilogue and the prefetch use are instead loaded there,
-// once per tile, by scalar loads that cannot be hoisted.
-typedef const __attribute__((address_space(4))) cl_mlp_args* cl_args_p;
-__device__ __forceinline__ cl_args_p kernargs_again() {
-    cl_args_p p = (cl_args_p)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
 // sum over the 64 lanes of a wave (returned in every lane's copy of a scalar): four DPP butterfly steps inside the 16-lane rows,
 // then the rows through row_bcast -- six VALU instructions and no LDS round trip (a shuffle loop is 6 x ds_bpermute + adds)
 __device__ __forceinline__ float wave_sum(float v) {

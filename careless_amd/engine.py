@@ -279,7 +279,7 @@ class ObsData:
     layers) the arrays the fused kernel streams are in the packed order of `pack_by_image`."""
 
     def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None,
-                 laue_groups=None, pack_images: bool = False, laue_single_pass: bool = True):
+                 laue_groups=None, pack_images: bool = False, laue_single_pass: bool = True, wide: bool = False):
         refl_id = _np(BaseModel.get_refl_id(inputs)).reshape(-1).astype(np.int64)
         image_id = _np(BaseModel.get_image_id(inputs)).reshape(-1).astype(np.int64)
         metadata = _np(BaseModel.get_metadata(inputs)).astype(np.float32).reshape(len(refl_id), -1)
@@ -360,6 +360,11 @@ class ObsData:
                     return out
                 rid_l, img_l = packed(rid_l, -1), packed(img_l, 0)
                 iobs_l, sig_l = packed(np.asarray(iobs_l), 0.0), packed(np.asarray(sig_l), 1.0)
+        elif wide:
+            # scaler wider than the fused kernel holds: library GEMMs on the row-major metadata (ElboEngine._data_term_wide)
+            self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
+            meta_t = np.zeros((4, 4), dtype=np.float32)
+            self.meta_rm = torch.as_tensor(np.ascontiguousarray(metadata[sl]), device=device)
         else:
             self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
             meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
@@ -378,7 +383,9 @@ class ObsData:
             if self.rows is not None:
                 hl = hl - laue_groups[0]
                 self.row_index = torch.as_tensor(self.rows.astype(np.int64), device=device)
-        if self.laue and not self.fused_laue:
+        if wide and not self.laue:
+            hl = np.arange(self.N)             # every row its own "harmonic group": the slot kernels then ARE the mono likelihood
+        if (self.laue and not self.fused_laue) or wide:
             self.harmonic_id = torch.as_tensor(hl.astype(np.int32), device=device)
             self.laue_loc = torch.empty(self.N, dtype=torch.float32, device=device)
             self.laue_sig = torch.empty(self.N, dtype=torch.float32, device=device)
@@ -386,7 +393,7 @@ class ObsData:
             self.laue_dO = torch.empty(self.N * 2, dtype=torch.float32, device=device)
         g = int(grid) if grid is not None else max(1, int(lib.cl_mlp_default_grid()))
         self.grid = min(g, self.n_pad // TILE)
-        self.partials = torch.empty(self.grid * P, dtype=torch.float32, device=device)
+        self.partials = torch.empty(0 if wide else self.grid * P, dtype=torch.float32, device=device)
         self.chain_act = self.chain_dact = None       # activations / their gradients at the block boundaries of a chained scaler
 
     def alloc_chain(self, lib, blocks, w, device):
@@ -473,10 +480,14 @@ class ElboEngine:
         self.dw_trainable = self.double_wilson and prior.r_raw is not None
         n_dwr = int(prior.r_raw.numel()) if self.dw_trainable else 0
         self.blocks = None
-        max_plain = int(self.lib.cl_mlp_max_layers(self.w))
-        if max_plain < 1:
-            raise NotImplementedError(f"scaler width {self.w}: the HIP engine supports hidden widths up to 64")
-        if imgl is None and self.L > max_plain:
+        # hidden or metadata width beyond 64: the activations of a layer no longer fit a wave's registers next to the weight-gradient
+        # blocks, so the scaler runs unfused -- one library GEMM (rocBLAS / hipBLASLt through torch.mm, exact fp32) per layer and
+        # direction, activations through HBM -- around the same HIP likelihood kernels (_data_term_wide)
+        self.wide = self.w > 64 or self.d > 64
+        max_plain = 1 if self.wide else int(self.lib.cl_mlp_max_layers(self.w))
+        if self.wide and imgl is not None:
+            raise NotImplementedError(f"per-image layers of width {self.w}: the HIP engine supports them up to width 64")
+        if not self.wide and imgl is None and self.L > max_plain:
             # deeper than one launch holds in registers: a chain of layer blocks, activations exchanged through HBM
             self.blocks = chain_plan(self.d, self.w, self.L, max_plain)
         if imgl is not None:
@@ -522,7 +533,8 @@ class ElboEngine:
             raise ValueError("mc_sample_size must be >= 1")
         self.obs = ObsData(self.lib, inputs, self.shard.start, self.shard.stop, self.S, lay.P, dev, grid=grid, n_refl=self.R,
                            n_images=self._max_images(), laue_groups=self.laue_groups, pack_images=imgl is not None,
-                           laue_single_pass=not getattr(model, "laue_two_pass", False) and self.blocks is None)
+                           laue_single_pass=not getattr(model, "laue_two_pass", False) and self.blocks is None and not self.wide,
+                           wide=self.wide)
         if self.blocks is not None:
             self.obs.alloc_chain(self.lib, self.blocks, self.w, dev)
         RS = self.R * self.S
@@ -695,6 +707,8 @@ class ElboEngine:
     def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st):
         """NLL of `obs` into scalars[NLL] and its gradient into dz_f / the flat gradient (scaler + image scales)."""
         lib, lay = self.lib, self.layout
+        if self.wide:
+            return self._data_term_wide(obs, step, eta, ipred_out, st)
         ma = self._mlp_args(step, eta, ipred_out, obs)
         if self.blocks is not None:
             return self._data_term_chain(ma, obs, step, eta, ipred_out, st)
@@ -775,7 +789,8 @@ class ElboEngine:
             raise ValueError("validation data and training data differ in kind (mono / Laue)")
         o = ObsData(self.lib, inputs, 0, None, self.S, self.layout.P, self.device, n_refl=self.R,
                     n_images=self._max_images(), pack_images=self.imgl is not None,
-                    laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None)
+                    laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None and not self.wide,
+                    wide=self.wide)
         if o.d != self.d:
             raise ValueError("validation metadata width differs from the training data")
         if self.blocks is not None:
@@ -788,6 +803,14 @@ class ElboEngine:
         lib = self.lib
         ma.loc_out, ma.sig_out = ptr(obs.laue_loc), ptr(obs.laue_sig)
         check(lib.cl_mlp_forward(C.byref(ma), obs.grid, st), "cl_mlp_forward")
+        self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
+        ma.dO_ext = ptr(obs.laue_dO)
+        check(lib.cl_mlp_backward_ext(C.byref(ma), obs.grid, st), "cl_mlp_backward_ext")
+
+    def _slot_likelihood(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
+        """From (loc, sigma) per row in obs.laue_loc / laue_sig: sample, predict, group sums, slot likelihood (NLL into the
+        scalars), its gradient back on the rows -> dz_f, d(image scales), obs.laue_dO = dL/d(loc, sigma) per row."""
+        lib = self.lib
         obs.laue_iconv.zero_()
         la = LaueArgs()
         la.refl_id, la.image_id, la.harmonic_id = ptr(obs.refl_id), ptr(obs.image_id), ptr(obs.harmonic_id)
@@ -806,9 +829,67 @@ class ElboEngine:
         check(lib.cl_laue_predict(C.byref(la), st), "cl_laue_predict")
         check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
         check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")
-        ma.dO_ext = ptr(obs.laue_dO)
-        check(lib.cl_mlp_backward_ext(C.byref(ma), obs.grid, st), "cl_mlp_backward_ext")
 
+    # -- scalers wider than 64 ---------------------------------------------------------------------------------------------
+    WIDE_CHUNK = 1 << 19      # rows per GEMM chunk: bounds the activation storage (L x chunk x w floats)
+
+    def _wide_weights(self, flat: torch.Tensor):
+        """[(W (in, out) view, b)] per Dense layer + the Dense(2) head, as views into a flat buffer in the W^T layout."""
+        base, out = self.layout.off_mlp, []
+        for off, o, i, boff in self.mlp.layer_slices(self.d):
+            out.append((flat[base + off: base + off + o * i].view(o, i), flat[base + boff: base + boff + o]))
+        return out          # kernels as (out, in): x @ Wt.t()
+
+    def _wide_forward(self, x: torch.Tensor, keep: bool):
+        """Dense stack on rows `x` (n, d): returns (activations [h_0 = x, h_1 .. h_L] if keep, loc, raw)."""
+        leak = self.mlp.leakiness
+        ws = self._wide_weights(self.params)
+        acts, h = [x], x
+        for Wt, b in ws[:-1]:
+            h = torch.nn.functional.leaky_relu(torch.addmm(b, h, Wt.t()), negative_slope=leak)
+            if keep:
+                acts.append(h)
+        o = torch.addmm(ws[-1][1], h, ws[-1][0].t())
+        return acts, o[:, 0], o[:, 1]
+
+    def _wide_sigma(self, raw: torch.Tensor):
+        """sigma = bijector(raw) + eps and d sigma / d raw (nn.py:22-25 with the CLI's chains, manager.py:450-463)."""
+        if self.mlp.scale_bijector == "exp":
+            e = torch.exp(raw)
+            return e + self.mlp.epsilon, e
+        return torch.nn.functional.softplus(raw) + self.mlp.epsilon, torch.sigmoid(raw)
+
+    def _data_term_wide(self, obs: ObsData, step: int, eta, ipred_out, st):
+        """Hidden / metadata width > 64: unfused scaler.  Forward GEMMs (chunks of rows) -> (loc, sigma) per row -> the HIP slot
+        likelihood kernels (mono rows are their own groups) -> dL/d(loc, sigma) -> backward GEMMs, the forward recomputed per
+        chunk so that only one chunk's activations are ever resident.  8 P_mm flops per observation; every product in exact fp32."""
+        ma = self._mlp_args(step, eta, ipred_out, obs)
+        x = obs.meta_rm
+        with torch.no_grad():
+            for a in range(0, obs.N, self.WIDE_CHUNK):
+                b = min(obs.N, a + self.WIDE_CHUNK)
+                _, loc, raw = self._wide_forward(x[a:b], keep=False)
+                obs.laue_loc[a:b] = loc
+                obs.laue_sig[a:b] = self._wide_sigma(raw)[0]
+            self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
+            leak = self.mlp.leakiness
+            ws = self._wide_weights(self.params)
+            gs = self._wide_weights(self.grads)
+            dO = obs.laue_dO.view(obs.N, 2)
+            for a in range(0, obs.N, self.WIDE_CHUNK):
+                b = min(obs.N, a + self.WIDE_CHUNK)
+                acts, _, raw = self._wide_forward(x[a:b], keep=True)
+                g = dO[a:b].clone()
+                g[:, 1] *= self._wide_sigma(raw)[1]                      # dL/d raw = dL/d sigma * d sigma / d raw
+                gs[-1][0].addmm_(g.t(), acts[-1])                        # dWo^T (2, w) += g^T h_L
+                gs[-1][1].add_(g.sum(0))
+                dh = g @ ws[-1][0]                                       # (n, w)
+                for l in range(self.L - 1, -1, -1):
+                    dz = torch.where(acts[l + 1] > 0, dh, leak * dh)
+                    gs[l][0].addmm_(dz.t(), acts[l])                     # dW_l^T (out, in) += dZ^T H_{l-1}
+                    gs[l][1].add_(dz.sum(0))
+                    if l > 0:
+                        dh = dz @ ws[l][0]
     def _allreduce(self):
         from careless_amd.distributed import allreduce_flat_
         allreduce_flat_(self.grads, self.process_group)
@@ -959,6 +1040,19 @@ def scaler_forward(mlp, metadata, imgl=None, image_id=None):
     mlp.build(d)
     if mlp.flat.device != dev:
         mlp.flat = mlp.flat.to(dev)
+    if mlp.width > 64 or d > 64:
+        # wider than the fused kernel holds: library GEMMs (see ElboEngine._data_term_wide)
+        if imgl is not None:
+            raise NotImplementedError(f"per-image layers of width {mlp.width}: the HIP engine supports them up to width 64")
+        h = torch.as_tensor(md, device=dev)
+        with torch.no_grad():
+            ws = mlp.weights
+            for k in range(mlp.n_layers):
+                h = torch.nn.functional.leaky_relu(torch.addmm(ws[2 * k + 1], h, ws[2 * k]), negative_slope=mlp.leakiness)
+            o = torch.addmm(ws[-1], h, ws[-2])
+            raw = o[:, 1]
+            sig = (torch.exp(raw) if mlp.scale_bijector == "exp" else torch.nn.functional.softplus(raw)) + mlp.epsilon
+        return o[:, 0].contiguous(), sig
     keep = []
     if imgl is not None:
         imgl.build(d)

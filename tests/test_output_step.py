@@ -23,6 +23,7 @@ CASES = {
     "image_layers2_3x8": dict(N=800, R=40, d0=5, L=3, w=8, S=1, n_images=5, image_layers=2, perturb=0.03),
     "laue_image_layers1": dict(N=600, R=60, L=2, w=32, S=1, laue=True, n_images=4, image_layers=1),
     "deep_12x64": dict(N=500, R=40, d0=5, L=12, w=64, S=1),
+    "wide_2x96": dict(N=400, R=40, d0=5, L=2, w=96, S=1),
 }
 
 
