@@ -38,10 +38,35 @@ def _prediction_tables(dm, model, inputs, test_value):
     return [{k: np.asarray(v)[cols["asu_id"] == i] for k, v in cols.items()} for i in range(len(rac))]
 
 
+def _data_parallel():
+    """(rank, world) of a one-process-per-GPU launch (`python -m torch.distributed.run --nproc-per-node N -m careless_amd mono ...`):
+    RANK / LOCAL_RANK / WORLD_SIZE in the environment select the data-parallel engine -- observations sharded over the ranks,
+    one all-reduce of the flat gradient per step (careless_amd/distributed.py).  The reference has no counterpart (it pins one
+    GPU, careless/parser.py:26-40).  Every rank formats the same files and draws the same splits; rank 0 writes the outputs."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if not dist.is_initialized():
+        backend = os.environ.get("CARELESS_DIST_BACKEND", "nccl")        # nccl = RCCL on ROCm; gloo rehearses on a single GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world
+
+
 def run_careless(parser):
     from careless_amd.io.formats import PREDICTION_TYPES, results_tables, write_history_csv, write_table_mtz
     from careless_amd.manager import DataManager
 
+    rank, world = _data_parallel()
     np.random.seed(parser.seed)                                    # reference parser.py:22-23
     inputs, rac = _format(parser)
     dm = DataManager(inputs, rac, parser=parser)
@@ -51,6 +76,8 @@ def run_careless(parser):
         train, test = dm.inputs, None
 
     model = dm.build_model()
+    if world > 1:
+        model.set_data_parallel(rank, world)
     if parser.scale_file is not None:
         model.scaling_model.load_weights(parser.scale_file)
     if parser.freeze_scales:
@@ -60,17 +87,20 @@ def run_careless(parser):
     if parser.freeze_structure_factors:
         model.surrogate_posterior.trainable = False
 
-    progress = not parser.disable_progress_bar
+    progress = not parser.disable_progress_bar and rank == 0
     history = model.train_model(train, parser.iterations, message="Training", validation_data=test,
                                 validation_frequency=parser.validation_frequency, progress=progress)
 
     asus = list(rac)
+    if rank != 0:                                                   # parameters are identical on every rank: rank 0 writes the files
+        write_table_mtz = write_history_csv = lambda *a, **k: None
     for i, table in enumerate(results_tables(dm.get_results(model.surrogate_posterior, inputs=train), rac)):
         write_table_mtz(parser.output_base + f"_{i}.mtz", table, asus[i])
     write_history_csv(parser.output_base + "_history.csv", history)
-    model.surrogate_posterior.save_weights(parser.output_base + "_structure_factor")
-    model.scaling_model.save_weights(parser.output_base + "_scale")
-    if getattr(parser, "save_data_manager", False):                 # reference careless.py:81-84
+    if rank == 0:
+        model.surrogate_posterior.save_weights(parser.output_base + "_structure_factor")
+        model.scaling_model.save_weights(parser.output_base + "_scale")
+    if getattr(parser, "save_data_manager", False) and rank == 0:   # reference careless.py:81-84
         import pickle
         with open(parser.output_base + "_data_manager.pickle", "wb") as out:
             pickle.dump(dm, out)
@@ -88,6 +118,8 @@ def run_careless(parser):
         for repeat in range(parser.half_dataset_repeats):
             for half_id, half in enumerate(dm.split_data_by_image()):
                 m = dm.build_model(scaling_model=scaling_model)
+                if world > 1:
+                    m.set_data_parallel(rank, world)
                 m.train_model(half, parser.iterations, message=f"Merging repeat {repeat + 1} half {half_id + 1}", progress=progress)
                 for file_id, t in enumerate(results_tables(dm.get_results(m.surrogate_posterior, inputs=half), rac)):
                     t["repeat"] = np.full(len(t["H"]), repeat)

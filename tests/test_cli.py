@@ -174,3 +174,30 @@ def test_preformatted_npz_input(tmp_path):
     out = str(tmp_path / "o")
     _, hist = run_careless(parser.parse_args(f"mono --iterations=5 --disable-progress-bar --mlp-layers 2 dHKL,image_id {npz} {out}".split()))
     assert len(hist["loss"]) == 5 and read_mtz(out + "_0.mtz").spacegroup_number == 173
+
+
+def test_data_parallel_cli_two_ranks_match_one(tmp_path):
+    """`python -m careless_amd mono ...` as two one-process-per-GPU ranks (here: both on this GPU, gloo backend) writes the same
+    merged amplitudes and history as the single-process run: observations sharded, one gradient all-reduce per step, in-kernel
+    noise keyed by global indices, rank 0 writes the files (careless_amd/careless.py: _data_parallel)."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = f"mono --iterations={niter} --disable-progress-bar --mlp-layers 3 --test-fraction 0.2 dHKL,image_id".split()
+    one = str(tmp_path / "one")
+    _run(" ".join(flags), [PYP], one, False)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = str(tmp_path / "two")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CARELESS_DIST_BACKEND="gloo", PYTHONPATH=root)
+        procs.append(subprocess.Popen([sys.executable, "-m", "careless_amd"] + flags + [PYP, two], env=env, cwd=root))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    a, b = read_mtz(one + "_0.mtz"), read_mtz(two + "_0.mtz")
+    assert np.array_equal(a.hkl(), b.hkl()) and np.array_equal(a.columns["N"], b.columns["N"])
+    assert np.allclose(a.columns["F"], b.columns["F"], rtol=1e-4) and np.allclose(a.columns["SigF"], b.columns["SigF"], rtol=1e-3)
+    ha = np.genfromtxt(one + "_history.csv", delimiter=",", names=True)
+    hb = np.genfromtxt(two + "_history.csv", delimiter=",", names=True)
+    assert np.allclose(ha["loss"], hb["loss"], rtol=1e-5) and np.allclose(ha["NLL_val"], hb["NLL_val"], rtol=1e-4)
