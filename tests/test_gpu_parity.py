@@ -33,6 +33,13 @@ CASES = {
     "mlp9x7_d6_S2": dict(N=700, R=40, d0=6, L=9, w=7, S=2, perturb=0.03, grid=2),
     "mlp7x12_S3_studentt": dict(N=500, R=40, d0=5, L=7, w=12, S=3, likelihood="studentt", dof=6.0, perturb=0.03),
     "mlp5x13_softplus": dict(N=400, R=30, d0=5, L=5, w=13, S=2, bijector="softplus", shift=1.5, perturb=0.03),
+    # the narrow kernel (csrc/elbo_narrow.hip: width <= 15, metadata <= 15 columns, plain mono layout) beyond the CLI default
+    "narrow_ev11_studentt_6x10_S5": dict(N=700, R=50, d0=5, L=6, w=10, S=5, ev11=True, likelihood="studentt", dof=6.0, perturb=0.03),
+    "narrow_klweight_4x10_S12_noimg": dict(N=500, R=40, d0=5, L=4, w=10, S=12, kl_weight=0.5, use_image_scales=False, perturb=0.03),
+    "narrow_rows_in_arbitrary_order_S3": dict(N=900, R=60, d0=5, L=5, w=10, S=3, n_images=9, shuffle_rows=True, perturb=0.03),
+    "narrow_three_observations": dict(N=3, R=2, d0=5, L=3, w=10, S=2, n_images=1, use_image_scales=False, perturb=0.03),
+    "narrow_one_layer_w15_d15_softplus": dict(N=333, R=30, d0=15, L=1, w=15, S=2, bijector="softplus", shift=0.5, perturb=0.03),
+    "narrow_20x4_d12": dict(N=600, R=40, d0=12, L=20, w=4, S=1, perturb=0.03, grid=2),
     "image_layers2_3x8": dict(N=800, R=40, d0=5, L=3, w=8, S=2, n_images=5, image_layers=2, perturb=0.03),
     "laue_two_pass_narrow_8x5": dict(N=500, R=40, L=8, w=5, S=2, laue=True, two_pass=True, perturb=0.03),
     "mlp8x24_S2_studentt": dict(N=300, R=30, d0=5, L=8, w=24, S=2, likelihood="studentt", dof=4.0, perturb=0.03),
@@ -236,6 +243,26 @@ def test_philox_mode_matches_oracle_on_dumped_noise():
     assert 0.0 < u.min() and u.max() < 1.0
     out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u, dtype=torch.float64),
                                         torch.as_tensor(e, dtype=torch.float64))
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(out["loss"])) <= 1e-4 * abs(float(out["loss"]))
+    errs = [util.rel_err(a.cpu().numpy(), b.numpy()) for a, b in zip(eng.grad_tensors(), grads)]
+    assert max(errs) < RTOL_GRAD, errs
+
+
+def test_philox_mode_on_the_narrow_kernel_with_twelve_samples():
+    """The narrow kernel walks the MC samples of an observation serially and shares one Box-Muller pair between samples s and
+    s + 4 (cl_math.h: cl_noise_normal_pair): twelve samples go through every branch of that bookkeeping."""
+    from careless_amd.engine import debug_noise
+    kw = dict(N=333, R=40, d0=5, L=4, w=10, S=12, perturb=0.03)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    model = util.build_model(data, cfg, params, 4, 10)
+    model.seed = 99
+    model(util.reference_inputs(data))
+    eng = model._engine
+    torch.cuda.synchronize()
+    u = debug_noise(99, 0, 12, 40, 0, kind=0).t().cpu().numpy()
+    e = debug_noise(99, 0, 12, 333, 0, kind=1).t().cpu().numpy()
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
     t = eng.loss_terms()
     assert abs(t["loss"] - float(out["loss"])) <= 1e-4 * abs(float(out["loss"]))
     errs = [util.rel_err(a.cpu().numpy(), b.numpy()) for a, b in zip(eng.grad_tensors(), grads)]
