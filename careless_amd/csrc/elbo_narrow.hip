@@ -140,7 +140,7 @@ struct NSmem {
     static constexpr int NACC = (NWAVES <= 4) ? 0 : (ROOM < NL - 8 ? (ROOM > 0 ? ROOM : 0) : NL - 8);
     static constexpr int LREG = NL - NACC;                    // layers < LREG accumulate in registers
     static constexpr int main_total = oA + NACC * SLOT;
-    static constexpr int flush_total = (NL + 1) * 256;
+    static constexpr int flush_total = (NWAVES / 2 > 0 ? NWAVES / 2 : 1) * (NL + 1) * 256;   // the flush parks half the waves' accumulators
     static constexpr int total = main_total > flush_total ? main_total : flush_total;
 };
 
@@ -172,11 +172,17 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
     // ---- weight images (W^T layout of cl_kernels.h -> slot-permuted, zero-padded 16 x 16 images) ------------------------
     {
         const float* __restrict__ P = A.mlp;
-        for (int idx = tid; idx < (NL + G) * 16 * NPW; idx += NT) {
+        // (all loads of a thread are issued before the first LDS store: a plain loop waits for every load in turn, ~14 serial
+        // round trips per launch -- a fixed cost that dominates small data sets)
+        constexpr int NIMG = (NL + G) * 16 * NPW, NIT = (NIMG + NT - 1) / NT;
+        float wv_[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * NT + tid;
             const int l = idx / (16 * NPW), r = idx - l * (16 * NPW);
             const int os = r / NPW, is = r - os * NPW;               // output slot (row), input slot (column)
             float v = 0.0f;
-            if (is < 16) {
+            if (idx < NIMG && is < 16) {
                 const int fi = slot_of(is);
                 if (l < L) {
                     const int fo = slot_of(os);
@@ -189,7 +195,12 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     if ((c == 0 || c == 1) && fi < w) v = Wo[c * w + fi];
                 }
             }
-            sW[idx] = v;
+            wv_[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * NT + tid;
+            if (idx < NIMG) sW[idx] = wv_[it];
         }
         for (int idx = tid; idx < (NL + 1) * 16; idx += NT) {
             const int l = idx >> 4, os = idx & 15;
@@ -205,11 +216,13 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
             sB[idx] = v;
         }
         // staging tiles: rows that are never written hold their constants (zero; row 15 of the input tile = the ones)
-        for (int idx = tid; idx < NWAVES * SM::TW; idx += NT) {
+        static_assert(SM::oT % 4 == 0 && SM::TW % 4 == 0 && PBW % 4 == 0, "16-byte zero fill");
+        for (int idx = 4 * tid; idx < NWAVES * SM::TW; idx += 4 * NT) {
             const int row = (idx % SM::TW) / PBW;                       // 0-15 sZ, 16-31 sH, 32-34 sD
-            smem[SM::oT + idx] = (row == 16 + 15) ? 1.0f : 0.0f;
+            const float v = (row == 16 + 15) ? 1.0f : 0.0f;
+            *reinterpret_cast<f32x4*>(smem + SM::oT + idx) = f32x4{v, v, v, v};
         }
-        for (int idx = tid; idx < SM::NACC * SM::SLOT; idx += NT) smem[SM::oA + idx] = 0.0f;
+        for (int idx = 4 * tid; idx < SM::NACC * SM::SLOT; idx += 4 * NT) *reinterpret_cast<f32x4*>(smem + SM::oA + idx) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     __syncthreads();
 
@@ -576,17 +589,33 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
     __syncthreads();
     const int offWo = w * d + w + (L - 1) * (w * w + w);
     const int Ptot = offWo + 2 * w + 2;
-    for (int pass = 0; pass < NWAVES; ++pass) {
-        if (wv == pass) {
+    // fixed binary tree over the waves (deterministic, log2(NWAVES) + 1 barriers): at stride s the waves with (wv & (2s - 1)) == s
+    // park their sums in the region of wave wv - s, which adds them to its own
+    constexpr int REG = (NL + 1) * 256;                    // floats of one wave's parked accumulators
+    static_assert((NWAVES / 2) * REG * 4 <= 160 * 1024, "flush regions");
+    f32x4 facc[NL + 1];
 #pragma unroll
-            for (int l = 0; l <= NL; ++l) {
-                f32x4* dst = reinterpret_cast<f32x4*>(smem + l * 256) + lane;
-                const f32x4 v = (l == NL) ? wacc_h : ((l >= LREG) ? acc_slot(l) : wacc[l < LREG ? l : 0]);
-                *dst = (pass == 0) ? v : *dst + v;
-            }
+    for (int l = 0; l <= NL; ++l) facc[l] = (l == NL) ? wacc_h : ((l >= LREG) ? acc_slot(l) : wacc[l < LREG ? l : 0]);
+    __syncthreads();                                       // every wave has read its LDS slots: the regions may overwrite them
+#pragma unroll
+    for (int s2 = 1; s2 < NWAVES; s2 <<= 1) {
+        f32x4* reg = reinterpret_cast<f32x4*>(smem + ((wv & ~(2 * s2 - 1)) / (2 * s2)) * REG) + lane;
+        if ((wv & (2 * s2 - 1)) == s2) {
+#pragma unroll
+            for (int l = 0; l <= NL; ++l) reg[l * 64] = facc[l];
+        }
+        __syncthreads();
+        if ((wv & (2 * s2 - 1)) == 0) {
+#pragma unroll
+            for (int l = 0; l <= NL; ++l) facc[l] += reg[l * 64];
         }
         __syncthreads();
     }
+    if (wv == 0) {
+#pragma unroll
+        for (int l = 0; l <= NL; ++l) reinterpret_cast<f32x4*>(smem + l * 256)[lane] = facc[l];
+    }
+    __syncthreads();
     float* __restrict__ part = A.partials + (size_t)blockIdx.x * Ptot;
     for (int idx = tid; idx < (NL + 1) * 256; idx += NT) {
         const int l = idx >> 8, r = idx & 255;                     // accumulator l < NL: Dense layer l; NL: the head
