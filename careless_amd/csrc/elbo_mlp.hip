@@ -1333,6 +1333,13 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }
 
+#if !CL_IMGL && !CL_CHAIN
+static bool narrow_enabled() {          // CARELESS_HIP_NARROW=0 keeps narrow scalers on the eight-wave instance of this file (A/B runs)
+    static const bool on = [] { const char* e = getenv("CARELESS_HIP_NARROW"); return !(e != nullptr && e[0] == '0'); }();
+    return on;
+}
+#endif
+
 #if CL_CHAIN
 int cl_launch_mlp_chain(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.row_map != nullptr || a.n_imgl > 0) return -2;                       // chains use the plain layout
@@ -1355,7 +1362,8 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
     if (a.n_imgl > 0) return cl_launch_mlp_imgl(a, mode, grid, st);            // packed layout + per-image layers
-    if (a.row_map != nullptr) return cl_launch_mlp_packed(a, mode, grid, st);    // packed layout (single-pass Laue)
+    if (a.row_map != nullptr && !(mode == 0 && cl_narrow_supports(a) && narrow_enabled()))
+        return cl_launch_mlp_packed(a, mode, grid, st);                          // packed layout (single-pass Laue)
 #endif
     if (a.n_pad % CL_TILE != 0 || a.n_pad <= 0) return -1;
     // 32-bit byte offsets / buffer sizes inside the kernel: metadata image < 4 GiB, z_f < 4 GiB (shard further across GPUs otherwise)
@@ -1367,10 +1375,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
 #if !CL_IMGL && !CL_CHAIN
     // hidden width <= 15 (the careless CLI default): the full step runs on the one-wave-per-SIMD kernel of elbo_narrow.hip
     // (CARELESS_HIP_NARROW=0 keeps the eight-wave instance below: A/B measurements)
-    if (mode == 0 && cl_narrow_supports(a)) {
-        static const bool narrow_on = [] { const char* e = getenv("CARELESS_HIP_NARROW"); return !(e != nullptr && e[0] == '0'); }();
-        if (narrow_on) return cl_launch_narrow(a, grid, st);
-    }
+    if (mode == 0 && cl_narrow_supports(a) && narrow_enabled()) return cl_launch_narrow(a, grid, st);
 #endif
     switch (mode) {
         case 0: return launch_mode<0>(a, grid, st);

@@ -40,9 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CL_NARROW_BFI
 #define CL_NARROW_BFI 0     /* 1: multiply + sign mask + bit select instead of compare + conditional move (measured slower: hipcc emits 5 ops) */
 #endif
-#ifndef CL_NARROW_WAVES
-#define CL_NARROW_WAVES 8      /* waves per workgroup: 8 = two per SIMD (G = 2 groups per wave), 4 = one per SIMD with 512 registers */
-#endif
+
 
 namespace {
 
@@ -146,7 +144,10 @@ struct NSmem {
 
 }  // namespace
 
-template <int G, int KS, int NWAVES>
+// PACKED: the packed observation layout of include/careless_hip.h (row_map; single-pass Laue: gmeta / tile_gmax / noise_row): rows the
+// engine ordered so that a harmonic group sits inside a 16-row granule, padding rows have refl_id = -1, n_obs == n_pad; everything
+// the caller indexes by row (eta, ipred_out, the noise key) goes through row_map.
+template <int G, int KS, int NWAVES, bool PACKED>
 __global__ __launch_bounds__(64 * NWAVES) __attribute__((amdgpu_waves_per_eu(NWAVES / 4, NWAVES / 4)))
 void elbo_narrow_kernel(const cl_mlp_args A) {
     using SM = NSmem<G, NWAVES>;
@@ -320,12 +321,20 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         const int rid = ridn, img = imgn;
         const float io = ion, sg = sgn;
         float aim = 1.0f, zf0 = 0.0f;
+        int rme = 0, gm = 0;                 // PACKED: the caller's row of this lane's packed row; (member index | group size << 8)
+        long long nkey = 0;                  // PACKED: noise key of this lane's row
         {
             // gathers that depend on the prefetched ids: issued now, consumed in the epilogue
             cl_args_p E0 = kernargs_again();
             if (rid >= 0) {
                 if (E0->use_img && img > 0) aim = ld_uo(E0->img, 4u * (unsigned)(img - 1));
                 zf0 = ld_uo(E0->z_f, 4u * (unsigned)rid * (unsigned)E0->S);       // sample 0
+                if (PACKED) {
+                    const unsigned pb = 4u * (unsigned)(wt * WT + lane);
+                    rme = ld_uo(E0->row_map, pb);
+                    if (E0->gmeta != nullptr) gm = ld_uo(E0->gmeta, pb);
+                    nkey = (E0->noise_row != nullptr) ? (long long)ld_uo(E0->noise_row, pb) : E0->obs_offset + rme;
+                }
             }
         }
         NSTAMP(0);
@@ -386,13 +395,20 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         cl_args_p E = kernargs_again();              // the epilogue's and the prefetch's arguments, loaded here (see kernargs_again)
         const int S = E->S;
         const float w_ll = E->w_ll;
-        const long long gobs = (long long)wt * WT + lane;            // this lane's observation (lane = observation)
+        const long long gobs = PACKED ? (long long)rme : (long long)wt * WT + lane;      // this lane's observation in the caller's order
         const unsigned zoff = 4u * (unsigned)(rid < 0 ? 0 : rid) * (unsigned)S;
         const float o0 = acc_h[0];
         float dsig_draw;
         const float sigma = cl_scale_bij(acc_h[1], E->bij_kind, E->eps, &dsig_draw);
         float pdl = 0.0f, pds = 0.0f, pda = 0.0f;
-        if (rid >= 0) {
+        // single-pass Laue (careless/models/likelihoods/laue.py:20-34): the predictions of the rows of one harmonic group SUM before
+        // the likelihood.  The members of a group are consecutive lanes; every lane collects its group's total with shuffles over a
+        // wave-uniform member count, every member evaluates the same likelihood derivative, member 0 alone counts the log-likelihood.
+        const bool laue = PACKED && E->gmeta != nullptr;                    // wave-uniform
+        const int mem = gm & 0xff, cnt = gm >> 8;
+        const int gmax = laue ? uniform(E->tile_gmax[(wt * WT) / CL_MLP_TILE]) : 0;
+        if (laue || rid >= 0) {
+            const bool act = rid >= 0;
             // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
             const float inv_sg = cl_fast_rcp(sg);
             const float log_sg = cl_fast_log(sg);
@@ -404,39 +420,51 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
             const float dof = E->dof, lik_const = E->lik_const, shift = E->shift;
             float esin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int s = 0; s < S; ++s) {
-                float eta;
-                if (eta_p != nullptr) {
+                float eta = 0.0f;
+                if (!act) {
+                } else if (eta_p != nullptr) {
                     eta = eta_p[s];
                 } else if (((s >> 2) & 1) == 0) {        // one Philox block + Box-Muller pair serves samples s and s + 4
                     float sn;
-                    cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)(E->obs_offset + gobs), &eta, &sn);
+                    cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)(PACKED ? nkey : E->obs_offset + gobs), &eta, &sn);
                     const int kk = s & 3;
                     if (kk == 0) esin[0] = sn; else if (kk == 1) esin[1] = sn; else if (kk == 2) esin[2] = sn; else esin[3] = sn;
                 } else {
                     const int kk = s & 3;
                     eta = (kk == 0) ? esin[0] : (kk == 1) ? esin[1] : (kk == 2) ? esin[2] : esin[3];
                 }
-                const float zf = (s == 0) ? zf0 : ld_uo(zf_p, zoff + 4u * s);
+                const float zf = !act ? 0.0f : ((s == 0) ? zf0 : ld_uo(zf_p, zoff + 4u * s));
                 const float tq = o0 + sigma * eta + shift;
                 const float zs = aim * tq;
-                const float ipred = zs * zf * zf;
-                if (ipred_p) ipred_p[s] = ipred;
-                float dll, ll;
-                if (use_ev11) {
-                    float gf, gb, ga;
-                    ll = cl_lik_ev11(ipred, io, sg, lik_kind, dof, lik_const, ev, &dll, &gf, &gb, &ga);
-                    ev_g0 -= gf * w_ll; ev_g1 -= ga * w_ll; ev_g2 -= gb * w_ll;     // order: Sdfac, Sdadd, SdB
-                } else {
-                    ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, lik_kind, dof, lik_const, &dll);
+                const float ipred = act ? zs * zf * zf : 0.0f;
+                if (act && ipred_p) ipred_p[s] = ipred;
+                float lin = ipred;                                   // what the likelihood sees: the prediction, or its group's total
+                if (laue) {
+                    lin = 0.0f;
+                    for (int mm = 0; mm < gmax; ++mm) {
+                        const float v = __shfl(ipred, (lane - mem + mm) & 63);
+                        lin += (mm < cnt) ? v : 0.0f;
+                    }
                 }
-                nll_acc -= ll * w_ll;
-                const float gi = -dll * w_ll;                 // dNLL / d ipred
-                const float dzs = gi * zf * zf;
-                atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
-                const float dt = dzs * aim;
-                pdl += dt;
-                pds += dt * eta;
-                pda += dzs * tq;
+                if (act) {
+                    const bool counts = !laue || mem == 0;
+                    float dll, ll;
+                    if (use_ev11) {
+                        float gf, gb, ga;
+                        ll = cl_lik_ev11(lin, io, sg, lik_kind, dof, lik_const, ev, &dll, &gf, &gb, &ga);
+                        if (counts) { ev_g0 -= gf * w_ll; ev_g1 -= ga * w_ll; ev_g2 -= gb * w_ll; }     // order: Sdfac, Sdadd, SdB
+                    } else {
+                        ll = cl_lik_log_prob2(lin, io, inv_sg, log_sg, lik_kind, dof, lik_const, &dll);
+                    }
+                    if (counts) nll_acc -= ll * w_ll;
+                    const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
+                    const float dzs = gi * zf * zf;
+                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
+                    const float dt = dzs * aim;
+                    pdl += dt;
+                    pds += dt * eta;
+                    pda += dzs * tq;
+                }
             }
         }
         if (E->use_img) {
@@ -661,12 +689,12 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
     }
 }
 
-template <int G, int KS, int NWAVES>
+template <int G, int KS, int NWAVES, bool PACKED>
 static int launch_narrow_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SM = NSmem<G, NWAVES>;
     const size_t sm = (size_t)SM::total * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_narrow_kernel<G, KS, NWAVES>;
+    auto kern = elbo_narrow_kernel<G, KS, NWAVES, PACKED>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -679,10 +707,18 @@ static int launch_narrow_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-// 1 = this geometry runs on the narrow kernel (full ELBO step, plain observation layout)
+// 1 = this geometry runs on the narrow kernel (full ELBO step; plain observation layout, or the packed one of single-pass Laue)
 int cl_narrow_supports(const cl_mlp_args& a) {
-    return a.w >= 1 && a.w <= 15 && a.d >= 1 && a.d <= 15 && a.L >= 1 && a.L <= NL && a.row_map == nullptr && a.n_imgl == 0 &&
-           a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.gmeta == nullptr;
+    return a.w >= 1 && a.w <= 15 && a.d >= 1 && a.d <= 15 && a.L >= 1 && a.L <= NL && a.n_imgl == 0 && a.act_out == nullptr &&
+           a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);
+}
+
+template <bool PACKED>
+static int launch_narrow_ks(const cl_mlp_args& a, int grid, hipStream_t st) {
+    const int m = a.w > a.d ? a.w : a.d;               // the metadata layer takes the same number of k-steps as the hidden ones
+    if (m <= 8) return launch_narrow_one<2, 2, 8, PACKED>(a, grid, st);
+    if (m <= 12) return launch_narrow_one<2, 3, 8, PACKED>(a, grid, st);
+    return launch_narrow_one<2, 4, 8, PACKED>(a, grid, st);
 }
 
 int cl_launch_narrow(const cl_mlp_args& a, int grid, hipStream_t st) {
@@ -692,14 +728,10 @@ int cl_launch_narrow(const cl_mlp_args& a, int grid, hipStream_t st) {
         4ull * (unsigned long long)a.R * (unsigned long long)a.S >= (1ull << 32))
         return -4;
     if (grid < 1) return -1;
-    const int m = a.w > a.d ? a.w : a.d;               // the metadata layer takes the same number of k-steps as the hidden ones
-#if CL_NARROW_WAVES == 4
-    if (m <= 8) return launch_narrow_one<4, 2, 4>(a, grid, st);
-    if (m <= 12) return launch_narrow_one<2, 3, 4>(a, grid, st);
-    return launch_narrow_one<2, 4, 4>(a, grid, st);
-#else
-    if (m <= 8) return launch_narrow_one<2, 2, 8>(a, grid, st);
-    if (m <= 12) return launch_narrow_one<2, 3, 8>(a, grid, st);
-    return launch_narrow_one<2, 4, 8>(a, grid, st);
-#endif
+    if (a.row_map != nullptr) {
+        if (a.n_obs != a.n_pad || (a.gmeta != nullptr && a.tile_gmax == nullptr)) return -1;
+        if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+        return launch_narrow_ks<true>(a, grid, st);
+    }
+    return launch_narrow_ks<false>(a, grid, st);
 }
