@@ -155,6 +155,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
     constexpr int LREG = SM::LREG;
     constexpr int PBW = SM::PBW;
     constexpr int WT = 16 * G;                        // observations of one wave tile
+    static_assert(WT == 32, "the epilogue's lane map (observation = lane & 31, sample parity = lane >> 5) assumes 32-observation wave tiles");
     static_assert(CL_MLP_TILE % WT == 0, "a wave tile must not straddle the end of the padded observation axis");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const sW = smem + SM::oW;
@@ -272,8 +273,8 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                 xn[g][t] = have ? v : 0.0f;
             }
         }
-        const int o = base + lane;
-        const bool ok = lane < WT && o <= last_obs;
+        const int o = base + (lane & (WT - 1));            // (the upper lanes mirror the lower ones' observation: they take the odd MC samples)
+        const bool ok = o <= last_obs;
         const unsigned ob = 4u * (unsigned)min(o, last_obs);
         const int rr = ld_uo(E->refl_id, ob);
         ridn = ok ? rr : -1;
@@ -328,9 +329,10 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
             cl_args_p E0 = kernargs_again();
             if (rid >= 0) {
                 if (E0->use_img && img > 0) aim = ld_uo(E0->img, 4u * (unsigned)(img - 1));
-                zf0 = ld_uo(E0->z_f, 4u * (unsigned)rid * (unsigned)E0->S);       // sample 0
+                const int S0 = E0->S;
+                if ((lane >> 5) < S0) zf0 = ld_uo(E0->z_f, 4u * ((unsigned)rid * (unsigned)S0 + (unsigned)(lane >> 5)));   // this lane's first sample
                 if (PACKED) {
-                    const unsigned pb = 4u * (unsigned)(wt * WT + lane);
+                    const unsigned pb = 4u * (unsigned)(wt * WT + (lane & (WT - 1)));
                     rme = ld_uo(E0->row_map, pb);
                     if (E0->gmeta != nullptr) gm = ld_uo(E0->gmeta, pb);
                     nkey = (E0->noise_row != nullptr) ? (long long)ld_uo(E0->noise_row, pb) : E0->obs_offset + rme;
@@ -395,11 +397,18 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         cl_args_p E = kernargs_again();              // the epilogue's and the prefetch's arguments, loaded here (see kernargs_again)
         const int S = E->S;
         const float w_ll = E->w_ll;
-        const long long gobs = PACKED ? (long long)rme : (long long)wt * WT + lane;      // this lane's observation in the caller's order
+        // lane map: observation = lane & 31 (the head left (loc, raw sigma) of observation e in lane e < 32), MC samples s = half,
+        // half + 2, ... with half = lane >> 5: the two lanes of an observation split its samples (one lane half idles when S = 1)
+        const int half = lane >> 5;
+        const long long gobs = PACKED ? (long long)rme : (long long)wt * WT + (lane & (WT - 1));      // this lane's observation in the caller's order
         const unsigned zoff = 4u * (unsigned)(rid < 0 ? 0 : rid) * (unsigned)S;
-        const float o0 = acc_h[0];
+        float o0 = acc_h[0], o1 = acc_h[1];
+        if (S > 1) {                                     // wave-uniform
+            o0 = __shfl(o0, lane & 31);
+            o1 = __shfl(o1, lane & 31);
+        }
         float dsig_draw;
-        const float sigma = cl_scale_bij(acc_h[1], E->bij_kind, E->eps, &dsig_draw);
+        const float sigma = cl_scale_bij(o1, E->bij_kind, E->eps, &dsig_draw);
         float pdl = 0.0f, pds = 0.0f, pda = 0.0f;
         // single-pass Laue (careless/models/likelihoods/laue.py:20-34): the predictions of the rows of one harmonic group SUM before
         // the likelihood.  The members of a group are consecutive lanes; every lane collects its group's total with shuffles over a
@@ -408,7 +417,6 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         const int mem = gm & 0xff, cnt = gm >> 8;
         const int gmax = laue ? uniform(E->tile_gmax[(wt * WT) / CL_MLP_TILE]) : 0;
         if (laue || rid >= 0) {
-            const bool act = rid >= 0;
             // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
             const float inv_sg = cl_fast_rcp(sg);
             const float log_sg = cl_fast_log(sg);
@@ -419,7 +427,10 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
             const int lik_kind = E->lik_kind;
             const float dof = E->dof, lik_const = E->lik_const, shift = E->shift;
             float esin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (int s = 0; s < S; ++s) {
+            const int nS = (S + 1) >> 1;                 // wave-uniform trip count (all lanes take part in the Laue shuffles)
+            for (int k = 0; k < nS; ++k) {
+                const int s = 2 * k + half;
+                const bool act = rid >= 0 && s < S;
                 float eta = 0.0f;
                 if (!act) {
                 } else if (eta_p != nullptr) {
@@ -433,7 +444,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     const int kk = s & 3;
                     eta = (kk == 0) ? esin[0] : (kk == 1) ? esin[1] : (kk == 2) ? esin[2] : esin[3];
                 }
-                const float zf = !act ? 0.0f : ((s == 0) ? zf0 : ld_uo(zf_p, zoff + 4u * s));
+                const float zf = !act ? 0.0f : ((k == 0) ? zf0 : ld_uo(zf_p, zoff + 4u * s));
                 const float tq = o0 + sigma * eta + shift;
                 const float zs = aim * tq;
                 const float ipred = act ? zs * zf * zf : 0.0f;
@@ -467,13 +478,18 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                 }
             }
         }
+        if (S > 1) {                                     // the two lanes of an observation add up their samples' sums
+            pdl += __shfl_xor(pdl, 32);
+            pds += __shfl_xor(pds, 32);
+            pda += __shfl_xor(pda, 32);
+        }
         if (E->use_img) {
             // image ids are sorted: the observations of a wave tile almost always share one image -> ONE atomic per wave
             const int img0 = uniform(img);
             if (__all(img == img0 || rid < 0)) {
-                const float v = wave_sum((rid >= 0) ? pda : 0.0f);
+                const float v = wave_sum((rid >= 0 && lane < WT) ? pda : 0.0f);
                 if (lane == 0 && img0 > 0) atomicAdd(E->d_img + (img0 - 1), v);
-            } else if (rid >= 0 && img > 0) {
+            } else if (rid >= 0 && img > 0 && lane < WT) {
                 atomicAdd(E->d_img + (img - 1), pda);
             }
         }
