@@ -328,6 +328,22 @@ def worker(args) -> int:
         extra_name = extra_name if args.extra not in ("auto", "none") else None
     extras = {}
     if extra_name:
+        # every rank builds the whole synthetic problem on the host before taking its shard: only with room for it
+        # (~250 B per observation and rank at the generator's peak); all ranks take the same decision
+        from careless_amd.workloads import WORKLOADS
+        need = 250.0 * WORKLOADS[extra_name]["N"] * world
+        try:
+            avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024.0
+        except Exception:
+            avail = float("inf")
+        if use_dist:
+            t = torch.tensor([avail], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            avail = float(t.item())
+        if avail < 1.5 * need:
+            extras[extra_name] = {"skipped": f"host memory: {avail / 2**30:.0f} GiB available, {1.5 * need / 2**30:.0f} GiB wanted for {world} ranks"}
+            extra_name = None
+    if extra_name:
         try:                                    # never lose the headline line to the extra configuration
             ex = run_workload(args, extra_name, None, min(args.steps, 10), min(args.warmup, 2), rank, world, use_dist)
             if ex is not None:
