@@ -140,6 +140,9 @@ def _assert_grads(g_hip, grads, prob):
     errs = [util.rel_err(a, b.numpy()) for a, b in zip(g_hip, grads)]
     if max(errs) < RTOL_GRAD:
         return
+    import warnings
+    warnings.warn(f"gradient check fell back to the fp32 oracle (largest fp64 error {max(errs):.2e} > {RTOL_GRAD}): a LeakyReLU branch "
+                  "flipped at fp32 rounding")           # shows in the pytest summary: the fallback must stay rare
     data, cfg, params, u_f, eta = prob
     x32 = O.inputs_from_numpy(data, dtype=torch.float32)
     _, g32 = O.elbo_value_and_grads(params.clone(dtype=torch.float32), x32, cfg, torch.as_tensor(u_f, dtype=torch.float32),
