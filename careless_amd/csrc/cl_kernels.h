@@ -37,7 +37,29 @@ __device__ __forceinline__ cl_args_p kernargs_again() {
     asm volatile("" : "+s"(p));
     return p;
 }
+
+// Cross-lane sums on the DPP network: no LDS round trip, one vector instruction per step (a __shfl_xor step is a ds_bpermute_b32
+// plus its address arithmetic and an LDS latency in the middle of a dependent chain).
+#define CL_DPP_ADD(x, ctrl, rmask) \
+    ((x) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xF, false)))
+// sum over each group of four consecutive lanes, left in all four
+__device__ __forceinline__ float cl_quad_sum(float v) {
+    v = CL_DPP_ADD(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+    v = CL_DPP_ADD(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+    return v;
+}
+// sum over the 64 lanes of a wave, returned as a wave-uniform value: a butterfly inside the 16-lane rows, then the rows through row_bcast
+__device__ __forceinline__ float cl_wave_sum(float v) {
+    v = cl_quad_sum(v);
+    v = CL_DPP_ADD(v, 0x141, 0xF);  // row_half_mirror
+    v = CL_DPP_ADD(v, 0x140, 0xF);  // row_mirror: every lane now holds its row's sum
+    v = CL_DPP_ADD(v, 0x142, 0xA);  // row_bcast15 into rows 1 and 3
+    v = CL_DPP_ADD(v, 0x143, 0xC);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 #else
 typedef const cl_mlp_args* cl_args_p;                                        // (host pass over the kernel bodies: never executed)
 __host__ __device__ inline cl_args_p kernargs_again() { return nullptr; }
+__host__ __device__ inline float cl_quad_sum(float v) { return v; }
+__host__ __device__ inline float cl_wave_sum(float v) { return v; }
 #endif

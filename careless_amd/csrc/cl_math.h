@@ -287,6 +287,24 @@ CL_HD float cl_lik_log_prob2(float ipred, float iobs, float inv_sig, float log_s
     return -0.5f * (dof + 1.0f) * cl_log1p_pos(y2 / dof) - log_sig + lik_const;
 }
 
+// same again with 1/nu hoisted and the one per-sample division of the Student-T derivative as a hardware reciprocal refined by one
+// Newton step (relative error ~1e-7): two accurate divisions are ~20 vector instructions per MC sample in the epilogue
+CL_HD float cl_lik_log_prob3(float ipred, float iobs, float inv_sig, float log_sig, int kind, float dof, float inv_dof,
+                             float lik_const, float* dll) {
+    const float y = (ipred - iobs) * inv_sig;
+    if (kind == CL_LIK_NORMAL) {
+        *dll = -y * inv_sig;
+        return -0.5f * y * y - 0.5f * CL_LOG_2PI_F - log_sig;
+    }
+    CL_KEEP_BRANCH();
+    const float y2 = y * y;
+    const float den = dof + y2;
+    float r = cl_fast_rcp(den);
+    r = r * (2.0f - den * r);
+    *dll = -(dof + 1.0f) * y * r * inv_sig;
+    return -0.5f * (dof + 1.0f) * cl_log1p_pos(y2 * inv_dof) - log_sig + lik_const;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Double-Wilson prior pieces (careless/models/priors/wilson.py:146-175; careless/utils/distributions.py:228-348):
 // exponentially scaled Bessel functions by Chebyshev series on the cephes intervals (|x| <= 8, |x| > 8); coefficients are a

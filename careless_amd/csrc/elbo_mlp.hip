@@ -63,6 +63,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CL_BIAS_ONE
 #define CL_BIAS_ONE 1
 #endif
+#ifndef CL_DPP_REDUCE
+#define CL_DPP_REDUCE 1
+#endif
+#ifndef CL_FAST_DIV
+#define CL_FAST_DIV 0     /* 1: reciprocal + Newton step for the Student-T derivative, 1/nu hoisted (measured: no gain) */
+#endif
 #ifndef CL_FAST_SG
 #define CL_FAST_SG 0     /* 1: hardware rcp / log for 1/sigma, log sigma in the epilogue (measured: no gain on the 64-wide instances) */
 #endif
@@ -670,6 +676,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
                 const float inv_sg = CL_FAST_SG ? cl_fast_rcp(sg) : 1.0f / sg;
                 const float log_sg = CL_FAST_SG ? cl_fast_log(sg) : logf(sg);
+                const float inv_dof = (E->lik_kind == CL_LIK_STUDENTT) ? 1.0f / E->dof : 0.0f;       // wave-uniform
                 float eta_sin = 0.0f;
                 const int K = (S + 3) >> 2;
                 for (int k = 0; k < K; ++k) {                     // wave-uniform trip count: all lanes take part in the shuffles
@@ -702,7 +709,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             ll = cl_lik_ev11(tot, io, sg, E->lik_kind, E->dof, E->lik_const, ev, &dll, &gf, &gb, &ga);
                             if (mem == 0) { ev_g0 -= gf * E->w_ll; ev_g1 -= ga * E->w_ll; ev_g2 -= gb * E->w_ll; }
                         } else {
-                            ll = cl_lik_log_prob2(tot, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
+                            ll = CL_FAST_DIV ? cl_lik_log_prob3(tot, io, inv_sg, log_sg, E->lik_kind, E->dof, inv_dof, E->lik_const, &dll) : cl_lik_log_prob2(tot, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
                         }
                         if (mem == 0) nll_acc -= ll * E->w_ll;
                         const float gi = -dll * E->w_ll;                 // dNLL / d iconv = dNLL / d ipred of every member
@@ -718,6 +725,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
                 const float inv_sg = CL_FAST_SG ? cl_fast_rcp(sg) : 1.0f / sg;
                 const float log_sg = CL_FAST_SG ? cl_fast_log(sg) : logf(sg);
+                const float inv_dof = (E->lik_kind == CL_LIK_STUDENTT) ? 1.0f / E->dof : 0.0f;       // wave-uniform
                 int k = 0;
                 float eta_sin = 0.0f;
                 for (int s = qe; s < S; s += 4, ++k) {
@@ -740,7 +748,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         ll = cl_lik_ev11(ipred, io, sg, E->lik_kind, E->dof, E->lik_const, ev, &dll, &gf, &gb, &ga);
                         ev_g0 -= gf * E->w_ll; ev_g1 -= ga * E->w_ll; ev_g2 -= gb * E->w_ll;     // order: Sdfac, Sdadd, SdB
                     } else {
-                        ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
+                        ll = CL_FAST_DIV ? cl_lik_log_prob3(ipred, io, inv_sg, log_sg, E->lik_kind, E->dof, inv_dof, E->lik_const, &dll) : cl_lik_log_prob2(ipred, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
                     }
                     nll_acc -= ll * E->w_ll;
                     const float gi = -dll * E->w_ll;                 // dNLL / d ipred
@@ -752,8 +760,12 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     pda += dzs * tq;
                 }
             }
+#if CL_DPP_REDUCE
+            pdl = cl_quad_sum(pdl); pds = cl_quad_sum(pds); pda = cl_quad_sum(pda);      // the four sample slots of an observation
+#else
             pdl += __shfl_xor(pdl, 1); pds += __shfl_xor(pds, 1); pda += __shfl_xor(pda, 1);
             pdl += __shfl_xor(pdl, 2); pds += __shfl_xor(pds, 2); pda += __shfl_xor(pda, 2);
+#endif
             STAMP(12);
             if (E->use_img) {
                 // image ids are sorted, so the 16 observations of a wave almost always share one image: reduce in the
@@ -761,8 +773,12 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 const int img0 = __builtin_amdgcn_readfirstlane(img);
                 if (__all(img == img0 || rid < 0)) {
                     float v = (qe == 0 && rid >= 0) ? pda : 0.0f;
+#if CL_DPP_REDUCE
+                    v = cl_wave_sum(v);
+#else
 #pragma unroll
                     for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off);
+#endif
                     if (lane == 0 && img0 > 0) atomicAdd(ptr_uo(E->d_img, 4u * (unsigned)(img0 - 1)), v);
                 } else if (qe == 0 && rid >= 0 && img > 0) {
                     atomicAdd(ptr_uo(E->d_img, 4u * (unsigned)(img - 1)), pda);

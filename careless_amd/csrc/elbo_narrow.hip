@@ -85,19 +85,6 @@ __device__ __forceinline__ unsigned top_layer_mask(int L) {
     asm volatile("" : "+s"(m));
     return m;
 }
-// sum over the 64 lanes of a wave (returned in every lane's copy of a scalar): four DPP butterfly steps inside the 16-lane rows,
-// then the rows through row_bcast -- six VALU instructions and no LDS round trip (a shuffle loop is 6 x ds_bpermute + adds)
-__device__ __forceinline__ float wave_sum(float v) {
-#define NDPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xF, false))
-    v += NDPP(v, 0xB1, 0xF);        // quad_perm [1,0,3,2]
-    v += NDPP(v, 0x4E, 0xF);        // quad_perm [2,3,0,1]
-    v += NDPP(v, 0x141, 0xF);       // row_half_mirror
-    v += NDPP(v, 0x140, 0xF);       // row_mirror: every lane now holds its row's sum
-    v += NDPP(v, 0x142, 0xA);       // row_bcast15 into rows 1 and 3
-    v += NDPP(v, 0x143, 0xC);       // row_bcast31 into rows 2 and 3: lane 63 holds the total
-#undef NDPP
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 template <class T>
 __device__ __forceinline__ T ld_uo(const T* base, unsigned byte_off) {       // (wave-uniform pointer)[32-bit per-lane byte offset]
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -487,7 +474,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
             // image ids are sorted: the observations of a wave tile almost always share one image -> ONE atomic per wave
             const int img0 = uniform(img);
             if (__all(img == img0 || rid < 0)) {
-                const float v = wave_sum((rid >= 0 && lane < WT) ? pda : 0.0f);
+                const float v = cl_wave_sum((rid >= 0 && lane < WT) ? pda : 0.0f);
                 if (lane == 0 && img0 > 0) atomicAdd(E->d_img + (img0 - 1), v);
             } else if (rid >= 0 && img > 0 && lane < WT) {
                 atomicAdd(E->d_img + (img - 1), pda);
