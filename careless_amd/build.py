@@ -19,6 +19,7 @@ UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=
          ("elbo_mlp.hip", "elbo_mlp_packed", ["-DCL_IMGL=2"]),
          ("elbo_mlp.hip", "elbo_mlp_chain", ["-DCL_CHAIN=1"]),
          ("elbo_narrow.hip", "elbo_narrow", ["-fno-slp-vectorize"]),     # (packed fp32 math costs more than it saves beside MFMAs)
+         ("elbo_lane.hip", "elbo_lane", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),   # (4x4x1 results feed vector code: no accumulator-register detour)
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", [])]
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["cl_math.h", "cl_kernels.h", os.path.join("..", "..", "include", "careless_hip.h")]

@@ -1350,6 +1350,10 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
 }
 
 #if !CL_IMGL && !CL_CHAIN
+static bool lane_enabled() {            // CARELESS_HIP_LANE=0 keeps narrow scalers off the lane-per-observation kernel (A/B runs)
+    static const bool on = [] { const char* e = getenv("CARELESS_HIP_LANE"); return !(e != nullptr && e[0] == '0'); }();
+    return on;
+}
 static bool narrow_enabled() {          // CARELESS_HIP_NARROW=0 keeps narrow scalers on the eight-wave instance of this file (A/B runs)
     static const bool on = [] { const char* e = getenv("CARELESS_HIP_NARROW"); return !(e != nullptr && e[0] == '0'); }();
     return on;
@@ -1378,7 +1382,7 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
     if (a.n_imgl > 0) return cl_launch_mlp_imgl(a, mode, grid, st);            // packed layout + per-image layers
-    if (a.row_map != nullptr && !(mode == 0 && cl_narrow_supports(a) && narrow_enabled()))
+    if (a.row_map != nullptr && !(mode == 0 && ((cl_narrow_supports(a) && narrow_enabled()) || (cl_lane_supports(a) && lane_enabled()))))
         return cl_launch_mlp_packed(a, mode, grid, st);                          // packed layout (single-pass Laue)
 #endif
     if (a.n_pad % CL_TILE != 0 || a.n_pad <= 0) return -1;
@@ -1391,6 +1395,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
 #if !CL_IMGL && !CL_CHAIN
     // hidden width <= 15 (the careless CLI default): the full step runs on the one-wave-per-SIMD kernel of elbo_narrow.hip
     // (CARELESS_HIP_NARROW=0 keeps the eight-wave instance below: A/B measurements)
+    if (mode == 0 && cl_lane_supports(a) && lane_enabled()) return cl_launch_lane(a, grid, st);      // width <= 10: lane = observation (elbo_lane.hip)
     if (mode == 0 && cl_narrow_supports(a) && narrow_enabled()) return cl_launch_narrow(a, grid, st);
 #endif
     switch (mode) {
