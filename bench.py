@@ -272,8 +272,11 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     ms = 1e3 * elapsed / steps
     F = flops_per_obs(spec["d"], spec["w"], spec["L"], spec.get("image_layers", 0))
     B = bytes_per_obs(spec["d"], spec["S"])
-    # widths <= 15 with metadata <= 15 columns run on the narrow kernel (careless_amd/csrc/elbo_narrow.hip), plain mono layout only
-    narrow = spec["w"] <= 15 and spec["d"] <= 15 and spec.get("kind", "mono") != "laue" and not spec.get("image_layers")
+    # widths <= 15 with metadata <= 15 columns run on the narrow kernels: lane-per-observation (careless_amd/csrc/elbo_lane.hip:
+    # width <= 10, <= 2 MC samples) or elbo_narrow.hip; the routing is cl_launch_mlp's (csrc/elbo_mlp.hip), restated here for the label
+    narrow = spec["w"] <= 15 and spec["d"] <= 15 and not spec.get("image_layers") and (spec.get("kind", "mono") != "laue" or eng.obs.fused_laue)
+    lane = narrow and spec["w"] <= 10 and spec["S"] <= 2 and os.environ.get("CARELESS_HIP_LANE", "1") != "0"
+    kernel_name = "elbo_lane_kernel" if lane else ("elbo_narrow_kernel" if narrow else "elbo_mlp_kernel")
     achieved = F * eng.N / (kern_ms * 1e-3) / 1e12
     achieved_step = F * eng.N / (ms * 1e-3) / 1e12         # SURVEY 8d defines `achieved` on the whole step time
     return {
@@ -286,7 +289,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
                    "image_layers": spec.get("image_layers", 0), "noise": "in-kernel philox",
                    "parallelism": f"obs-shard x{world}" if world > 1 else "single",
                    "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
-        "roofline": {"bound": "mfma", "kernel": (("elbo_narrow_kernel" if narrow else "elbo_mlp_kernel") + " (" + ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd") + ")"),
+        "roofline": {"bound": "mfma", "kernel": (kernel_name + " (" + ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd") + ")"),
                      "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
                      "traffic": traffic_bytes(name, world), "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
                      "achieved_on_step_time": achieved_step, "frac_on_step_time": achieved_step / 157.3,

@@ -49,6 +49,7 @@ constexpr int NWV = 4;                // waves of a workgroup (one per SIMD)
 constexpr int NT = 64 * NWV;
 constexpr int WT = 64;                // observations of a wave tile
 constexpr int PIT = 68;               // row pitch of a staging tile [16 features][64 observations]
+constexpr int SPRE = 8;               // MC samples whose amplitudes are gathered at the start of the tile
 constexpr int ONE = 15;               // block of a weight register (= row of a staging tile) that belongs to the constant-one feature
 
 template <int K, int N, class F>
@@ -151,7 +152,7 @@ struct LSmem {
     static constexpr int oF = 0;                              // forward images, layers 0 .. NL-1 and the head (NL)
     static constexpr int oK = oF + (NL + 1) * IMG;            // transposed (dgrad) images, same numbering
     static constexpr int oT = oK + (NL + 1) * IMG;            // per wave: sZ[2], sH[2] (by layer parity), sX   [16][PIT] each
-    static constexpr int TW = 5 * 16 * PIT;
+    static constexpr int TW = 5 * 16 * PIT + SPRE * 64;       // (+ sS: the lane's first SPRE sampled amplitudes)
     static constexpr int main_total = oT + NWV * TW;
     static constexpr int REG = NL * 256;                      // floats of one wave's parked accumulators (flush)
     static constexpr int flush_total = (NWV / 2) * REG + NWV * 2 * 16;
@@ -239,6 +240,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     float* const sZ = smem + SM::oT + wv * SM::TW;     // dZ_l                       [feature][observation]
     float* const sH = sZ + 32 * PIT;                   // the layer's input (layers >= 1)
     float* const sX = sH + 32 * PIT;                   // the metadata of the tile (layer 0's input)
+    float* const sS = sX + 16 * PIT;                   // sampled amplitudes of samples 1 .. SPRE-1   [sample][lane]
     constexpr int PAR = 16 * PIT;                      // second copy of sZ / sH (FULL: layers alternate between the two)
 
     // ---- accumulators that live across all tiles of this wave ----------------------------------------------------------
@@ -321,20 +323,24 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         const bool in_range = wt * WT + lane < A.n_obs;
         const int rid = in_range ? ridn : -1, img = imgn;
         const float io = ion, sg = in_range ? sgn : 1.0f;
-        float aim = 1.0f, zf0 = 0.0f;
+        // Gathers that depend on the prefetched ids: issued now, consumed in the epilogue.  Every lane loads from a valid (clamped)
+        // address and nothing is done with the values here: a select or a merge under a divergent branch would make this lone wave
+        // wait for each gather in turn.
+        float aim_raw = 1.0f, zf0;
+        float zfv[SPRE];                     // samples 1 .. SPRE-1 of this lane's reflection (a lone wave cannot afford a gather per sample)
         int rme = 0, gm = 0;                 // PACKED: the caller's row of this lane's packed row; (member index | group size << 8)
         long long nkey = 0;                  // PACKED: noise key of this lane's row
         {
-            // gathers that depend on the prefetched ids: issued now, consumed in the epilogue
-            if (rid >= 0) {
-                if (A.use_img && img > 0) aim = ld_uo(A.img, 4u * (unsigned)(img - 1));
-                zf0 = ld_uo(A.z_f, 4u * (unsigned)rid * (unsigned)A.S);          // this lane's first sample
-                if (PACKED) {
-                    const unsigned pb = 4u * (unsigned)(wt * WT + lane);
-                    rme = ld_uo(A.row_map, pb);
-                    if (A.gmeta != nullptr) gm = ld_uo(A.gmeta, pb);
-                    nkey = (A.noise_row != nullptr) ? (long long)ld_uo(A.noise_row, pb) : A.obs_offset + rme;
-                }
+            const unsigned zb = 4u * (unsigned)max(rid, 0) * (unsigned)A.S;
+            if (A.use_img) aim_raw = ld_uo(A.img, 4u * (unsigned)max(img - 1, 0));
+            zf0 = ld_uo(A.z_f, zb);
+#pragma unroll
+            for (int j = 1; j < SPRE; ++j) zfv[j] = ld_uo(A.z_f, zb + 4u * (unsigned)min(j, A.S - 1));
+            if (PACKED) {
+                const unsigned pb = 4u * (unsigned)(wt * WT + lane);
+                rme = ld_uo(A.row_map, pb);
+                if (A.gmeta != nullptr) gm = ld_uo(A.gmeta, pb);
+                nkey = (A.noise_row != nullptr) ? (long long)ld_uo(A.noise_row, pb) : A.obs_offset + rme;
             }
         }
         LSTAMP(0);
@@ -410,6 +416,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         //  segment at the point of use, as the two-waves-per-SIMD kernels do, would leave a lone wave waiting ~150 cycles per read)
         const int S = A.S;
         const float w_ll = A.w_ll;
+        const float aim = (A.use_img && img > 0 && rid >= 0) ? aim_raw : 1.0f;
         const long long gobs = PACKED ? (long long)rme : (long long)wt * WT + lane;      // this lane's observation in the caller's order
         const unsigned zoff = 4u * (unsigned)(rid < 0 ? 0 : rid) * (unsigned)S;
         float dsig_draw;
@@ -433,21 +440,14 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             const float dof = A.dof, lik_const = A.lik_const, shift = A.shift;
             float esin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             const bool act = rid >= 0;
-            for (int s = 0; s < S; ++s) {                // wave-uniform trip count (all lanes take part in the Laue shuffles)
-                float eta = 0.0f;
-                if (!act) {
-                } else if (eta_p != nullptr) {
-                    eta = eta_p[s];
-                } else if (((s >> 2) & 1) == 0) {        // one Philox block + Box-Muller pair serves samples s and s + 4
-                    float sn;
-                    cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(PACKED ? nkey : A.obs_offset + gobs), &eta, &sn);
-                    const int kk = s & 3;
-                    if (kk == 0) esin[0] = sn; else if (kk == 1) esin[1] = sn; else if (kk == 2) esin[2] = sn; else esin[3] = sn;
-                } else {
-                    const int kk = s & 3;
-                    eta = (kk == 0) ? esin[0] : (kk == 1) ? esin[1] : (kk == 2) ? esin[2] : esin[3];
-                }
-                const float zf = !act ? 0.0f : ((s == 0) ? zf0 : ld_uo(zf_p, zoff + 4u * s));
+            // The amplitudes gathered at the start of the tile wait in LDS: inside the loop every wait on a global load would also
+            // wait for the previous sample's atomics (one in-order counter), a few microseconds each for a lone wave.
+            if (S > 1) {
+#pragma unroll
+                for (int j = 1; j < SPRE; ++j) sS[j * 64 + lane] = zfv[j];
+            }
+            // one MC sample of this lane's observation, given its noise and its sampled amplitude (all lanes take part in the Laue shuffles)
+            auto sample = [&](int s, float eta, float zf) {
                 const float tq = o0 + sigma * eta + shift;
                 const float zs = aim * tq;
                 const float ipred = act ? zs * zf * zf : 0.0f;
@@ -478,6 +478,40 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     pdl += dt;
                     pds += dt * eta;
                     pda += dzs * tq;
+                }
+            };
+            auto philox_eta = [&](int s) -> float {      // one Philox block + Box-Muller pair serves samples s and s + 4
+                float eta = 0.0f;
+                if (!act) {
+                } else if (((s >> 2) & 1) == 0) {
+                    float sn;
+                    cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(PACKED ? nkey : A.obs_offset + gobs), &eta, &sn);
+                    const int kk = s & 3;
+                    if (kk == 0) esin[0] = sn; else if (kk == 1) esin[1] = sn; else if (kk == 2) esin[2] = sn; else esin[3] = sn;
+                } else {
+                    const int kk = s & 3;
+                    eta = (kk == 0) ? esin[0] : (kk == 1) ? esin[1] : (kk == 2) ? esin[2] : esin[3];
+                }
+                return eta;
+            };
+            // Three loops over the samples (wave-uniform trip counts), so that the common one -- in-kernel noise, amplitudes
+            // from LDS -- contains no global load at all: any load in the loop makes the compiler wait on the one in-order
+            // memory counter, i.e. for the previous sample's atomics, a few microseconds each for a lone wave.
+            if (eta_p != nullptr) {
+                for (int s = 0; s < S; ++s) {
+                    float zf = zf0;
+                    if (s > 0) zf = (s < SPRE) ? sS[s * 64 + lane] : ld_uo(zf_p, zoff + 4u * (unsigned)s);
+                    sample(s, act ? eta_p[s] : 0.0f, act ? zf : 0.0f);
+                }
+            } else {
+                const int Sf = S < SPRE ? S : SPRE;
+                for (int s = 0; s < Sf; ++s) {
+                    const float zf = (s > 0) ? sS[s * 64 + lane] : zf0;
+                    sample(s, philox_eta(s), act ? zf : 0.0f);
+                }
+                for (int s = Sf; s < S; ++s) {
+                    const float zf = ld_uo(zf_p, zoff + 4u * (unsigned)s);
+                    sample(s, philox_eta(s), act ? zf : 0.0f);
                 }
             }
         }
@@ -819,9 +853,15 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_WMAX 10
 #endif
 
-// 1 = this geometry runs on the lane-per-observation kernel (full ELBO step; plain observation layout, or the packed one of single-pass Laue)
+#ifndef CL_LANE_SMAX
+#define CL_LANE_SMAX 2
+#endif
+
+// 1 = this geometry runs on the lane-per-observation kernel (full ELBO step; plain observation layout, or the packed one of single-pass Laue).
+// More than two MC samples go to elbo_narrow.hip: the sampling epilogue is a serial dependent chain per sample, which one wave per
+// SIMD cannot hide (4 M observations, 20 x 10, Student-T: 0.144 ms per extra sample here, 0.032 ms there; S = 1: 0.96 against 1.12 ms).
 int cl_lane_supports(const cl_mlp_args& a) {
-    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.d >= 1 && a.d <= 15 && a.L >= 1 && a.L <= NL && a.n_imgl == 0 && a.act_out == nullptr &&
+    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= 15 && a.L >= 1 && a.L <= NL && a.n_imgl == 0 && a.act_out == nullptr &&
            a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);
 }
 
@@ -832,8 +872,14 @@ static bool full_enabled() {            // CARELESS_HIP_LANE_FULL=0: full-depth 
 
 template <bool PACKED>
 static int launch_lane_w(const cl_mlp_args& a, int grid, hipStream_t st) {
-    if (a.L == NL && full_enabled()) return launch_lane_one<10, PACKED, true>(a, grid, st);
-    return launch_lane_one<10, PACKED, false>(a, grid, st);
+    const bool full = a.L == NL && full_enabled();
+    // the instance whose compile-time width is the smallest one that holds the scaler (zero-padded features cost MFMA steps)
+#define CL_LANE_CASE(WW) (full ? launch_lane_one<WW, PACKED, true>(a, grid, st) : launch_lane_one<WW, PACKED, false>(a, grid, st))
+    if (a.w <= 4) return CL_LANE_CASE(4);
+    if (a.w <= 6) return CL_LANE_CASE(6);
+    if (a.w <= 8) return CL_LANE_CASE(8);
+    return CL_LANE_CASE(10);
+#undef CL_LANE_CASE
 }
 
 int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {

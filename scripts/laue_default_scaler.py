@@ -19,4 +19,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(20):
     eng.train_step(5 + i)
 torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 20
-print("laue %d rows, 20x10 scaler: %.3f ms/step, %.3e rows/s, single pass %s, CARELESS_HIP_NARROW=%s" % (N, 1e3 * t, N / t, eng.obs.fused_laue, os.environ.get("CARELESS_HIP_NARROW", "1")))
+print("laue %d rows, 20x10 scaler: %.3f ms/step, %.3e rows/s, single pass %s, CARELESS_HIP_LANE=%s CARELESS_HIP_NARROW=%s" % (N, 1e3 * t, N / t, eng.obs.fused_laue, os.environ.get("CARELESS_HIP_LANE", "1"), os.environ.get("CARELESS_HIP_NARROW", "1")))

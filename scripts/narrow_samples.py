@@ -11,5 +11,5 @@ for S,dof in ((1,None),(8,16.0)):
     torch.cuda.synchronize(); t0=time.perf_counter()
     for i in range(20): eng.train_step(5+i)
     torch.cuda.synchronize(); t=(time.perf_counter()-t0)/20
-    print("mono 4M 20x10 S=%d %s: %.3f ms/step %.3e refl/s NARROW=%s"%(S, "studentt" if dof else "normal", 1e3*t, N/t, os.environ.get("CARELESS_HIP_NARROW","1")))
+    print("mono 4M 20x10 S=%d %s: %.3f ms/step %.3e refl/s LANE=%s NARROW=%s"%(S, "studentt" if dof else "normal", 1e3*t, N/t, os.environ.get("CARELESS_HIP_LANE","1"), os.environ.get("CARELESS_HIP_NARROW","1")))
     del eng, model
