@@ -1,4 +1,4 @@
-// Lane-per-observation instance of the fused ELBO step for narrow scalers (gfx950 / CDNA4 only): hidden width <= 12, metadata
+// Lane-per-observation instance of the fused ELBO step for narrow scalers (gfx950 / CDNA4 only): hidden width <= 10, metadata
 // width <= 15, up to 20 Dense layers -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width = metadata width
 // or 10).
 //
@@ -854,12 +854,13 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #endif
 
 #ifndef CL_LANE_SMAX
-#define CL_LANE_SMAX 2
+#define CL_LANE_SMAX 3
 #endif
 
 // 1 = this geometry runs on the lane-per-observation kernel (full ELBO step; plain observation layout, or the packed one of single-pass Laue).
-// More than two MC samples go to elbo_narrow.hip: the sampling epilogue is a serial dependent chain per sample, which one wave per
-// SIMD cannot hide (4 M observations, 20 x 10, Student-T: 0.144 ms per extra sample here, 0.032 ms there; S = 1: 0.96 against 1.12 ms).
+// More than three MC samples go to elbo_narrow.hip: the sampling epilogue is a serial dependent chain per sample, which one wave per
+// SIMD cannot hide (4 M observations, 20 x 10, Student-T, ms per step here / there: S = 1 0.97 / 1.11, 2: 1.03 / 1.12, 3: 1.13 / 1.18,
+// 4: 1.25 / 1.19, 8: 1.93 / 1.34; scripts/narrow_samples.py).
 int cl_lane_supports(const cl_mlp_args& a) {
     return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= 15 && a.L >= 1 && a.L <= NL && a.n_imgl == 0 && a.act_out == nullptr &&
            a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);

@@ -66,6 +66,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CL_DPP_REDUCE
 #define CL_DPP_REDUCE 1
 #endif
+#ifndef CL_LEAK_VGPR
+#define CL_LEAK_VGPR 0
+#endif
 #ifndef CL_FAST_DIV
 #define CL_FAST_DIV 0     /* 1: reciprocal + Newton step for the Student-T derivative, 1/nu hoisted (measured: no gain) */
 #endif
@@ -277,7 +280,12 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     const int d = A.d, w = A.w;
     const int Ld = A.L;                              // Dense layers (parameters in A.mlp)
     const int L = ILAY ? A.L + A.n_imgl : A.L;       // all hidden layers (Dense + per-image)
+#if CL_LEAK_VGPR
+    float leak = A.leak;                 // (in a vector register: a vector instruction with a scalar-register operand issues at half rate beside a second wave)
+    asm volatile("" : "+v"(leak));
+#else
     const float leak = A.leak;
+#endif
     const bool no_head = CHAIN && ((MODE == 1 && A.act_out != nullptr) || (MODE == 2 && A.dH_ext != nullptr));
 
     // ---- stage the weights (global W^T layout, see cl_kernels.h) into padded LDS images, zero-filled ---------

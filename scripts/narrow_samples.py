@@ -4,7 +4,7 @@ from careless_amd.workloads import build_model, reference_inputs
 from careless_amd.synthetic import make_synthetic
 N=4000000
 data=make_synthetic(N, d0=5, posenc=False, outliers=True)
-for S,dof in ((1,None),(8,16.0)):
+for S,dof in [(int(x), 16.0) for x in os.environ.get("SAMPLES", "1,2,3,4,6,8").split(",")]:
     model=build_model(data, 20, 10, S, dof=dof)
     eng=model.engine(reference_inputs(data)); eng.alloc_history(30)
     for i in range(5): eng.train_step(i)

@@ -40,7 +40,7 @@ CASES = {
     "narrow_three_observations": dict(N=3, R=2, d0=5, L=3, w=10, S=2, n_images=1, use_image_scales=False, perturb=0.03),
     "narrow_one_layer_w15_d15_softplus": dict(N=333, R=30, d0=15, L=1, w=15, S=2, bijector="softplus", shift=0.5, perturb=0.03),
     "narrow_20x4_d12": dict(N=600, R=40, d0=12, L=20, w=4, S=1, perturb=0.03, grid=2),
-    # the lane-per-observation kernel (csrc/elbo_lane.hip: width <= 10, <= 2 MC samples; compile-time widths 4 / 6 / 8 / 10, a
+    # the lane-per-observation kernel (csrc/elbo_lane.hip: width <= 10, <= 3 MC samples; compile-time widths 4 / 6 / 8 / 10, a
     # full-depth instance for 20 layers and a generic-depth one) beyond the CLI-default cases above
     "lane_ev11_studentt_6x10_S2": dict(N=700, R=50, d0=5, L=6, w=10, S=2, ev11=True, likelihood="studentt", dof=6.0, perturb=0.03),
     "lane_rows_in_arbitrary_order_5x7_S1": dict(N=900, R=60, d0=5, L=5, w=7, S=1, n_images=9, shuffle_rows=True, perturb=0.03),
