@@ -172,6 +172,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     using SM = LSmem<W>;
     constexpr int NC = SM::NC;
     constexpr int IMG = SM::IMG;
+    // LeakyReLU derivative: compares into scalar-register pairs in groups of SELG, then the group's selects (equal groups of at
+    // most five: a scalar register written by a vector instruction wants two instructions before a vector instruction reads it)
+    constexpr int SELG = (W + (W + 4) / 5 - 1) / ((W + 4) / 5);
     static_assert(W >= 1 && W <= 15, "block 15 of a weight register is the bias");
     static_assert(CL_MLP_TILE % WT == 0, "a wave tile must not straddle the end of the padded observation axis");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -332,8 +335,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         long long nkey = 0;                  // PACKED: noise key of this lane's row
         {
             const unsigned zb = 4u * (unsigned)max(rid, 0) * (unsigned)A.S;
+#ifdef X_NOGATHER
+            zf0 = 1.0f + 1e-9f * (float)zb;
+#else
             if (A.use_img) aim_raw = ld_uo(A.img, 4u * (unsigned)max(img - 1, 0));
             zf0 = ld_uo(A.z_f, zb);
+#endif
 #pragma unroll
             for (int j = 1; j < SPRE; ++j) zfv[j] = ld_uo(A.z_f, zb + 4u * (unsigned)min(j, A.S - 1));
             if (PACKED) {
@@ -473,7 +480,11 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     if (counts) nll_acc -= ll * w_ll;
                     const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
                     const float dzs = gi * zf * zf;
+#ifdef X_NOATOMIC
+                    pda += gi * zs * 2.0f * zf;
+#else
                     atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
+#endif
                     const float dt = dzs * aim;
                     pdl += dt;
                     pds += dt * eta;
@@ -482,6 +493,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             };
             auto philox_eta = [&](int s) -> float {      // one Philox block + Box-Muller pair serves samples s and s + 4
                 float eta = 0.0f;
+#ifdef X_NOPHILOX
+                return 0.3f + 1e-6f * (float)lane;
+#endif
                 if (!act) {
                 } else if (((s >> 2) & 1) == 0) {
                     float sn;
@@ -559,13 +573,13 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) lk[c] = dh[c] * leak;
 #pragma unroll
-                for (int f0 = 0; f0 < W; f0 += 5) {
-                    unsigned long long m[5];
+                for (int f0 = 0; f0 < W; f0 += SELG) {
+                    unsigned long long m[SELG];
 #pragma unroll
-                    for (int i = 0; i < 5; ++i)
+                    for (int i = 0; i < SELG; ++i)
                         if (f0 + i < W) asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[i]) : "v"(h[f0 + i < W ? f0 + i : 0]));
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) {
+                    for (int i = 0; i < SELG; ++i) {
                         const int f = f0 + i < W ? f0 + i : 0;
                         if (f0 + i < W)
                             asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dz[f]) : "v"(lk[f >> 2][f & 3]), "v"(dh[f >> 2][f & 3]), "s"(m[i]));
@@ -656,13 +670,13 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     // lone wave pays ~9 cycles per instruction; compares into scalar register pairs first and the selects after
                     // them issue back to back (scripts/probe/pkfma_probe.hip: 5.4 cycles).
 #pragma unroll
-                    for (int f0 = 0; f0 < W; f0 += 5) {
-                        unsigned long long m[5];
+                    for (int f0 = 0; f0 < W; f0 += SELG) {
+                        unsigned long long m[SELG];
 #pragma unroll
-                        for (int i = 0; i < 5; ++i)
+                        for (int i = 0; i < SELG; ++i)
                             if (f0 + i < W) asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[i]) : "v"(hs[l][f0 + i < W ? f0 + i : 0]));
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) {
+                        for (int i = 0; i < SELG; ++i) {
                             const int f = f0 + i < W ? f0 + i : 0;
                             if (f0 + i < W)
                                 asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dz[f]) : "v"(lk[f >> 2][f & 3]), "v"(dH[f >> 2][f & 3]), "s"(m[i]));
