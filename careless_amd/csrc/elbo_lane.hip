@@ -1,6 +1,6 @@
 // Lane-per-observation instance of the fused ELBO step for narrow scalers (gfx950 / CDNA4 only): hidden width <= 10, metadata
-// width <= 15, up to 20 Dense layers -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width = metadata width
-// or 10).
+// width <= 15, exactly 20 Dense layers, <= 3 MC samples -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width
+// = metadata width or 10, --mc-samples 1); other depths, widths 11-15 and more samples run on elbo_narrow.hip.
 //
 // Same arithmetic and the same reference lines as elbo_mlp.hip (scaler forward / sample / predict / likelihood / backward:
 // careless/models/scaling/nn.py:92-120, image.py:53-63, models/merging/variational.py:156-181, 197-202,
@@ -34,12 +34,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef CL_LANE_SCHED
 #define CL_LANE_SCHED 1
-#endif
-#ifndef CL_LANE_SGPR_SELECT
-#define CL_LANE_SGPR_SELECT 1
-#endif
-#ifndef CL_LANE_INTERLEAVE
-#define CL_LANE_INTERLEAVE 1
 #endif
 
 namespace {
@@ -78,50 +72,13 @@ __device__ __forceinline__ void mfma16_acc(f32x4& acc, float a, float b) {
 #endif
 }
 
-__device__ __forceinline__ float lrelu(float x, float leak) {
-#ifdef X_NOLRELU
-    return x;
-#endif
-    const float m = leak * x;
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
-    return r;
-}
 __device__ __forceinline__ float lrelu2(float x, float lx) {          // max(x, leak x), leak x given
-#ifdef X_NOLRELU
-    return x;
-#endif
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lx));
     return r;
 }
-__device__ __forceinline__ float lrelu_bwd2(float h, float dh, float ldh) {
-#ifdef X_NODZ
-    return dh;
-#endif
-    return (h > 0.0f) ? dh : ldh;
-}
-// dZ = dH * lrelu'(h): dH where h > 0, leak dH otherwise (h == 0 takes the leak branch, like `h > 0 ? ... : ...`)
-__device__ __forceinline__ float lrelu_bwd(float h, float dh, float leak) {
-#ifdef X_NODZ
-    return dh;
-#endif
-    return (h > 0.0f) ? dh : leak * dh;
-}
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int opaque_uniform(int v) {
-    v = __builtin_amdgcn_readfirstlane(v);
-    asm volatile("" : "+s"(v));
-    return v;
-}
-// "Is layer l the top layer?" as a bit test on an opaque SGPR mask (see elbo_narrow.hip: written as `l == Lt - 1` hipcc merges
-// the twenty unrolled blocks into one that indexes the activations at run time -- in scratch memory)
-__device__ __forceinline__ unsigned top_layer_mask(int L) {
-    unsigned m = 1u << (unsigned)(__builtin_amdgcn_readfirstlane(L) - 1);
-    asm volatile("" : "+s"(m));
-    return m;
-}
 template <class T>
 __device__ __forceinline__ T ld_uo(const T* base, unsigned byte_off) {       // (wave-uniform pointer)[32-bit per-lane byte offset]
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
@@ -164,9 +121,11 @@ struct LSmem {
 // PACKED: the packed observation layout of include/careless_hip.h (row_map; single-pass Laue: gmeta / tile_gmax / noise_row): rows the
 // engine ordered so that a harmonic group sits inside a 16-row granule, padding rows have refl_id = -1, n_obs == n_pad; everything
 // the caller indexes by row (eta, ipred_out, the noise key) goes through row_map.
-// FULL: the scaler has all NL layers (the careless default): no per-layer depth tests -- a lone wave pays every taken or untaken
-// branch in full -- and a backward pass whose LDS traffic rides in the shadow of the previous layer's weight-gradient MFMAs.
-template <int W, bool PACKED, bool FULL>
+// The scaler has all NL layers (the careless default; cl_lane_supports): no per-layer depth tests -- a lone wave pays every taken or
+// untaken branch in full (a generic-depth instance of this kernel lost to elbo_narrow.hip at every depth below NL: 12 x 10 at 4 M
+// observations 1.27 against 0.80 ms per step) -- and a backward pass whose LDS traffic rides in the shadow of the previous layer's
+// weight-gradient MFMAs.
+template <int W, bool PACKED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void elbo_lane_kernel(const cl_mlp_args A) {
     using SM = LSmem<W>;
@@ -244,7 +203,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     float* const sH = sZ + 32 * PIT;                   // the layer's input (layers >= 1)
     float* const sX = sH + 32 * PIT;                   // the metadata of the tile (layer 0's input)
     float* const sS = sX + 16 * PIT;                   // sampled amplitudes of samples 1 .. SPRE-1   [sample][lane]
-    constexpr int PAR = 16 * PIT;                      // second copy of sZ / sH (FULL: layers alternate between the two)
+    constexpr int PAR = 16 * PIT;                      // second copy of sZ / sH (layers alternate between the two)
 
     // ---- accumulators that live across all tiles of this wave ----------------------------------------------------------
     f32x4 wacc[NL], wacd[NL];           // dW_l = wacc + wacd: lane (j, q), element t = dW_l[out 4 q + t][in j]  (in 15: the bias)
@@ -309,8 +268,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     for (int wt = wt_begin; wt < n_wt; wt += wt_step) {
-        const int Lt = FULL ? NL : opaque_uniform(L);
-        const unsigned topm = FULL ? (1u << (NL - 1)) : top_layer_mask(L);
         float x0[15];
 #pragma unroll
         for (int k = 0; k < 15; ++k) x0[k] = xn[k];          // (rows >= d of meta_t are zero by contract, groups past them were never loaded)
@@ -335,12 +292,8 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         long long nkey = 0;                  // PACKED: noise key of this lane's row
         {
             const unsigned zb = 4u * (unsigned)max(rid, 0) * (unsigned)A.S;
-#ifdef X_NOGATHER
-            zf0 = 1.0f + 1e-9f * (float)zb;
-#else
             if (A.use_img) aim_raw = ld_uo(A.img, 4u * (unsigned)max(img - 1, 0));
             zf0 = ld_uo(A.z_f, zb);
-#endif
 #pragma unroll
             for (int j = 1; j < SPRE; ++j) zfv[j] = ld_uo(A.z_f, zb + 4u * (unsigned)min(j, A.S - 1));
             if (PACKED) {
@@ -352,19 +305,17 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         }
         LSTAMP(0);
         // ================= forward ==========================================================================================
-        // `top` = the top layer's activations (the head's input), copied out where the depth puts them.
         float hs[NL][W];
-        float top[W];
         float wan[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) wan[c] = sF[c * 64];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            if (l < Lt) {
+            {
                 float wa[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) wa[c] = wan[c];
-                // the next layer's weight registers, in flight under this layer's MFMAs (past the depth: the head's)
+                // the next layer's weight registers, in flight under this layer's MFMAs (after the top layer: the head's)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) wan[c] = sF[(l + 1) * IMG + c * 64];
                 f32x4 acc[NC];
@@ -397,12 +348,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #pragma unroll
                     for (int f = 0; f < W; ++f) hs[l][f] = lrelu2(acc[f >> 2][f & 3], lk[f >> 2][f & 3]);
                 }
-                if (topm & (1u << l)) {
-#pragma unroll
-                    for (int f = 0; f < W; ++f) top[f] = hs[l][f];
-                }
             }
         }
+        const float (&top)[W] = hs[NL - 1];              // the head's input
         LSTAMP(1);
         // Dense(2) head: outputs 0, 1 of one more chunk
         float o0, o1;
@@ -480,11 +428,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     if (counts) nll_acc -= ll * w_ll;
                     const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
                     const float dzs = gi * zf * zf;
-#ifdef X_NOATOMIC
-                    pda += gi * zs * 2.0f * zf;
-#else
                     atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
-#endif
                     const float dt = dzs * aim;
                     pdl += dt;
                     pds += dt * eta;
@@ -493,9 +437,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             };
             auto philox_eta = [&](int s) -> float {      // one Philox block + Box-Muller pair serves samples s and s + 4
                 float eta = 0.0f;
-#ifdef X_NOPHILOX
-                return 0.3f + 1e-6f * (float)lane;
-#endif
                 if (!act) {
                 } else if (((s >> 2) & 1) == 0) {
                     float sn;
@@ -564,7 +505,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             dH[c] = a;
         }
         LSTAMP(4);
-        if constexpr (FULL) {
             // dZ of a layer: dH where the activation is positive, leak dH otherwise.  As the compiler writes the select (compare
             // into VCC, wait states, select, per element) a lone wave pays ~9 cycles per instruction; compares into scalar
             // register pairs first and the selects after them issue back to back (scripts/probe/pkfma_probe.hip: 5.4 cycles).
@@ -643,116 +583,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 });
                 static_assert(NOPS + NC <= 32, "LDS operations of a layer fit the shadow of sixteen MFMAs");
             });
-        } else {
-        // Layer l: dZ_l from dH_l and the layer's activations; dZ_l and the layer's input staged for the weight gradient; dgrad
-        // (small MFMAs, under which the staging writes complete and the transposed operands are read back); the 16 MFMAs of the
-        // weight gradient in two chains.  One wave's LDS operations execute in order and a wave only touches its own tiles.
-        float wkn[NC];
-        const int Ltb = FULL ? NL : opaque_uniform(L);           // (a second copy: the forward pass's twenty layer predicates need not stay in scalar registers)
-        {
-            const int lt1 = Ltb > 1 ? Ltb - 1 : 1;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) wkn[c] = sK[lt1 * IMG + c * 64];
-        }
-#pragma unroll
-        for (int l = NL - 1; l >= 0; --l) {
-            if (l < Ltb) {
-                float wk[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) wk[c] = wkn[c];
-                float dz[W];
-                {
-                    f32x4 lk[NC];                    // leak * dH
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) lk[c] = dH[c] * leak;
-#if CL_LANE_SGPR_SELECT
-                    // dZ = h > 0 ? dH : leak dH.  As the compiler writes it (compare into VCC, wait states, select, per element) a
-                    // lone wave pays ~9 cycles per instruction; compares into scalar register pairs first and the selects after
-                    // them issue back to back (scripts/probe/pkfma_probe.hip: 5.4 cycles).
-#pragma unroll
-                    for (int f0 = 0; f0 < W; f0 += SELG) {
-                        unsigned long long m[SELG];
-#pragma unroll
-                        for (int i = 0; i < SELG; ++i)
-                            if (f0 + i < W) asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[i]) : "v"(hs[l][f0 + i < W ? f0 + i : 0]));
-#pragma unroll
-                        for (int i = 0; i < SELG; ++i) {
-                            const int f = f0 + i < W ? f0 + i : 0;
-                            if (f0 + i < W)
-                                asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dz[f]) : "v"(lk[f >> 2][f & 3]), "v"(dH[f >> 2][f & 3]), "s"(m[i]));
-                        }
-                    }
-#else
-#pragma unroll
-                    for (int f = 0; f < W; ++f) dz[f] = lrelu_bwd2(hs[l][f], dH[f >> 2][f & 3], lk[f >> 2][f & 3]);
-#endif
-                }
-                // Staging writes (dZ_l, the layer's input: feature pairs), then the transposed reads of the weight gradient's
-                // operands: LDS operation number i of the layer.  A lone wave issues up to two of them for free in the shadow of
-                // an MFMA, so they ride on the dgrad chain, two per step, in exactly this order (one wave's LDS operations
-                // execute in order; a wave only touches its own tiles).
-                f32x4 pa[4], pb[4];
-                constexpr int WP = (W + 1) / 2, NOPS = 2 * WP + 8;
-                auto lds_op = [&](auto ic_) {
-                    constexpr int i = decltype(ic_)::value;
-                    if constexpr (i < WP) {
-                        sZ[(2 * i) * PIT + lane] = dz[2 * i];
-                        if constexpr (2 * i + 1 < W) sZ[(2 * i + 1) * PIT + lane] = dz[2 * i + 1];
-                    } else if constexpr (i < 2 * WP) {
-                        constexpr int f = 2 * (i - WP);
-                        if (l > 0) {
-                            sH[f * PIT + lane] = hs[l > 0 ? l - 1 : 0][f];
-                            if constexpr (f + 1 < W) sH[(f + 1) * PIT + lane] = hs[l > 0 ? l - 1 : 0][f + 1];
-                        }
-                    } else if constexpr (i < NOPS) {
-                        constexpr int j = i - 2 * WP, c = j >> 1;
-                        if constexpr ((j & 1) == 0) pa[c] = *reinterpret_cast<const f32x4*>(rdZ + 16 * c);
-                        else pb[c] = *reinterpret_cast<const f32x4*>((l == 0 ? rdX : rdH) + 16 * c);
-                    }
-                };
-                if (l > 0) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) dH[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    static_for<0, W>([&](auto oc_) {
-                        constexpr int o = decltype(oc_)::value;
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) dH[c] = mfma_bk<o>(wk[c], dz[o], dH[c]);
-#if CL_LANE_INTERLEAVE
-                        lds_op(std::integral_constant<int, 2 * o>{});
-                        lds_op(std::integral_constant<int, 2 * o + 1>{});
-                        LFENCE();
-#endif
-                    });
-#if CL_LANE_INTERLEAVE
-                    static_for<2 * W, (NOPS > 2 * W ? NOPS : 2 * W)>(lds_op);
-#else
-                    static_for<0, NOPS>(lds_op);
-#endif
-                } else {
-                    static_for<0, NOPS>(lds_op);
-                }
-                LFENCE();
-                // the dgrad weights of the layer below, in flight under the weight gradient's MFMAs
-                if (l > 1) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) wkn[c] = sK[(l > 1 ? l - 1 : 1) * IMG + c * 64];
-                }
-#ifdef X_NOWGRAD
-                wacc[l] += pa[0] + pa[1] + pa[2] + pa[3] + pb[0] + pb[1] + pb[2] + pb[3];
-#else
-#pragma unroll
-                for (int c = 0; c < 4; c += 2) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        mfma16_acc(wacc[l], pa[c][t], pb[c][t]);
-                        mfma16_acc(wacd[l], pa[c + 1][t], pb[c + 1][t]);
-                    }
-                }
-#endif
-                LFENCE();
-            }
-        }
-        }       // (generic depth)
         LSTAMP(5);
     }
 #ifdef CL_STAMPS
@@ -764,6 +594,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #endif
 
     // ================= flush: sum the waves' accumulators, scatter into the flat W^T layout of this workgroup's partial ====
+#if CL_LANE_ASM_ACC
+    asm volatile("s_nop 15\n\ts_nop 15");     // (the compiler does not know that the inline-assembly MFMAs' results take eight passes to land)
+#endif
     __syncthreads();
     const int offWo = w * d + w + (L - 1) * (w * w + w);
     const int Ptot = offWo + 2 * w + 2;
@@ -845,12 +678,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     }
 }
 
-template <int W, bool PACKED, bool FULL>
+template <int W, bool PACKED>
 static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SM = LSmem<W>;
     const size_t sm = (size_t)SM::total * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_lane_kernel<W, PACKED, FULL>;
+    auto kern = elbo_lane_kernel<W, PACKED>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -871,30 +704,23 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_SMAX 3
 #endif
 
-// 1 = this geometry runs on the lane-per-observation kernel (full ELBO step; plain observation layout, or the packed one of single-pass Laue).
+// 1 = this geometry runs on the lane-per-observation kernel (full ELBO step of a scaler of exactly NL layers -- the default depth --;
+// plain observation layout, or the packed one of single-pass Laue).
 // More than three MC samples go to elbo_narrow.hip: the sampling epilogue is a serial dependent chain per sample, which one wave per
 // SIMD cannot hide (4 M observations, 20 x 10, Student-T, ms per step here / there: S = 1 0.97 / 1.11, 2: 1.03 / 1.12, 3: 1.13 / 1.18,
 // 4: 1.25 / 1.19, 8: 1.93 / 1.34; scripts/narrow_samples.py).
 int cl_lane_supports(const cl_mlp_args& a) {
-    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= 15 && a.L >= 1 && a.L <= NL && a.n_imgl == 0 && a.act_out == nullptr &&
+    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= 15 && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
            a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);
-}
-
-static bool full_enabled() {            // CARELESS_HIP_LANE_FULL=0: full-depth scalers on the generic-depth instance (A/B runs, tests)
-    static const bool on = [] { const char* e = getenv("CARELESS_HIP_LANE_FULL"); return !(e != nullptr && e[0] == '0'); }();
-    return on;
 }
 
 template <bool PACKED>
 static int launch_lane_w(const cl_mlp_args& a, int grid, hipStream_t st) {
-    const bool full = a.L == NL && full_enabled();
     // the instance whose compile-time width is the smallest one that holds the scaler (zero-padded features cost MFMA steps)
-#define CL_LANE_CASE(WW) (full ? launch_lane_one<WW, PACKED, true>(a, grid, st) : launch_lane_one<WW, PACKED, false>(a, grid, st))
-    if (a.w <= 4) return CL_LANE_CASE(4);
-    if (a.w <= 6) return CL_LANE_CASE(6);
-    if (a.w <= 8) return CL_LANE_CASE(8);
-    return CL_LANE_CASE(10);
-#undef CL_LANE_CASE
+    if (a.w <= 4) return launch_lane_one<4, PACKED>(a, grid, st);
+    if (a.w <= 6) return launch_lane_one<6, PACKED>(a, grid, st);
+    if (a.w <= 8) return launch_lane_one<8, PACKED>(a, grid, st);
+    return launch_lane_one<10, PACKED>(a, grid, st);
 }
 
 int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {

@@ -1403,7 +1403,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
 #if !CL_IMGL && !CL_CHAIN
     // hidden width <= 15 (the careless CLI default): the full step runs on the one-wave-per-SIMD kernel of elbo_narrow.hip
     // (CARELESS_HIP_NARROW=0 keeps the eight-wave instance below: A/B measurements)
-    if (mode == 0 && cl_lane_supports(a) && lane_enabled()) return cl_launch_lane(a, grid, st);      // width <= 10: lane = observation (elbo_lane.hip)
+    if (mode == 0 && cl_lane_supports(a) && lane_enabled()) return cl_launch_lane(a, grid, st);      // the default scaler's shape: lane = observation (elbo_lane.hip)
     if (mode == 0 && cl_narrow_supports(a) && narrow_enabled()) return cl_launch_narrow(a, grid, st);
 #endif
     switch (mode) {
