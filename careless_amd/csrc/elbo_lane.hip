@@ -32,6 +32,9 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CL_LANE_COALESCE
+#define CL_LANE_COALESCE 2      /* smallest number of MC samples whose amplitude gradients leave through LDS (0: never) */
+#endif
 #ifndef CL_LANE_SCHED
 #define CL_LANE_SCHED 1
 #endif
@@ -43,6 +46,11 @@ constexpr int NWV = 4;                // waves of a workgroup (one per SIMD)
 constexpr int NT = 64 * NWV;
 constexpr int WT = 64;                // observations of a wave tile
 constexpr int PIT = 68;               // row pitch of a staging tile [16 features][64 observations]
+#ifndef CL_LANE_DMAX
+#define CL_LANE_DMAX 8
+#endif
+constexpr int DMAX = CL_LANE_DMAX;    // metadata columns (more: elbo_narrow.hip; every column is a register of the lane here)
+constexpr int DGMAX = (DMAX + 3) / 4;
 constexpr int SPRE = 8;               // MC samples whose amplitudes are gathered at the start of the tile
 constexpr int ONE = 15;               // block of a weight register (= row of a staging tile) that belongs to the constant-one feature
 
@@ -109,7 +117,7 @@ struct LSmem {
     static constexpr int oF = 0;                              // forward images, layers 0 .. NL-1 and the head (NL)
     static constexpr int oK = oF + (NL + 1) * IMG;            // transposed (dgrad) images, same numbering
     static constexpr int oT = oK + (NL + 1) * IMG;            // per wave: sZ[2], sH[2] (by layer parity), sX   [16][PIT] each
-    static constexpr int TW = 5 * 16 * PIT + SPRE * 64;       // (+ sS: the lane's first SPRE sampled amplitudes)
+    static constexpr int TW = 5 * 16 * PIT + (SPRE + 1) * 64; // (+ sS: the lane's first SPRE sampled amplitudes / amplitude gradients; sQ)
     static constexpr int main_total = oT + NWV * TW;
     static constexpr int REG = NL * 256;                      // floats of one wave's parked accumulators (flush)
     static constexpr int flush_total = (NWV / 2) * REG + NWV * 2 * 16;
@@ -202,7 +210,8 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     float* const sZ = smem + SM::oT + wv * SM::TW;     // dZ_l                       [feature][observation]
     float* const sH = sZ + 32 * PIT;                   // the layer's input (layers >= 1)
     float* const sX = sH + 32 * PIT;                   // the metadata of the tile (layer 0's input)
-    float* const sS = sX + 16 * PIT;                   // sampled amplitudes of samples 1 .. SPRE-1   [sample][lane]
+    float* const sS = sX + 16 * PIT;                   // sampled amplitudes of samples 1 .. SPRE-1, then their gradients   [sample][lane]
+    unsigned* const sQ = reinterpret_cast<unsigned*>(sS + SPRE * 64);       // byte offset of the lane's reflection in dz_f (~0: none)
     constexpr int PAR = 16 * PIT;                      // second copy of sZ / sH (layers alternate between the two)
 
     // ---- accumulators that live across all tiles of this wave ----------------------------------------------------------
@@ -224,9 +233,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 
     // per-observation inputs of a wave tile, loaded one tile ahead (a wave tile never leaves the padded metadata rows because 64
     // divides CL_MLP_TILE, the per-observation arrays are clamped to their last element)
-    float xn[15];
+    float xn[DMAX];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) xn[k] = 0.0f;
+    for (int k = 0; k < DMAX; ++k) xn[k] = 0.0f;
     int ridn = -1, imgn = 0;
     float ion = 0.0f, sgn = 1.0f;
     auto prefetch = [&](int wt_in) {
@@ -237,12 +246,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         const float* __restrict__ mt = A.meta_t + base;
         const int dd = A.d;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < DGMAX; ++g) {
             if (4 * g < dd) {                                            // wave-uniform
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int k = 4 * g + t;
-                    if (k < 15) xn[k] = ld_uo(mt + (size_t)k * n_pad_u, 4u * (unsigned)lane);    // (rows d .. 4 dg - 1: zeroed at the use)
+                    if (k < DMAX) xn[k] = ld_uo(mt + (size_t)k * n_pad_u, 4u * (unsigned)lane);    // (rows d .. 4 dg - 1: zeroed at the use)
                 }
             }
         }
@@ -268,16 +277,16 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     for (int wt = wt_begin; wt < n_wt; wt += wt_step) {
-        float x0[15];
+        float x0[DMAX];
 #pragma unroll
-        for (int k = 0; k < 15; ++k) x0[k] = xn[k];          // (rows >= d of meta_t are zero by contract, groups past them were never loaded)
+        for (int k = 0; k < DMAX; ++k) x0[k] = xn[k];          // (rows >= d of meta_t are zero by contract, groups past them were never loaded)
         // layer 0's input, staged for its weight gradient at the end of the backward pass
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < DGMAX; ++g) {
             if (g < dg) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (4 * g + t < 15) sX[(4 * g + t) * PIT + lane] = x0[4 * g + t];
+                    if (4 * g + t < DMAX) sX[(4 * g + t) * PIT + lane] = x0[4 * g + t];
             }
         }
         const bool in_range = wt * WT + lane < A.n_obs;
@@ -322,10 +331,10 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 if (l == 0) {
-                    static_for<0, 4>([&](auto gc) {
+                    static_for<0, DGMAX>([&](auto gc) {
                         constexpr int g = decltype(gc)::value;
                         if (g < dg) {                                    // wave-uniform
-                            static_for<4 * g, (4 * g + 4 < 15 ? 4 * g + 4 : 15)>([&](auto kc) {
+                            static_for<4 * g, (4 * g + 4 < DMAX ? 4 * g + 4 : DMAX)>([&](auto kc) {
                                 constexpr int k = decltype(kc)::value;
 #pragma unroll
                                 for (int c = 0; c < NC; ++c) acc[c] = mfma_bk<k>(wa[c], x0[k], acc[c]);
@@ -383,12 +392,17 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         const bool laue = PACKED && A.gmeta != nullptr;                    // wave-uniform
         const int mem = gm & 0xff, cnt = gm >> 8;
         const int gmax = laue ? uniform(A.tile_gmax[(wt * WT) / CL_MLP_TILE]) : 0;
+        // The S amplitude gradients of an observation are S consecutive floats of dz_f.  Issued as they are computed -- one atomic
+        // instruction per sample, 64 lanes on 64 different lines, the same lines again a sample later -- they cost this kernel 0.12 ms
+        // per sample at 4 M observations (the memory side executes one request per lane and serialises the ones that hit a line in
+        // flight).  For 2 <= S <= SPRE they go through LDS instead and leave as eight instructions in which eight consecutive lanes
+        // carry the eight samples of one observation: one 32-byte request per observation.
+        const bool coal = CL_LANE_COALESCE && S >= CL_LANE_COALESCE && S <= SPRE;      // wave-uniform
         if (laue || rid >= 0) {
             // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
             const float inv_sg = cl_fast_rcp(sg);
             const float log_sg = cl_fast_log(sg);
-            const float* __restrict__ eta_p = A.eta ? A.eta + (size_t)gobs * S : nullptr;
-            float* __restrict__ ipred_p = A.ipred_out ? A.ipred_out + (size_t)gobs * S : nullptr;
+            // (per-lane 64-bit addresses of the optional arrays are formed where they are used: test / output paths only)
             const float* __restrict__ zf_p = A.z_f;
             float* __restrict__ dzf_p = A.dz_f;
             const int lik_kind = A.lik_kind;
@@ -406,7 +420,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 const float tq = o0 + sigma * eta + shift;
                 const float zs = aim * tq;
                 const float ipred = act ? zs * zf * zf : 0.0f;
-                if (act && ipred_p) ipred_p[s] = ipred;
+                if (A.ipred_out != nullptr && act) A.ipred_out[(size_t)gobs * S + s] = ipred;
                 float lin = ipred;                                   // what the likelihood sees: the prediction, or its group's total
                 if (laue) {
                     lin = 0.0f;
@@ -428,7 +442,8 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     if (counts) nll_acc -= ll * w_ll;
                     const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
                     const float dzs = gi * zf * zf;
-                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
+                    if (coal) sS[s * 64 + lane] = gi * zs * 2.0f * zf;      // (slot s: its amplitude was read at the start of this sample)
+                    else atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
                     const float dt = dzs * aim;
                     pdl += dt;
                     pds += dt * eta;
@@ -452,7 +467,8 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             // Three loops over the samples (wave-uniform trip counts), so that the common one -- in-kernel noise, amplitudes
             // from LDS -- contains no global load at all: any load in the loop makes the compiler wait on the one in-order
             // memory counter, i.e. for the previous sample's atomics, a few microseconds each for a lone wave.
-            if (eta_p != nullptr) {
+            if (A.eta != nullptr) {
+                const float* __restrict__ eta_p = A.eta + (size_t)gobs * S;
                 for (int s = 0; s < S; ++s) {
                     float zf = zf0;
                     if (s > 0) zf = (s < SPRE) ? sS[s * 64 + lane] : ld_uo(zf_p, zoff + 4u * (unsigned)s);
@@ -468,6 +484,16 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     const float zf = ld_uo(zf_p, zoff + 4u * (unsigned)s);
                     sample(s, philox_eta(s), act ? zf : 0.0f);
                 }
+            }
+        }
+        if (coal) {
+            sQ[lane] = (rid >= 0) ? zoff : 0xFFFFFFFFu;
+            const int ss = lane & 7, oj = lane >> 3;             // this lane's sample, its observation within a group of eight
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned zq = sQ[8 * j + oj];
+                const float g = sS[ss * 64 + 8 * j + oj];
+                if (ss < S && zq != 0xFFFFFFFFu) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(A.dz_f) + zq + 4u * (unsigned)ss), g);
             }
         }
         if (A.use_img) {
@@ -710,7 +736,7 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 // SIMD cannot hide (4 M observations, 20 x 10, Student-T, ms per step here / there: S = 1 0.97 / 1.11, 2: 1.03 / 1.12, 3: 1.13 / 1.18,
 // 4: 1.25 / 1.19, 8: 1.93 / 1.34; scripts/narrow_samples.py).
 int cl_lane_supports(const cl_mlp_args& a) {
-    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= 15 && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
+    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= DMAX && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
            a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);
 }
 
