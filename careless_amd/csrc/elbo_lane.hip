@@ -1,6 +1,6 @@
 // Lane-per-observation instance of the fused ELBO step for narrow scalers (gfx950 / CDNA4 only): hidden width <= 10, metadata
-// width <= 15, exactly 20 Dense layers, <= 3 MC samples -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width
-// = metadata width or 10, --mc-samples 1); other depths, widths 11-15 and more samples run on elbo_narrow.hip.
+// width <= 8, exactly 20 Dense layers, <= 8 MC samples -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width
+// = metadata width or 10, --mc-samples 1); other depths, widths 11-15, more than 8 metadata columns or samples run on elbo_narrow.hip.
 //
 // Same arithmetic and the same reference lines as elbo_mlp.hip (scaler forward / sample / predict / likelihood / backward:
 // careless/models/scaling/nn.py:92-120, image.py:53-63, models/merging/variational.py:156-181, 197-202,
@@ -296,15 +296,20 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         // address and nothing is done with the values here: a select or a merge under a divergent branch would make this lone wave
         // wait for each gather in turn.
         float aim_raw = 1.0f, zf0;
-        float zfv[SPRE];                     // samples 1 .. SPRE-1 of this lane's reflection (a lone wave cannot afford a gather per sample)
         int rme = 0, gm = 0;                 // PACKED: the caller's row of this lane's packed row; (member index | group size << 8)
         long long nkey = 0;                  // PACKED: noise key of this lane's row
         {
             const unsigned zb = 4u * (unsigned)max(rid, 0) * (unsigned)A.S;
             if (A.use_img) aim_raw = ld_uo(A.img, 4u * (unsigned)max(img - 1, 0));
             zf0 = ld_uo(A.z_f, zb);
+            // samples 1 .. SPRE-1 of this lane's reflection go straight to LDS (global_load_lds: no registers in between; a lone
+            // wave cannot afford a gather per sample inside the sample loop)
+            if (A.S > 1) {
 #pragma unroll
-            for (int j = 1; j < SPRE; ++j) zfv[j] = ld_uo(A.z_f, zb + 4u * (unsigned)min(j, A.S - 1));
+                for (int j = 1; j < SPRE; ++j)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(A.z_f) + (zb + 4u * (unsigned)min(j, A.S - 1)),
+                                                     (__attribute__((address_space(3))) void*)(sS + j * 64), 4, 0, 0);
+            }
             if (PACKED) {
                 const unsigned pb = 4u * (unsigned)(wt * WT + lane);
                 rme = ld_uo(A.row_map, pb);
@@ -409,12 +414,8 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             const float dof = A.dof, lik_const = A.lik_const, shift = A.shift;
             float esin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             const bool act = rid >= 0;
-            // The amplitudes gathered at the start of the tile wait in LDS: inside the loop every wait on a global load would also
-            // wait for the previous sample's atomics (one in-order counter), a few microseconds each for a lone wave.
-            if (S > 1) {
-#pragma unroll
-                for (int j = 1; j < SPRE; ++j) sS[j * 64 + lane] = zfv[j];
-            }
+            // (The amplitudes gathered at the start of the tile wait in LDS: inside the loop every wait on a global load would also
+            //  wait for the previous sample's atomics -- one in-order counter --, a few microseconds each for a lone wave.)
             // one MC sample of this lane's observation, given its noise and its sampled amplitude (all lanes take part in the Laue shuffles)
             auto sample = [&](int s, float eta, float zf) {
                 const float tq = o0 + sigma * eta + shift;
@@ -727,14 +728,14 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #endif
 
 #ifndef CL_LANE_SMAX
-#define CL_LANE_SMAX 3
+#define CL_LANE_SMAX 8
 #endif
 
 // 1 = this geometry runs on the lane-per-observation kernel (full ELBO step of a scaler of exactly NL layers -- the default depth --;
 // plain observation layout, or the packed one of single-pass Laue).
-// More than three MC samples go to elbo_narrow.hip: the sampling epilogue is a serial dependent chain per sample, which one wave per
-// SIMD cannot hide (4 M observations, 20 x 10, Student-T, ms per step here / there: S = 1 0.97 / 1.11, 2: 1.03 / 1.12, 3: 1.13 / 1.18,
-// 4: 1.25 / 1.19, 8: 1.93 / 1.34; scripts/narrow_samples.py).
+// More than eight MC samples go to elbo_narrow.hip (the amplitudes and amplitude gradients of up to SPRE = 8 samples pass through
+// LDS).  4 M observations, 20 x 10, Student-T, ms per step here / there (scripts/narrow_samples.py): S = 1 0.96 / 1.11, 2: 1.01 / 1.12,
+// 4: 1.07 / 1.19, 8: 1.16 / 1.34.
 int cl_lane_supports(const cl_mlp_args& a) {
     return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= DMAX && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
            a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);
