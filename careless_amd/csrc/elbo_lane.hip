@@ -45,7 +45,10 @@ constexpr int NL = CL_MLP_LMAX_W16;   // Dense layers one launch holds
 constexpr int NWV = 4;                // waves of a workgroup (one per SIMD)
 constexpr int NT = 64 * NWV;
 constexpr int WT = 64;                // observations of a wave tile
-constexpr int PIT = 68;               // row pitch of a staging tile [16 features][64 observations]
+#ifndef CL_LANE_PIT
+#define CL_LANE_PIT 68
+#endif
+constexpr int PIT = CL_LANE_PIT;               // row pitch of a staging tile [16 features][64 observations]
 #ifndef CL_LANE_DMAX
 #define CL_LANE_DMAX 8
 #endif
