@@ -273,9 +273,9 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     F = flops_per_obs(spec["d"], spec["w"], spec["L"], spec.get("image_layers", 0))
     B = bytes_per_obs(spec["d"], spec["S"])
     # widths <= 15 with metadata <= 15 columns run on the narrow kernels: lane-per-observation (careless_amd/csrc/elbo_lane.hip:
-    # 20 layers, width <= 10, <= 8 metadata columns, <= 8 MC samples) or elbo_narrow.hip; the routing is cl_launch_mlp's (csrc/elbo_mlp.hip), restated here for the label
+    # 20 layers, width <= 10, <= 8 MC samples) or elbo_narrow.hip; the routing is cl_launch_mlp's (csrc/elbo_mlp.hip), restated here for the label
     narrow = spec["w"] <= 15 and spec["d"] <= 15 and not spec.get("image_layers") and (spec.get("kind", "mono") != "laue" or eng.obs.fused_laue)
-    lane = narrow and spec["L"] == 20 and spec["w"] <= 10 and spec["d"] <= 8 and spec["S"] <= 8 and os.environ.get("CARELESS_HIP_LANE", "1") != "0"
+    lane = narrow and spec["L"] == 20 and spec["w"] <= 10 and spec["S"] <= 8 and os.environ.get("CARELESS_HIP_LANE", "1") != "0"
     kernel_name = "elbo_lane_kernel" if lane else ("elbo_narrow_kernel" if narrow else "elbo_mlp_kernel")
     achieved = F * eng.N / (kern_ms * 1e-3) / 1e12
     achieved_step = F * eng.N / (ms * 1e-3) / 1e12         # SURVEY 8d defines `achieved` on the whole step time

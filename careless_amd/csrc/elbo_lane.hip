@@ -1,6 +1,6 @@
 // Lane-per-observation instance of the fused ELBO step for narrow scalers (gfx950 / CDNA4 only): hidden width <= 10, metadata
-// width <= 8, exactly 20 Dense layers, <= 8 MC samples -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width
-// = metadata width or 10, --mc-samples 1); other depths, widths 11-15, more than 8 metadata columns or samples run on elbo_narrow.hip.
+// width <= 15, exactly 20 Dense layers, <= 8 MC samples -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width
+// = metadata width or 10, --mc-samples 1); other depths, widths 11-15 or more than 8 samples run on elbo_narrow.hip.
 //
 // Same arithmetic and the same reference lines as elbo_mlp.hip (scaler forward / sample / predict / likelihood / backward:
 // careless/models/scaling/nn.py:92-120, image.py:53-63, models/merging/variational.py:156-181, 197-202,
@@ -49,11 +49,7 @@ constexpr int WT = 64;                // observations of a wave tile
 #define CL_LANE_PIT 68
 #endif
 constexpr int PIT = CL_LANE_PIT;               // row pitch of a staging tile [16 features][64 observations]
-#ifndef CL_LANE_DMAX
-#define CL_LANE_DMAX 8
-#endif
-constexpr int DMAX = CL_LANE_DMAX;    // metadata columns (more: elbo_narrow.hip; every column is a register of the lane here)
-constexpr int DGMAX = (DMAX + 3) / 4;
+constexpr int DMAX_ALL = 15;          // metadata columns (block 15 of a weight register is the bias); every column is a register of the lane
 constexpr int SPRE = 8;               // MC samples whose amplitudes are gathered at the start of the tile
 constexpr int ONE = 15;               // block of a weight register (= row of a staging tile) that belongs to the constant-one feature
 
@@ -136,10 +132,12 @@ struct LSmem {
 // untaken branch in full (a generic-depth instance of this kernel lost to elbo_narrow.hip at every depth below NL: 12 x 10 at 4 M
 // observations 1.27 against 0.80 ms per step) -- and a backward pass whose LDS traffic rides in the shadow of the previous layer's
 // weight-gradient MFMAs.
-template <int W, bool PACKED>
+// DMAX: metadata columns the instance holds (8 or 15: the registers of seven more columns cost the common narrow case 8 %).
+template <int W, int DMAX, bool PACKED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void elbo_lane_kernel(const cl_mlp_args A) {
     using SM = LSmem<W>;
+    constexpr int DGMAX = (DMAX + 3) / 4;
     constexpr int NC = SM::NC;
     constexpr int IMG = SM::IMG;
     // LeakyReLU derivative: compares into scalar-register pairs in groups of SELG, then the group's selects (equal groups of at
@@ -708,12 +706,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     }
 }
 
-template <int W, bool PACKED>
+template <int W, int DMAX, bool PACKED>
 static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SM = LSmem<W>;
     const size_t sm = (size_t)SM::total * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_lane_kernel<W, PACKED>;
+    auto kern = elbo_lane_kernel<W, DMAX, PACKED>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -740,17 +738,19 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 // LDS).  4 M observations, 20 x 10, Student-T, ms per step here / there (scripts/narrow_samples.py): S = 1 0.96 / 1.11, 2: 1.01 / 1.12,
 // 4: 1.07 / 1.19, 8: 1.16 / 1.34.
 int cl_lane_supports(const cl_mlp_args& a) {
-    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= DMAX && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
+    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= DMAX_ALL && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
            a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);
 }
 
 template <bool PACKED>
 static int launch_lane_w(const cl_mlp_args& a, int grid, hipStream_t st) {
     // the instance whose compile-time width is the smallest one that holds the scaler (zero-padded features cost MFMA steps)
-    if (a.w <= 4) return launch_lane_one<4, PACKED>(a, grid, st);
-    if (a.w <= 6) return launch_lane_one<6, PACKED>(a, grid, st);
-    if (a.w <= 8) return launch_lane_one<8, PACKED>(a, grid, st);
-    return launch_lane_one<10, PACKED>(a, grid, st);
+#define CL_LANE_CASE(WW) (a.d <= 8 ? launch_lane_one<WW, 8, PACKED>(a, grid, st) : launch_lane_one<WW, DMAX_ALL, PACKED>(a, grid, st))
+    if (a.w <= 4) return CL_LANE_CASE(4);
+    if (a.w <= 6) return CL_LANE_CASE(6);
+    if (a.w <= 8) return CL_LANE_CASE(8);
+    return CL_LANE_CASE(10);
+#undef CL_LANE_CASE
 }
 
 int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {

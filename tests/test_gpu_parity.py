@@ -40,16 +40,17 @@ CASES = {
     "narrow_three_observations": dict(N=3, R=2, d0=5, L=3, w=10, S=2, n_images=1, use_image_scales=False, perturb=0.03),
     "narrow_one_layer_w15_d15_softplus": dict(N=333, R=30, d0=15, L=1, w=15, S=2, bijector="softplus", shift=0.5, perturb=0.03),
     "narrow_20x4_d12": dict(N=600, R=40, d0=12, L=20, w=4, S=1, perturb=0.03, grid=2),
-    # the lane-per-observation kernel (csrc/elbo_lane.hip: 20 layers, width <= 10, <= 8 metadata columns, <= 8 MC samples; compile-time widths
-    # 4 / 6 / 8 / 10) beyond the CLI-default cases above; other depths of the same widths run on the narrow kernel
+    # the lane-per-observation kernel (csrc/elbo_lane.hip: 20 layers, width <= 10, <= 15 metadata columns, <= 8 MC samples; compile-time widths
+    # 4 / 6 / 8 / 10 x metadata capacities 8 / 15) beyond the CLI-default cases above; other depths of the same widths run on the narrow kernel
     "lane_ev11_studentt_20x10_S2": dict(N=700, R=50, d0=5, L=20, w=10, S=2, ev11=True, likelihood="studentt", dof=6.0, perturb=0.02),
     "lane_rows_in_arbitrary_order_20x7_S1": dict(N=900, R=60, d0=5, L=20, w=7, S=1, n_images=9, shuffle_rows=True, perturb=0.02),
-    "lane_softplus_shift_20x5_d8_S3": dict(N=400, R=30, d0=8, L=20, w=5, S=3, bijector="softplus", shift=1.5, perturb=0.02),
+    "lane_softplus_shift_20x5_d9_S3": dict(N=400, R=30, d0=9, L=20, w=5, S=3, bijector="softplus", shift=1.5, perturb=0.02),
     "lane_studentt_20x10_S8": dict(N=700, R=50, d0=5, L=20, w=10, S=8, likelihood="studentt", dof=6.0, perturb=0.02, grid=2),
     "lane_normal_20x10_S5_noimg": dict(N=500, R=40, d0=7, L=20, w=10, S=5, use_image_scales=False, perturb=0.02),
     "lane_laue_single_pass_20x10_S7": dict(N=900, R=40, L=20, w=10, S=7, laue=True, perturb=0.02, grid=2),
     "lane_klweight_20x3_S2_noimg": dict(N=500, R=40, d0=5, L=20, w=3, S=2, kl_weight=0.5, use_image_scales=False, perturb=0.02),
-    "lane_20x8_d8_S1_studentt": dict(N=700, R=40, d0=8, L=20, w=8, S=1, likelihood="studentt", dof=5.0, perturb=0.02, grid=2),
+    "lane_20x10_d12_S2": dict(N=600, R=40, d0=12, L=20, w=10, S=2, perturb=0.02),
+    "lane_20x8_d15_S1_studentt": dict(N=700, R=40, d0=15, L=20, w=8, S=1, likelihood="studentt", dof=5.0, perturb=0.02, grid=2),
     "lane_20x6_S2": dict(N=1300, R=60, d0=6, L=20, w=6, S=2, perturb=0.02, grid=2),
     "lane_20x9_d1_three_observations": dict(N=3, R=2, d0=1, L=20, w=9, S=1, n_images=1, use_image_scales=False, perturb=0.02),
     "lane_laue_single_pass_20x10_S2": dict(N=900, R=40, L=20, w=10, S=2, laue=True, perturb=0.02, grid=2),
