@@ -18,7 +18,8 @@
 //   * activations never visit LDS on the forward pass; LeakyReLU, its derivative, the sampling epilogue are plain per-lane code;
 //   * the weight gradient contracts over observations, i.e. over lanes: dZ_l and the layer's input are staged [feature][observation]
 //     in LDS (conflict-free: a lane writes its own column) and read back as operands of 16 v_mfma_f32_16x16x4_f32 per layer;
-//     all accumulators (20 blocks of 16 x 16) stay in registers for the whole launch;
+//     all accumulators (two 16 x 16 blocks per layer, in accumulator registers) stay put for the whole launch; the LDS traffic of
+//     layer l - 1 rides in the shadow of layer l's weight-gradient MFMAs;
 //   * the Dense(2) head is one more 4-row chunk (its outputs are the lane's loc and raw sigma); its weight gradient is 2 (w + 1)
 //     per-lane sums, reduced across lanes once at the end of the launch;
 //   * ONE wave per SIMD with the whole 512-register file: 20 layers x w activations per observation stay in registers.
