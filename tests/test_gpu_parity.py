@@ -289,6 +289,28 @@ def test_philox_mode_on_the_narrow_kernel_with_twelve_samples():
     assert max(errs) < RTOL_GRAD, errs
 
 
+@pytest.mark.parametrize("S,w,d0", [(8, 10, 5), (5, 6, 12), (1, 10, 5)], ids=["S8_20x10", "S5_20x6_d12", "S1_20x10"])
+def test_philox_mode_on_the_lane_kernel(S, w, d0):
+    """The lane-per-observation kernel (20 layers) with in-kernel noise: every lane walks its observation's samples serially, samples
+    s and s + 4 share a Box-Muller pair, the amplitudes of samples 1 .. 7 arrive through LDS and the amplitude gradients leave
+    through it (csrc/elbo_lane.hip); 191 observations = two full wave tiles and a ragged third."""
+    from careless_amd.engine import debug_noise
+    kw = dict(N=191, R=40, d0=d0, L=20, w=w, S=S, perturb=0.02)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    model = util.build_model(data, cfg, params, 20, w)
+    model.seed = 7
+    model(util.reference_inputs(data))
+    eng = model._engine
+    torch.cuda.synchronize()
+    u = debug_noise(7, 0, S, 40, 0, kind=0).t().cpu().numpy()
+    e = debug_noise(7, 0, S, 191, 0, kind=1).t().cpu().numpy()
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(out["loss"])) <= 1e-4 * abs(float(out["loss"]))
+    errs = [util.rel_err(a.cpu().numpy(), b.numpy()) for a, b in zip(eng.grad_tensors(), grads)]
+    assert max(errs) < RTOL_GRAD, errs
+
+
 def test_image_layers_philox_noise_is_keyed_by_the_callers_rows():
     """--image-layers packs the observations by image inside the engine; the in-kernel noise must still be keyed by the caller's
     row index (rows arrive in arbitrary image order here), so the dumped stream replayed through the oracle gives the same loss."""
