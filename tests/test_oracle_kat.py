@@ -192,6 +192,35 @@ def test_adam_first_step_and_clipping():
     assert torch.allclose(c[0], T([0.5, 0.5])) and torch.allclose(c[1], T([0.3]))
 
 
+def test_adam_trajectory_vs_an_independent_implementation():
+    """Thirty steps of the oracle's tf_keras Adam against torch.optim.Adam, an implementation the oracle shares no code with.  The
+    two differ only in where epsilon enters (Keras: sqrt(v) + eps under the bias-corrected step size; torch: sqrt(v / (1 - b2^t)) + eps),
+    i.e. torch with eps / sqrt(1 - b2^t) per step IS the Keras update: checked exactly that way, and with the plain eps to the
+    accuracy the eps placement allows."""
+    cfg = O.ElboConfig()
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(40, generator=g, dtype=torch.float64)
+    grads = [torch.randn(40, generator=g, dtype=torch.float64) * (1.0 + 0.1 * i) for i in range(30)]
+    p = [p0.clone()]
+    st = O.AdamState.zeros_like(p)
+    q = torch.nn.Parameter(p0.clone())
+    q2 = torch.nn.Parameter(p0.clone())
+    opt2 = torch.optim.Adam([q2], lr=cfg.learning_rate, betas=(cfg.beta_1, cfg.beta_2), eps=cfg.adam_epsilon)
+    for t, gr in enumerate(grads, start=1):
+        O.adam_apply(p, [gr], st, cfg)
+        # torch, with the epsilon that makes its formula the Keras one at this step
+        opt = torch.optim.Adam([q], lr=cfg.learning_rate, betas=(cfg.beta_1, cfg.beta_2), eps=cfg.adam_epsilon / math.sqrt(1.0 - cfg.beta_2 ** t))
+        if t > 1:
+            opt.load_state_dict({"state": state, "param_groups": opt.state_dict()["param_groups"]})
+        q.grad = gr.clone()
+        opt.step()
+        state = opt.state_dict()["state"]
+        q2.grad = gr.clone()
+        opt2.step()
+        assert torch.allclose(p[0], q.detach(), rtol=0, atol=1e-13), t
+    assert torch.allclose(p[0], q2.detach(), rtol=0, atol=1e-5)          # (an element with |g| ~ 1e-3 feels the epsilon placement at 1e-6 per step)
+
+
 def test_loss_reductions_sum_vs_kl_weight():
     """variational.py:172-177: default = sums / S; with kl_weight = means and weighted KL"""
     from tests import util
