@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP ELBO engine (through the C-ABI) against the fp64 CPU oracle on identical inputs and
 identical injected Monte-Carlo noise.  Tolerance per BASELINE.json north_star: index gathers bit-exact, ELBO and
 gradients within 1e-4 relative (fp32 engine vs fp64 oracle)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -176,6 +178,56 @@ def test_loss_and_gradients_match_oracle(name):
     assert abs(terms["loss"] - float(out["loss"])) <= RTOL_LOSS * abs(float(out["loss"]))
     assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
     assert len(g_hip) == len(grads)
+    _assert_grads(g_hip, grads, prob)
+
+
+def _random_lane_cases(n=14, seed=2024):
+    """Seeded random draws from the lane-per-observation kernel's support (20 layers, width <= 10, <= 15 metadata columns, <= 8 MC
+    samples; csrc/elbo_lane.hip): ragged observation counts, one or several tiles per workgroup, every likelihood / bijector /
+    loss-reduction switch, mono and single-pass Laue."""
+    rng = np.random.default_rng(seed)
+    cases = {}
+    for i in range(n):
+        laue = bool(i % 5 == 4)
+        w = int(rng.integers(1, 11)); S = int(rng.integers(1, 9))
+        kw = dict(N=int(rng.integers(3, 1400)), R=int(rng.integers(2, 70)), L=20, w=w, S=S, perturb=0.02)
+        if laue:
+            kw["laue"] = True
+            kw["N"] = max(kw["N"], 100)
+        else:
+            kw["d0"] = int(rng.integers(1, 16))
+            if rng.random() < 0.3:
+                kw["shuffle_rows"] = True
+                kw["n_images"] = int(rng.integers(1, 12))
+        if rng.random() < 0.5:
+            kw.update(likelihood="studentt", dof=float(rng.choice([3.0, 8.0, 32.0])))
+        if rng.random() < 0.3:
+            kw["ev11"] = True
+        if rng.random() < 0.3:
+            kw.update(bijector="softplus", shift=float(rng.choice([0.0, 1.5])))
+        if rng.random() < 0.25:
+            kw["kl_weight"] = 0.5
+        if rng.random() < 0.3:
+            kw["use_image_scales"] = False
+        if rng.random() < 0.5:
+            kw["grid"] = int(rng.integers(1, 4))
+        kw["R"] = min(kw["R"], kw["N"])
+        if kw.get("n_images") == 1:
+            kw["use_image_scales"] = False        # (one image: no image-scale parameter; the engine then has no such tensor)
+        cases[f"lane_random_{i:02d}_20x{w}_S{S}" + ("_laue" if laue else f"_d{kw['d0']}")] = kw
+    return cases
+
+
+# (a longer sweep on demand: LANE_RANDOM_N=200 LANE_RANDOM_SEED=7 python -m pytest tests/test_gpu_parity.py -k random_shapes)
+RANDOM_LANE_CASES = _random_lane_cases(int(os.environ.get("LANE_RANDOM_N", "14")), int(os.environ.get("LANE_RANDOM_SEED", "2024")))
+
+
+@pytest.mark.parametrize("name", list(RANDOM_LANE_CASES))
+def test_random_shapes_on_the_lane_kernel(name):
+    out, grads, ipred, terms, g_hip, eng, prob = _run_case(RANDOM_LANE_CASES[name])
+    assert abs(terms["nll"] - float(out["nll"])) <= RTOL_LOSS * abs(float(out["nll"])), (terms, float(out["nll"]))
+    assert abs(terms["kl"] - float(out["kl"])) <= RTOL_LOSS * max(abs(float(out["kl"])), 1.0), (terms, float(out["kl"]))
+    assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
     _assert_grads(g_hip, grads, prob)
 
 
