@@ -231,6 +231,83 @@ def test_random_shapes_on_the_lane_kernel(name):
     _assert_grads(g_hip, grads, prob)
 
 
+def _random_engine_cases(n=12, seed=11):
+    """Seeded random draws over everything the engine routes: widths 1 .. 100 (lane / narrow / 32- and 64-wide fused instances,
+    chains of launches for deep scalers, library GEMMs beyond width 64), depths 1 .. 24, 1 .. 40 metadata columns, 1 .. 12 MC samples,
+    mono / Laue / double-Wilson / per-image layers, every likelihood, bijector and reduction switch."""
+    rng = np.random.default_rng(seed)
+    cases = {}
+    for i in range(n):
+        kind = ["mono", "mono", "mono", "laue", "double_wilson", "image_layers"][int(rng.integers(0, 6))]
+        w = int(rng.choice([rng.integers(1, 16), rng.integers(16, 33), rng.integers(33, 65), rng.integers(65, 101)], p=[0.4, 0.25, 0.25, 0.1]))
+        L = int(rng.choice([rng.integers(1, 6), rng.integers(6, 21), rng.integers(21, 25)], p=[0.5, 0.4, 0.1]))
+        S = int(rng.integers(1, 13))
+        kw = dict(N=int(rng.integers(3, 1200)), R=int(rng.integers(2, 70)), L=L, w=w, S=S, perturb=0.02 if L > 8 else 0.05)
+        if kind == "laue":
+            kw["laue"] = True
+            kw["N"] = max(kw["N"], 100)
+            if rng.random() < 0.3:
+                kw["two_pass"] = True
+        else:
+            kw["d0"] = int(rng.integers(1, 41)) if rng.random() < 0.7 else 5
+            if kind == "mono" and rng.random() < 0.2:
+                kw["posenc"] = True
+                kw["d0"] = 5
+        if kind == "double_wilson":
+            kw["double_wilson"] = True
+            kw["R"] = max(kw["R"], 8)
+            if rng.random() < 0.4:
+                kw["optimize_dw_r"] = True
+        if kind == "image_layers":
+            kw["image_layers"] = int(rng.integers(1, 3))
+            kw["n_images"] = int(rng.integers(2, 8))
+            kw["w"] = min(kw["w"], 64)
+            kw["L"] = min(kw["L"], 10)
+            kw["N"] = max(kw["N"], 50)
+        elif rng.random() < 0.3 and kind == "mono":
+            kw["shuffle_rows"] = True
+            kw["n_images"] = int(rng.integers(2, 12))
+        if rng.random() < 0.5:
+            kw.update(likelihood="studentt", dof=float(rng.choice([3.0, 8.0, 32.0])))
+        if rng.random() < 0.25 and kind != "double_wilson":
+            kw["ev11"] = True
+        if rng.random() < 0.3:
+            kw.update(bijector="softplus", shift=float(rng.choice([0.0, 1.5])))
+        if rng.random() < 0.25:
+            kw["kl_weight"] = 0.5
+        if rng.random() < 0.25 and kind != "image_layers":
+            kw["use_image_scales"] = False
+        if rng.random() < 0.4:
+            kw["grid"] = int(rng.integers(1, 4))
+        kw["R"] = min(kw["R"], kw["N"])
+        one_launch = 20 if kw["w"] <= 15 else (10 if kw["w"] <= 32 else 5)         # layers one fused launch holds at this width
+        if kind == "image_layers":
+            # Dense + per-image layers must fit one launch (deeper ones raise NotImplementedError: DESIGN.md 4.7)
+            kw["L"] = max(1, min(kw["L"], (16 if kw["w"] <= 15 else one_launch) - kw["image_layers"]))
+        if kind == "laue" and kw["w"] <= 64:
+            kw["L"] = min(kw["L"], one_launch)     # (chained scalers take the two-pass Laue path; _run_case asserts the single pass)
+        if kind == "double_wilson":
+            kw["R"] += kw["R"] % 2                 # two half-datasets of R / 2 reflections
+            kw["N"] = max(kw["N"], kw["R"])
+        if kw.get("n_images") == 1:
+            kw["use_image_scales"] = False
+        cases[f"random_{i:02d}_{kind}_{kw['L']}x{kw['w']}_S{S}"] = kw
+    return cases
+
+
+# (a longer sweep on demand: ENGINE_RANDOM_N=150 ENGINE_RANDOM_SEED=3 python -m pytest tests/test_gpu_parity.py -k random_engine)
+RANDOM_ENGINE_CASES = _random_engine_cases(int(os.environ.get("ENGINE_RANDOM_N", "12")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")))
+
+
+@pytest.mark.parametrize("name", list(RANDOM_ENGINE_CASES))
+def test_random_engine_configurations(name):
+    out, grads, ipred, terms, g_hip, eng, prob = _run_case(RANDOM_ENGINE_CASES[name])
+    assert abs(terms["nll"] - float(out["nll"])) <= RTOL_LOSS * abs(float(out["nll"])), (terms, float(out["nll"]))
+    assert abs(terms["kl"] - float(out["kl"])) <= RTOL_LOSS * max(abs(float(out["kl"])), 1.0), (terms, float(out["kl"]))
+    assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
+    _assert_grads(g_hip, grads, prob)
+
+
 def test_refl_gather_is_bit_exact():
     """ipred = z_scale * z_f[refl_id]^2: with loc=1, sigma~0 and no image scales, ipred/1 must equal z_f[refl_id]^2 exactly."""
     kw = dict(N=300, R=40, d0=5, L=2, w=32, S=2, use_image_scales=False, perturb=0.0)
