@@ -221,8 +221,9 @@ def chain_plan(d: int, w: int, L: int, max_layers: int) -> List[LayerBlock]:
 
 def pack_laue(harmonic_id: np.ndarray, image_id: np.ndarray, by_image: bool):
     """Packed order of the single-pass Laue kernel: the rows of a harmonic group are consecutive and inside one 16-row granule.
-    Groups are padded to the next power of two and laid out class by class (all groups of padded size p of an image are
-    contiguous, p rows apart), classes aligned to granules, images aligned to tiles when `by_image` (per-image layers).
+    Groups are laid out class by class (all groups of s rows of an image are contiguous: floor(16 / s) of them per granule, s rows
+    apart, the rest of the granule padding -- triplets fill 15 of 16 rows, where padding them to four rows would fill 12), classes
+    aligned to granules, images aligned to tiles when `by_image` (per-image layers).
     Returns (pos, n_pad, gmeta, tile_gmax, row_map, tile_img) or None when a group has more than 16 rows."""
     hid = np.asarray(harmonic_id).astype(np.int64)
     img = np.asarray(image_id).astype(np.int64)
@@ -233,16 +234,15 @@ def pack_laue(harmonic_id: np.ndarray, image_id: np.ndarray, by_image: bool):
         return None
     member = np.arange(n) - np.repeat(first, size)                       # member index of every sorted row
     gimg = img[order][first] if by_image else np.zeros(len(gid), dtype=np.int64)
-    cls = np.ones(len(gid), dtype=np.int64)
-    for p in (2, 4, 8, 16):
-        cls[size > p // 2] = p
+    cls = size.astype(np.int64)                                          # class = exact group size
+    per = GRANULE // cls                                                 # groups of that class per granule
     # regions = (image, class) pairs in sorted order; groups ranked inside their region
     key = gimg * 32 + cls
     gorder = np.argsort(key, kind="stable")
     rkey, rfirst, rcount = np.unique(key[gorder], return_index=True, return_counts=True)
     rcls = rkey % 32
     rimg = rkey // 32
-    rrows = -(-(rcount * rcls) // GRANULE) * GRANULE                     # rows of a region, aligned to granules
+    rrows = -(-rcount // (GRANULE // rcls)) * GRANULE                    # rows of a region: whole granules
     # image blocks aligned to tiles when the tiles must be single-image
     if by_image:
         ids, ifirst = np.unique(rimg, return_index=True)
@@ -261,7 +261,7 @@ def pack_laue(harmonic_id: np.ndarray, image_id: np.ndarray, by_image: bool):
     grank[gorder] = np.arange(len(gid)) - np.repeat(rfirst, rcount)
     gregion = np.empty(len(gid), dtype=np.int64)
     gregion[gorder] = np.repeat(np.arange(len(rkey)), rcount)
-    gstart = rbase[gregion] + grank * cls                                # packed position of member 0
+    gstart = rbase[gregion] + (grank // per) * GRANULE + (grank % per) * cls      # packed position of member 0
     pos = np.empty(n, dtype=np.int64)
     pos[order] = np.repeat(gstart, size) + member
     gmeta = np.zeros(n_pad, dtype=np.int32)
