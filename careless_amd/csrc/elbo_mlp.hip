@@ -75,6 +75,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CL_FAST_SG
 #define CL_FAST_SG 0     /* 1: hardware rcp / log for 1/sigma, log sigma in the epilogue (measured: no gain on the 64-wide instances) */
 #endif
+#ifndef CL_ASM_STAGE
+#define CL_ASM_STAGE 1     /* staging writes of the dgrad phase as single ds_write_b32 with immediate offsets (inline assembly): +0.4 % on the bench line */
+#endif
 #ifndef CL_VOL_STAGE
 #define CL_VOL_STAGE 0
 #endif
@@ -1013,8 +1016,14 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                                     // (CL_VOL_STAGE: volatile stores are not merged into ds_write2_b32, whose 8-bit offsets cost a
                                     // v_add_u32 of the base per pair -- a vector instruction beside the MFMAs -- where single
                                     // ds_write_b32 take the whole offset as an immediate)
+#if CL_ASM_STAGE
+                                    // single ds_write_b32 with the whole offset as an immediate (no ds_write2 merge, no re-basing add)
+                                    if (e < 4 * FB) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"((unsigned)(size_t)stz), "v"(dH[(e / 4) % FB][e % 4]), "n"(4 * (16 * (e / 4) + (e % 4)) * PB) : "memory");
+                                    else asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"((unsigned)(size_t)sth), "v"(hs[l > 0 ? l - 1 : 0][((e - 4 * FB) / 4) % FB][e % 4]), "n"(4 * (16 * ((e - 4 * FB) / 4) + (e % 4)) * PB) : "memory");
+#else
                                     if (e < 4 * FB) *(CL_STAGE_Q float*)&stz[(16 * (e / 4) + (e % 4)) * PB] = dH[(e / 4) % FB][e % 4];
                                     else *(CL_STAGE_Q float*)&sth[(16 * ((e - 4 * FB) / 4) + (e % 4)) * PB] = hs[l > 0 ? l - 1 : 0][((e - 4 * FB) / 4) % FB][e % 4];
+#endif
                                 }
 #pragma unroll
                                 for (int k = 0; k < IPG; ++k) {
