@@ -46,6 +46,9 @@ def parse(argv=None):
                                                             "takes minutes and tens of GB of host memory)")
     ap.add_argument("--extra", default="auto", help="'auto': with 4 (8) ranks also time the Laue (double-Wilson) configuration "
                                                     "BASELINE.json quotes on 4 (8) GPUs and report it under 'extra_configs'; 'none'; or a workload name")
+    ap.add_argument("--extra-nobs", type=int, default=None, help="observations of the extra configuration (rehearsals on a small box)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="seconds after which the launcher (bare `bench.py --gpus N`) "
+                                                                         "terminates its ranks and exits non-zero")
     ap.add_argument("--sim-world", type=int, default=0, help="diagnostic: run rank 0's shard of a W-rank job on this one GPU "
                                                              "(per-rank step time of the strong-scaling runs; not a bench line)")
     return ap.parse_args(argv)
@@ -77,10 +80,13 @@ def launch(args, argv, script=None) -> int:
     reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout.readlines()), daemon=True)
     reader.start()
     failed = None
+    t_start = time.monotonic()
     while failed is None and any(p.poll() is None for p in procs):
         for r, p in enumerate(procs):
             if p.poll() not in (None, 0):
                 failed = (r, p.returncode)
+        if failed is None and time.monotonic() - t_start > args.launch_timeout:
+            failed = (-1, "timeout")             # ranks stuck (e.g. in mismatched collectives): never wait forever
         time.sleep(0.2)
     if failed is None:
         for r, p in enumerate(procs):
@@ -95,7 +101,8 @@ def launch(args, argv, script=None) -> int:
                 p.wait(timeout=20)
             except Exception:
                 p.kill()
-        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}", file=sys.stderr)
+        print(f"bench.py: rank {failed[0]} exited with code {failed[1]}" if failed[0] >= 0 else
+              f"bench.py: ranks still running after --launch-timeout {args.launch_timeout:.0f} s: terminated", file=sys.stderr)
         return 1
     reader.join(timeout=30)
     out = None
@@ -113,6 +120,9 @@ def launch(args, argv, script=None) -> int:
         print(f"bench.py: asked for {n} ranks, the job saw {out.get('ranks_seen')}", file=sys.stderr)
         return 1
     print(json.dumps(out), flush=True)
+    if out.get("extra_failed"):                  # the configuration BASELINE.json quotes at this GPU count did not get measured
+        print(f"bench.py: extra configuration not measured: {out['extra_failed']}", file=sys.stderr)
+        return 1
     return 0
 
 
@@ -202,12 +212,60 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     import torch.distributed as dist
     from careless_amd.workloads import bytes_per_obs, flops_per_obs, make_workload
 
-    model, inputs, data, spec = make_workload(name, N=nobs)
-    if args.sim_world > 1:
-        model.set_data_parallel(0, args.sim_world)
-    elif use_dist:
-        model.set_data_parallel(rank, world)
-    eng = model.engine(inputs)
+    class BuildFailed(RuntimeError):
+        pass
+
+    def agree(ok: bool, what: str):
+        """All ranks learn whether every rank got through a phase that has no collective of its own (host generation, engine build,
+        upload): a rank that failed there must not leave the others waiting in the next collective."""
+        if use_dist:
+            t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(t.item() > 0.5)
+        if not ok:
+            raise BuildFailed(what)
+
+    share_dir = None
+    if use_dist and world > 1:
+        # ONE copy of the synthetic problem per node: rank 0 generates it into /dev/shm, every rank maps it and uploads its own rows
+        share_dir = f"/dev/shm/careless_bench_{os.environ.get('MASTER_PORT', '0')}_{name}"
+    err = None
+    try:
+        if share_dir is not None and rank == 0:
+            import shutil
+            shutil.rmtree(share_dir, ignore_errors=True)       # (left-overs of a killed run)
+        gen_ok = {"ok": True}
+
+        def gen_barrier():          # rank 0 is back from the generator (or failed in it): everybody learns which
+            agree(gen_ok["ok"], f"{name}: rank 0 could not generate the problem")
+
+        try:
+            model, inputs, data, spec = make_workload(name, N=nobs, rank=rank, world=world, share_dir=share_dir,
+                                                      barrier=gen_barrier if share_dir else None)
+        except BuildFailed:
+            raise
+        except Exception as e:       # noqa: BLE001  (only rank 0 can fail before the barrier: it generates)
+            if share_dir is None or rank != 0:
+                raise
+            gen_ok["ok"] = False
+            err = e
+            gen_barrier()
+        if args.sim_world > 1:
+            model.set_data_parallel(0, args.sim_world)
+        elif use_dist:
+            model.set_data_parallel(rank, world)
+        eng = model.engine(inputs)
+    except BuildFailed:
+        raise
+    except Exception as e:           # noqa: BLE001
+        err = e
+    agree(err is None, f"{name}: engine build failed on a rank" + (f" (this rank: {err!r})" if err is not None else ""))
+    if share_dir is not None:                       # every rank has uploaded its shard: the files can go (the maps die with `data`)
+        dist.barrier()
+        if rank == 0:
+            import shutil
+            shutil.rmtree(share_dir, ignore_errors=True)
+    del inputs, data
     eng.force_allreduce = bool(args.force_dist)
     steps_total = warmup + steps
     eng.alloc_history(steps_total)
@@ -254,13 +312,15 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     t1 = time.perf_counter()
     eng.lib = real_lib
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
-    per_rank = torch.tensor([float(eng.N)], dtype=torch.float64, device="cuda")
-    obs_per_rank = [int(eng.N)]
+    import resource
+    per_rank = torch.tensor([float(eng.N), resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2.0 ** 20], dtype=torch.float64, device="cuda")
+    obs_per_rank, rss_per_rank = [int(eng.N)], [round(float(per_rank[1].item()), 2)]
     if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         gathered = [torch.zeros_like(per_rank) for _ in range(world)]
         dist.all_gather(gathered, per_rank)
-        obs_per_rank = [int(g.item()) for g in gathered]
+        obs_per_rank = [int(g[0].item()) for g in gathered]
+        rss_per_rank = [round(float(g[1].item()), 2) for g in gathered]
     elapsed = float(elapsed.item())
     kern_ms = float(np.sum([a.elapsed_time(b) for a, b in ev[:slot["i"]]])) / steps        # fused-kernel time per step
     launches_per_step = slot["i"] // steps
@@ -272,11 +332,8 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     ms = 1e3 * elapsed / steps
     F = flops_per_obs(spec["d"], spec["w"], spec["L"], spec.get("image_layers", 0))
     B = bytes_per_obs(spec["d"], spec["S"])
-    # widths <= 15 with metadata <= 15 columns run on the narrow kernels: lane-per-observation (careless_amd/csrc/elbo_lane.hip:
-    # 20 layers, width <= 10, <= 8 MC samples) or elbo_narrow.hip; the routing is cl_launch_mlp's (csrc/elbo_mlp.hip), restated here for the label
-    narrow = spec["w"] <= 15 and spec["d"] <= 15 and not spec.get("image_layers") and (spec.get("kind", "mono") != "laue" or eng.obs.fused_laue)
-    lane = narrow and spec["L"] == 20 and spec["w"] <= 10 and spec["S"] <= 8 and os.environ.get("CARELESS_HIP_LANE", "1") != "0"
-    kernel_name = "elbo_lane_kernel" if lane else ("elbo_narrow_kernel" if narrow else "elbo_mlp_kernel")
+    # the label of the dominant kernel comes from the library's own routing (cl_mlp_kernel_name), not from a restatement of it
+    kernel_name = eng.kernel_name()
     achieved = F * eng.N / (kern_ms * 1e-3) / 1e12
     achieved_step = F * eng.N / (ms * 1e-3) / 1e12         # SURVEY 8d defines `achieved` on the whole step time
     return {
@@ -294,7 +351,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
                      "traffic": traffic_bytes(name, world), "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
                      "achieved_on_step_time": achieved_step, "frac_on_step_time": achieved_step / 157.3,
                      "hbm_secondary": {"achieved_GBps": B * eng.N / (kern_ms * 1e-3) / 1e9, "bytes_per_obs": B}},
-        "obs_per_rank": obs_per_rank,
+        "obs_per_rank": obs_per_rank, "host_peak_rss_gib_per_rank": rss_per_rank,
     }
 
 
@@ -329,12 +386,16 @@ def worker(args) -> int:
     extra_name = EXTRA_AT.get(world) if args.extra == "auto" else (None if args.extra == "none" else args.extra)
     if args.workload != HEADLINE or args.nobs is not None or args.sim_world > 1:
         extra_name = extra_name if args.extra not in ("auto", "none") else None
-    extras = {}
+    extras, extra_failed = {}, None
+    if rank == 0:
+        # backup of the headline numbers before anything else runs (stderr: stdout carries exactly ONE JSON line, at the end)
+        print("bench.py headline (backup): " + json.dumps({k: res[k] for k in ("value", "ms_per_step", "obs_per_rank")}), file=sys.stderr, flush=True)
     if extra_name:
-        # every rank builds the whole synthetic problem on the host before taking its shard: only with room for it
-        # (~250 B per observation and rank at the generator's peak); all ranks take the same decision
+        # ONE generator peak (~250 B per observation, rank 0) plus the shared copy and the ranks' shard conversions: every rank takes
+        # the same decision
         from careless_amd.workloads import WORKLOADS
-        need = 250.0 * WORKLOADS[extra_name]["N"] * world
+        n_extra = args.extra_nobs or WORKLOADS[extra_name]["N"]
+        need = 400.0 * n_extra
         try:
             avail = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024.0
         except Exception:
@@ -343,17 +404,20 @@ def worker(args) -> int:
             t = torch.tensor([avail], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             avail = float(t.item())
-        if avail < 1.5 * need:
-            extras[extra_name] = {"skipped": f"host memory: {avail / 2**30:.0f} GiB available, {1.5 * need / 2**30:.0f} GiB wanted for {world} ranks"}
+        if avail < need:
+            extras[extra_name] = {"skipped": f"host memory: {avail / 2**30:.0f} GiB available, {need / 2**30:.0f} GiB wanted"}
+            extra_failed = f"{extra_name} skipped ({extras[extra_name]['skipped']})"
             extra_name = None
     if extra_name:
         try:                                    # never lose the headline line to the extra configuration
-            ex = run_workload(args, extra_name, None, min(args.steps, 10), min(args.warmup, 2), rank, world, use_dist)
+            ex = run_workload(args, extra_name, args.extra_nobs, min(args.steps, 10), min(args.warmup, 2), rank, world, use_dist)
             if ex is not None:
                 extras[extra_name] = {"value": ex["value"], "unit": "reflections/s", "n_gpus": world, "ms_per_step": ex["ms_per_step"],
-                                      "config": ex["config"], "roofline": ex["roofline"], "obs_per_rank": ex["obs_per_rank"]}
-        except Exception as e:                   # noqa: BLE001
+                                      "config": ex["config"], "roofline": ex["roofline"], "obs_per_rank": ex["obs_per_rank"],
+                                      "host_peak_rss_gib_per_rank": ex["host_peak_rss_gib_per_rank"]}
+        except Exception as e:                   # noqa: BLE001  (BuildFailed is raised on every rank alike: nobody waits in a collective)
             extras[extra_name] = {"error": repr(e)}
+            extra_failed = f"{extra_name} failed: {e!r}"
 
     out = None
     if rank == 0:
@@ -362,9 +426,12 @@ def worker(args) -> int:
                "n_gpus": world, "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None),
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": res["config"], "roofline": res["roofline"], "obs_per_rank": res["obs_per_rank"]}
+               "config": res["config"], "roofline": res["roofline"], "obs_per_rank": res["obs_per_rank"],
+               "host_peak_rss_gib_per_rank": res["host_peak_rss_gib_per_rank"]}
         if extras:
             out["extra_configs"] = extras
+        if extra_failed:
+            out["extra_failed"] = extra_failed
         if args.sim_world > 1:
             out["diagnostic"] = f"rank 0 shard of a simulated {args.sim_world}-rank job: value is NOT a throughput of this workload"
             out["value"] = None

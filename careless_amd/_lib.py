@@ -114,6 +114,7 @@ EXPORTS = {
     "cl_elbo_mono_fwd_bwd": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
     "cl_mlp_forward": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
     "cl_mlp_backward_ext": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
+    "cl_mlp_kernel_name": (C.c_int, [C.POINTER(MlpArgs), C.c_int, C.c_char_p, C.c_size_t]),
     "cl_laue_predict": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_laue_likelihood": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_laue_backward": (C.c_int, [C.POINTER(LaueArgs), _vp]),

@@ -19,7 +19,11 @@ UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=
          ("elbo_mlp.hip", "elbo_mlp_packed", ["-DCL_IMGL=2"]),
          ("elbo_mlp.hip", "elbo_mlp_chain", ["-DCL_CHAIN=1"]),
          ("elbo_narrow.hip", "elbo_narrow", ["-fno-slp-vectorize"]),     # (packed fp32 math costs more than it saves beside MFMAs)
-         ("elbo_lane.hip", "elbo_lane", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),   # (4x4x1 results feed vector code: no accumulator-register detour)
+         # (4x4x1 results feed vector code: no accumulator-register detour); four parts = four groups of instances, compiled in parallel
+         ("elbo_lane.hip", "elbo_lane0", ["-DCL_LANE_PART=0", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+         ("elbo_lane.hip", "elbo_lane1", ["-DCL_LANE_PART=1", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+         ("elbo_lane.hip", "elbo_lane2", ["-DCL_LANE_PART=2", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+         ("elbo_lane.hip", "elbo_lane3", ["-DCL_LANE_PART=3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", [])]
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["cl_math.h", "cl_kernels.h", os.path.join("..", "..", "include", "careless_hip.h")]

@@ -62,6 +62,17 @@ def _data_parallel():
     return rank, world
 
 
+def _leave_data_parallel(world: int) -> None:
+    """End of a one-process-per-GPU run: wait for rank 0's output step, then tear the process group down (RCCL otherwise warns --
+    or hangs -- at interpreter exit)."""
+    if world <= 1:
+        return
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def run_careless(parser):
     from careless_amd.io.formats import PREDICTION_TYPES, results_tables, write_history_csv, write_table_mtz
     from careless_amd.manager import DataManager
@@ -92,24 +103,24 @@ def run_careless(parser):
                                 validation_frequency=parser.validation_frequency, progress=progress)
 
     asus = list(rac)
-    if rank != 0:                                                   # parameters are identical on every rank: rank 0 writes the files
-        write_table_mtz = write_history_csv = lambda *a, **k: None
-    for i, table in enumerate(results_tables(dm.get_results(model.surrogate_posterior, inputs=train), rac)):
-        write_table_mtz(parser.output_base + f"_{i}.mtz", table, asus[i])
-    write_history_csv(parser.output_base + "_history.csv", history)
+    # The output step has no collective and the parameters are identical on every rank: rank 0 alone computes and writes it (the
+    # other ranks skip the result tables and the full-size prediction pass instead of computing them for no-op writers)
     if rank == 0:
+        for i, table in enumerate(results_tables(dm.get_results(model.surrogate_posterior, inputs=train), rac)):
+            write_table_mtz(parser.output_base + f"_{i}.mtz", table, asus[i])
+        write_history_csv(parser.output_base + "_history.csv", history)
         model.surrogate_posterior.save_weights(parser.output_base + "_structure_factor")
         model.scaling_model.save_weights(parser.output_base + "_scale")
-    if getattr(parser, "save_data_manager", False) and rank == 0:   # reference careless.py:81-84
-        import pickle
-        with open(parser.output_base + "_data_manager.pickle", "wb") as out:
-            pickle.dump(dm, out)
+        if getattr(parser, "save_data_manager", False):             # reference careless.py:81-84
+            import pickle
+            with open(parser.output_base + "_data_manager.pickle", "wb") as out:
+                pickle.dump(dm, out)
 
-    tables = _prediction_tables(dm, model, train, 0)
-    if test is not None:
-        tables = [{k: np.concatenate([a[k], b[k]]) for k in a} for a, b in zip(tables, _prediction_tables(dm, model, test, 1))]
-    for i, table in enumerate(tables):
-        write_table_mtz(parser.output_base + f"_predictions_{i}.mtz", table, asus[i], PREDICTION_TYPES)
+        tables = _prediction_tables(dm, model, train, 0)
+        if test is not None:
+            tables = [{k: np.concatenate([a[k], b[k]]) for k in a} for a, b in zip(tables, _prediction_tables(dm, model, test, 1))]
+        for i, table in enumerate(tables):
+            write_table_mtz(parser.output_base + f"_predictions_{i}.mtz", table, asus[i], PREDICTION_TYPES)
 
     if parser.merge_half_datasets:
         scaling_model = model.scaling_model
@@ -121,13 +132,16 @@ def run_careless(parser):
                 if world > 1:
                     m.set_data_parallel(rank, world)
                 m.train_model(half, parser.iterations, message=f"Merging repeat {repeat + 1} half {half_id + 1}", progress=progress)
+                if rank != 0:                                       # (the trainings are collective; the tables are rank 0's)
+                    continue
                 for file_id, t in enumerate(results_tables(dm.get_results(m.surrogate_posterior, inputs=half), rac)):
                     t["repeat"] = np.full(len(t["H"]), repeat)
                     t["half"] = np.full(len(t["H"]), half_id)
                     xval[file_id] = t if xval[file_id] is None else {k: np.concatenate([xval[file_id][k], t[k]]) for k in t}
-        for file_id, t in enumerate(xval):
+        for file_id, t in enumerate(xval if rank == 0 else []):
             types = {"H": "H", "K": "H", "L": "H", "F": "F", "SigF": "Q", "I": "J", "SigI": "Q", "N": "I", "repeat": "I", "half": "I"}
             write_table_mtz(parser.output_base + f"_xval_{file_id}.mtz", t, asus[file_id], types)
+    _leave_data_parallel(world)
     return model, history
 
 

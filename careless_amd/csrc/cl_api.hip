@@ -69,6 +69,11 @@ int cl_mlp_backward_ext(const cl_mlp_args* a, int grid, void* stream) {
     return cl_launch_mlp(*a, 2, grid, (hipStream_t)stream);
 }
 
+int cl_mlp_kernel_name(const cl_mlp_args* a, int mode, char* out, size_t n) {
+    if (a == nullptr || out == nullptr || n == 0 || mode < 0 || mode > 2) return -1;
+    return cl_mlp_kernel_name_of(*a, mode, out, n);
+}
+
 int cl_reduce_partials(const float* partials, int nparts, int P, float* grad_mlp, const int* stop_flag, void* stream) {
     if (partials == nullptr || grad_mlp == nullptr || nparts < 1 || P < 1) return -1;
     return cl_launch_reduce_partials(partials, nparts, P, grad_mlp, stop_flag, (hipStream_t)stream);

@@ -11,7 +11,10 @@ int cl_launch_mlp_packed(const cl_mlp_args& a, int mode, int grid, hipStream_t s
 int cl_launch_mlp_chain(const cl_mlp_args& a, int mode, int grid, hipStream_t st);  // elbo_mlp.hip compiled with -DCL_CHAIN=1
 int cl_narrow_supports(const cl_mlp_args& a);                                       // elbo_narrow.hip: width <= 15, metadata <= 15, plain layout
 int cl_launch_narrow(const cl_mlp_args& a, int grid, hipStream_t st);               // ... the full ELBO step on that kernel
-int cl_lane_supports(const cl_mlp_args& a);                                         // elbo_lane.hip: lane = observation; 20 layers, width <= 10, metadata <= 15, <= 8 MC samples
+int cl_lane_supports(const cl_mlp_args& a);                                         // elbo_lane.hip: lane = observation; 20 layers, width <= 10, metadata <= 31 columns
+int cl_lane_kernel_name(const cl_mlp_args& a, char* out, size_t n);
+int cl_narrow_kernel_name(const cl_mlp_args& a, char* out, size_t n);
+int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n);     // elbo_mlp.hip: the routing of cl_launch_mlp, as a name
 int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st);                 // ... the full ELBO step on that kernel
 int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st);
 int cl_launch_tn_forward(const cl_tn_args& a, hipStream_t st);

@@ -1,6 +1,7 @@
 // Lane-per-observation instance of the fused ELBO step for narrow scalers (gfx950 / CDNA4 only): hidden width <= 10, metadata
-// width <= 15, exactly 20 Dense layers, <= 8 MC samples -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width
-// = metadata width or 10, --mc-samples 1); other depths, widths 11-15 or more than 8 samples run on elbo_narrow.hip.
+// width <= 31, exactly 20 Dense layers, any number of MC samples -- the geometry of the careless CLI default (--mlp-layers 20,
+// --mlp-width 10, --mc-samples 1: careless/args/scaling.py:21-31), also with the 16 extra metadata columns of
+// --positional-encoding-keys X,Y (careless/utils/positional_encoding.py:3-17); other depths and widths 11-15 run on elbo_narrow.hip.
 //
 // Same arithmetic and the same reference lines as elbo_mlp.hip (scaler forward / sample / predict / likelihood / backward:
 // careless/models/scaling/nn.py:92-120, image.py:53-63, models/merging/variational.py:156-181, 197-202,
@@ -26,6 +27,7 @@
 // Roofline: fp32 MFMA; algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdio>
 #include <type_traits>
 #include "cl_math.h"
 #include "cl_kernels.h"
@@ -39,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CL_LANE_SCHED
 #define CL_LANE_SCHED 1
 #endif
+#ifndef CL_LANE_FAST_DIV
+#define CL_LANE_FAST_DIV 1      /* Student-T: 1/nu hoisted, the per-sample division as reciprocal + Newton step (a lone wave pays ~8 cycles per instruction of the two IEEE divisions) */
+#endif
 
 namespace {
 
@@ -50,8 +55,9 @@ constexpr int WT = 64;                // observations of a wave tile
 #define CL_LANE_PIT 68
 #endif
 constexpr int PIT = CL_LANE_PIT;               // row pitch of a staging tile [16 features][64 observations]
-constexpr int DMAX_ALL = 15;          // metadata columns (block 15 of a weight register is the bias); every column is a register of the lane
-constexpr int SPRE = 8;               // MC samples whose amplitudes are gathered at the start of the tile
+constexpr int DMAX_ALL = 15;          // metadata columns of the register instances (block 15 of a weight register is the bias): every column is a register of the lane
+constexpr int DMAX_LX = 31;           // ... of the LDS-row instances (DMAX = 0): two input blocks of layer 0, the ones row in block 0
+constexpr int SPRE = 8;               // MC samples of a batch: their amplitudes are gathered into LDS together, their amplitude gradients leave through it
 constexpr int ONE = 15;               // block of a weight register (= row of a staging tile) that belongs to the constant-one feature
 
 template <int K, int N, class F>
@@ -110,18 +116,41 @@ __device__ __forceinline__ T ld_uo(const T* base, unsigned byte_off) {       // 
 #define LSTAMP(k)
 #endif
 
-template <int W>
+// LX: the metadata of a wave tile do not pass through registers at all (16 .. 31 columns: with every column a register of the lane,
+// twice with the prefetch, the 512-register file is over).  The next tile's rows are copied global -> LDS by the DMA path
+// (global_load_lds: no registers in between) into the second of two row buffers while the backward pass of the current tile runs,
+// layer 0 reads its B operands row by row from the current buffer, and its weight gradient -- two 16-row input blocks, the ones
+// row of the bias in block 0 -- reads the same rows back transposed.  The staging tiles of dZ / H then come in ONE copy instead of
+// one per layer parity (a wave's LDS operations execute in order, so the second copy only ever bought scheduling freedom): that
+// is what pays for the row buffers.
+template <int W, bool LX>
 struct LSmem {
     static constexpr int NC = (W + 3) / 4;                    // 4-feature chunks of a layer's outputs
     static constexpr int IMG = NC * 64;                       // one layer's weight registers: [chunk][lane]
-    static constexpr int oF = 0;                              // forward images, layers 0 .. NL-1 and the head (NL)
-    static constexpr int oK = oF + (NL + 1) * IMG;            // transposed (dgrad) images, same numbering
-    static constexpr int oT = oK + (NL + 1) * IMG;            // per wave: sZ[2], sH[2] (by layer parity), sX   [16][PIT] each
-    static constexpr int TW = 5 * 16 * PIT + (SPRE + 1) * 64; // (+ sS: the lane's first SPRE sampled amplitudes / amplitude gradients; sQ)
-    static constexpr int main_total = oT + NWV * TW;
-    static constexpr int REG = NL * 256;                      // floats of one wave's parked accumulators (flush)
+    static constexpr int NF = NL + 1 + (LX ? 1 : 0);          // forward images: layers 0 .. NL-1, the head (NL), LX: layer 0's second input block (NL + 1)
+    static constexpr int TPAR = LX ? 1 : 2;                   // copies of the dZ / H staging tiles
+    static constexpr int oF = 0;
+    static constexpr int oK = oF + NF * IMG;                  // transposed (dgrad) images, layers 0 .. NL-1 and the head
+    static constexpr int oT = oK + (NL + 1) * IMG;            // per wave: sZ[TPAR], sH[TPAR] (by layer parity), sX (not LX)   [16][PIT] each
+    static constexpr int oS = (2 * TPAR + (LX ? 0 : 1)) * 16 * PIT;   // (within a wave's region) sS: the lane's SPRE sampled amplitudes / amplitude gradients; sQ
+    static constexpr int oX = oS + (SPRE + 1) * 64;           // LX: two buffers of `xrows` metadata rows [row][PIT]
+    static constexpr int TWF = oX;                            // floats of a wave's region without the row buffers
+    static constexpr int NACCB = NL + (LX ? 1 : 0);           // 16 x 16 accumulator blocks a wave parks in the flush
+    static constexpr int REG = NACCB * 256;
     static constexpr int flush_total = (NWV / 2) * REG + NWV * 2 * 16;
-    static constexpr int total = main_total > flush_total ? main_total : flush_total;
+    // rows of a metadata buffer: input k sits in row k (k < 15) or k + 1 (row 15 holds the ones of the bias), whole groups of four
+    // inputs are read by layer 0 (the rows past d stay zero)
+    static constexpr int xrows(int d) {
+        if (!LX) return 0;
+        int klast = ((d + 3) & ~3) - 1;                       // last input layer 0 reads (input 31 never is: d <= 31)
+        if (klast > 30) klast = 30;
+        const int r = (klast < 15 ? klast : klast + 1) + 1;
+        return r < 16 ? 16 : r;
+    }
+    static constexpr int tw(int d) { return TWF + 2 * xrows(d) * PIT; }
+    // (the transposed reads of the second buffer's upper block run up to row 31: kept inside the allocation)
+    static constexpr int main_total(int d) { return oT + NWV * tw(d) + (LX ? (32 - xrows(d)) * PIT : 0); }
+    static constexpr int total(int d) { return main_total(d) > flush_total ? main_total(d) : flush_total; }
 };
 
 }  // namespace
@@ -133,12 +162,16 @@ struct LSmem {
 // untaken branch in full (a generic-depth instance of this kernel lost to elbo_narrow.hip at every depth below NL: 12 x 10 at 4 M
 // observations 1.27 against 0.80 ms per step) -- and a backward pass whose LDS traffic rides in the shadow of the previous layer's
 // weight-gradient MFMAs.
-// DMAX: metadata columns the instance holds (8 or 15: the registers of seven more columns cost the common narrow case 8 %).
+// DMAX: metadata columns the instance holds in registers (8 or 15: the registers of seven more columns cost the common narrow case
+// 8 %); 0 = the LDS-row instance (LX, see LSmem) for 16 .. 31 columns.
 template <int W, int DMAX, bool PACKED>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void elbo_lane_kernel(const cl_mlp_args A) {
-    using SM = LSmem<W>;
-    constexpr int DGMAX = (DMAX + 3) / 4;
+    constexpr bool LX = (DMAX == 0);
+    constexpr int DREG = LX ? 1 : DMAX;               // metadata registers of the lane (LX: none; arrays keep one element)
+    using SM = LSmem<W, LX>;
+    constexpr int DGMAX = LX ? 8 : (DMAX + 3) / 4;
+    constexpr int TPAR = SM::TPAR;
     constexpr int NC = SM::NC;
     constexpr int IMG = SM::IMG;
     // LeakyReLU derivative: compares into scalar-register pairs in groups of SELG, then the group's selects (equal groups of at
@@ -160,23 +193,25 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     //      transposed weights W_l[b][4 c + i] ---------------------------------------------------------------------------------
     {
         const float* __restrict__ P = A.mlp;
-        constexpr int NIMG = 2 * (NL + 1) * IMG, NIT = (NIMG + NT - 1) / NT;
+        constexpr int NIMG = (SM::NF + NL + 1) * IMG, NIT = (NIMG + NT - 1) / NT;
         float v_[NIT];
         const int offWo = w * d + w + (L - 1) * (w * w + w);
         // (all loads of a thread are issued before the first LDS store: see elbo_narrow.hip)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = it * NT + tid;
-            const int tr = idx / ((NL + 1) * IMG), r = idx - tr * ((NL + 1) * IMG);
+            const int tr = idx >= SM::NF * IMG ? 1 : 0, r = idx - tr * (SM::NF * IMG);
             const int l = r / IMG, c = (r - l * IMG) >> 6, ln = r & 63;
             const int b = ln >> 2, f = 4 * c + (ln & 3);
             float v = 0.0f;
             if (idx < NIMG) {
-                if (l < L) {
+                if (LX && tr == 0 && l == NL + 1) {                 // layer 0, second input block: block b = metadata column 15 + b
+                    if (f < w && 15 + b < d) v = P[f * d + 15 + b];
+                } else if (l < L) {
                     const int in_dim = (l == 0) ? d : w;
                     const int base = (l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w));
                     if (tr == 0) {
-                        if (f < w && b < in_dim) v = P[base + f * in_dim + b];
+                        if (f < w && b < in_dim && b < ONE) v = P[base + f * in_dim + b];
                         else if (f < w && b == ONE) v = P[base + w * in_dim + f];
                     } else if (l > 0) {
                         if (b < w && f < w) v = P[base + b * w + f];
@@ -198,28 +233,43 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             if (idx < NIMG) smem[SM::oF + idx] = v_[it];
         }
         // staging tiles: rows that are never written hold their constants (zero; row 15 of the input tiles = the ones)
-        static_assert(SM::oT % 4 == 0 && SM::TW % 4 == 0 && PIT % 4 == 0, "16-byte fill");
-        for (int idx = 4 * tid; idx < NWV * SM::TW; idx += 4 * NT) {
-            const int row = (idx % SM::TW) / PIT;                       // 0-31 sZ, 32-63 sH, 64-79 sX
-            const float v = (row == 32 + ONE || row == 48 + ONE || row == 64 + ONE) ? 1.0f : 0.0f;
+        static_assert(SM::oT % 4 == 0 && SM::TWF % 4 == 0 && PIT % 4 == 0 && SM::oS % PIT == 0, "16-byte fill");
+        const int TWr = SM::tw(d), xrows = SM::xrows(d);
+        for (int idx = 4 * tid; idx < NWV * TWr; idx += 4 * NT) {
+            const int off = idx % TWr;
+            bool one;
+            if (off < SM::oS) {
+                const int row = off / PIT;                              // sZ[TPAR], sH[TPAR], (not LX) sX: 16 rows each
+                one = row >= TPAR * 16 && (row & 15) == ONE;
+            } else {
+                const int xo = off - SM::oX;                            // LX: the two row buffers
+                one = LX && xo >= 0 && (xo / PIT) % (xrows > 0 ? xrows : 1) == ONE;
+            }
+            const float v = one ? 1.0f : 0.0f;
             *reinterpret_cast<f32x4*>(smem + SM::oT + idx) = f32x4{v, v, v, v};
+        }
+        if (LX) {                                                       // (tail that the upper-block reads of the last wave's second buffer touch)
+            for (int idx = 4 * tid; idx < (32 - xrows) * PIT; idx += 4 * NT) *reinterpret_cast<f32x4*>(smem + SM::oT + NWV * TWr + idx) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
     __syncthreads();
 
     const float* const sF = smem + SM::oF + lane;      // forward weight register c of layer l: sF[l * IMG + c * 64]
     const float* const sK = smem + SM::oK + lane;
-    float* const sZ = smem + SM::oT + wv * SM::TW;     // dZ_l                       [feature][observation]
-    float* const sH = sZ + 32 * PIT;                   // the layer's input (layers >= 1)
-    float* const sX = sH + 32 * PIT;                   // the metadata of the tile (layer 0's input)
-    float* const sS = sX + 16 * PIT;                   // sampled amplitudes of samples 1 .. SPRE-1, then their gradients   [sample][lane]
+    const int xrows = SM::xrows(d);                    // LX: rows of a metadata buffer
+    float* const sZ = smem + SM::oT + wv * SM::tw(d);  // dZ_l                       [feature][observation]
+    float* const sH = sZ + TPAR * 16 * PIT;            // the layer's input (layers >= 1)
+    float* const sX = sH + TPAR * 16 * PIT;            // (not LX) the metadata of the tile (layer 0's input)
+    float* const sS = sZ + SM::oS;                     // sampled amplitudes of a batch of SPRE samples, then their gradients   [sample][lane]
     unsigned* const sQ = reinterpret_cast<unsigned*>(sS + SPRE * 64);       // byte offset of the lane's reflection in dz_f (~0: none)
-    constexpr int PAR = 16 * PIT;                      // second copy of sZ / sH (layers alternate between the two)
+    float* const sXb = sZ + SM::oX;                    // LX: metadata rows of the current / the next tile: buffer (tile parity) x [xrows][PIT]
+    constexpr int PAR = (TPAR - 1) * 16 * PIT;         // second copy of sZ / sH (layers alternate between the two; LX: one copy)
 
     // ---- accumulators that live across all tiles of this wave ----------------------------------------------------------
     f32x4 wacc[NL], wacd[NL];           // dW_l = wacc + wacd: lane (j, q), element t = dW_l[out 4 q + t][in j]  (in 15: the bias)
 #pragma unroll
     for (int l = 0; l < NL; ++l) { wacc[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; wacd[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    f32x4 wacc0b = {0.0f, 0.0f, 0.0f, 0.0f}, wacd0b = {0.0f, 0.0f, 0.0f, 0.0f};      // LX: layer 0's second input block (columns 15 .. 30)
     f32x2 hacc[W + 1];                  // head: per-lane sums of (dloc, draw) x top activation k; [W]: the bias
 #pragma unroll
     for (int k = 0; k <= W; ++k) hacc[k] = f32x2{0.0f, 0.0f};
@@ -235,25 +285,42 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 
     // per-observation inputs of a wave tile, loaded one tile ahead (a wave tile never leaves the padded metadata rows because 64
     // divides CL_MLP_TILE, the per-observation arrays are clamped to their last element)
-    float xn[DMAX];
+    float xn[DREG];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) xn[k] = 0.0f;
+    for (int k = 0; k < DREG; ++k) xn[k] = 0.0f;
     int ridn = -1, imgn = 0;
     float ion = 0.0f, sgn = 1.0f;
-    auto prefetch = [&](int wt_in) {
+    // `xbuf`: LX only -- the row buffer the tile's metadata go to
+    auto prefetch = [&](int wt_in, int xbuf) {
         const int wt = uniform(wt_in);
         const int base = wt * WT;
         const unsigned n_pad_u = (unsigned)A.n_pad;
         const int last_obs = A.n_obs - 1;
         const float* __restrict__ mt = A.meta_t + base;
         const int dd = A.d;
+        if constexpr (LX) {
+            // rows of meta_t (cl_mlp_meta_rows(d) of them: whole groups of four, zero past d) -> rows of the buffer, by the DMA path:
+            // lane i of a row instruction fetches observation i, the data land at (row base) + 4 i
+            float* const dst = sXb + uniform(xbuf) * xrows * PIT;
+            static_for<0, DGMAX>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (4 * g < dd) {                                        // wave-uniform
+                    static_for<4 * g, (4 * g + 4 < DMAX_LX ? 4 * g + 4 : DMAX_LX)>([&](auto kc) {
+                        constexpr int k = decltype(kc)::value, r = k < ONE ? k : k + 1;
+                        __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(mt + (size_t)k * n_pad_u) + 4u * (unsigned)lane,
+                                                         (__attribute__((address_space(3))) void*)(dst + r * PIT), 4, 0, 0);
+                    });
+                }
+            });
+        } else {
 #pragma unroll
-        for (int g = 0; g < DGMAX; ++g) {
-            if (4 * g < dd) {                                            // wave-uniform
+            for (int g = 0; g < DGMAX; ++g) {
+                if (4 * g < dd) {                                            // wave-uniform
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int k = 4 * g + t;
-                    if (k < DMAX) xn[k] = ld_uo(mt + (size_t)k * n_pad_u, 4u * (unsigned)lane);    // (rows d .. 4 dg - 1: zeroed at the use)
+                    for (int t = 0; t < 4; ++t) {
+                        const int k = 4 * g + t;
+                        if (k < DMAX) xn[k] = ld_uo(mt + (size_t)k * n_pad_u, 4u * (unsigned)lane);    // (rows d .. 4 dg - 1: zeroed at the use)
+                    }
                 }
             }
         }
@@ -265,32 +332,36 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         imgn = A.use_img ? ld_uo(A.image_id, ob) : 0;
     };
     const int wt_begin = (int)blockIdx.x * NWV + wv;
-    if (wt_begin < n_wt) prefetch(wt_begin);
+    if (wt_begin < n_wt) prefetch(wt_begin, 0);
 
     const float ones = 1.0f;
     const int rr16 = lane & 15, kq = lane >> 4;
     const float* const rdZ = sZ + rr16 * PIT + 4 * kq;       // wgrad operands: row (lane & 15), observations 16 c + 4 kq .. + 3
     const float* const rdH = sH + rr16 * PIT + 4 * kq;
-    const float* const rdX = sX + rr16 * PIT + 4 * kq;
+    const float* const rdX = (LX ? sXb : sX) + rr16 * PIT + 4 * kq;      // (LX: + the current buffer)
 
 #ifdef CL_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
-    for (int wt = wt_begin; wt < n_wt; wt += wt_step) {
-        float x0[DMAX];
+    int xcur = 0;                                             // LX: buffer of the current tile's metadata rows
+    for (int wt = wt_begin; wt < n_wt; wt += wt_step, xcur ^= 1) {
+        float x0[DREG];
 #pragma unroll
-        for (int k = 0; k < DMAX; ++k) x0[k] = xn[k];          // (rows >= d of meta_t are zero by contract, groups past them were never loaded)
+        for (int k = 0; k < DREG; ++k) x0[k] = xn[k];          // (rows >= d of meta_t are zero by contract, groups past them were never loaded)
         // layer 0's input, staged for its weight gradient at the end of the backward pass
+        if constexpr (!LX) {
 #pragma unroll
-        for (int g = 0; g < DGMAX; ++g) {
-            if (g < dg) {
+            for (int g = 0; g < DGMAX; ++g) {
+                if (g < dg) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (4 * g + t < DMAX) sX[(4 * g + t) * PIT + lane] = x0[4 * g + t];
+                    for (int t = 0; t < 4; ++t)
+                        if (4 * g + t < DMAX) sX[(4 * g + t) * PIT + lane] = x0[4 * g + t];
+                }
             }
         }
+        const int xoff = LX ? uniform(xcur) * xrows * PIT : 0;   // the current tile's row buffer
         const bool in_range = wt * WT + lane < A.n_obs;
         const int rid = in_range ? ridn : -1, img = imgn;
         const float io = ion, sg = in_range ? sgn : 1.0f;
@@ -337,11 +408,35 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 f32x4 acc[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (l == 0) {
+                if (l == 0 && LX) {
+                    // metadata column k: row k (k < 15) or k + 1 of the tile's row buffer, block k of the first / block k - 15 of the
+                    // second weight register of a chunk; whole groups of four rows (the ones past d are zero)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the rows were requested a backward pass ago
+                    const float* const xr = sXb + xoff + lane;
+                    float wb[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) wb[c] = sF[(NL + 1) * IMG + c * 64];
                     static_for<0, DGMAX>([&](auto gc) {
                         constexpr int g = decltype(gc)::value;
                         if (g < dg) {                                    // wave-uniform
-                            static_for<4 * g, (4 * g + 4 < DMAX ? 4 * g + 4 : DMAX)>([&](auto kc) {
+                            constexpr int k1 = (4 * g + 4 < DMAX_LX ? 4 * g + 4 : DMAX_LX);
+                            float xv[4];
+                            static_for<4 * g, k1>([&](auto kc) {
+                                constexpr int k = decltype(kc)::value;
+                                xv[k & 3] = xr[(k < ONE ? k : k + 1) * PIT];
+                            });
+                            static_for<4 * g, k1>([&](auto kc) {
+                                constexpr int k = decltype(kc)::value;
+#pragma unroll
+                                for (int c = 0; c < NC; ++c) acc[c] = mfma_bk<(k < ONE ? k : k - ONE)>(k < ONE ? wa[c] : wb[c], xv[k & 3], acc[c]);
+                            });
+                        }
+                    });
+                } else if (l == 0) {
+                    static_for<0, DGMAX>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value;
+                        if (g < dg) {                                    // wave-uniform
+                            static_for<4 * g, (4 * g + 4 < DREG ? 4 * g + 4 : DREG)>([&](auto kc) {
                                 constexpr int k = decltype(kc)::value;
 #pragma unroll
                                 for (int c = 0; c < NC; ++c) acc[c] = mfma_bk<k>(wa[c], x0[k], acc[c]);
@@ -402,103 +497,114 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         // The S amplitude gradients of an observation are S consecutive floats of dz_f.  Issued as they are computed -- one atomic
         // instruction per sample, 64 lanes on 64 different lines, the same lines again a sample later -- they cost this kernel 0.12 ms
         // per sample at 4 M observations (the memory side executes one request per lane and serialises the ones that hit a line in
-        // flight).  For 2 <= S <= SPRE they go through LDS instead and leave as eight instructions in which eight consecutive lanes
-        // carry the eight samples of one observation: one 32-byte request per observation.
-        const bool coal = CL_LANE_COALESCE && S >= CL_LANE_COALESCE && S <= SPRE;      // wave-uniform
-        if (laue || rid >= 0) {
-            // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
-            const float inv_sg = cl_fast_rcp(sg);
-            const float log_sg = cl_fast_log(sg);
-            // (per-lane 64-bit addresses of the optional arrays are formed where they are used: test / output paths only)
-            const float* __restrict__ zf_p = A.z_f;
-            float* __restrict__ dzf_p = A.dz_f;
-            const int lik_kind = A.lik_kind;
-            const float dof = A.dof, lik_const = A.lik_const, shift = A.shift;
-            float esin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            const bool act = rid >= 0;
-            // (The amplitudes gathered at the start of the tile wait in LDS: inside the loop every wait on a global load would also
-            //  wait for the previous sample's atomics -- one in-order counter --, a few microseconds each for a lone wave.)
-            // one MC sample of this lane's observation, given its noise and its sampled amplitude (all lanes take part in the Laue shuffles)
-            auto sample = [&](int s, float eta, float zf) {
-                const float tq = o0 + sigma * eta + shift;
-                const float zs = aim * tq;
-                const float ipred = act ? zs * zf * zf : 0.0f;
-                if (A.ipred_out != nullptr && act) A.ipred_out[(size_t)gobs * S + s] = ipred;
-                float lin = ipred;                                   // what the likelihood sees: the prediction, or its group's total
-                if (laue) {
-                    lin = 0.0f;
-                    for (int mm = 0; mm < gmax; ++mm) {
-                        const float v = __shfl(ipred, (lane - mem + mm) & 63);
-                        lin += (mm < cnt) ? v : 0.0f;
-                    }
+        // flight).  From two samples on they go through LDS instead and leave as eight instructions in which eight consecutive lanes
+        // carry the eight samples (of a batch) of one observation: one 32-byte request per observation.
+        const bool coal = CL_LANE_COALESCE && S >= CL_LANE_COALESCE;      // wave-uniform
+        // The samples go in batches of SPRE (one batch unless S > SPRE): a batch's amplitudes wait in LDS (the first batch's were
+        // gathered at the start of the tile), its amplitude gradients leave through it.
+        // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
+        const float inv_sg = cl_fast_rcp(sg);
+        const float log_sg = cl_fast_log(sg);
+        // (per-lane 64-bit addresses of the optional arrays are formed where they are used: test / output paths only)
+        float* __restrict__ dzf_p = A.dz_f;
+        const int lik_kind = A.lik_kind;
+        const float dof = A.dof, lik_const = A.lik_const, shift = A.shift;
+        const float inv_dof = (lik_kind == CL_LIK_STUDENTT) ? 1.0f / dof : 0.0f;       // wave-uniform
+        float esin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const bool act = rid >= 0;
+        // (The amplitudes wait in LDS: inside the loop every wait on a global load would also wait for the previous sample's
+        //  atomics -- one in-order counter --, a few microseconds each for a lone wave.)
+        // one MC sample of this lane's observation, given its noise and its sampled amplitude (all lanes take part in the Laue shuffles)
+        auto sample = [&](int s, float eta, float zf) {
+            const float tq = o0 + sigma * eta + shift;
+            const float zs = aim * tq;
+            const float ipred = act ? zs * zf * zf : 0.0f;
+            if (A.ipred_out != nullptr && act) A.ipred_out[(size_t)gobs * S + s] = ipred;
+            float lin = ipred;                                   // what the likelihood sees: the prediction, or its group's total
+            if (laue) {
+                lin = 0.0f;
+                for (int mm = 0; mm < gmax; ++mm) {
+                    const float v = __shfl(ipred, (lane - mem + mm) & 63);
+                    lin += (mm < cnt) ? v : 0.0f;
                 }
-                if (act) {
-                    const bool counts = !laue || mem == 0;
-                    float dll, ll;
-                    if (use_ev11) {
-                        float gf, gb, ga;
-                        ll = cl_lik_ev11(lin, io, sg, lik_kind, dof, lik_const, ev, &dll, &gf, &gb, &ga);
-                        if (counts) { ev_g0 -= gf * w_ll; ev_g1 -= ga * w_ll; ev_g2 -= gb * w_ll; }     // order: Sdfac, Sdadd, SdB
-                    } else {
-                        ll = cl_lik_log_prob2(lin, io, inv_sg, log_sg, lik_kind, dof, lik_const, &dll);
-                    }
-                    if (counts) nll_acc -= ll * w_ll;
-                    const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
-                    const float dzs = gi * zf * zf;
-                    if (coal) sS[s * 64 + lane] = gi * zs * 2.0f * zf;      // (slot s: its amplitude was read at the start of this sample)
-                    else atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
-                    const float dt = dzs * aim;
-                    pdl += dt;
-                    pds += dt * eta;
-                    pda += dzs * tq;
-                }
-            };
-            auto philox_eta = [&](int s) -> float {      // one Philox block + Box-Muller pair serves samples s and s + 4
-                float eta = 0.0f;
-                if (!act) {
-                } else if (((s >> 2) & 1) == 0) {
-                    float sn;
-                    cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(PACKED ? nkey : A.obs_offset + gobs), &eta, &sn);
-                    const int kk = s & 3;
-                    if (kk == 0) esin[0] = sn; else if (kk == 1) esin[1] = sn; else if (kk == 2) esin[2] = sn; else esin[3] = sn;
+            }
+            if (act) {
+                const bool counts = !laue || mem == 0;
+                float dll, ll;
+                if (use_ev11) {
+                    float gf, gb, ga;
+                    ll = cl_lik_ev11(lin, io, sg, lik_kind, dof, lik_const, ev, &dll, &gf, &gb, &ga);
+                    if (counts) { ev_g0 -= gf * w_ll; ev_g1 -= ga * w_ll; ev_g2 -= gb * w_ll; }     // order: Sdfac, Sdadd, SdB
                 } else {
-                    const int kk = s & 3;
-                    eta = (kk == 0) ? esin[0] : (kk == 1) ? esin[1] : (kk == 2) ? esin[2] : esin[3];
+                    ll = CL_LANE_FAST_DIV ? cl_lik_log_prob3(lin, io, inv_sg, log_sg, lik_kind, dof, inv_dof, lik_const, &dll)
+                                          : cl_lik_log_prob2(lin, io, inv_sg, log_sg, lik_kind, dof, lik_const, &dll);
                 }
-                return eta;
-            };
-            // Three loops over the samples (wave-uniform trip counts), so that the common one -- in-kernel noise, amplitudes
-            // from LDS -- contains no global load at all: any load in the loop makes the compiler wait on the one in-order
-            // memory counter, i.e. for the previous sample's atomics, a few microseconds each for a lone wave.
-            if (A.eta != nullptr) {
-                const float* __restrict__ eta_p = A.eta + (size_t)gobs * S;
-                for (int s = 0; s < S; ++s) {
-                    float zf = zf0;
-                    if (s > 0) zf = (s < SPRE) ? sS[s * 64 + lane] : ld_uo(zf_p, zoff + 4u * (unsigned)s);
-                    sample(s, act ? eta_p[s] : 0.0f, act ? zf : 0.0f);
-                }
+                if (counts) nll_acc -= ll * w_ll;
+                const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
+                const float dzs = gi * zf * zf;
+                if (coal) sS[(s & (SPRE - 1)) * 64 + lane] = gi * zs * 2.0f * zf;      // (the sample's slot: its amplitude was read at the start of this sample)
+                else atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
+                const float dt = dzs * aim;
+                pdl += dt;
+                pds += dt * eta;
+                pda += dzs * tq;
+            }
+        };
+        auto philox_eta = [&](int s) -> float {      // one Philox block + Box-Muller pair serves samples s and s + 4
+            float eta = 0.0f;
+            if (!act) {
+            } else if (((s >> 2) & 1) == 0) {
+                float sn;
+                cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(PACKED ? nkey : A.obs_offset + gobs), &eta, &sn);
+                const int kk = s & 3;
+                if (kk == 0) esin[0] = sn; else if (kk == 1) esin[1] = sn; else if (kk == 2) esin[2] = sn; else esin[3] = sn;
             } else {
-                const int Sf = S < SPRE ? S : SPRE;
-                for (int s = 0; s < Sf; ++s) {
-                    const float zf = (s > 0) ? sS[s * 64 + lane] : zf0;
-                    sample(s, philox_eta(s), act ? zf : 0.0f);
-                }
-                for (int s = Sf; s < S; ++s) {
-                    const float zf = ld_uo(zf_p, zoff + 4u * (unsigned)s);
-                    sample(s, philox_eta(s), act ? zf : 0.0f);
-                }
+                const int kk = s & 3;
+                eta = (kk == 0) ? esin[0] : (kk == 1) ? esin[1] : (kk == 2) ? esin[2] : esin[3];
             }
-        }
-        if (coal) {
-            sQ[lane] = (rid >= 0) ? zoff : 0xFFFFFFFFu;
-            const int ss = lane & 7, oj = lane >> 3;             // this lane's sample, its observation within a group of eight
+            return eta;
+        };
+        if (coal) sQ[lane] = (rid >= 0) ? zoff : 0xFFFFFFFFu;
+        int sb = 0;                                      // first sample of the batch
+        do {
+            const int se = (sb + SPRE < S) ? sb + SPRE : S;
+            if (sb > 0) {
+                // a later batch (S > SPRE): its amplitudes, gathered here (every lane, clamped addresses); the previous batch's
+                // gradients have left the slots (their reads fed atomics that are issued)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned zq = sQ[8 * j + oj];
-                const float g = sS[ss * 64 + 8 * j + oj];
-                if (ss < S && zq != 0xFFFFFFFFu) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(A.dz_f) + zq + 4u * (unsigned)ss), g);
+                for (int j = 0; j < SPRE; ++j)
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(A.z_f) + (zoff + 4u * (unsigned)min(sb + j, S - 1)),
+                                                     (__attribute__((address_space(3))) void*)(sS + j * 64), 4, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-        }
+            if (laue || rid >= 0) {
+                // Two loops over the batch (wave-uniform trip counts), so that the common one -- in-kernel noise -- contains no
+                // global load at all: any load in the loop makes the compiler wait on the one in-order memory counter, i.e.
+                // for the previous sample's atomics, a few microseconds each for a lone wave.
+                if (A.eta != nullptr) {
+                    const float* __restrict__ eta_p = A.eta + (size_t)gobs * S;
+                    for (int s = sb; s < se; ++s) {
+                        const float zf = (s > 0) ? sS[(s & (SPRE - 1)) * 64 + lane] : zf0;
+                        sample(s, act ? eta_p[s] : 0.0f, act ? zf : 0.0f);
+                    }
+                } else {
+                    for (int s = sb; s < se; ++s) {
+                        const float zf = (s > 0) ? sS[(s & (SPRE - 1)) * 64 + lane] : zf0;
+                        sample(s, philox_eta(s), act ? zf : 0.0f);
+                    }
+                }
+            }
+            if (coal) {
+                const int ss = lane & 7, oj = lane >> 3;             // this lane's sample of the batch, its observation within a group of eight
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned zq = sQ[8 * j + oj];
+                    const float g = sS[ss * 64 + 8 * j + oj];
+                    if (sb + ss < S && zq != 0xFFFFFFFFu) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(A.dz_f) + zq + 4u * (unsigned)(sb + ss)), g);
+                }
+            }
+            sb += SPRE;
+        } while (sb < S);
         if (A.use_img) {
             // image ids are sorted: the observations of a wave tile almost always share one image -> ONE atomic per wave
             const int img0 = uniform(img);
@@ -513,7 +619,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 
         LSTAMP(2);
         // next tile's inputs: their latency hides under the backward pass
-        if (wt + wt_step < n_wt) prefetch(wt + wt_step);
+        if (wt + wt_step < n_wt) prefetch(wt + wt_step, xcur ^ 1);
         LSTAMP(3);
 
         // ================= backward =========================================================================================
@@ -576,7 +682,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 } else if constexpr (i < NOPS) {
                     constexpr int j = i - 2 * WP, c = j >> 1;
                     if constexpr ((j & 1) == 0) pa[q][c] = *reinterpret_cast<const f32x4*>(rdZ + q * PAR + 16 * c);
-                    else pb[q][c] = *reinterpret_cast<const f32x4*>((ll == 0 ? rdX : rdH + q * PAR) + 16 * c);
+                    else pb[q][c] = *reinterpret_cast<const f32x4*>((ll == 0 ? rdX + xoff : rdH + q * PAR) + 16 * c);
                 } else if constexpr (i < NOPS + NC) {
                     if constexpr (ll > 0) wk[q][i - NOPS] = sK[ll * IMG + (i - NOPS) * 64];       // dgrad weights of layer ll (input side: layer ll - 1)
                 }
@@ -607,10 +713,22 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     if constexpr (l > 0) {
                         lds_op(std::integral_constant<int, (l > 0 ? l - 1 : 0)>{}, std::integral_constant<int, 2 * i>{});
                         lds_op(std::integral_constant<int, (l > 0 ? l - 1 : 0)>{}, std::integral_constant<int, 2 * i + 1>{});
+                    } else if constexpr (LX && i < 4) {
+                        // layer 0's second input block (rows 16 .. 31 of the row buffer), read in the shadow of the first block's
+                        // MFMAs into the operand registers of the other layer parity (layer 1 is done with them)
+                        pb[1][i] = *reinterpret_cast<const f32x4*>(rdX + xoff + 16 * PIT + 16 * i);
                     }
                     LFENCE();
                 });
                 static_assert(NOPS + NC <= 32, "LDS operations of a layer fit the shadow of sixteen MFMAs");
+                if constexpr (LX && l == 0) {
+                    static_for<0, 16>([&](auto ic_) {
+                        constexpr int i = decltype(ic_)::value, c = (i >> 3) * 2, t = (i >> 1) & 3;
+                        if constexpr ((i & 1) == 0) mfma16_acc(wacc0b, pa[0][c][t], pb[1][c][t]);
+                        else mfma16_acc(wacd0b, pa[0][c + 1][t], pb[1][c + 1][t]);
+                        LFENCE();
+                    });
+                }
             });
         LSTAMP(5);
     }
@@ -634,6 +752,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     constexpr int REG = SM::REG;
 #pragma unroll
     for (int l = 0; l < NL; ++l) wacc[l] += wacd[l];
+    wacc0b += wacd0b;
     float* const sHead = smem + (NWV / 2) * REG;            // [wave][2 * 16]: the head's sums of every wave
     {
         // head: wave sums of the per-lane sums
@@ -652,29 +771,34 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         if ((wv & (2 * s2 - 1)) == s2) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) reg[l * 64] = wacc[l];
+            if (LX) reg[NL * 64] = wacc0b;
         }
         __syncthreads();
         if ((wv & (2 * s2 - 1)) == 0) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) wacc[l] += reg[l * 64];
+            if (LX) wacc0b += reg[NL * 64];
         }
         __syncthreads();
     }
     if (wv == 0) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) reinterpret_cast<f32x4*>(smem + l * 256)[lane] = wacc[l];
+        if (LX) reinterpret_cast<f32x4*>(smem + NL * 256)[lane] = wacc0b;
     }
     __syncthreads();
     float* __restrict__ part = A.partials + (size_t)blockIdx.x * Ptot;
-    for (int idx = tid; idx < NL * 256; idx += NT) {
-        const int l = idx >> 8, r = idx & 255;                     // accumulator l: Dense layer l
+    for (int idx = tid; idx < SM::NACCB * 256; idx += NT) {
+        const int l = idx >> 8, r = idx & 255;                     // accumulator l: Dense layer l (LX: NL = layer 0's second input block)
         const int ln = r >> 2, t = r & 3;
         const int fo = 4 * (ln >> 4) + t, fi = ln & 15;            // output feature (row), input feature (column; 15: the ones) of this element
         const float v = smem[idx];
-        if (l < L) {
+        if (LX && l == NL) {
+            if (fo < w && ONE + fi < d) part[fo * d + ONE + fi] = v;                      // metadata columns 15 .. 30
+        } else if (l < L) {
             const int in_dim = (l == 0) ? d : w;
             const int off = (l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w));
-            if (fo < w && fi < in_dim) part[off + fo * in_dim + fi] = v;
+            if (fo < w && fi < in_dim && fi < ONE) part[off + fo * in_dim + fi] = v;
             if (fo < w && fi == ONE) part[off + w * in_dim + fo] = v;                     // bias gradient: the ones column
         }
     }
@@ -707,10 +831,16 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     }
 }
 
+// The instances are spread over four compilations of this file (build.py: -DCL_LANE_PART=0 .. 3, in parallel; a part takes 25 - 50 s):
+// part 0 = plain layout, metadata in registers (+ the dispatch); 1 = packed layout, registers; 2 = plain, LDS rows (LX); 3 = packed, LX.
+#ifndef CL_LANE_PART
+#define CL_LANE_PART 0
+#endif
+
 template <int W, int DMAX, bool PACKED>
 static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
-    using SM = LSmem<W>;
-    const size_t sm = (size_t)SM::total * sizeof(float);
+    using SM = LSmem<W, DMAX == 0>;
+    const size_t sm = (size_t)SM::total(a.d) * sizeof(float);
     if (sm > 160 * 1024) return -3;
     auto kern = elbo_lane_kernel<W, DMAX, PACKED>;
     static std::atomic<size_t> configured{0};
@@ -729,29 +859,47 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_WMAX 10
 #endif
 
-#ifndef CL_LANE_SMAX
-#define CL_LANE_SMAX 8
-#endif
+// the instance whose compile-time width is the smallest one that holds the scaler (zero-padded features cost MFMA steps)
+#define CL_LANE_WIDTHS(CASE)      \
+    if (a.w <= 4) return CASE(4); \
+    if (a.w <= 6) return CASE(6); \
+    if (a.w <= 8) return CASE(8); \
+    return CASE(10);
 
-// 1 = this geometry runs on the lane-per-observation kernel (full ELBO step of a scaler of exactly NL layers -- the default depth --;
-// plain observation layout, or the packed one of single-pass Laue).
-// More than eight MC samples go to elbo_narrow.hip (the amplitudes and amplitude gradients of up to SPRE = 8 samples pass through
-// LDS).  4 M observations, 20 x 10, Student-T, ms per step here / there (scripts/narrow_samples.py): S = 1 0.96 / 1.11, 2: 1.01 / 1.12,
-// 4: 1.07 / 1.19, 8: 1.16 / 1.34.
-int cl_lane_supports(const cl_mlp_args& a) {
-    return a.w >= 1 && a.w <= CL_LANE_WMAX && a.S <= CL_LANE_SMAX && a.d >= 1 && a.d <= DMAX_ALL && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
-           a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);
+int cl_launch_lane_plain_reg(const cl_mlp_args& a, int grid, hipStream_t st);
+int cl_launch_lane_packed_reg(const cl_mlp_args& a, int grid, hipStream_t st);
+int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st);
+int cl_launch_lane_packed_rows(const cl_mlp_args& a, int grid, hipStream_t st);
+
+#if CL_LANE_PART == 0
+int cl_launch_lane_plain_reg(const cl_mlp_args& a, int grid, hipStream_t st) {
+#define CL_LANE_CASE(WW) (a.d <= 8 ? launch_lane_one<WW, 8, false>(a, grid, st) : launch_lane_one<WW, DMAX_ALL, false>(a, grid, st))
+    CL_LANE_WIDTHS(CL_LANE_CASE)
+#undef CL_LANE_CASE
 }
 
-template <bool PACKED>
-static int launch_lane_w(const cl_mlp_args& a, int grid, hipStream_t st) {
-    // the instance whose compile-time width is the smallest one that holds the scaler (zero-padded features cost MFMA steps)
-#define CL_LANE_CASE(WW) (a.d <= 8 ? launch_lane_one<WW, 8, PACKED>(a, grid, st) : launch_lane_one<WW, DMAX_ALL, PACKED>(a, grid, st))
-    if (a.w <= 4) return CL_LANE_CASE(4);
-    if (a.w <= 6) return CL_LANE_CASE(6);
-    if (a.w <= 8) return CL_LANE_CASE(8);
-    return CL_LANE_CASE(10);
-#undef CL_LANE_CASE
+// LDS bytes the LDS-row instance of hidden width w needs for d metadata columns
+static size_t lane_rows_lds(int w, int d) {
+    const int t = w <= 4 ? LSmem<4, true>::total(d) : (w <= 6 ? LSmem<6, true>::total(d) : (w <= 8 ? LSmem<8, true>::total(d) : LSmem<10, true>::total(d)));
+    return (size_t)t * sizeof(float);
+}
+
+// 1 = this geometry runs on the lane-per-observation kernel (full ELBO step of a scaler of exactly NL layers -- the default depth --;
+// plain observation layout, or the packed one of single-pass Laue).  Up to 15 metadata columns are registers of the lane, 16 .. 31
+// are rows of an LDS buffer (LX); any number of MC samples (batches of SPRE).  4 M observations, 20 x 10, Student-T, ms per step
+// here / on elbo_narrow.hip (scripts/narrow_samples.py): S = 1 0.96 / 1.11, 2: 1.01 / 1.12, 4: 1.07 / 1.19, 8: 1.16 / 1.34.
+int cl_lane_supports(const cl_mlp_args& a) {
+    if (!(a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_LX && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
+          a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr)))
+        return 0;
+    return a.d <= DMAX_ALL || lane_rows_lds(a.w, a.d) <= 160 * 1024;
+}
+
+// name of the instance cl_launch_lane runs (cl_mlp_kernel_name)
+int cl_lane_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
+    const int W = a.w <= 4 ? 4 : (a.w <= 6 ? 6 : (a.w <= 8 ? 8 : 10));
+    const int DM = a.d <= 8 ? 8 : (a.d <= DMAX_ALL ? DMAX_ALL : 0);
+    return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s>", W, DM, a.row_map != nullptr ? "true" : "false");
 }
 
 int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {
@@ -761,10 +909,30 @@ int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {
         4ull * (unsigned long long)a.R * (unsigned long long)a.S >= (1ull << 32))
         return -4;
     if (grid < 1) return -1;
+    const bool rows = a.d > DMAX_ALL;
     if (a.row_map != nullptr) {
         if (a.n_obs != a.n_pad || (a.gmeta != nullptr && a.tile_gmax == nullptr)) return -1;
         if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
-        return launch_lane_w<true>(a, grid, st);
+        return rows ? cl_launch_lane_packed_rows(a, grid, st) : cl_launch_lane_packed_reg(a, grid, st);
     }
-    return launch_lane_w<false>(a, grid, st);
+    return rows ? cl_launch_lane_plain_rows(a, grid, st) : cl_launch_lane_plain_reg(a, grid, st);
 }
+#elif CL_LANE_PART == 1
+int cl_launch_lane_packed_reg(const cl_mlp_args& a, int grid, hipStream_t st) {
+#define CL_LANE_CASE(WW) (a.d <= 8 ? launch_lane_one<WW, 8, true>(a, grid, st) : launch_lane_one<WW, DMAX_ALL, true>(a, grid, st))
+    CL_LANE_WIDTHS(CL_LANE_CASE)
+#undef CL_LANE_CASE
+}
+#elif CL_LANE_PART == 2
+int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st) {
+#define CL_LANE_CASE(WW) launch_lane_one<WW, 0, false>(a, grid, st)
+    CL_LANE_WIDTHS(CL_LANE_CASE)
+#undef CL_LANE_CASE
+}
+#else
+int cl_launch_lane_packed_rows(const cl_mlp_args& a, int grid, hipStream_t st) {
+#define CL_LANE_CASE(WW) launch_lane_one<WW, 0, true>(a, grid, st)
+    CL_LANE_WIDTHS(CL_LANE_CASE)
+#undef CL_LANE_CASE
+}
+#endif

@@ -32,6 +32,7 @@
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include "cl_math.h"
 #include "cl_kernels.h"
@@ -1424,6 +1425,27 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
 }
 
 #if !CL_IMGL && !CL_CHAIN
+// Name of the kernel instance cl_launch_mlp(a, mode, ...) runs -- the same routing, restated once, here, next to it (bench.py and the
+// profiling scripts label their rows with it instead of guessing).  Returns the length written (snprintf semantics).
+int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
+    const char* unit = "";
+    bool packed = false;
+    if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
+    else if (a.n_imgl > 0) unit = ", image layers";
+    else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }
+    if (unit[0] == 0 || packed) {
+        if (mode == 0 && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
+        if (mode == 0 && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
+    }
+    if (a.w < 1 || a.w > 64 || a.d < 1 || a.d > 64) return snprintf(out, n, "(unsupported)");
+    const int imgl = a.n_imgl > 0 ? a.n_imgl : 0;
+    const int WP = a.w <= 15 ? 16 : (a.w <= 32 ? 32 : 64);
+    const int DP = a.d <= 8 ? 8 : (a.d <= 32 ? 32 : 64);
+    const int LM = a.w <= 15 ? (imgl ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16) : (a.w <= 32 ? (a.L + imgl <= 5 ? 5 : CL_MLP_LMAX_W32) : CL_MLP_LMAX_W64);
+    const int KS = (a.w <= 15 && mode != 1 && CL_KPERM) ? (a.w <= 8 ? 2 : (a.w <= 12 ? 3 : 4)) : 4;
+    return snprintf(out, n, "elbo_mlp_kernel<%d, %d, %d, %d%s, KS=%d>", WP, DP, LM, mode, unit, KS);
+}
+
 int cl_launch_reduce_partials(const float* partials, int nparts, int P, float* out, const int* stop_flag, hipStream_t st) {
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((P + 31) / 32), dim3(256), 0, st, partials, nparts, P, out, stop_flag);

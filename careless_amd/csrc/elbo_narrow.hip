@@ -23,6 +23,8 @@
 // Roofline: fp32 MFMA; algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include "cl_math.h"
 #include "cl_kernels.h"
 
@@ -716,11 +718,21 @@ int cl_narrow_supports(const cl_mlp_args& a) {
            a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr);
 }
 
+// name of the instance cl_launch_narrow runs (cl_mlp_kernel_name)
+int cl_narrow_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
+    const int m = a.w > a.d ? a.w : a.d;
+    return snprintf(out, n, "elbo_narrow_kernel<2, %d, 8, %s>", m <= 8 ? 2 : (m <= 12 ? 3 : 4), a.row_map != nullptr ? "true" : "false");
+}
+
 template <bool PACKED>
 static int launch_narrow_ks(const cl_mlp_args& a, int grid, hipStream_t st) {
     const int m = a.w > a.d ? a.w : a.d;               // the metadata layer takes the same number of k-steps as the hidden ones
     if (m <= 8) return launch_narrow_one<2, 2, 8, PACKED>(a, grid, st);
     if (m <= 12) return launch_narrow_one<2, 3, 8, PACKED>(a, grid, st);
+    // widths 13 .. 15: four k-steps.  Two waves per SIMD spill ~90 registers at that size; one wave per SIMD holds everything
+    // (CARELESS_HIP_NARROW_W4=1 selects it: A/B runs)
+    static const bool w4 = [] { const char* e = getenv("CARELESS_HIP_NARROW_W4"); return e != nullptr && e[0] == '1'; }();
+    if (w4) return launch_narrow_one<2, 4, 4, PACKED>(a, grid, st);
     return launch_narrow_one<2, 4, 8, PACKED>(a, grid, st);
 }
 

@@ -273,6 +273,16 @@ def pack_laue(harmonic_id: np.ndarray, image_id: np.ndarray, by_image: bool):
     return pos, n_pad, gmeta, tile_gmax, row_map, tile_img
 
 
+class _ShardRows:
+    """`x[sl]` of a (possibly memory-mapped) 2-D array as float32: the conversion happens on the selected rows only."""
+
+    def __init__(self, a: np.ndarray, sl):
+        self.a, self.shape = a, a.shape
+
+    def __getitem__(self, sl) -> np.ndarray:
+        return np.asarray(self.a[sl], dtype=np.float32)
+
+
 class ObsData:
     """refl_id / image_id int32 [N], meta_t fp32 [rows][n_pad], iobs / sig fp32 [N], optional harmonic_id + Laue work
     buffers, and the per-launch workspace of the fused kernel (grid, gradient partials).  With `pack_images` (per-image
@@ -280,17 +290,20 @@ class ObsData:
 
     def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None,
                  laue_groups=None, pack_images: bool = False, laue_single_pass: bool = True, wide: bool = False):
-        refl_id = _np(BaseModel.get_refl_id(inputs)).reshape(-1).astype(np.int64)
-        image_id = _np(BaseModel.get_image_id(inputs)).reshape(-1).astype(np.int64)
-        metadata = _np(BaseModel.get_metadata(inputs)).astype(np.float32).reshape(len(refl_id), -1)
-        iobs = _np(BaseModel.get_intensities(inputs)).reshape(-1).astype(np.float32)
-        sig = _np(BaseModel.get_uncertainties(inputs)).reshape(-1).astype(np.float32)
-        self.N_total = int(len(refl_id))
+        # Views of the caller's arrays (possibly memory-mapped files shared by the ranks of a node): only this shard's rows are
+        # ever copied / converted -- a rank of an 8-GPU job does not hold eight copies' worth of the 50 M-observation problem
+        refl_all = _np(BaseModel.get_refl_id(inputs)).reshape(-1)
+        image_all = _np(BaseModel.get_image_id(inputs)).reshape(-1)
+        meta_all = _np(BaseModel.get_metadata(inputs))
+        meta_all = meta_all.reshape(len(refl_all), -1)
+        iobs_all = _np(BaseModel.get_intensities(inputs)).reshape(-1)
+        sig_all = _np(BaseModel.get_uncertainties(inputs)).reshape(-1)
+        self.N_total = int(len(refl_all))
         stop = self.N_total if stop is None else stop
         self.laue = BaseModel.is_laue(inputs)
         self.rows = None                      # explicit row list when the shard is not a contiguous range
         if self.laue and laue_groups is not None:
-            hid_all = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1).astype(np.int64)
+            hid_all = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1)
             g0, g1, pad0, pad1 = laue_groups
             self.rows = np.nonzero((hid_all >= g0) & (hid_all < g1))[0]
             sl = self.rows
@@ -298,21 +311,22 @@ class ObsData:
             # per-slot arrays of this shard: its own groups first, then its share of the padded slots (formatter.py:637-640)
             slot_idx = np.concatenate([np.arange(g0, g1), np.arange(pad0, pad1)])
             assert len(slot_idx) == len(self.rows)
-            iobs_l, sig_l = iobs[slot_idx], sig[slot_idx]
+            iobs_l, sig_l = iobs_all[slot_idx].astype(np.float32), sig_all[slot_idx].astype(np.float32)
         else:
             sl = slice(start, stop)
-            iobs_l, sig_l = iobs[sl], sig[sl]
+            iobs_l, sig_l = iobs_all[sl].astype(np.float32), sig_all[sl].astype(np.float32)
         self.start, self.N = int(start), int(stop - start)
         if self.N <= 0:
             raise ValueError("empty observation shard")
-        if n_refl is not None and refl_id.size and (refl_id.min() < 0 or refl_id.max() >= n_refl):
+        if n_refl is not None and refl_all.size and (refl_all.min() < 0 or refl_all.max() >= n_refl):
             raise ValueError("refl_id outside the range of the surrogate posterior")
-        if n_images is not None and image_id.size and image_id.max() >= n_images:
+        if n_images is not None and image_all.size and image_all.max() >= n_images:
             raise ValueError("image_id exceeds ImageScaler.max_images")
+        metadata = _ShardRows(meta_all, sl)       # metadata[sl] -> this shard's rows as float32
         self.d = int(metadata.shape[1])
         self.tile_img = self.row_map = self.gmeta = self.tile_gmax = None
         self.fused_laue = False
-        rid_l, img_l = refl_id[sl].astype(np.int32), image_id[sl].astype(np.int32)
+        rid_l, img_l = refl_all[sl].astype(np.int32), image_all[sl].astype(np.int32)
         lp = None
         if self.laue:
             hid_all0 = _np(BaseModel.get_harmonic_id(inputs)).reshape(-1).astype(np.int64)
@@ -668,6 +682,22 @@ class ElboEngine:
             a.ev11 = self.params.data_ptr() + 4 * lay.off_ev11
             a.d_ev11 = self.grads.data_ptr() + 4 * lay.off_ev11
         return a
+
+    def kernel_name(self, mode: int = 0) -> str:
+        """Name of the kernel instance the scaler launches of this engine run (`cl_mlp_kernel_name`: the library's own routing):
+        what a rocprofv3 kernel trace lists for the dominant kernel."""
+        if self.wide:
+            return "wide_gemm_kernel"
+        ma = self._mlp_args(0, None, None, self.obs)
+        if self.blocks is not None:
+            ma = self._block_args(ma, self.obs, len(self.blocks) - 1)
+            ma.dX_out = ptr(self.obs.chain_dact[len(self.blocks) - 2])
+        elif self.laue and not self.obs.fused_laue:
+            mode = 2 if mode == 0 else mode
+            ma.dO_ext = ptr(self.obs.laue_dO)
+        buf = C.create_string_buffer(128)
+        check(min(0, self.lib.cl_mlp_kernel_name(C.byref(ma), mode, buf, 128)), "cl_mlp_kernel_name")
+        return buf.value.decode()
 
     def _w_ll(self, obs: ObsData) -> float:
         """Weight of one log-likelihood term: sum / S, or with `kl_weight` the mean over the S x N terms of the observation set

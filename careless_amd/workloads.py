@@ -23,6 +23,9 @@ WORKLOADS: Dict[str, dict] = {
     "dw_50M_normal_5x64_S1": dict(N=50_000_000, d0=5, posenc=False, L=5, w=64, S=1, dof=None, outliers=False, kind="double_wilson"),
     # the careless CLI defaults: --mlp-layers 20 --mlp-width 10 (args/scaling.py), Normal likelihood, mc-samples 1
     "mono_10M_cli_default_20x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False),
+    # configs[2]'s data (Student-T, positional encodings of X, Y: 5 + 16 metadata columns, mc-samples 8) on the CLI-default scaler:
+    # what `careless mono --positional-encoding-keys X,Y --studentt-likelihood-dof 16 --mc-samples 8` runs
+    "mono_10M_studentt_posenc_20x10_S8": dict(N=10_000_000, d0=5, posenc=True, L=20, w=10, S=8, dof=16.0, outliers=True),
     # half the default depth (register-pressure experiments on the narrow kernel)
     "mono_10M_10x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=10, w=10, S=1, dof=None, outliers=False),
     # --image-layers 1 on the headline configuration (one Dense layer traded for a per-image layer)
@@ -44,9 +47,9 @@ def bytes_per_obs(d: int, S: int, image_scales: bool = True) -> int:
 
 def reference_inputs(data) -> Tuple[np.ndarray, ...]:
     """`inputs` in BaseModel.input_index order with the reference's shapes and dtypes (formatter.py:382-394)."""
-    col = lambda a, t: np.asarray(a).astype(t)[:, None]
+    col = lambda a, t: np.asarray(a).astype(t, copy=False)[:, None]       # (views: the arrays may be memory maps shared by the ranks)
     return (col(data["refl_id"], np.int64), col(data["image_id"], np.int64), col(data["file_id"], np.int64),
-            np.asarray(data["metadata"], dtype=np.float32), col(data["iobs"], np.float32), col(data["sigiobs"], np.float32))
+            np.asarray(data["metadata"]).astype(np.float32, copy=False), col(data["iobs"], np.float32), col(data["sigiobs"], np.float32))
 
 
 def build_model(data, L: int, w: int, S: int, dof: Optional[float] = None, image_scales: bool = True,
@@ -84,19 +87,63 @@ def build_model(data, L: int, w: int, S: int, dof: Optional[float] = None, image
     return model
 
 
-def make_workload(name: str, N: Optional[int] = None, seed: int = 1234):
-    """Returns (model, inputs, data, spec) for a named workload; `N` overrides the observation count (bounded samples)."""
+def _generate(spec: dict, seed: int) -> dict:
+    kind = spec["kind"]
+    if kind == "laue":
+        return make_synthetic_laue(spec["N"], seed=seed)
+    if kind == "double_wilson":
+        return make_synthetic_double_wilson(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
+    return make_synthetic(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
+
+
+def _share_save(data: dict, path: str) -> None:
+    """Rank 0: every array of the problem as a `.npy` file under `path` (a directory in /dev/shm), scalars in a manifest."""
+    import json
+    import os
+    os.makedirs(path, exist_ok=True)
+    scalars = {}
+    for k, v in data.items():
+        if isinstance(v, np.ndarray):
+            np.save(os.path.join(path, k + ".npy"), v)
+        else:
+            scalars[k] = v if not isinstance(v, np.generic) else v.item()
+    with open(os.path.join(path, "manifest.json.tmp"), "w") as f:
+        json.dump(scalars, f)
+    os.replace(os.path.join(path, "manifest.json.tmp"), os.path.join(path, "manifest.json"))
+
+
+def _share_load(path: str) -> dict:
+    """Any rank: the problem as read-only memory maps of rank 0's files (pages are shared between the ranks of the node)."""
+    import json
+    import os
+    with open(os.path.join(path, "manifest.json")) as f:
+        data = json.load(f)
+    for fn in os.listdir(path):
+        if fn.endswith(".npy"):
+            data[fn[:-4]] = np.load(os.path.join(path, fn), mmap_mode="r")
+    return data
+
+
+def make_workload(name: str, N: Optional[int] = None, seed: int = 1234, rank: int = 0, world: int = 1, share_dir: Optional[str] = None,
+                  barrier=None):
+    """Returns (model, inputs, data, spec) for a named workload; `N` overrides the observation count (bounded samples).
+    With `world > 1` and a `share_dir` (a directory every rank of the node sees, e.g. under /dev/shm) only rank 0 runs the
+    generator -- its peak is ~250 B per observation -- and writes the arrays there; after `barrier()` every rank (rank 0 too: it
+    drops its in-memory copy) maps the files read-only, so the node holds ONE copy of the inputs instead of `world` generator
+    peaks (configs[4]: 50 M observations x 8 ranks).  The engine copies only its own shard's rows (`engine.ObsData`)."""
     spec = dict(WORKLOADS[name])
     if N is not None:
         spec["N"] = int(N)
     kind = spec.setdefault("kind", "mono")
     spec.setdefault("image_layers", 0)
-    if kind == "laue":
-        data = make_synthetic_laue(spec["N"], seed=seed)
-    elif kind == "double_wilson":
-        data = make_synthetic_double_wilson(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
+    if world > 1 and share_dir is not None:
+        if rank == 0:
+            _share_save(_generate(spec, seed), share_dir)
+        if barrier is not None:
+            barrier()
+        data = _share_load(share_dir)
     else:
-        data = make_synthetic(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
+        data = _generate(spec, seed)
     model = build_model(data, spec["L"], spec["w"], spec["S"], dof=spec["dof"], kind=kind, image_layers=spec["image_layers"])
     inputs = reference_inputs(data)
     if kind == "laue":

@@ -175,6 +175,10 @@ int cl_mlp_meta_rows(int d);                         /* rows of meta_t: d rounde
 int cl_elbo_mono_fwd_bwd(const cl_mlp_args* args, int grid, void* stream);
 int cl_mlp_forward(const cl_mlp_args* args, int grid, void* stream);
 int cl_mlp_backward_ext(const cl_mlp_args* args, int grid, void* stream);
+/* Diagnostics: the name of the kernel instance the three calls above run for these arguments (mode 0 = cl_elbo_mono_fwd_bwd,
+ * 1 = cl_mlp_forward, 2 = cl_mlp_backward_ext), e.g. "elbo_lane_kernel<10, 0, false>": what a rocprofv3 kernel trace lists.
+ * Writes at most n bytes (NUL-terminated), returns the length of the name or < 0 for bad arguments.  No reference counterpart. */
+int cl_mlp_kernel_name(const cl_mlp_args* args, int mode, char* out, size_t n);
 /* grad_mlp[P] += sum over the `nparts` workgroup partials, in index order (deterministic) */
 int cl_reduce_partials(const float* partials, int nparts, int P, float* grad_mlp, const int* stop_flag, void* stream);
 

@@ -10,5 +10,8 @@ for u in "cl_api: " "elbo_mlp:-DCL_IMGL=0" "elbo_mlp_imgl:-DCL_IMGL=1" "elbo_mlp
 done
 wait
 fi
-hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c elbo_lane.hip -o /tmp/t/lexp/$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|AGPRs|VGPRs Spill|ScratchSize" | sed 's/.*remark: *//;s/\[-Rpass.*//' | paste - - - - - -
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/exp_$name.so $B/*.o /tmp/t/lexp/$name.o && echo built exp_$name.so
+for part in 0 1 2 3; do
+  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -mllvm -amdgpu-mfma-vgpr-form=1 -DCL_LANE_PART=$part "$@" -c elbo_lane.hip -o /tmp/t/lexp/$name.$part.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|AGPRs|VGPRs Spill|ScratchSize" | sed 's/.*remark: *//;s/\[-Rpass.*//' | paste - - - - - - | sort | uniq -c &
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/exp_$name.so $B/*.o /tmp/t/lexp/$name.[0-3].o && echo built exp_$name.so

@@ -18,7 +18,7 @@ STUB = textwrap.dedent("""
     mode = sys.argv[sys.argv.index("--workload") + 1]
     if mode == "die" and rank == 1:
         sys.exit(3)
-    if mode == "die":                        # rank 0 would wait for rank 1 forever: the parent has to end it
+    if mode in ("die", "hang"):              # rank 0 would wait (for rank 1 / in a collective) forever: the parent has to end it
         import time; time.sleep(600)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)])
@@ -27,18 +27,21 @@ STUB = textwrap.dedent("""
     dist.barrier(); dist.destroy_process_group()
     print("noise on stdout of rank", rank)
     if rank == 0:
-        print(json.dumps({"n_gpus": world, "ranks_seen": seen, "sum": float(t), "local_rank": os.environ["LOCAL_RANK"]}))
+        out = {"n_gpus": world, "ranks_seen": seen, "sum": float(t), "local_rank": os.environ["LOCAL_RANK"]}
+        if mode == "extra_skipped":
+            out["extra_failed"] = "dw_50M_normal_5x64_S1 skipped (host memory)"
+        print(json.dumps(out))
 """)
 
 
-def _launch(tmp_path, mode, n=2):
+def _launch(tmp_path, mode, n=2, extra_args=()):
     stub = tmp_path / "stub_rank.py"
     stub.write_text(STUB)
     code = textwrap.dedent(f"""
         import sys
         sys.path.insert(0, {ROOT!r})
         import bench
-        argv = ["--gpus", "{n}", "--workload", "{mode}"]
+        argv = ["--gpus", "{n}", "--workload", "{mode}"] + {list(extra_args)!r}
         sys.exit(bench.launch(bench.parse(argv), argv, script={str(stub)!r}))
     """)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
@@ -59,6 +62,16 @@ def test_launcher_fails_when_a_rank_dies_or_the_world_is_short(tmp_path):
     assert r.returncode != 0 and "rank 1 exited with code 3" in r.stderr and not r.stdout.strip()
     r = _launch(tmp_path, "lie")
     assert r.returncode != 0 and "asked for 2 ranks" in r.stderr and not r.stdout.strip()
+
+
+def test_launcher_times_out_and_reports_an_unmeasured_extra_configuration(tmp_path):
+    """Ranks stuck in mismatched collectives must not hold the launcher forever (--launch-timeout); a line whose extra configuration
+    (the one BASELINE.json quotes at this GPU count) was skipped or failed is relayed, but the exit code is non-zero."""
+    r = _launch(tmp_path, "hang", extra_args=("--launch-timeout", "3"))
+    assert r.returncode != 0 and "--launch-timeout" in r.stderr and not r.stdout.strip()
+    r = _launch(tmp_path, "extra_skipped")
+    assert r.returncode != 0 and "extra configuration not measured" in r.stderr
+    assert json.loads(r.stdout.strip())["extra_failed"].startswith("dw_50M")
 
 
 def test_worker_refuses_a_world_that_is_not_gpus(monkeypatch):

@@ -79,6 +79,43 @@ def test_two_rank_shards_sum_to_full_batch():
     assert hist[1, 0] == 0.0 and hist[1, 4] == 1.0      # a skipped record keeps its (zero) loss; the flag column is not summed
 
 
+def _share_worker(rank, world, port, share_dir, q):
+    from careless_amd.workloads import make_workload
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the host side of the multi-GPU bench: rank 0 generates, every rank maps the files (no GPU: the model objects are descriptions)
+    model, inputs, data, spec = make_workload("dw_50M_normal_5x64_S1", N=20_000, rank=rank, world=world, share_dir=share_dir,
+                                              barrier=dist.barrier)
+    mapped = all(isinstance(data[k], np.memmap) for k in ("refl_id", "metadata", "iobs", "parent_ids"))
+    views = all(np.shares_memory(a, data[k]) for a, k in zip((inputs[0], inputs[3], inputs[4]), ("refl_id", "metadata", "iobs")))
+    q.put((rank, mapped, views, int(np.asarray(inputs[0]).sum()), float(np.asarray(inputs[3], dtype=np.float64).sum()), spec["R"], spec["d"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_share_one_generated_problem_through_memory_maps(tmp_path):
+    """bench.py --gpus N: only rank 0 runs the synthetic generator; every rank maps its files read-only and builds the `inputs`
+    tuple as views of the maps (careless_amd/workloads.py: make_workload(share_dir=...)), so a node holds one copy of the problem."""
+    from careless_amd.workloads import make_workload
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    share = str(tmp_path / "share")
+    procs = [ctx.Process(target=_share_worker, args=(r, world, port, share, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, inputs, data, spec = make_workload("dw_50M_normal_5x64_S1", N=20_000)
+    want = (int(np.asarray(inputs[0]).sum()), float(np.asarray(inputs[3], dtype=np.float64).sum()), spec["R"], spec["d"])
+    for rank, mapped, views, *rest in got:
+        assert mapped and views and tuple(rest) == want, (rank, mapped, views, rest, want)
+
+
 def test_make_shard_never_hands_out_an_empty_range():
     """Every rank of a data-parallel job owns at least one observation (an idle rank would meet the others only inside the
     collective); impossible splits raise on every rank alike."""

@@ -57,6 +57,18 @@ CASES = {
     "lane_20x9_d1_three_observations": dict(N=3, R=2, d0=1, L=20, w=9, S=1, n_images=1, use_image_scales=False, perturb=0.02),
     "lane_laue_single_pass_20x10_S2": dict(N=900, R=40, L=20, w=10, S=2, laue=True, perturb=0.02, grid=2),
     "lane_laue_single_pass_20x6_S1_ev11": dict(N=600, R=40, L=20, w=6, S=1, laue=True, ev11=True, perturb=0.02),
+    # ... with 16 .. 31 metadata columns (positional encodings: + 16 columns; the rows of a tile then live in LDS, layer 0 has two
+    # input blocks) and with more than eight MC samples (batches of eight through LDS)
+    "lane_20x10_d21_S8_studentt": dict(N=900, R=50, d0=5, posenc=True, L=20, w=10, S=8, likelihood="studentt", dof=16.0, outliers=True, perturb=0.02, grid=2),
+    "lane_20x10_d31_S3": dict(N=700, R=40, d0=31, L=20, w=10, S=3, perturb=0.02, grid=2),
+    "lane_20x10_d16_S1_softplus": dict(N=500, R=40, d0=16, L=20, w=10, S=1, bijector="softplus", shift=1.5, perturb=0.02),
+    "lane_20x4_d29_S2_ev11": dict(N=333, R=30, d0=29, L=20, w=4, S=2, ev11=True, perturb=0.02),
+    "lane_20x7_d24_S12_klweight": dict(N=600, R=40, d0=24, L=20, w=7, S=12, kl_weight=0.5, likelihood="studentt", dof=8.0, perturb=0.02),
+    "lane_20x10_S12": dict(N=500, R=40, d0=5, L=20, w=10, S=12, perturb=0.02),
+    "lane_20x10_S17_studentt_noimg": dict(N=300, R=30, d0=9, L=20, w=10, S=17, likelihood="studentt", dof=6.0, use_image_scales=False, perturb=0.02),
+    "lane_laue_single_pass_20x10_S11": dict(N=700, R=40, L=20, w=10, S=11, laue=True, perturb=0.02, grid=2),
+    "lane_laue_single_pass_20x8_d22_S3": dict(N=900, R=40, L=20, w=8, S=3, laue=True, extra_meta=16, perturb=0.02, grid=2),
+    "lane_d21_three_observations": dict(N=3, R=2, d0=21, L=20, w=10, S=2, n_images=1, use_image_scales=False, perturb=0.02),
     "narrow_one_layer_w9_d1": dict(N=333, R=30, d0=1, L=1, w=9, S=1, perturb=0.03),
     "narrow_laue_single_pass_7x6_S1_ev11": dict(N=600, R=40, L=7, w=6, S=1, laue=True, ev11=True, perturb=0.03),
     "image_layers2_3x8": dict(N=800, R=40, d0=5, L=3, w=8, S=2, n_images=5, image_layers=2, perturb=0.03),
@@ -236,8 +248,43 @@ def _random_lane_cases(n=14, seed=2024):
     return cases
 
 
+def _random_lane_rows_cases(n=8, seed=77):
+    """The same for the part of the lane kernel's support that round 3 added: 16 .. 31 metadata columns (rows of an LDS buffer, two
+    input blocks of layer 0) and up to 20 MC samples (batches of eight)."""
+    rng = np.random.default_rng(seed)
+    cases = {}
+    for i in range(n):
+        laue = bool(i % 4 == 3)
+        w = int(rng.integers(1, 11)); S = int(rng.integers(1, 21)); d = int(rng.integers(16, 32))
+        kw = dict(N=int(rng.integers(3, 1100)), R=int(rng.integers(2, 60)), L=20, w=w, S=S, perturb=0.02)
+        if laue:
+            kw.update(laue=True, extra_meta=d - 6)
+            kw["N"] = max(kw["N"], 100)
+        else:
+            kw["d0"] = d
+            if rng.random() < 0.3:
+                kw["shuffle_rows"] = True
+                kw["n_images"] = int(rng.integers(2, 12))
+        if rng.random() < 0.5:
+            kw.update(likelihood="studentt", dof=float(rng.choice([3.0, 8.0, 32.0])))
+        if rng.random() < 0.3:
+            kw["ev11"] = True
+        if rng.random() < 0.3:
+            kw.update(bijector="softplus", shift=float(rng.choice([0.0, 1.5])))
+        if rng.random() < 0.25:
+            kw["kl_weight"] = 0.5
+        if rng.random() < 0.3:
+            kw["use_image_scales"] = False
+        if rng.random() < 0.5:
+            kw["grid"] = int(rng.integers(1, 4))
+        kw["R"] = min(kw["R"], kw["N"])
+        cases[f"lane_rows_random_{i:02d}_20x{w}_S{S}_d{d}" + ("_laue" if laue else "")] = kw
+    return cases
+
+
 # (a longer sweep on demand: LANE_RANDOM_N=200 LANE_RANDOM_SEED=7 python -m pytest tests/test_gpu_parity.py -k random_shapes)
 RANDOM_LANE_CASES = _random_lane_cases(int(os.environ.get("LANE_RANDOM_N", "14")), int(os.environ.get("LANE_RANDOM_SEED", "2024")))
+RANDOM_LANE_CASES.update(_random_lane_rows_cases(int(os.environ.get("LANE_ROWS_RANDOM_N", "8")), int(os.environ.get("LANE_ROWS_RANDOM_SEED", "77"))))
 
 
 @pytest.mark.parametrize("name", list(RANDOM_LANE_CASES))
@@ -436,7 +483,8 @@ def test_philox_mode_on_the_narrow_kernel_with_twelve_samples():
     assert max(errs) < RTOL_GRAD, errs
 
 
-@pytest.mark.parametrize("S,w,d0", [(8, 10, 5), (5, 6, 12), (1, 10, 5)], ids=["S8_20x10", "S5_20x6_d12", "S1_20x10"])
+@pytest.mark.parametrize("S,w,d0", [(8, 10, 5), (5, 6, 12), (1, 10, 5), (8, 10, 21), (13, 8, 27)],
+                         ids=["S8_20x10", "S5_20x6_d12", "S1_20x10", "S8_20x10_d21", "S13_20x8_d27"])
 def test_philox_mode_on_the_lane_kernel(S, w, d0):
     """The lane-per-observation kernel (20 layers) with in-kernel noise: every lane walks its observation's samples serially, samples
     s and s + 4 share a Box-Muller pair, the amplitudes of samples 1 .. 7 arrive through LDS and the amplitude gradients leave
@@ -704,8 +752,14 @@ def test_freeze_flags_and_early_stop():
                                 dict(N=700, R=40, d0=5, L=2, w=32, S=2, n_images=5, image_layers=1),
                                 dict(N=600, R=40, d0=5, L=12, w=32, S=2),
                                 dict(N=600, R=50, L=2, w=32, S=2, laue=True, image_layers=1, n_images=4),
-                                dict(N=900, R=40, d0=5, L=20, w=10, S=2, perturb=0.02)],
-                         ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers", "cli_default_20x10"])
+                                dict(N=900, R=40, d0=5, L=20, w=10, S=2, perturb=0.02),
+                                dict(N=700, R=40, d0=5, posenc=True, L=20, w=10, S=9, likelihood="studentt", dof=8.0, perturb=0.02),
+                                dict(N=600, R=40, d0=5, L=2, w=32, S=3, ev11=True, likelihood="studentt", dof=6.0),
+                                dict(N=500, R=60, d0=5, L=2, w=32, S=2, double_wilson=True, optimize_dw_r=True),
+                                dict(N=600, R=40, d0=5, L=2, w=96, S=2),
+                                dict(N=600, R=50, L=2, w=32, S=2, laue=True, ev11=True)],
+                         ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers", "cli_default_20x10",
+                              "cli_default_posenc_d21_S9", "ev11", "trainable_double_wilson_r", "wide_2x96", "laue_ev11"])
 def test_rank_shards_sum_to_full_batch_on_gpu(kw):
     """Data-parallel decomposition on ONE GPU: the engines of rank 0 and rank 1 of a 2-rank world (all-reduce skipped) produce
     partial losses / gradients that add up to the single-rank result; in-kernel noise is keyed by global indices, so the shards

@@ -279,3 +279,32 @@ def test_pack_by_image_and_pack_laue_layouts():
         else:
             assert tile_img is None
     assert pack_laue(np.zeros(17, int), np.zeros(17, int), False) is None      # a group larger than a wave: two-pass path
+
+
+def test_kernel_name_follows_the_librarys_routing():
+    """`cl_mlp_kernel_name` restates `cl_launch_mlp`'s routing inside the library (bench.py labels its roofline row with it): the
+    CLI-default scaler runs lane-per-observation up to 31 metadata columns and any number of MC samples, other depths / widths 11-15
+    on the narrow kernel, everything else on the 16- / 32- / 64-wide fused instances.  Host function: no GPU needed."""
+    import ctypes as C
+    from careless_amd import _lib
+    lib = _lib.get_lib()
+
+    def name(mode=0, **kw):
+        a = _lib.MlpArgs()
+        for k, v in kw.items():
+            setattr(a, k, v)
+        buf = C.create_string_buffer(128)
+        n = lib.cl_mlp_kernel_name(C.byref(a), mode, buf, 128)
+        assert n == len(buf.value)
+        return buf.value.decode()
+
+    assert name(d=5, w=10, L=20, S=1) == "elbo_lane_kernel<10, 8, false>"
+    assert name(d=12, w=7, L=20, S=3) == "elbo_lane_kernel<8, 15, false>"
+    assert name(d=21, w=10, L=20, S=8) == "elbo_lane_kernel<10, 0, false>"          # positional encodings: rows of an LDS buffer
+    assert name(d=31, w=4, L=20, S=40, row_map=1) == "elbo_lane_kernel<4, 0, true>"
+    assert name(d=32, w=10, L=20, S=1).startswith("elbo_mlp_kernel<16, 32, 20, 0")
+    assert name(d=5, w=13, L=12, S=8) == "elbo_narrow_kernel<2, 4, 8, false>"
+    assert name(d=21, w=64, L=5, S=8) == "elbo_mlp_kernel<64, 32, 5, 0, KS=4>"
+    assert name(d=21, w=64, L=5, S=8, mode=1) == "elbo_mlp_kernel<64, 32, 5, 1, KS=4>"
+    assert name(d=5, w=10, L=20, S=1, act_out=1, mode=1).startswith("elbo_mlp_kernel<16, 8, 20, 1, chain")
+    assert lib.cl_mlp_kernel_name(None, 0, C.create_string_buffer(8), 8) < 0

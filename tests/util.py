@@ -9,7 +9,7 @@ from oracle import elbo_oracle as O
 
 def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, likelihood="normal", dof=None,
                  bijector="exp", shift=0.0, use_image_scales=True, kl_weight=None, perturb=0.05, seed=7,
-                 outliers=False, double_wilson=False, laue=False, ev11=False, optimize_dw_r=False, image_layers=0, **opt):
+                 outliers=False, double_wilson=False, laue=False, ev11=False, optimize_dw_r=False, image_layers=0, extra_meta=0, **opt):
     if image_layers > 0:
         use_image_scales = False        # NeuralImageScaler replaces the HybridImageScaler (manager.py:467-489)
         opt["image_layers"] = image_layers
@@ -20,6 +20,9 @@ def make_problem(N=300, R=40, d0=5, posenc=False, n_images=4, L=2, w=32, S=3, li
                                               outliers=outliers)
     else:
         data = O.make_synthetic(N, R=R, d0=d0, posenc=posenc, n_images=n_images, seed=seed, outliers=outliers)
+    if extra_meta:                      # more metadata columns than the generator makes (Laue data with positional encodings)
+        more = np.random.default_rng(seed + 5).normal(size=(N, extra_meta)).astype(np.float32)
+        data["metadata"] = np.concatenate([np.asarray(data["metadata"], dtype=np.float32), more], axis=1)
     cfg = O.ElboConfig(mc_samples=S, likelihood=likelihood, dof=dof, scale_bijector=bijector, scale_shift=shift,
                        use_image_scales=use_image_scales, kl_weight=kl_weight,
                        prior="double_wilson" if double_wilson else "wilson", laue=laue, ev11=ev11, optimize_dw_r=optimize_dw_r, **opt)
