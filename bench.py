@@ -283,12 +283,15 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     # the fused scaler kernel, one launch per step (mono, single-pass Laue), or forward + backward launches around the
     # harmonic sums (two-pass Laue fallback)
     timed_names = ("cl_elbo_mono_fwd_bwd", "cl_mlp_forward", "cl_mlp_backward_ext")
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps * 2)]
+    if eng.wide:                    # width > 64: the layer-by-layer GEMM launches of csrc/wide_gemm.hip are the dominant kernels
+        timed_names = ("cl_wide_dense_forward", "cl_wide_dense_dgrad", "cl_wide_dense_wgrad", "cl_wide_head_forward", "cl_wide_head_backward")
+    ev = []
     slot = {"i": 0}
 
     def timed(fn):
         def call(*a):
-            e0, e1 = ev[slot["i"]]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev.append((e0, e1))
             e0.record()
             rc = fn(*a)
             e1.record()
@@ -346,7 +349,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
                    "image_layers": spec.get("image_layers", 0), "noise": "in-kernel philox",
                    "parallelism": f"obs-shard x{world}" if world > 1 else "single",
                    "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
-        "roofline": {"bound": "mfma", "kernel": (kernel_name + " (" + ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd") + ")"),
+        "roofline": {"bound": "mfma", "kernel": (kernel_name + " (" + ("cl_wide_* GEMM launches" if eng.wide else ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd")) + ")"),
                      "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
                      "traffic": traffic_bytes(name, world), "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
                      "achieved_on_step_time": achieved_step, "frac_on_step_time": achieved_step / 157.3,

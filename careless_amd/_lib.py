@@ -115,6 +115,14 @@ EXPORTS = {
     "cl_mlp_forward": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
     "cl_mlp_backward_ext": (C.c_int, [C.POINTER(MlpArgs), C.c_int, _vp]),
     "cl_mlp_kernel_name": (C.c_int, [C.POINTER(MlpArgs), C.c_int, C.c_char_p, C.c_size_t]),
+    "cl_wide_ld": (C.c_int, [C.c_int]),
+    "cl_wide_dense_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_dense_dgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_wgrad_splits": (C.c_int, [C.c_longlong]),
+    "cl_wide_dense_wgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_head_forward": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
+    "cl_wide_head_blocks": (C.c_int, [C.c_longlong]),
+    "cl_wide_head_backward": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_float, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
     "cl_laue_predict": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_laue_likelihood": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_laue_backward": (C.c_int, [C.POINTER(LaueArgs), _vp]),

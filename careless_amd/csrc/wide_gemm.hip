@@ -1,0 +1,579 @@
+// Scalers wider than the fused kernels hold (hidden or metadata width > 64): the Dense stack of `MLPScaler` layer by layer on
+// hand-written fp32-MFMA GEMM kernels (gfx950 / CDNA4 only), activations through HBM.
+//
+// Reference: `MetadataScaler.call` / `NormalLayer` (careless/models/scaling/nn.py:55-68, 92-120) and `tape.gradient` of it
+// (careless/models/merging/variational.py:197-202): h_l = LeakyReLU(h_{l-1} W_l + b_l), o = h_L W_o + b_o.  The reference takes any
+// width; up to 64 the whole stack runs inside ONE launch with nothing per-observation in HBM (elbo_mlp.hip).  Past that a
+// layer's activations of a 128-observation tile no longer fit a wave's registers next to its weight-gradient blocks, so the
+// layers run one GEMM each, in row chunks (engine._data_term_wide), around the same likelihood kernels as the two-pass Laue path.
+//
+// One kernel template, v_mfma_f32_16x16x4_f32 (exact fp32: the parity bar of the narrow path holds here too), three uses:
+//   forward   Y[n][out]  = LeakyReLU(X[n][in] Wt[out][in]^T + b)                 A, B contraction-contiguous      epilogue: bias, LeakyReLU
+//   dgrad     dX[n][in]  = (dZ[n][out] Wt[out][in]) * LeakyReLU'(H[n][in])       B contraction-major              epilogue: derivative mask
+//   wgrad     dWt[out][in] = dZ[n][out]^T H[n][in], db = column sums of dZ     A, B contraction-major, split over the observations:
+//                                   every workgroup writes its partial sums in the layer's flat W^T layout; cl_reduce_partials
+//                                   adds them in index order (deterministic, as for the fused kernels)
+// Activation buffers are row-major [rows][ld] with ld = the width rounded up to 4.
+// Tiled kernel (any width; the weight gradient always): 128 x 128 (or 64) outputs per 256-thread workgroup (4 waves, 32 rows each), 32-deep
+// contraction chunks through double-buffered LDS; an operand stored contraction-contiguous is staged [row][32 + 4] and read as one
+// ds_read_b128 per four MFMA steps, one stored contraction-major is staged [32][rows + 4] and read as four ds_read_b32.
+// Streaming kernel (forward and dgrad of layers up to 128 x 128 -- widths 65 .. 128, the range past the fused kernels that matters):
+// the layer's weights stay in LDS for the whole launch, every wave walks 16-row blocks on its own -- its rows' operand straight from
+// global memory into the MFMA B-operand layout (one float4 per lane and 16-deep chunk, the next block's in flight), the transposed
+// output tile in accumulators, one float4 store per lane and 16 output columns -- with no workgroup barrier in the loop.
+// Roofline: the layers are unfused, so a layer moves 4 (in + out) bytes per observation for 2 in out flops -- at width 128 that is
+// 32 flop / B against a ridge of 19.7: HBM and the fp32 matrix rate bind about equally; 8 P_mm flops per observation in all
+// (forward, recomputed forward, dgrad, wgrad).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include "cl_math.h"
+#include "cl_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 128, BK = 32;
+constexpr int PK = BK + 4;          // pitch of a contraction-contiguous tile [rows][BK]
+constexpr int PMA = BM + 4;         // pitch of a contraction-major tile [BK][rows] (rows + 4: the four k-groups of a b32 read hit different banks)
+constexpr int SA = (BM * PK > BK * PMA) ? BM * PK : BK * PMA;
+
+enum { EPI_BIAS_LRELU = 0, EPI_DLRELU = 1, EPI_WGRAD = 2 };
+
+struct GemmArgs {
+    const float* A; int lda;        // not AK: A[m][k] at A[m * lda + k];  AK: A[k][m] at A[k * lda + m]
+    const float* B; int ldb;        // not BK_: B[n][k] at B[n * ldb + k]; BK_: B[k][n] at B[k * ldb + n]
+    float* C; int ldc;              // C[m][n] (EPI_WGRAD: the layer's flat W^T slice of this workgroup's partial)
+    int M, N, K;
+    const float* bias;              // EPI_BIAS_LRELU: [N]
+    const float* H; int ldh;        // EPI_DLRELU: activations whose sign selects the derivative, H[m][n]
+    float leak;
+    int act;                        // EPI_BIAS_LRELU: 0 = no activation
+    int ksplit;                     // EPI_WGRAD: contraction range of a z-block; partial stride (floats)
+    long long pstride;
+    int n_in;                       // EPI_WGRAD: N = n_in (the bias gradient = column sums of A, taken on the way)
+    const int* stop_flag;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// global -> registers: one tile of an operand (ROWS x BK), zero outside [0, rows_lim) x [0, k_lim)
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int row0, int k0, int rows_lim, int k_lim, bool vec_ok,
+                                          f32x4 (&r)[ROWS * BK / 1024], int tid) {
+    constexpr int NV = ROWS * BK / 1024;          // float4 per thread
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int idx = v * 256 + tid;
+        int row, k;
+        if (!KMAJOR) { row = row0 + idx / (BK / 4); k = k0 + 4 * (idx % (BK / 4)); }          // 8 threads per row: 128 contiguous bytes
+        else { k = k0 + idx / (ROWS / 4); row = row0 + 4 * (idx % (ROWS / 4)); }              // ROWS / 4 threads per contraction index
+        f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!KMAJOR) {
+            if (row < rows_lim) {
+                const float* p = P + (size_t)row * ld + k;
+                if (vec_ok && k + 3 < k_lim) x = *reinterpret_cast<const f32x4*>(p);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (k + e < k_lim) x[e] = p[e];
+                }
+            }
+        } else {
+            if (k < k_lim) {
+                const float* p = P + (size_t)k * ld + row;
+                if (vec_ok && row + 3 < rows_lim) x = *reinterpret_cast<const f32x4*>(p);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (row + e < rows_lim) x[e] = p[e];
+                }
+            }
+        }
+        r[v] = x;
+    }
+}
+
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&r)[ROWS * BK / 1024], int tid) {
+    constexpr int NV = ROWS * BK / 1024;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int idx = v * 256 + tid;
+        if (!KMAJOR) *reinterpret_cast<f32x4*>(s + (idx / (BK / 4)) * PK + 4 * (idx % (BK / 4))) = r[v];
+        else *reinterpret_cast<f32x4*>(s + (idx / (ROWS / 4)) * (ROWS + 4) + 4 * (idx % (ROWS / 4))) = r[v];
+    }
+}
+
+// BN: 64 or 128 output columns per workgroup (128: the row operand of a layer of width <= 128 is read once)
+template <bool AK, bool BK_, int EPI, int BN>
+__global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
+    if (G.stop_flag != nullptr && *G.stop_flag != 0) return;      // a previous step hit a non-finite gradient norm
+    constexpr int PMB = BN + 4, NB = BN / 16;
+    constexpr int SB = (BN * PK > BK * PMB) ? BN * PK : BK * PMB;
+    __shared__ __attribute__((aligned(16))) float sA[2][SA];
+    __shared__ __attribute__((aligned(16))) float sB[2][SB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int kbeg = 0, kend = G.K;
+    if (EPI == EPI_WGRAD) {
+        kbeg = (int)min((long long)blockIdx.z * G.ksplit, (long long)G.K);
+        kend = (int)min((long long)kbeg + G.ksplit, (long long)G.K);
+    }
+    const bool vecA = (G.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(G.A) & 15) == 0);
+    const bool vecB = (G.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(G.B) & 15) == 0);
+
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum = 0.0f;              // EPI_WGRAD: bias gradient of output unit m0 + tid = column sum of the A operand (dZ)
+
+    f32x4 ra[BM * BK / 1024], rb[BN * BK / 1024];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile<BM, AK>(G.A, G.lda, m0, kbeg, G.M, kend, vecA, ra, tid);
+        load_tile<BN, BK_>(G.B, G.ldb, n0, kbeg, G.N, kend, vecB, rb, tid);
+        store_tile<BM, AK>(sA[0], ra, tid);
+        store_tile<BN, BK_>(sB[0], rb, tid);
+    }
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nk) {           // the next chunk's global loads fly under this chunk's MFMAs
+            load_tile<BM, AK>(G.A, G.lda, m0, kbeg + (it + 1) * BK, G.M, kend, vecA, ra, tid);
+            load_tile<BN, BK_>(G.B, G.ldb, n0, kbeg + (it + 1) * BK, G.N, kend, vecB, rb, tid);
+        }
+        const float* a_s = sA[cur];
+        const float* b_s = sB[cur];
+#pragma unroll
+        for (int kc = 0; kc < BK / 16; ++kc) {
+            // MFMA step t of this 16-deep sub-chunk contracts k = 16 kc + 4 q + t (q = lane >> 4), the same map for both operands
+            f32x4 af[2], bf[NB];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int row = 32 * wv + 16 * a + j;
+                if (!AK) af[a] = *reinterpret_cast<const f32x4*>(a_s + row * PK + 16 * kc + 4 * q);
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) af[a][t] = a_s[(16 * kc + 4 * q + t) * PMA + row];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int col = 16 * b + j;
+                if (!BK_) bf[b] = *reinterpret_cast<const f32x4*>(b_s + col * PK + 16 * kc + 4 * q);
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) bf[b][t] = b_s[(16 * kc + 4 * q + t) * PMB + col];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[a][b] = mfma4(af[a][t], bf[b][t], acc[a][b]);
+        }
+        if (EPI == EPI_WGRAD && AK && blockIdx.y == 0 && tid < BM) {
+            // (the A tile is staged contraction-major: thread m sums its column over the chunk's 32 rows)
+#pragma unroll
+            for (int k = 0; k < BK; ++k) bsum += a_s[k * PMA + tid];
+        }
+        if (it + 1 < nk) {
+            store_tile<BM, AK>(sA[cur ^ 1], ra, tid);
+            store_tile<BN, BK_>(sB[cur ^ 1], rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: accumulator (a, b), element t of lane (j, q) = C[m0 + 32 wv + 16 a + 4 q + t][n0 + 16 b + j]
+    if (EPI == EPI_WGRAD && blockIdx.y == 0 && tid < BM && m0 + tid < G.M)
+        (G.C + (size_t)blockIdx.z * G.pstride)[(size_t)G.M * G.n_in + m0 + tid] = bsum;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int n = n0 + 16 * b + j;
+            if (n >= G.N) continue;
+            const float bias = (EPI == EPI_BIAS_LRELU) ? G.bias[n] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = m0 + 32 * wv + 16 * a + 4 * q + t;
+                if (m >= G.M) continue;
+                float v = acc[a][b][t];
+                if (EPI == EPI_BIAS_LRELU) {
+                    v += bias;
+                    if (G.act) v = fmaxf(v, G.leak * v);
+                    G.C[(size_t)m * G.ldc + n] = v;
+                } else if (EPI == EPI_DLRELU) {
+                    if (G.H != nullptr) v = (G.H[(size_t)m * G.ldh + n] > 0.0f) ? v : G.leak * v;
+                    G.C[(size_t)m * G.ldc + n] = v;
+                } else {
+                    // m = output unit, n = input feature; flat W^T layout [Wt (M x n_in) | b (M)]
+                    float* part = G.C + (size_t)blockIdx.z * G.pstride;
+                    part[(size_t)m * G.n_in + n] = v;
+                }
+            }
+        }
+}
+
+// Dense(2) head, forward: loc = h . Wo[0] + bo[0], sigma = bijector(h . Wo[1] + bo[1]) + eps   (nn.py:22-25, 84-87); a wave per 64 rows,
+// lane = row would stride the loads by ld: instead 16 lanes share a row (coalesced 64-byte pieces), 4 rows per wave pass
+__global__ __launch_bounds__(256) void wide_head_forward_kernel(const float* __restrict__ H, int ldh, const float* __restrict__ Wo, int n, int w,
+                                                                int bij_kind, float eps, float* __restrict__ loc_out, float* __restrict__ sig_out,
+                                                                const int* stop_flag) {
+    if (stop_flag != nullptr && *stop_flag != 0) return;
+    const int sub = threadIdx.x & 15;
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    float o0 = 0.0f, o1 = 0.0f;
+    if (row < n) {
+        const float* h = H + (size_t)row * ldh;
+        for (int k = sub; k < w; k += 16) {
+            const float x = h[k];
+            o0 = fmaf(x, Wo[k], o0);
+            o1 = fmaf(x, Wo[w + k], o1);
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) { o0 += __shfl_xor(o0, off); o1 += __shfl_xor(o1, off); }
+    if (row < n && sub == 0) {
+        float d;
+        loc_out[row] = o0 + Wo[2 * w];
+        sig_out[row] = cl_scale_bij(o1 + Wo[2 * w + 1], bij_kind, eps, &d);
+    }
+}
+
+// Dense(2) head, backward, from dL/d(loc, sigma) per row: dZ_L = (g Wo) * LeakyReLU'(h_L) per row, and this workgroup's partial
+// sums of dWo (2 x w), dbo (2) in the head's flat layout [Wo (2 x w) | bo (2)].  32 lanes share a row (one float4 each per 128
+// columns: whole 512-byte pieces), 8 rows per workgroup pass; the lane's columns of dWo accumulate in registers.
+// NP: 128-column passes an instance holds (width <= 128 NP)
+template <int NP>
+__global__ __launch_bounds__(256) void wide_head_backward_kernel(const float* __restrict__ H, int ldh, const float* __restrict__ Wo, const float* __restrict__ dO,
+                                                                 int n, int w, int bij_kind, float eps, float leak, int rows_per_block,
+                                                                 float* __restrict__ dZ, int lddz, float* __restrict__ partials, const int* stop_flag) {
+    if (stop_flag != nullptr && *stop_flag != 0) return;
+    extern __shared__ float sh[];                 // [8 row slots][2 w + 2]
+    const int sub = threadIdx.x & 31, slot = threadIdx.x >> 5;
+    const int P = 2 * w + 2;
+    f32x4 w0[NP], w1[NP], a0[NP], a1[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int c = 128 * p + 4 * sub;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            w0[p][e] = (c + e < w) ? Wo[c + e] : 0.0f;
+            w1[p][e] = (c + e < w) ? Wo[w + c + e] : 0.0f;
+            a0[p][e] = 0.0f; a1[p][e] = 0.0f;
+        }
+    }
+    const float bo1 = Wo[2 * w + 1];
+    float sb0 = 0.0f, sb1 = 0.0f;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(r0 + rows_per_block, (long long)n);
+    for (long long row = r0 + slot; row < r1; row += 8) {
+        f32x4 h[NP];
+        float o1 = 0.0f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c = 128 * p + 4 * sub;
+            h[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (c < ldh) h[p] = *reinterpret_cast<const f32x4*>(H + (size_t)row * ldh + c);      // (ld is a multiple of four, the padding columns are zero)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o1 = fmaf(h[p][e], w1[p][e], o1);
+        }
+        // raw sigma again (the forward pass kept sigma only): d sigma / d raw
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) o1 += __shfl_xor(o1, off);
+        float dsig_draw;
+        (void)cl_scale_bij(o1 + bo1, bij_kind, eps, &dsig_draw);
+        const float g0 = dO[2 * (size_t)row], g1 = dO[2 * (size_t)row + 1] * dsig_draw;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c = 128 * p + 4 * sub;
+            if (c < lddz && c < ((w + 3) & ~3)) {
+                f32x4 dz;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dh = g0 * w0[p][e] + g1 * w1[p][e];
+                    dz[e] = (h[p][e] > 0.0f) ? dh : leak * dh;
+                }
+                *reinterpret_cast<f32x4*>(dZ + (size_t)row * lddz + c) = dz;
+            }
+            a0[p] += h[p] * g0;
+            a1[p] += h[p] * g1;
+        }
+        sb0 += g0; sb1 += g1;                     // (the same in all 32 lanes of the row)
+    }
+    float* mine = sh + slot * P;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int c = 128 * p + 4 * sub;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < w) { mine[c + e] = a0[p][e]; mine[w + c + e] = a1[p][e]; }
+    }
+    if (sub == 0) { mine[2 * w] = sb0; mine[2 * w + 1] = sb1; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += 256) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k * P + i];
+        partials[(size_t)blockIdx.x * P + i] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// streaming form: Y^T[N][rows] = W'[N][K] X^T[K][rows], W' resident in LDS (N, K <= 128)
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int SMAX = 128;            // largest layer side the streaming kernel holds
+constexpr int SKP = SMAX + 4;        // pitch of the weight image [N][K]
+struct StreamArgs {
+    const float* X; int ldx;         // [n][K] rows (contraction-contiguous)
+    const float* W; int ldw;         // WKM = false: W[N][K] at W[o * ldw + k] (forward: Wt[out][in]); true: W[K][N] at W[k * ldw + o] (dgrad: Wt[out][in], N = in)
+    float* Y; int ldy;               // [n][N]
+    long long n; int N, K;
+    const float* bias;               // EPI_BIAS_LRELU
+    const float* H; int ldh;         // EPI_DLRELU
+    float leak; int act;
+    const int* stop_flag;
+};
+
+// NAT: 16-column blocks of the output an instance holds (4: N <= 64, 8: N <= 128)
+template <bool WKM, int EPI, int NAT>
+__global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
+    if (S.stop_flag != nullptr && *S.stop_flag != 0) return;
+    extern __shared__ __attribute__((aligned(16))) float sW[];      // [16 NA][SKP], zero outside N x K
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int N = S.N, K = S.K;
+    const int NA = (N + 15) >> 4, KC = (K + 15) >> 4;               // 16-column blocks of the output, 16-deep chunks of the contraction
+    // (eight independent loads in flight per thread: a plain loop waits for every load in turn -- a fixed cost per launch; consecutive
+    //  threads walk the contiguous axis of the stored weights)
+    const int tot = 16 * NA * SKP;
+    for (int base = 0; base < tot; base += 8 * 512) {
+        float v[8];
+        int at[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 512 + tid;
+            int o, k;
+            if (!WKM) { o = idx / SKP; k = idx - o * SKP; }
+            else { k = idx / (16 * NA); o = idx - k * (16 * NA); }
+            at[u] = (idx < tot && k < SKP) ? o * SKP + k : -1;
+            v[u] = 0.0f;
+            if (idx < tot && o < N && k < K) v[u] = WKM ? S.W[(size_t)k * S.ldw + o] : S.W[(size_t)o * S.ldw + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (at[u] >= 0) sW[at[u]] = v[u];
+    }
+    __syncthreads();
+    const long long nblk = (S.n + 15) >> 4;
+    const bool vec = (S.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.X) & 15) == 0);
+    // the rows' operand: lane (row j, k-group q) holds X[row][16 kc + 4 q .. + 3] of chunk kc (MFMA step t contracts k = 16 kc + 4 q + t)
+    auto load_x = [&](long long b, int kc) -> f32x4 {
+        const long long row = b * 16 + j;
+        f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row < S.n) {
+            const int k = 16 * kc + 4 * q;
+            const float* p = S.X + (size_t)row * S.ldx + k;
+            if (vec && k + 3 < K) x = *reinterpret_cast<const f32x4*>(p);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (k + e < K) x[e] = p[e];
+            }
+        }
+        return x;
+    };
+    long long blk = (long long)blockIdx.x * 8 + wv;
+    const long long bstep = (long long)gridDim.x * 8;
+    f32x4 xc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (blk < nblk) xc = load_x(blk, 0);
+    const float* const wrow = sW + j * SKP + 4 * q;
+    for (; blk < nblk; blk += bstep) {
+        f32x4 acc[NAT];
+#pragma unroll
+        for (int a = 0; a < NAT; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int kc = 0; kc < KC; ++kc) {
+            // the next chunk of the rows' operand (or the first chunk of the wave's next block) flies under this chunk's MFMAs
+            f32x4 xnx = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (kc + 1 < KC) xnx = load_x(blk, kc + 1);
+            else if (blk + bstep < nblk) xnx = load_x(blk + bstep, 0);
+#pragma unroll
+            for (int a = 0; a < NAT; ++a) {
+                if (a < NA) {
+                    const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + 16 * a * SKP + 16 * kc);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[a] = mfma4(wf[t], xc[t], acc[a]);
+                }
+            }
+            xc = xnx;
+        }
+        // accumulator a, element t of lane (j, q) = Y[row = 16 blk + j][column 16 a + 4 q + t]: four consecutive columns of the lane's row
+        const long long row = blk * 16 + j;
+        if (row < S.n) {
+#pragma unroll
+            for (int a = 0; a < NAT; ++a) {
+                const int c = 16 * a + 4 * q;
+                if (a < NA && c < N) {
+                    f32x4 v = acc[a];
+                    if (EPI == EPI_BIAS_LRELU) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float b = (c + t < N) ? S.bias[c + t] : 0.0f;
+                            v[t] += b;
+                            if (S.act) v[t] = fmaxf(v[t], S.leak * v[t]);
+                        }
+                    } else if (S.H != nullptr) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float h = (c + t < N) ? S.H[(size_t)row * S.ldh + c + t] : 1.0f;
+                            v[t] = (h > 0.0f) ? v[t] : S.leak * v[t];
+                        }
+                    }
+                    float* y = S.Y + (size_t)row * S.ldy + c;
+                    if (c + 3 < N && (S.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.Y) & 15) == 0)) *reinterpret_cast<f32x4*>(y) = v;
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (c + t < N) y[t] = v[t];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool WKM, int EPI, int NAT>
+int launch_stream_n(const StreamArgs& s, hipStream_t st) {
+    const int NA = (s.N + 15) >> 4;
+    const size_t sm = (size_t)16 * NA * SKP * sizeof(float);
+    auto kern = wide_stream_kernel<WKM, EPI, NAT>;
+    static std::atomic<size_t> configured{0};
+    size_t have = configured.load(std::memory_order_acquire);
+    if (have < sm) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        while (have < sm && !configured.compare_exchange_weak(have, sm, std::memory_order_release, std::memory_order_acquire)) {}
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long nblk = (s.n + 15) >> 4;
+    long long grid = (nblk + 7) / 8;
+    if (grid > 2LL * cus) grid = 2LL * cus;          // two 8-wave workgroups per CU (2 x 67.6 KB of LDS at 128 x 128)
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sm, st, s);
+    return (int)hipGetLastError();
+}
+
+template <bool WKM, int EPI>
+int launch_stream(const StreamArgs& s, hipStream_t st) {
+    if (s.N <= 64) return launch_stream_n<WKM, EPI, 4>(s, st);
+    return launch_stream_n<WKM, EPI, 8>(s, st);
+}
+
+template <bool AK, bool BK_, int EPI>
+int launch_gemm(const GemmArgs& g, int zsplit, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
+    (void)hipGetLastError();
+    if (g.N > 64) hipLaunchKernelGGL((wide_gemm_kernel<AK, BK_, EPI, 128>), dim3((g.M + BM - 1) / BM, (g.N + 127) / 128, zsplit), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((wide_gemm_kernel<AK, BK_, EPI, 64>), dim3((g.M + BM - 1) / BM, 1, zsplit), dim3(256), 0, st, g);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cl_wide_ld(int width) { return width < 1 ? 0 : ((width + 3) & ~3); }
+
+int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak, int act,
+                          float* Y, int ldy, const int* stop_flag, void* stream) {
+    if (X == nullptr || Wt == nullptr || b == nullptr || Y == nullptr || n < 1 || n > 0x7fffffffLL || n_in < 1 || n_out < 1 || ldx < n_in || ldy < n_out) return -1;
+    if (n_in <= SMAX && n_out <= SMAX) {
+        StreamArgs s = {};
+        s.X = X; s.ldx = ldx; s.W = Wt; s.ldw = n_in; s.Y = Y; s.ldy = ldy; s.n = n; s.N = n_out; s.K = n_in;
+        s.bias = b; s.leak = leak; s.act = act; s.stop_flag = stop_flag;
+        return launch_stream<false, EPI_BIAS_LRELU>(s, (hipStream_t)stream);
+    }
+    GemmArgs g = {};
+    g.A = X; g.lda = ldx; g.B = Wt; g.ldb = n_in; g.C = Y; g.ldc = ldy;
+    g.M = (int)n; g.N = n_out; g.K = n_in; g.bias = b; g.leak = leak; g.act = act; g.stop_flag = stop_flag;
+    return launch_gemm<false, false, EPI_BIAS_LRELU>(g, 1, (hipStream_t)stream);
+}
+
+int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* Hprev, int ldh, float leak,
+                        float* dX, int ldo, const int* stop_flag, void* stream) {
+    if (dZ == nullptr || Wt == nullptr || dX == nullptr || n < 1 || n > 0x7fffffffLL || n_in < 1 || n_out < 1 || lddz < n_out || ldo < n_in) return -1;
+    if (n_in <= SMAX && n_out <= SMAX) {
+        StreamArgs s = {};
+        s.X = dZ; s.ldx = lddz; s.W = Wt; s.ldw = n_in; s.Y = dX; s.ldy = ldo; s.n = n; s.N = n_in; s.K = n_out;
+        s.H = Hprev; s.ldh = ldh; s.leak = leak; s.stop_flag = stop_flag;
+        return launch_stream<true, EPI_DLRELU>(s, (hipStream_t)stream);
+    }
+    GemmArgs g = {};
+    g.A = dZ; g.lda = lddz; g.B = Wt; g.ldb = n_in; g.C = dX; g.ldc = ldo;
+    g.M = (int)n; g.N = n_in; g.K = n_out; g.H = Hprev; g.ldh = ldh; g.leak = leak; g.stop_flag = stop_flag;
+    return launch_gemm<false, true, EPI_DLRELU>(g, 1, (hipStream_t)stream);
+}
+
+int cl_wide_wgrad_splits(long long n) {
+    long long s = (n + 511) / 512;                 // >= 512 observations per split (16 chunks of the contraction), at most 512 splits:
+    return (int)(s < 1 ? 1 : (s > 512 ? 512 : s)); // a layer's output is one or a few tiles, the splits are what fills the chip
+}
+
+int cl_wide_dense_wgrad(const float* dZ, int lddz, const float* H, int ldh, long long n, int n_out, int n_in, float* partials, int nsplit,
+                        const int* stop_flag, void* stream) {
+    if (dZ == nullptr || H == nullptr || partials == nullptr || n < 1 || n > 0x7fffffffLL || n_in < 1 || n_out < 1 || nsplit < 1 || lddz < n_out ||
+        ldh < n_in)
+        return -1;
+    GemmArgs g = {};
+    g.A = dZ; g.lda = lddz; g.B = H; g.ldb = ldh; g.C = partials;
+    g.M = n_out; g.N = n_in; g.K = (int)n; g.n_in = n_in;
+    g.ksplit = (int)((n + nsplit - 1) / nsplit);
+    g.ksplit = (g.ksplit + BK - 1) / BK * BK;
+    g.pstride = (long long)n_out * n_in + n_out;
+    g.stop_flag = stop_flag;
+    return launch_gemm<true, true, EPI_WGRAD>(g, nsplit, (hipStream_t)stream);
+}
+
+int cl_wide_head_forward(const float* H, int ldh, const float* Wo, long long n, int w, int bij_kind, float eps, float* loc_out, float* sig_out,
+                         const int* stop_flag, void* stream) {
+    if (H == nullptr || Wo == nullptr || loc_out == nullptr || sig_out == nullptr || n < 1 || w < 1 || ldh < w) return -1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(wide_head_forward_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, H, ldh, Wo, (int)n, w, bij_kind, eps,
+                       loc_out, sig_out, stop_flag);
+    return (int)hipGetLastError();
+}
+
+int cl_wide_head_blocks(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+int cl_wide_head_backward(const float* H, int ldh, const float* Wo, const float* dO, long long n, int w, int bij_kind, float eps, float leak,
+                          float* dZ, int lddz, float* partials, int nblocks, const int* stop_flag, void* stream) {
+    if (H == nullptr || Wo == nullptr || dO == nullptr || dZ == nullptr || partials == nullptr || n < 1 || n > 0x7fffffffLL || w < 1 || nblocks < 1 ||
+        ldh < w || lddz < w || ldh % 4 != 0 || lddz % 4 != 0 || (reinterpret_cast<uintptr_t>(H) & 15) != 0 || (reinterpret_cast<uintptr_t>(dZ) & 15) != 0)
+        return -1;
+    if (w > 1024) return -2;
+    const size_t sm = (size_t)8 * (2 * w + 2) * sizeof(float);
+    const int rpb = (int)((n + nblocks - 1) / nblocks);
+    const int rows = (rpb + 7) / 8 * 8;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+#define CL_HEAD_BWD(NP) \
+    hipLaunchKernelGGL(wide_head_backward_kernel<NP>, dim3(nblocks), dim3(256), sm, st, H, ldh, Wo, dO, (int)n, w, bij_kind, eps, leak, rows, dZ, lddz, partials, stop_flag)
+    if (w <= 128) CL_HEAD_BWD(1);
+    else if (w <= 256) CL_HEAD_BWD(2);
+    else if (w <= 512) CL_HEAD_BWD(4);
+    else {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_head_backward_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        CL_HEAD_BWD(8);
+    }
+#undef CL_HEAD_BWD
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -375,10 +375,13 @@ class ObsData:
                 rid_l, img_l = packed(rid_l, -1), packed(img_l, 0)
                 iobs_l, sig_l = packed(np.asarray(iobs_l), 0.0), packed(np.asarray(sig_l), 1.0)
         elif wide:
-            # scaler wider than the fused kernel holds: library GEMMs on the row-major metadata (ElboEngine._data_term_wide)
+            # scaler wider than the fused kernel holds: layer-by-layer GEMMs on the row-major metadata (ElboEngine._data_term_wide)
             self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
             meta_t = np.zeros((4, 4), dtype=np.float32)
-            self.meta_rm = torch.as_tensor(np.ascontiguousarray(metadata[sl]), device=device)
+            self.meta_ld = int(lib.cl_wide_ld(self.d))                 # [rows][ld]: the features, zero padding to a multiple of four
+            rm = np.zeros((self.N, self.meta_ld), dtype=np.float32)
+            rm[:, : self.d] = metadata[sl]
+            self.meta_rm = torch.as_tensor(rm, device=device)
         else:
             self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
             meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
@@ -495,8 +498,8 @@ class ElboEngine:
         n_dwr = int(prior.r_raw.numel()) if self.dw_trainable else 0
         self.blocks = None
         # hidden or metadata width beyond 64: the activations of a layer no longer fit a wave's registers next to the weight-gradient
-        # blocks, so the scaler runs unfused -- one library GEMM (rocBLAS / hipBLASLt through torch.mm, exact fp32) per layer and
-        # direction, activations through HBM -- around the same HIP likelihood kernels (_data_term_wide)
+        # blocks, so the scaler runs unfused -- one fp32-MFMA GEMM launch (csrc/wide_gemm.hip) per layer and direction, activations
+        # through HBM -- around the same HIP likelihood kernels (_data_term_wide)
         self.wide = self.w > 64 or self.d > 64
         max_plain = 1 if self.wide else int(self.lib.cl_mlp_max_layers(self.w))
         if self.wide and imgl is not None:
@@ -861,65 +864,89 @@ class ElboEngine:
         check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")
 
     # -- scalers wider than 64 ---------------------------------------------------------------------------------------------
-    WIDE_CHUNK = 1 << 19      # rows per GEMM chunk: bounds the activation storage (L x chunk x w floats)
+    WIDE_BUDGET = 1 << 30     # bytes of activation storage a row chunk may take ((L + 2) buffers of chunk x ld floats)
 
-    def _wide_weights(self, flat: torch.Tensor):
-        """[(W (in, out) view, b)] per Dense layer + the Dense(2) head, as views into a flat buffer in the W^T layout."""
-        base, out = self.layout.off_mlp, []
-        for off, o, i, boff in self.mlp.layer_slices(self.d):
-            out.append((flat[base + off: base + off + o * i].view(o, i), flat[base + boff: base + boff + o]))
-        return out          # kernels as (out, in): x @ Wt.t()
+    def _wide_setup(self):
+        """Work buffers of the unfused path (csrc/wide_gemm.hip): L activation buffers + two gradient buffers of `chunk` rows, the
+        per-layer weight-gradient partials.  The chunk is sized from the layer count and width so the buffers stay inside
+        WIDE_BUDGET (and, with it, inside the device memory next to the shard)."""
+        if getattr(self, "_wide", None) is not None:
+            return self._wide
+        lib, dev = self.lib, self.device
+        ldw = int(lib.cl_wide_ld(self.w))
+        per_row = 4 * (self.L + 2) * ldw
+        free = torch.cuda.mem_get_info(dev)[0]
+        budget = min(self.WIDE_BUDGET, max(free // 4, 64 << 20))
+        chunk = max(128, min(budget // per_row, 1 << 20) // 128 * 128)
+        acts = [torch.zeros(chunk * ldw, dtype=torch.float32, device=dev) for _ in range(max(2, self.L))]
+        dz = [torch.empty(chunk * ldw, dtype=torch.float32, device=dev) for _ in range(2)]
+        nsplit = int(lib.cl_wide_wgrad_splits(chunk))
+        pmax = max(self.w * self.d + self.w, self.w * self.w + self.w)
+        nblk = int(lib.cl_wide_head_blocks(chunk))
+        self._wide = dict(ldw=ldw, chunk=chunk, acts=acts, dz=dz, nsplit=nsplit, nblk=nblk,
+                          wpart=torch.empty(nsplit * pmax, dtype=torch.float32, device=dev),
+                          hpart=torch.empty(nblk * (2 * self.w + 2), dtype=torch.float32, device=dev))
+        return self._wide
 
-    def _wide_forward(self, x: torch.Tensor, keep: bool):
-        """Dense stack on rows `x` (n, d): returns (activations [h_0 = x, h_1 .. h_L] if keep, loc, raw)."""
-        leak = self.mlp.leakiness
-        ws = self._wide_weights(self.params)
-        acts, h = [x], x
-        for Wt, b in ws[:-1]:
-            h = torch.nn.functional.leaky_relu(torch.addmm(b, h, Wt.t()), negative_slope=leak)
-            if keep:
-                acts.append(h)
-        o = torch.addmm(ws[-1][1], h, ws[-1][0].t())
-        return acts, o[:, 0], o[:, 1]
+    def _wide_layers(self):
+        """(offset of Wt, offset of b, fan-in) of every Dense layer inside the scaler's flat W^T layout, then the head's offset."""
+        out, off, fan_in = [], 0, self.d
+        for _ in range(self.L):
+            out.append((off, off + self.w * fan_in, fan_in))
+            off += self.w * fan_in + self.w
+            fan_in = self.w
+        return out, off
 
-    def _wide_sigma(self, raw: torch.Tensor):
-        """sigma = bijector(raw) + eps and d sigma / d raw (nn.py:22-25 with the CLI's chains, manager.py:450-463)."""
-        if self.mlp.scale_bijector == "exp":
-            e = torch.exp(raw)
-            return e + self.mlp.epsilon, e
-        return torch.nn.functional.softplus(raw) + self.mlp.epsilon, torch.sigmoid(raw)
+    def _wide_forward(self, obs: ObsData, a: int, b: int, keep: bool, st):
+        """Dense stack on rows [a, b) of `obs`: layer l's output lands in acts[l] when `keep` (else two buffers alternate); returns
+        the (buffer, ld) pairs of h_0 .. h_L."""
+        lib, W = self.lib, self._wide_setup()
+        n, ldw, base = b - a, W["ldw"], self.params.data_ptr() + 4 * self.layout.off_mlp
+        layers, _ = self._wide_layers()
+        hs = [(obs.meta_rm.data_ptr() + 4 * a * obs.meta_ld, obs.meta_ld)]
+        for l, (ow, ob, fan_in) in enumerate(layers):
+            dst = W["acts"][l if keep else l & 1]
+            check(lib.cl_wide_dense_forward(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, self.mlp.leakiness, 1,
+                                            ptr(dst), ldw, ptr(self.stop_flag), st), "cl_wide_dense_forward")
+            hs.append((dst.data_ptr(), ldw))
+        return hs
 
     def _data_term_wide(self, obs: ObsData, step: int, eta, ipred_out, st):
-        """Hidden / metadata width > 64: unfused scaler.  Forward GEMMs (chunks of rows) -> (loc, sigma) per row -> the HIP slot
-        likelihood kernels (mono rows are their own groups) -> dL/d(loc, sigma) -> backward GEMMs, the forward recomputed per
-        chunk so that only one chunk's activations are ever resident.  8 P_mm flops per observation; every product in exact fp32."""
+        """Hidden / metadata width > 64: unfused scaler on the GEMM kernels of csrc/wide_gemm.hip.  Forward (row chunks) -> (loc,
+        sigma) per row -> the HIP slot likelihood kernels (mono rows are their own groups) -> dL/d(loc, sigma) -> per chunk: forward
+        again (activations kept), head backward, then weight gradient and dgrad layer by layer, top down.  8 P_mm flops per
+        observation; every product in exact fp32."""
+        lib, lay, W = self.lib, self.layout, self._wide_setup()
         ma = self._mlp_args(step, eta, ipred_out, obs)
-        x = obs.meta_rm
-        with torch.no_grad():
-            for a in range(0, obs.N, self.WIDE_CHUNK):
-                b = min(obs.N, a + self.WIDE_CHUNK)
-                _, loc, raw = self._wide_forward(x[a:b], keep=False)
-                obs.laue_loc[a:b] = loc
-                obs.laue_sig[a:b] = self._wide_sigma(raw)[0]
-            self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
-            leak = self.mlp.leakiness
-            ws = self._wide_weights(self.params)
-            gs = self._wide_weights(self.grads)
-            dO = obs.laue_dO.view(obs.N, 2)
-            for a in range(0, obs.N, self.WIDE_CHUNK):
-                b = min(obs.N, a + self.WIDE_CHUNK)
-                acts, _, raw = self._wide_forward(x[a:b], keep=True)
-                g = dO[a:b].clone()
-                g[:, 1] *= self._wide_sigma(raw)[1]                      # dL/d raw = dL/d sigma * d sigma / d raw
-                gs[-1][0].addmm_(g.t(), acts[-1])                        # dWo^T (2, w) += g^T h_L
-                gs[-1][1].add_(g.sum(0))
-                dh = g @ ws[-1][0]                                       # (n, w)
-                for l in range(self.L - 1, -1, -1):
-                    dz = torch.where(acts[l + 1] > 0, dh, leak * dh)
-                    gs[l][0].addmm_(dz.t(), acts[l])                     # dW_l^T (out, in) += dZ^T H_{l-1}
-                    gs[l][1].add_(dz.sum(0))
-                    if l > 0:
-                        dh = dz @ ws[l][0]
+        layers, off_head = self._wide_layers()
+        pbase = self.params.data_ptr() + 4 * lay.off_mlp
+        gbase = self.grads.data_ptr() + 4 * lay.off_mlp
+        sf, leak, w, ldw = ptr(self.stop_flag), self.mlp.leakiness, self.w, W["ldw"]
+        for a in range(0, obs.N, W["chunk"]):
+            b = min(obs.N, a + W["chunk"])
+            hs = self._wide_forward(obs, a, b, False, st)
+            check(lib.cl_wide_head_forward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, b - a, w, self.bij_kind, self.mlp.epsilon,
+                                           obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a, sf, st), "cl_wide_head_forward")
+        self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
+        for a in range(0, obs.N, W["chunk"]):
+            b = min(obs.N, a + W["chunk"])
+            n = b - a
+            hs = self._wide_forward(obs, a, b, True, st)
+            dz, dzn = W["dz"]
+            nblk = min(W["nblk"], int(lib.cl_wide_head_blocks(n)))
+            check(lib.cl_wide_head_backward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, obs.laue_dO.data_ptr() + 8 * a, n, w, self.bij_kind,
+                                            self.mlp.epsilon, leak, ptr(dz), ldw, ptr(W["hpart"]), nblk, sf, st), "cl_wide_head_backward")
+            check(lib.cl_reduce_partials(ptr(W["hpart"]), nblk, 2 * w + 2, gbase + 4 * off_head, sf, st), "cl_reduce_partials")
+            nsplit = min(W["nsplit"], int(lib.cl_wide_wgrad_splits(n)))
+            for l in range(self.L - 1, -1, -1):
+                ow, ob, fan_in = layers[l]
+                check(lib.cl_wide_dense_wgrad(ptr(dz), ldw, hs[l][0], hs[l][1], n, w, fan_in, ptr(W["wpart"]), nsplit, sf, st), "cl_wide_dense_wgrad")
+                check(lib.cl_reduce_partials(ptr(W["wpart"]), nsplit, w * fan_in + w, gbase + 4 * ow, sf, st), "cl_reduce_partials")
+                if l > 0:
+                    check(lib.cl_wide_dense_dgrad(ptr(dz), ldw, pbase + 4 * ow, n, w, fan_in, hs[l][0], hs[l][1], leak, ptr(dzn), ldw, sf, st),
+                          "cl_wide_dense_dgrad")
+                    dz, dzn = dzn, dz
+
     def _allreduce(self):
         from careless_amd.distributed import allreduce_flat_
         allreduce_flat_(self.grads, self.process_group)
@@ -1071,18 +1098,30 @@ def scaler_forward(mlp, metadata, imgl=None, image_id=None):
     if mlp.flat.device != dev:
         mlp.flat = mlp.flat.to(dev)
     if mlp.width > 64 or d > 64:
-        # wider than the fused kernel holds: library GEMMs (see ElboEngine._data_term_wide)
+        # wider than the fused kernel holds: the layer-by-layer GEMM kernels (see ElboEngine._data_term_wide), forward only
         if imgl is not None:
             raise NotImplementedError(f"per-image layers of width {mlp.width}: the HIP engine supports them up to width 64")
-        h = torch.as_tensor(md, device=dev)
-        with torch.no_grad():
-            ws = mlp.weights
-            for k in range(mlp.n_layers):
-                h = torch.nn.functional.leaky_relu(torch.addmm(ws[2 * k + 1], h, ws[2 * k]), negative_slope=mlp.leakiness)
-            o = torch.addmm(ws[-1], h, ws[-2])
-            raw = o[:, 1]
-            sig = (torch.exp(raw) if mlp.scale_bijector == "exp" else torch.nn.functional.softplus(raw)) + mlp.epsilon
-        return o[:, 0].contiguous(), sig
+        w, L, st = mlp.width, mlp.n_layers, _stream()
+        ld0, ldw = int(lib.cl_wide_ld(d)), int(lib.cl_wide_ld(w))
+        chunk = max(128, min(N, ((256 << 20) // (8 * max(ld0, ldw))) // 128 * 128))
+        loc = torch.empty(N, dtype=torch.float32, device=dev)
+        sig = torch.empty(N, dtype=torch.float32, device=dev)
+        x = torch.zeros(chunk * ld0, dtype=torch.float32, device=dev)
+        hb = [torch.empty(chunk * ldw, dtype=torch.float32, device=dev) for _ in range(2)]
+        bij = _lib.CL_BIJ_EXP if mlp.scale_bijector == "exp" else _lib.CL_BIJ_SOFTPLUS
+        base = mlp.flat.data_ptr()
+        for a in range(0, N, chunk):
+            b = min(N, a + chunk)
+            x.view(chunk, ld0)[: b - a, :d] = torch.as_tensor(md[a:b], device=dev)
+            src, off, fan_in = (x.data_ptr(), ld0), 0, d
+            for l in range(L):
+                dst = hb[l & 1]
+                check(lib.cl_wide_dense_forward(src[0], src[1], base + 4 * off, base + 4 * (off + w * fan_in), b - a, fan_in, w, mlp.leakiness, 1,
+                                                ptr(dst), ldw, None, st), "cl_wide_dense_forward")
+                src, off, fan_in = (dst.data_ptr(), ldw), off + w * fan_in + w, w
+            check(lib.cl_wide_head_forward(src[0], src[1], base + 4 * off, b - a, w, bij, mlp.epsilon, loc.data_ptr() + 4 * a,
+                                           sig.data_ptr() + 4 * a, None, st), "cl_wide_head_forward")
+        return loc, sig
     keep = []
     if imgl is not None:
         imgl.build(d)

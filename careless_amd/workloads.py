@@ -26,6 +26,8 @@ WORKLOADS: Dict[str, dict] = {
     # configs[2]'s data (Student-T, positional encodings of X, Y: 5 + 16 metadata columns, mc-samples 8) on the CLI-default scaler:
     # what `careless mono --positional-encoding-keys X,Y --studentt-likelihood-dof 16 --mc-samples 8` runs
     "mono_10M_studentt_posenc_20x10_S8": dict(N=10_000_000, d0=5, posenc=True, L=20, w=10, S=8, dof=16.0, outliers=True),
+    # a scaler wider than the fused kernels hold (hidden width > 64): layer-by-layer GEMM kernels (csrc/wide_gemm.hip)
+    "mono_2M_studentt_3x128_S4": dict(N=2_000_000, d0=5, posenc=False, L=3, w=128, S=4, dof=16.0, outliers=True),
     # half the default depth (register-pressure experiments on the narrow kernel)
     "mono_10M_10x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=10, w=10, S=1, dof=None, outliers=False),
     # --image-layers 1 on the headline configuration (one Dense layer traded for a per-image layer)

@@ -182,6 +182,34 @@ int cl_mlp_kernel_name(const cl_mlp_args* args, int mode, char* out, size_t n);
 /* grad_mlp[P] += sum over the `nparts` workgroup partials, in index order (deterministic) */
 int cl_reduce_partials(const float* partials, int nparts, int P, float* grad_mlp, const int* stop_flag, void* stream);
 
+/* --- scalers wider than 64 ---------------------------------------------------------------------------------------------
+ * replaces: the Dense stack of MetadataScaler / MLPScaler (careless/models/scaling/nn.py:55-68, 92-120) and its gradient
+ *           (careless/models/merging/variational.py:197-202) when the hidden or the metadata width exceeds what the fused kernels
+ *           hold (64): one fp32-MFMA GEMM per layer and direction, activations in HBM, in row chunks chosen by the caller.
+ * Activation buffers are row-major [rows][ld], ld = cl_wide_ld(width) = the width rounded up to 4.
+ * Weights in the W^T layout of the flat parameter vector (Wt[out][in], then b[out]).
+ * Call order per row chunk: cl_wide_dense_forward x L -> cl_wide_head_forward -> [likelihood: cl_laue_predict / _likelihood /
+ * _backward with every row its own slot] -> cl_wide_dense_forward x L (recompute, kept) -> cl_wide_head_backward ->
+ * per layer, top down: cl_wide_dense_wgrad (+ cl_reduce_partials into the layer's gradient slice), cl_wide_dense_dgrad.          */
+int cl_wide_ld(int width);
+/* Y[n][n_out] = act(X[n][n_in] Wt^T + b), act = LeakyReLU(leak) or identity */
+int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak, int act,
+                          float* Y, int ldy, const int* stop_flag, void* stream);
+/* dX[n][n_in] = (dZ[n][n_out] Wt) * LeakyReLU'(Hprev[n][n_in])   (Hprev = the layer's input = the previous layer's output; NULL: no mask) */
+int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* Hprev, int ldh, float leak,
+                        float* dX, int ldo, const int* stop_flag, void* stream);
+/* partials[s][n_out * n_in + n_out] = (dWt | db) over the s-th of nsplit row ranges; H is the layer's input */
+int cl_wide_wgrad_splits(long long n);
+int cl_wide_dense_wgrad(const float* dZ, int lddz, const float* H, int ldh, long long n, int n_out, int n_in, float* partials, int nsplit,
+                        const int* stop_flag, void* stream);
+/* Dense(2) head: Wo = [Wo^T (2 x w) | bo (2)]; forward writes loc and sigma = bijector(raw) + eps per row; backward takes
+ * dO[n][2] = dL/d(loc, sigma), writes dZ of the top layer and partials[nblocks][2 w + 2] of the head's gradient              */
+int cl_wide_head_forward(const float* H, int ldh, const float* Wo, long long n, int w, int bij_kind, float eps, float* loc_out, float* sig_out,
+                         const int* stop_flag, void* stream);
+int cl_wide_head_blocks(long long n);
+int cl_wide_head_backward(const float* H, int ldh, const float* Wo, const float* dO, long long n, int w, int bij_kind, float eps, float leak,
+                          float* dZ, int lddz, float* partials, int nblocks, const int* stop_flag, void* stream);
+
 /* --- Laue harmonic deconvolution -----------------------------------------------------------------------------------
  * replaces: ConvolvedLikelihood.convolve / .log_prob, LaueBase.call (careless/models/likelihoods/laue.py:9-47) and their gradient.
  * Call order inside a step: cl_mlp_forward -> cl_laue_predict -> cl_laue_likelihood -> cl_laue_backward -> cl_mlp_backward_ext.
