@@ -367,6 +367,8 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (at[u] >= 0) sW[at[u]] = v[u];
     }
+    float* const sBias = sW + tot;                                   // [16 NA] (forward), zero past N
+    if (EPI == EPI_BIAS_LRELU && tid < 16 * NA) sBias[tid] = (tid < N) ? S.bias[tid] : 0.0f;
     __syncthreads();
     const long long nblk = (S.n + 15) >> 4;
     const bool vec = (S.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.X) & 15) == 0);
@@ -413,27 +415,41 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
         // accumulator a, element t of lane (j, q) = Y[row = 16 blk + j][column 16 a + 4 q + t]: four consecutive columns of the lane's row
         const long long row = blk * 16 + j;
         if (row < S.n) {
+            const bool vecy = (S.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.Y) & 15) == 0);
+            const bool vech = (S.ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.H) & 15) == 0);
+            f32x4 hm[NAT];                           // dgrad: the activations whose sign selects the derivative, all requested before the first use
+            if (EPI == EPI_DLRELU && S.H != nullptr) {
+#pragma unroll
+                for (int a = 0; a < NAT; ++a) {
+                    const int c = 16 * a + 4 * q;
+                    hm[a] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+                    if (a < NA && c < N) {
+                        const float* hp = S.H + (size_t)row * S.ldh + c;
+                        if (vech && c + 3 < S.ldh) hm[a] = *reinterpret_cast<const f32x4*>(hp);
+                        else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) if (c + t < N) hm[a][t] = hp[t];
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int a = 0; a < NAT; ++a) {
                 const int c = 16 * a + 4 * q;
                 if (a < NA && c < N) {
                     f32x4 v = acc[a];
                     if (EPI == EPI_BIAS_LRELU) {
+                        v += *reinterpret_cast<const f32x4*>(sBias + c);
+                        if (S.act) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float b = (c + t < N) ? S.bias[c + t] : 0.0f;
-                            v[t] += b;
-                            if (S.act) v[t] = fmaxf(v[t], S.leak * v[t]);
+                            for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], S.leak * v[t]);
                         }
                     } else if (S.H != nullptr) {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float h = (c + t < N) ? S.H[(size_t)row * S.ldh + c + t] : 1.0f;
-                            v[t] = (h > 0.0f) ? v[t] : S.leak * v[t];
-                        }
+                        for (int t = 0; t < 4; ++t) v[t] = (hm[a][t] > 0.0f) ? v[t] : S.leak * v[t];
                     }
                     float* y = S.Y + (size_t)row * S.ldy + c;
-                    if (c + 3 < N && (S.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.Y) & 15) == 0)) *reinterpret_cast<f32x4*>(y) = v;
+                    if (c + 3 < N && vecy) *reinterpret_cast<f32x4*>(y) = v;
                     else {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) if (c + t < N) y[t] = v[t];
@@ -447,7 +463,7 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
 template <bool WKM, int EPI, int NAT>
 int launch_stream_n(const StreamArgs& s, hipStream_t st) {
     const int NA = (s.N + 15) >> 4;
-    const size_t sm = (size_t)16 * NA * SKP * sizeof(float);
+    const size_t sm = (size_t)(16 * NA * SKP + 16 * NA) * sizeof(float);
     auto kern = wide_stream_kernel<WKM, EPI, NAT>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);

@@ -277,16 +277,52 @@ def mlp_identity_init(d: int, width: int, n_layers: int, dtype=np.float32):
     return ws, bs
 
 
+def _leaky_relu(z, leakiness: float, layer: int, flips, near, near_k: int):
+    """LeakyReLU of the pre-activations `z` (N, w) of hidden layer `layer`.  Test hooks (the reference has neither):
+    `flips` -- a collection of (layer, row, unit): those units take the OTHER branch than the sign of z says.  A pre-activation
+    that lies within fp32 rounding of zero comes out on either side in an fp32 implementation; the value hardly moves
+    (z ~ 0) but the derivative does (1 vs leakiness), so an fp32 engine is compared with the oracle under the engine's branches.
+    `near` -- a list that receives (|z| / bound, layer, row, unit) of the pre-activations whose magnitude is below `bound`, the
+    rounding error of their fp32 dot product (see `mlp_forward`)."""
+    if near is not None:
+        absz, bound = z.detach().abs(), near_k
+        idx = torch.nonzero(absz <= bound)
+        for r, u in idx.tolist():
+            near.append((float(absz[r, u] / bound[r, u]), layer, r, u))
+    if not flips or not any(f[0] == layer for f in flips):
+        return torch.nn.functional.leaky_relu(z, negative_slope=leakiness)
+    pos = z > 0
+    flip = torch.zeros_like(pos)
+    for l, r, u in flips:
+        if l == layer:
+            flip[r, u] = True
+    return torch.where(pos ^ flip, z, leakiness * z)
+
+
 def mlp_forward(metadata, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor], leakiness: float,
-                image_id=None, imgl_w: Sequence[torch.Tensor] = (), imgl_b: Sequence[torch.Tensor] = ()):
+                image_id=None, imgl_w: Sequence[torch.Tensor] = (), imgl_b: Sequence[torch.Tensor] = (), flips=None, near=None):
     """`MetadataScaler.call` (nn.py:92-103): L x Dense(w, LeakyReLU) then Dense(2, linear).  Returns (N, 2).
     With `imgl_w` / `imgl_b` it is `NeuralImageScaler.call` (image.py:116-125): after the Dense stack, one
-    `ImageLayer` (image.py:90-96) per entry: act(matmul(w[image_id], h[..., None])[..., 0] + b[image_id])."""
-    h = metadata
+    `ImageLayer` (image.py:90-96) per entry: act(matmul(w[image_id], h[..., None])[..., 0] + b[image_id]).
+    `flips` / `near`: test hooks, see `_leaky_relu`; hidden layers are numbered through the Dense stack, then the image layers.
+    The bound of `near` is 4 sqrt(k) eps32 (|h| |W| + |b|), k = the layer's fan-in: the statistical size of the rounding error of an
+    fp32 dot product with a safety factor, not its worst case."""
+    eps32 = float(np.finfo(np.float32).eps)
+    h, layer = metadata, 0
     for w, b in zip(weights[:-1], biases[:-1]):
-        h = torch.nn.functional.leaky_relu(h @ w + b, negative_slope=leakiness)
+        z = h @ w + b
+        bound = None
+        if near is not None:
+            bound = 4.0 * w.shape[0] ** 0.5 * eps32 * (h.detach().abs() @ w.detach().abs() + b.detach().abs())
+        h = _leaky_relu(z, leakiness, layer, flips, near, bound)
+        layer += 1
     for w, b in zip(imgl_w, imgl_b):
-        h = torch.nn.functional.leaky_relu(torch.einsum("noi,ni->no", w[image_id], h) + b[image_id], negative_slope=leakiness)
+        z = torch.einsum("noi,ni->no", w[image_id], h) + b[image_id]
+        bound = None
+        if near is not None:
+            bound = 4.0 * w.shape[-1] ** 0.5 * eps32 * (torch.einsum("noi,ni->no", w[image_id].detach().abs(), h.detach().abs()) + b[image_id].detach().abs())
+        h = _leaky_relu(z, leakiness, layer, flips, near, bound)
+        layer += 1
     return h @ weights[-1] + biases[-1]
 
 
@@ -396,7 +432,7 @@ class ElboInputs:
 
 
 def elbo_forward(p: ElboParams, x: ElboInputs, cfg: ElboConfig, u_f: torch.Tensor, eta: torch.Tensor,
-                 kl_mask: Optional[torch.Tensor] = None):
+                 kl_mask: Optional[torch.Tensor] = None, flips=None, near=None):
     """One forward pass of `VariationalMergingModel.call` (variational.py:141-183).
 
     u_f: (S, R) uniforms for the truncated normal; eta: (S, N) standard normals for the scale sample.
@@ -409,7 +445,8 @@ def elbo_forward(p: ElboParams, x: ElboInputs, cfg: ElboConfig, u_f: torch.Tenso
     z_f = tn_sample(loc, scale, x.low, high, u_f)                              # variational.py:154
 
     out = mlp_forward(x.metadata, p.mlp_w, p.mlp_b, cfg.leakiness,            # variational.py:156 -> nn.py:106-120
-                      x.image_id, p.imgl_w or (), p.imgl_b or ())             # --image-layers: image.py:116-125
+                      x.image_id, p.imgl_w or (), p.imgl_b or (),             # --image-layers: image.py:116-125
+                      flips=flips, near=near)                                  # (test hooks: LeakyReLU branches at fp32 rounding)
     s_loc = out[:, 0]
     s_sig = scale_bijector(out[:, 1], cfg.scale_bijector, cfg.epsilon)
     z_scale = s_loc[None, :] + s_sig[None, :] * eta + cfg.scale_shift          # variational.py:157; tfb.Shift(istd) nn.py:84-87
@@ -457,10 +494,10 @@ def elbo_forward(p: ElboParams, x: ElboInputs, cfg: ElboConfig, u_f: torch.Tenso
     return dict(loss=loss, nll=nll, kl=kl, ipred=ipred, z_f=z_f)
 
 
-def elbo_value_and_grads(p: ElboParams, x: ElboInputs, cfg: ElboConfig, u_f, eta, kl_mask=None):
-    """Loss + reverse-mode gradients of every trainable tensor (variational.py:197-202)."""
+def elbo_value_and_grads(p: ElboParams, x: ElboInputs, cfg: ElboConfig, u_f, eta, kl_mask=None, flips=None, near=None):
+    """Loss + reverse-mode gradients of every trainable tensor (variational.py:197-202).  `flips` / `near`: see `_leaky_relu`."""
     q = p.clone(requires_grad=True)
-    out = elbo_forward(q, x, cfg, u_f, eta, kl_mask)
+    out = elbo_forward(q, x, cfg, u_f, eta, kl_mask, flips=flips, near=near)
     ts = q.tensors()
     grads = torch.autograd.grad(out["loss"], ts, allow_unused=True)
     grads = [torch.zeros_like(t) if g is None else g for g, t in zip(grads, ts)]

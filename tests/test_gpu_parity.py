@@ -163,41 +163,47 @@ def _run_case(kw):
     return out, grads, ipred.cpu().numpy(), terms, [g.cpu().numpy() for g in eng.grad_tensors()], eng, (data, cfg, params, u_f, eta)
 
 
-def _assert_grads(g_hip, grads, prob):
-    """Every gradient tensor within RTOL_GRAD (max-norm) of the fp64 oracle.  A LeakyReLU pre-activation that lies within
-    fp32 rounding of zero takes the other branch in fp32 than in fp64, which moves the lower layers' gradients by O(1e-4) in ANY
-    fp32 implementation (the reference's included); such a tensor must then agree with the oracle re-run in fp32 instead."""
+MAX_FLIP_CANDIDATES = 10     # pre-activations within fp32 rounding of zero that the gate is prepared to resolve (2^k oracle runs at most)
+FLIP_CASES = []              # cases that needed a forced branch (reported; test_flip_resolutions_stay_rare bounds their number)
+
+
+def _assert_grads(g_hip, grads, prob, name=""):
+    """Every gradient tensor within RTOL_GRAD (max-norm) of the fp64 oracle -- no looser fallback.
+
+    The one way an exact-fp32 engine legitimately leaves that band: a LeakyReLU pre-activation that lies within the rounding error of
+    its fp32 dot product of zero comes out on the other side of zero than in fp64 (in ANY fp32 implementation, the reference's
+    included; which side depends on the summation order).  The activation hardly moves, its derivative switches between 1 and the
+    leak, and the gradients below that unit move by that one observation's share, O(1 / N).  The gate resolves this EXACTLY: the
+    oracle lists the pre-activations inside the rounding bound (`near`), and the fp64 oracle is re-run with subsets of them forced
+    onto the other branch (`flips`); the engine must agree with ONE such assignment on EVERY tensor at the full RTOL_GRAD.  A kernel
+    bug does not survive this: it would have to equal the effect of flipping a unit that is provably at rounding distance."""
     assert len(g_hip) == len(grads)
     errs = [util.rel_err(a, b.numpy()) for a, b in zip(g_hip, grads)]
     if max(errs) < RTOL_GRAD:
         return
-    import warnings
-    warnings.warn(f"gradient check fell back to the fp32 oracle (largest fp64 error {max(errs):.2e} > {RTOL_GRAD}): a LeakyReLU branch "
-                  "flipped at fp32 rounding")           # shows in the pytest summary: the fallback must stay rare
+    import itertools
     data, cfg, params, u_f, eta = prob
-    x32 = O.inputs_from_numpy(data, dtype=torch.float32)
-    _, g32 = O.elbo_value_and_grads(params.clone(dtype=torch.float32), x32, cfg, torch.as_tensor(u_f, dtype=torch.float32),
-                                    torch.as_tensor(eta, dtype=torch.float32))
-    e32 = [util.rel_err(a, c.numpy()) for a, c in zip(g_hip, g32)]
-    if all(e < RTOL_GRAD or f < 2e-5 for e, f in zip(errs, e32)):
-        return
-    # Neither oracle agrees.  Two fp32 implementations that sum a dot product in different orders (MFMA chains, library GEMMs, the
-    # CPU's) put a pre-activation that lies within the dot product's rounding error of zero on different LeakyReLU branches; the
-    # gradients below that layer then differ by that one observation's contribution (O(1 / N)).  Count such pre-activations in the
-    # fp64 forward pass (|z| <= 2 sqrt(k) eps32 (|h| |W| + |b|), k = the layer's input width: the statistical size of the rounding
-    # error, not its worst case): with at least one, accept up to 5e-3; with none, this is an error.
     x = O.inputs_from_numpy(data)
-    h = x.metadata.double()
-    near = 0
-    eps32 = float(np.finfo(np.float32).eps)
-    for wt, b in zip(params.mlp_w[:-1], params.mlp_b[:-1]):
-        z = h @ wt.double() + b.double()
-        bound = 2.0 * wt.shape[0] ** 0.5 * eps32 * (h.abs() @ wt.double().abs() + b.double().abs())
-        near += int((z.abs() <= bound).sum())
-        h = torch.nn.functional.leaky_relu(z, negative_slope=cfg.leakiness)
-    assert near > 0 and max(min(e, f) for e, f in zip(errs, e32)) < 5e-3, (near, errs, e32)
-    warnings.warn(f"{near} LeakyReLU pre-activation(s) within the rounding error of their dot product of zero: gradients accepted at "
-                  f"{max(min(e, f) for e, f in zip(errs, e32)):.1e}")
+    u64, e64 = torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64)
+    near = []
+    O.elbo_value_and_grads(params, x, cfg, u64, e64, near=near)
+    near.sort()
+    cand = [(l, r, u) for _, l, r, u in near[:MAX_FLIP_CANDIDATES]]
+    assert cand, f"gradient errors {errs} and no LeakyReLU pre-activation within fp32 rounding of zero: not a branch flip"
+    best = (max(errs), ())
+    for k in range(1, len(cand) + 1):
+        for sub in itertools.combinations(cand, k):
+            _, gf = O.elbo_value_and_grads(params, x, cfg, u64, e64, flips=sub)
+            e = max(util.rel_err(a, b.numpy()) for a, b in zip(g_hip, gf))
+            if e < best[0]:
+                best = (e, sub)
+            if e < RTOL_GRAD:
+                FLIP_CASES.append((name, sub, e))
+                import warnings
+                warnings.warn(f"{name}: gradients match the fp64 oracle at {e:.1e} with the LeakyReLU unit(s) (layer, row, unit) {list(sub)} on the "
+                              f"engine's branch (pre-activation within fp32 rounding of zero; {max(errs):.1e} on the fp64 branch)")
+                return
+    raise AssertionError(f"gradient errors {errs}; best forced-branch assignment {best[1]} still at {best[0]:.2e} (candidates {cand})")
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -208,7 +214,7 @@ def test_loss_and_gradients_match_oracle(name):
     assert abs(terms["loss"] - float(out["loss"])) <= RTOL_LOSS * abs(float(out["loss"]))
     assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
     assert len(g_hip) == len(grads)
-    _assert_grads(g_hip, grads, prob)
+    _assert_grads(g_hip, grads, prob, name)
 
 
 def _random_lane_cases(n=14, seed=2024):
@@ -293,7 +299,7 @@ def test_random_shapes_on_the_lane_kernel(name):
     assert abs(terms["nll"] - float(out["nll"])) <= RTOL_LOSS * abs(float(out["nll"])), (terms, float(out["nll"]))
     assert abs(terms["kl"] - float(out["kl"])) <= RTOL_LOSS * max(abs(float(out["kl"])), 1.0), (terms, float(out["kl"]))
     assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
-    _assert_grads(g_hip, grads, prob)
+    _assert_grads(g_hip, grads, prob, name)
 
 
 def _random_engine_cases(n=12, seed=11):
@@ -370,7 +376,7 @@ def test_random_engine_configurations(name):
     assert abs(terms["nll"] - float(out["nll"])) <= RTOL_LOSS * abs(float(out["nll"])), (terms, float(out["nll"]))
     assert abs(terms["kl"] - float(out["kl"])) <= RTOL_LOSS * max(abs(float(out["kl"])), 1.0), (terms, float(out["kl"]))
     assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
-    _assert_grads(g_hip, grads, prob)
+    _assert_grads(g_hip, grads, prob, name)
 
 
 def test_refl_gather_is_bit_exact():
@@ -816,3 +822,9 @@ def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch()
     for lo, hi in zip(lay.seg_off[:-1], lay.seg_off[1:]):                      # per trainable tensor (fp32 atomics: summation order only)
         a, b = g_sum[lo:hi], g_full[lo:hi]
         assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6), (lo, hi)
+
+
+def test_flip_resolutions_stay_rare():
+    """Runs after the parity cases of this module (pytest keeps file order): the forced-branch resolution is for measure-zero events,
+    not a habit -- a handful of cases among the few hundred at most."""
+    assert len(FLIP_CASES) <= 6, FLIP_CASES

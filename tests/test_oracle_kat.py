@@ -283,3 +283,35 @@ def test_merged_results_follow_the_reference_floor_on_sigi():
     assert bool((r["SigI"] >= 1e-5 * r["I"]).all())
     hi = O.merged_results(params, x, cfg, max_intensity_snr=10.0)       # a huge floor takes over
     assert torch.allclose(hi["SigI"], 10.0 * hi["I"])
+
+
+def test_forced_leaky_relu_branches_and_the_rounding_candidates():
+    """The gradient gate of the GPU parity tests (tests/test_gpu_parity.py: _assert_grads) re-runs the oracle with LeakyReLU units
+    forced onto the other branch.  Pin those hooks on the CPU: no flips = the plain oracle, bit for bit; a pre-activation placed at
+    1e-9 is the first candidate `near` reports; forcing it changes the loss by O(1e-9) and the gradient of its own bias from
+    leak * g to g -- the derivative of the other branch."""
+    from tests import util
+    data, cfg, params, x, u_f, eta = util.make_problem(N=40, R=8, d0=5, L=3, w=8, S=2, use_image_scales=False)
+    u, e = torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64)
+    # put pre-activation (layer 1, row 5, unit 3) at -1e-9 by shifting that unit's bias by the amount row 5 needs (other rows move too)
+    h = x.metadata.double()
+    h = torch.nn.functional.leaky_relu(h @ params.mlp_w[0] + params.mlp_b[0], negative_slope=cfg.leakiness)
+    z = h @ params.mlp_w[1] + params.mlp_b[1]
+    params.mlp_b[1][3] += -1e-9 - z[5, 3]
+    out0, g0 = O.elbo_value_and_grads(params, x, cfg, u, e)
+    near = []
+    out1, g1 = O.elbo_value_and_grads(params, x, cfg, u, e, flips=(), near=near)
+    assert float(out0["loss"]) == float(out1["loss"]) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    near.sort()
+    assert near and near[0][1:] == (1, 5, 3) and near[0][0] < 1e-2
+    out2, g2 = O.elbo_value_and_grads(params, x, cfg, u, e, flips=[(1, 5, 3)])
+    assert abs(float(out2["loss"]) - float(out0["loss"])) < 1e-6 * abs(float(out0["loss"]))
+    d = [float((a - b).abs().max()) for a, b in zip(g0, g2)]
+    assert max(d) > 0.0
+    # tensors: q_loc, q_scale, W0, b0, W1, b1, ...: the flipped unit's bias gradient gains row 5's share scaled 1 / leak
+    # d loss / d z[5, 3] on the negative branch is leak * G, on the positive one G: the two bias gradients differ by (1 - leak) G
+    diff_b1 = (g2[5] - g0[5])
+    others = torch.cat([diff_b1[:3], diff_b1[4:]]).abs().max()
+    assert diff_b1.abs().argmax().item() == 3 and float(others) < 1e-8 * float(diff_b1[3].abs())      # (the others move with the 1e-9 of activation)
+    # the layers ABOVE the unit see the same activations to 1e-9: their gradients do not move beyond that
+    assert float((g2[-1] - g0[-1]).abs().max()) <= 1e-6 * float(g0[-1].abs().max())
