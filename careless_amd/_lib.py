@@ -65,6 +65,17 @@ class MlpArgs(C.Structure):
         ("imgl", _vp), ("d_imgl", _vp), ("n_imgl", C.c_int), ("n_images", C.c_int), ("tile_img", _vp), ("row_map", _vp),
         ("gmeta", _vp), ("tile_gmax", _vp), ("noise_row", _vp),
         ("act_out", _vp), ("dH_ext", _vp), ("dX_out", _vp),
+        ("dzf_obs", _vp), ("dimg_obs", _vp), ("nll_part", _vp),
+    ]
+
+
+class DetArgs(C.Structure):
+    """mirror of `cl_det_args` (include/careless_hip.h)"""
+    _fields_ = [
+        ("dzf_obs", _vp), ("perm_refl", _vp), ("seg_refl", _vp), ("R", C.c_int), ("S", C.c_int), ("dz_f", _vp),
+        ("dimg_obs", _vp), ("perm_img", _vp), ("seg_img", _vp), ("n_images", C.c_int), ("d_img", _vp),
+        ("nll_part", _vp), ("nparts", C.c_int), ("scalars", _vp),
+        ("stop_flag", _vp),
     ]
 
 
@@ -123,6 +134,7 @@ EXPORTS = {
     "cl_wide_head_forward": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
     "cl_wide_head_blocks": (C.c_int, [C.c_longlong]),
     "cl_wide_head_backward": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_float, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "cl_det_reduce": (C.c_int, [C.POINTER(DetArgs), _vp]),
     "cl_laue_predict": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_laue_likelihood": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_laue_backward": (C.c_int, [C.POINTER(LaueArgs), _vp]),
@@ -163,9 +175,9 @@ def get_lib() -> C.CDLL:
             raise CarelessHipError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
-    sizes = (C.c_size_t * 4)()
+    sizes = (C.c_size_t * 5)()
     lib.cl_abi_sizes(sizes)
-    mine = (C.sizeof(TnArgs), C.sizeof(MlpArgs), C.sizeof(AdamArgs), C.sizeof(LaueArgs))
+    mine = (C.sizeof(TnArgs), C.sizeof(MlpArgs), C.sizeof(AdamArgs), C.sizeof(LaueArgs), C.sizeof(DetArgs))
     if tuple(sizes) != mine:
         raise CarelessHipError(f"ABI mismatch between careless_amd/_lib.py {mine} and the library {tuple(sizes)}")
     _lib = lib

@@ -6,11 +6,20 @@ extern "C" {
 
 const char* cl_version(void) { return "careless_hip 0.1.0 (gfx950)"; }
 
-void cl_abi_sizes(size_t out[4]) {
+void cl_abi_sizes(size_t out[5]) {
     out[0] = sizeof(cl_tn_args);
     out[1] = sizeof(cl_mlp_args);
     out[2] = sizeof(cl_adam_args);
     out[3] = sizeof(cl_laue_args);
+    out[4] = sizeof(cl_det_args);
+}
+
+int cl_det_reduce(const cl_det_args* a, void* stream) {
+    if (a == nullptr || a->dzf_obs == nullptr || a->perm_refl == nullptr || a->seg_refl == nullptr || a->dz_f == nullptr || a->R < 1 || a->S < 1 ||
+        a->nll_part == nullptr || a->nparts < 1 || a->scalars == nullptr)
+        return -1;
+    if (a->d_img != nullptr && (a->dimg_obs == nullptr || a->perm_img == nullptr || a->seg_img == nullptr || a->n_images < 1)) return -1;
+    return cl_launch_det_reduce(*a, (hipStream_t)stream);
 }
 
 int cl_laue_predict(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_predict(*a, (hipStream_t)stream) : -1; }

@@ -311,3 +311,50 @@ int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, 
     hipLaunchKernelGGL(noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, step, S, n, offset, kind, out);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// deterministic mode (include/careless_hip.h: cl_det_args): fixed-order sums of the per-observation stores of elbo_mlp.hip (-DCL_DET=1)
+// ---------------------------------------------------------------------------------------------------------
+// dz_f[r][s] += sum over the observations of reflection r, in row order.  One thread per (r, s): the S threads of a reflection read
+// S consecutive floats of an observation's record.
+__global__ __launch_bounds__(256) void det_refl_kernel(const cl_det_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)A.R * A.S) return;
+    const int r = (int)(t / A.S), s = (int)(t - (long long)r * A.S);
+    float acc = 0.0f;
+    for (int k = A.seg_refl[r]; k < A.seg_refl[r + 1]; ++k) acc += A.dzf_obs[(size_t)A.perm_refl[k] * A.S + s];
+    A.dz_f[t] += acc;
+}
+
+// d_img[m - 1] += sum over the observations of image m (m >= 1), one wave per image: lane l takes the rows l, l + 64, ... of the
+// image's range in order, the 64 lane sums combine in a fixed butterfly
+__global__ __launch_bounds__(256) void det_img_kernel(const cl_det_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const int m = 1 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= A.n_images) return;
+    float acc = 0.0f;
+    for (int k = A.seg_img[m] + lane; k < A.seg_img[m + 1]; k += 64) acc += A.dimg_obs[A.perm_img[k]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) A.d_img[m - 1] += acc;
+}
+
+// scalars[NLL] += the workgroups' NLL in index order (one wave; lane l sums parts l, l + 64, ..., then the fixed butterfly)
+__global__ __launch_bounds__(64) void det_nll_kernel(const cl_det_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < A.nparts; k += 64) acc += A.nll_part[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (threadIdx.x == 0) A.scalars[CL_SC_NLL] += acc;
+}
+
+int cl_launch_det_reduce(const cl_det_args& a, hipStream_t st) {
+    (void)hipGetLastError();
+    const long long n = (long long)a.R * a.S;
+    hipLaunchKernelGGL(det_refl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    if (a.d_img != nullptr && a.n_images > 1) hipLaunchKernelGGL(det_img_kernel, dim3((a.n_images - 1 + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(det_nll_kernel, dim3(1), dim3(64), 0, st, a);
+    return (int)hipGetLastError();
+}

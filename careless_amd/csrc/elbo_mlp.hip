@@ -26,7 +26,8 @@
 //     by all of them: LDS operands are double-buffered by hand one MFMA group ahead (CL_SCHED_FENCE) and the post-barrier
 //     latency windows are filled with independent work (bias-gradient reads, the next layer's dZ, staging writes between the
 //     dgrad MFMAs) -- DESIGN.md section 4.1.
-// The file is compiled four times (build.py): plain; packed layout + per-image layers (-DCL_IMGL=1, NeuralImageScaler); packed
+// The file is compiled five times (build.py): plain; the same with the epilogue's atomics turned into stores (-DCL_DET=1, the
+// deterministic mode of include/careless_hip.h: dzf_obs / dimg_obs / nll_part); packed layout + per-image layers (-DCL_IMGL=1, NeuralImageScaler); packed
 // layout only (-DCL_IMGL=2, single-pass Laue: harmonic group sums as lane reductions in the epilogue); layer-block chains
 // (-DCL_CHAIN=1, scalers deeper than one launch holds).
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
@@ -90,6 +91,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CL_PF_NEXT
 #define CL_PF_NEXT 1
 #endif
+#ifndef CL_DET
+#define CL_DET 0             // 1: the deterministic compilation (build.py: elbo_mlp_det) -- the epilogue's float atomics (dz_f, image scales) and
+#endif                       // the NLL's fp64 atomic become per-observation / per-workgroup STORES that cl_det_reduce sums in a fixed order
 #define CL_TILE CL_MLP_TILE
 #define CL_NW 8              // waves per workgroup
 #define CL_WOBS 16           // observations per wave in forward / dgrad
@@ -231,7 +235,9 @@ struct AccPlan {
 // w.r.t. its input (A.dX_out: the first layer gets a dgrad too).
 // ILAY: the packed unit is compiled with (ILAY) and without the per-image-layer code: single-pass Laue only needs the packed layout
 // KS: narrow kernel only -- number of 4-feature MFMA steps the hidden width needs (2, 3 or 4; see KPERM)
-template <int WP, int DP, int LMAX, int MODE, bool IMGL, bool CHAIN = false, bool ILAY = IMGL, int KS = 4>
+// DET: names the deterministic compilation's instances (their bodies differ by preprocessor: without a template argument of their own
+// they would be the same symbols as the plain unit's and the linker would keep one of the two)
+template <int WP, int DP, int LMAX, int MODE, bool IMGL, bool CHAIN = false, bool ILAY = IMGL, int KS = 4, bool DET = (CL_DET != 0)>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void elbo_mlp_kernel(const cl_mlp_args A) {
     using SL = SmemLayout<WP, DP, LMAX>;
@@ -765,7 +771,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     nll_acc -= ll * E->w_ll;
                     const float gi = -dll * E->w_ll;                 // dNLL / d ipred
                     const float dzs = gi * zf * zf;
+#if CL_DET
+                    *ptr_uo(E->dzf_obs + (size_t)tile_u * CL_TILE * S, eoff_t + 4u * s) = gi * zs * 2.0f * zf;      // summed per reflection, in row order, by cl_det_reduce
+#else
                     atomicAdd(ptr_uo(E->dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
+#endif
                     const float dt = dzs * aim;
                     pdl += dt;
                     pds += dt * eta;
@@ -779,6 +789,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             pdl += __shfl_xor(pdl, 2); pds += __shfl_xor(pds, 2); pda += __shfl_xor(pda, 2);
 #endif
             STAMP(12);
+#if CL_DET
+            if (E->use_img) {
+                if (qe == 0 && rid >= 0) E->dimg_obs[gobs_e] = pda;      // summed per image, in row order, by cl_det_reduce
+            }
+#else
             if (E->use_img) {
                 // image ids are sorted, so the 16 observations of a wave almost always share one image: reduce in the
                 // wave and issue ONE atomic instead of 16 same-address ones (which serialise in the L2 atomic unit)
@@ -796,6 +811,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     atomicAdd(ptr_uo(E->d_img, 4u * (unsigned)(img - 1)), pda);
                 }
             }
+#endif
             // back to the MFMA lane map: lane (j, q) needs dL/dloc and dL/dsigma of observation j, held by lanes 4j..4j+3
             dloc = __shfl(pdl, 4 * j);
             draw = __shfl(pds, 4 * j) * dsig_draw;
@@ -1260,7 +1276,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         if (tid == 0) {
             double t = 0.0;
             for (int k = 0; k < CL_NW; ++k) t += (double)smem[k];
+#if CL_DET
+            A.nll_part[blockIdx.x] = t;          // (every workgroup of the launch writes its slot: workgroups without tiles write 0)
+#else
             atomicAdd(A.scalars + CL_SC_NLL, t);
+#endif
         }
         if (use_ev11) {
 #pragma unroll
@@ -1281,7 +1301,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 // ---------------------------------------------------------------------------------------------------------
 // block = 32 consecutive elements x 8 chunks of the partial list; a thread sums its chunk (coalesced 128-B rows), the 8 chunk
 // sums are combined through LDS in chunk order => the result does not depend on scheduling
-#if !CL_IMGL && !CL_CHAIN
+#if !CL_IMGL && !CL_CHAIN && !CL_DET
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int P,
                                                                float* __restrict__ out, const int* stop_flag) {
     if (stop_flag != nullptr && *stop_flag != 0) return;
@@ -1326,7 +1346,7 @@ static int launch_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     using AP = AccPlan<WP, DP, LMAX, MODE, (CL_IMGL == 1)>;
     if (AP::NACC > 0) sm = (size_t)AP::total * sizeof(float);                                       // + LDS-resident accumulators
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0), (CL_IMGL == 1), KS>;
+    auto kern = elbo_mlp_kernel<WP, DP, LMAX, MODE, (CL_IMGL != 0), (CL_CHAIN != 0), (CL_IMGL == 1), KS, (CL_DET != 0)>;
     // largest dynamic-LDS size this instance has been configured for (one process drives one device; host threads may race here:
     // setting the attribute twice is harmless, publishing a size that was not set is not, hence set first, then raise the mark)
     static std::atomic<size_t> configured{0};
@@ -1367,7 +1387,7 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }
 
-#if !CL_IMGL && !CL_CHAIN
+#if !CL_IMGL && !CL_CHAIN && !CL_DET
 static bool lane_enabled() {            // CARELESS_HIP_LANE=0 keeps narrow scalers off the lane-per-observation kernel (A/B runs)
     static const bool on = [] { const char* e = getenv("CARELESS_HIP_LANE"); return !(e != nullptr && e[0] == '0'); }();
     return on;
@@ -1378,7 +1398,13 @@ static bool narrow_enabled() {          // CARELESS_HIP_NARROW=0 keeps narrow sc
 }
 #endif
 
-#if CL_CHAIN
+#if CL_DET
+int cl_launch_mlp_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    // plain layout, full step, no Evans-2011 terms (their gradients are wave atomics), every store target present
+    if (mode != 0 || a.row_map != nullptr || a.n_imgl > 0 || a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr || a.ev11 != nullptr) return -2;
+    if (a.dzf_obs == nullptr || a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
+    if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+#elif CL_CHAIN
 int cl_launch_mlp_chain(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.row_map != nullptr || a.n_imgl > 0) return -2;                       // chains use the plain layout
     if (a.act_out != nullptr && mode != 1) return -1;
@@ -1398,6 +1424,7 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (a.dzf_obs != nullptr) return cl_launch_mlp_det(a, mode, grid, st);      // deterministic mode: every width <= 64 on the fused kernel of this file
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
     if (a.n_imgl > 0) return cl_launch_mlp_imgl(a, mode, grid, st);            // packed layout + per-image layers
     if (a.row_map != nullptr && !(mode == 0 && ((cl_narrow_supports(a) && narrow_enabled()) || (cl_lane_supports(a) && lane_enabled()))))
@@ -1410,7 +1437,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     const int ntiles = a.n_pad / CL_TILE;
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) return -1;
-#if !CL_IMGL && !CL_CHAIN
+#if !CL_IMGL && !CL_CHAIN && !CL_DET
     // hidden width <= 15 (the careless CLI default): the full step runs on the one-wave-per-SIMD kernel of elbo_narrow.hip
     // (CARELESS_HIP_NARROW=0 keeps the eight-wave instance below: A/B measurements)
     if (mode == 0 && cl_lane_supports(a) && lane_enabled()) return cl_launch_lane(a, grid, st);      // the default scaler's shape: lane = observation (elbo_lane.hip)
@@ -1424,16 +1451,17 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     return -1;
 }
 
-#if !CL_IMGL && !CL_CHAIN
+#if !CL_IMGL && !CL_CHAIN && !CL_DET
 // Name of the kernel instance cl_launch_mlp(a, mode, ...) runs -- the same routing, restated once, here, next to it (bench.py and the
 // profiling scripts label their rows with it instead of guessing).  Returns the length written (snprintf semantics).
 int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     const char* unit = "";
     bool packed = false;
-    if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
+    if (a.dzf_obs != nullptr) unit = ", deterministic";
+    else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
     else if (a.n_imgl > 0) unit = ", image layers";
     else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }
-    if (unit[0] == 0 || packed) {
+    if (a.dzf_obs == nullptr && (unit[0] == 0 || packed)) {
         if (mode == 0 && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
         if (mode == 0 && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
     }

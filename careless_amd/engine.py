@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from careless_amd import _lib
-from careless_amd._lib import AdamArgs, LaueArgs, MlpArgs, TnArgs, check, ptr
+from careless_amd._lib import AdamArgs, DetArgs, LaueArgs, MlpArgs, TnArgs, check, ptr
 from careless_amd.models.base import BaseModel
 
 TILE = _lib.CL_MLP_TILE
@@ -420,6 +420,36 @@ class ObsData:
         self.chain_dact = [torch.zeros(rows, self.n_pad, dtype=torch.float32, device=device) for _ in range(n)]
 
 
+class ObsChunks:
+    """A shard whose metadata image does not fit one launch of the fused kernels (their per-lane offsets are 32-bit: a launch
+    addresses < 4 GiB of metadata; 50 M observations with positional encodings are 4.8 GB): consecutive `ObsData` pieces that are
+    launched one after the other.  The reference is full-batch at any N (careless/models/merging/variational.py:255-256) and so is
+    this: the weight-gradient partials reduce per launch into the same gradient, NLL and dz_f accumulate, the noise is keyed by
+    the global row.  Only the plain observation layout is cut (packed layouts keep whole groups / images per launch)."""
+
+    def __init__(self, children: List[ObsData]):
+        self.children = children
+        c0 = children[0]
+        self.start, self.N, self.N_total, self.d = c0.start, sum(c.N for c in children), c0.N_total, c0.d
+        self.n_pad, self.grid, self.partials = sum(c.n_pad for c in children), c0.grid, c0.partials
+        self.laue, self.fused_laue, self.rows, self.row_map, self.row0 = False, False, None, None, 0
+        for c in children:
+            c.row0 = c.start - self.start           # first row of the piece inside the shard's eta / ipred arrays
+
+    def alloc_chain(self, lib, blocks, w, device):
+        self.children[0].alloc_chain(lib, blocks, w, device)         # the pieces run one after the other: one set of buffers
+        for c in self.children[1:]:
+            c.chain_act, c.chain_dact = self.children[0].chain_act, self.children[0].chain_dact
+
+
+def launch_row_limit(d: int) -> int:
+    """Most rows of the plain layout one launch takes: 4 * cl_mlp_meta_rows(d) * n_pad bytes of metadata must stay below 4 GiB
+    (include/careless_hip.h: return code -4).  CARELESS_HIP_MAX_LAUNCH_BYTES lowers the bound (tests of the chunked path)."""
+    import os
+    lim = int(os.environ.get("CARELESS_HIP_MAX_LAUNCH_BYTES", str((1 << 32) - (1 << 24))))
+    return max(TILE, lim // (4 * ((d + 3) // 4 * 4)) // TILE * TILE)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # the engine
 # ------------------------------------------------------------------------------------------------------------
@@ -513,6 +543,14 @@ class ElboEngine:
             if self.L + imgl.n_image_layers > max_l:
                 raise NotImplementedError(f"{self.L} Dense + {imgl.n_image_layers} image layers of width {self.w}: the HIP engine "
                                           f"supports {max_l} hidden layers in total at this width")
+        # Deterministic mode (`model.deterministic = True` or CARELESS_HIP_DETERMINISTIC=1): no float atomics anywhere in the step --
+        # per-observation stores + fixed-order sums (cl_det_reduce) -- so two runs give bit-identical gradients and parameters
+        import os
+        self.deterministic = bool(getattr(model, "deterministic", False)) or os.environ.get("CARELESS_HIP_DETERMINISTIC", "0") == "1"
+        if self.deterministic and (self.laue or self.wide or imgl is not None or self.ev11 or self.double_wilson or self.blocks is not None):
+            raise NotImplementedError("deterministic mode covers monochromatic data, the Wilson prior, Normal / Student-T likelihoods and "
+                                      "scalers of one launch (width <= 64); Laue, double-Wilson, Evans-2011, per-image layers, chained and "
+                                      "wide scalers keep their float atomics")
         self.layout = make_layout(self.R, self.d, self.w, self.L, n_img, 3 if self.ev11 else 0, n_dwr,
                                   imgl=(imgl.n_image_layers, imgl.max_images) if imgl is not None else None)
         lay = self.layout
@@ -548,10 +586,7 @@ class ElboEngine:
         self.S = int(model.mc_sample_size)
         if self.S < 1:
             raise ValueError("mc_sample_size must be >= 1")
-        self.obs = ObsData(self.lib, inputs, self.shard.start, self.shard.stop, self.S, lay.P, dev, grid=grid, n_refl=self.R,
-                           n_images=self._max_images(), laue_groups=self.laue_groups, pack_images=imgl is not None,
-                           laue_single_pass=not getattr(model, "laue_two_pass", False) and self.blocks is None and not self.wide,
-                           wide=self.wide)
+        self.obs = self._build_obs(inputs, self.shard.start, self.shard.stop, grid, self.laue_groups)
         if self.blocks is not None:
             self.obs.alloc_chain(self.lib, self.blocks, self.w, dev)
         RS = self.R * self.S
@@ -571,6 +606,49 @@ class ElboEngine:
         self.history_buf: Optional[torch.Tensor] = None
         self._keep = None
         self.refresh_config()
+
+    def _build_obs(self, inputs, start, stop, grid, laue_groups):
+        """Device image of rows [start, stop) of `inputs`: one `ObsData`, or -- plain layout only -- as many pieces as the 4-GiB
+        bound of a launch asks for (`ObsChunks`)."""
+        kw = dict(grid=grid, n_refl=self.R, n_images=self._max_images(), laue_groups=laue_groups, pack_images=self.imgl is not None,
+                  laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None and not self.wide, wide=self.wide)
+        n_total = int(_np(BaseModel.get_refl_id(inputs)).reshape(-1).shape[0])
+        stop = n_total if stop is None else stop
+        per = launch_row_limit(self.d)
+        if self.laue or self.imgl is not None or self.wide or stop - start <= per:
+            o = ObsData(self.lib, inputs, start, stop, self.S, self.layout.P, self.device, **kw)
+            if self.deterministic:
+                self._det_attach(o, [o])
+            return o
+        pieces = []
+        for a in range(start, stop, per):
+            pieces.append(ObsData(self.lib, inputs, a, min(stop, a + per), self.S, self.layout.P, self.device, **kw))
+            kw["n_refl"] = kw["n_images"] = None          # (the id ranges were checked over the whole input by the first piece)
+            if len(pieces) > 1:
+                pieces[-1].partials = pieces[0].partials  # launches are serialised on one stream: one partial buffer
+        o = ObsChunks(pieces)
+        if self.deterministic:
+            self._det_attach(o, pieces)
+        return o
+
+    def _det_attach(self, obs, pieces):
+        """Buffers of the deterministic mode for one observation set: the per-observation stores of the fused kernel and the sort
+        orders (by reflection, by image; stable, so sums run in row order) that `cl_det_reduce` walks."""
+        dev = self.device
+        rid = torch.cat([p.refl_id[: p.N] for p in pieces]).cpu().numpy()
+        img = torch.cat([p.image_id[: p.N] for p in pieces]).cpu().numpy()
+        n = len(rid)
+
+        def order(ids, nbins):
+            perm = np.argsort(ids, kind="stable").astype(np.int32)
+            seg = np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=nbins))]).astype(np.int32)
+            return torch.as_tensor(perm, device=dev), torch.as_tensor(seg, device=dev)
+        M = self._max_images() or 1
+        obs.det = dict(dzf=torch.zeros(n * self.S, dtype=torch.float32, device=dev), dimg=torch.zeros(n, dtype=torch.float32, device=dev),
+                       nll=torch.zeros(len(pieces) * pieces[0].grid, dtype=torch.float64, device=dev),
+                       refl=order(rid, self.R), img=order(img, M), M=M, pieces=len(pieces), grid=pieces[0].grid)
+        for k, p in enumerate(pieces):
+            p.det_parent, p.det_index = obs, k
 
     def _max_images(self):
         if self.img is not None:
@@ -673,17 +751,23 @@ class ElboEngine:
         a.bij_kind, a.eps = self.bij_kind, self.mlp.epsilon
         a.shift = self.mlp.scale_multiplier or 0.0
         a.w_ll = self._w_ll(obs)
-        a.eta = ptr(eta)
+        row0 = getattr(obs, "row0", 0)                  # piece of a chunked shard: its rows inside the shard's eta / ipred arrays
+        a.eta = ptr(eta) + 4 * self.S * row0 if eta is not None else None
         a.seed, a.step = self.seed, step & 0xFFFFFFFF
         a.dz_f = ptr(self.dz_f)
         a.d_img = (self.grads.data_ptr() + 4 * lay.off_img) if lay.n_img > 0 else None
         a.partials = ptr(obs.partials)
         a.scalars = ptr(self.scalars)
-        a.ipred_out = ptr(ipred_out)
+        a.ipred_out = ptr(ipred_out) + 4 * self.S * row0 if ipred_out is not None else None
         a.stop_flag = ptr(self.stop_flag)
         if self.ev11:
             a.ev11 = self.params.data_ptr() + 4 * lay.off_ev11
             a.d_ev11 = self.grads.data_ptr() + 4 * lay.off_ev11
+        if self.deterministic:
+            det = obs.det_parent.det
+            a.dzf_obs = det["dzf"].data_ptr() + 4 * self.S * row0
+            a.dimg_obs = det["dimg"].data_ptr() + 4 * row0
+            a.nll_part = det["nll"].data_ptr() + 8 * det["grid"] * obs.det_index
         return a
 
     def kernel_name(self, mode: int = 0) -> str:
@@ -691,13 +775,14 @@ class ElboEngine:
         what a rocprofv3 kernel trace lists for the dominant kernel."""
         if self.wide:
             return "wide_gemm_kernel"
-        ma = self._mlp_args(0, None, None, self.obs)
+        obs = self.obs.children[0] if isinstance(self.obs, ObsChunks) else self.obs
+        ma = self._mlp_args(0, None, None, obs)
         if self.blocks is not None:
-            ma = self._block_args(ma, self.obs, len(self.blocks) - 1)
-            ma.dX_out = ptr(self.obs.chain_dact[len(self.blocks) - 2])
-        elif self.laue and not self.obs.fused_laue:
+            ma = self._block_args(ma, obs, len(self.blocks) - 1)
+            ma.dX_out = ptr(obs.chain_dact[len(self.blocks) - 2])
+        elif self.laue and not obs.fused_laue:
             mode = 2 if mode == 0 else mode
-            ma.dO_ext = ptr(self.obs.laue_dO)
+            ma.dO_ext = ptr(obs.laue_dO)
         buf = C.create_string_buffer(128)
         check(min(0, self.lib.cl_mlp_kernel_name(C.byref(ma), mode, buf, 128)), "cl_mlp_kernel_name")
         return buf.value.decode()
@@ -737,9 +822,27 @@ class ElboEngine:
             self._allreduce()        # local_only: a test hook that leaves the per-rank partial gradient in place
         self._keep = (u_f, eta, ipred_out)
 
-    def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st):
+    def _det_reduce(self, obs, st):
+        det, lay = obs.det, self.layout
+        a = DetArgs()
+        a.dzf_obs, a.perm_refl, a.seg_refl = ptr(det["dzf"]), ptr(det["refl"][0]), ptr(det["refl"][1])
+        a.R, a.S, a.dz_f = self.R, self.S, ptr(self.dz_f)
+        if lay.n_img > 0:
+            a.dimg_obs, a.perm_img, a.seg_img = ptr(det["dimg"]), ptr(det["img"][0]), ptr(det["img"][1])
+            a.n_images, a.d_img = det["M"], self.grads.data_ptr() + 4 * lay.off_img
+        a.nll_part, a.nparts, a.scalars = ptr(det["nll"]), det["pieces"] * det["grid"], ptr(self.scalars)
+        a.stop_flag = ptr(self.stop_flag)
+        check(self.lib.cl_det_reduce(C.byref(a), st), "cl_det_reduce")
+
+    def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st, _piece: bool = False):
         """NLL of `obs` into scalars[NLL] and its gradient into dz_f / the flat gradient (scaler + image scales)."""
         lib, lay = self.lib, self.layout
+        if isinstance(obs, ObsChunks):
+            for piece in obs.children:
+                self._data_term(piece, step, eta, ipred_out, st, _piece=True)
+            if self.deterministic:
+                self._det_reduce(obs, st)
+            return
         if self.wide:
             return self._data_term_wide(obs, step, eta, ipred_out, st)
         ma = self._mlp_args(step, eta, ipred_out, obs)
@@ -763,9 +866,13 @@ class ElboEngine:
         elif self.laue:
             self._laue_passes(ma, obs, step, eta, ipred_out, st)
         else:
+            if self.deterministic:
+                obs.det_parent.det["nll"][obs.det_index * obs.grid:(obs.det_index + 1) * obs.grid].zero_()
             check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
         check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
                                      ptr(self.stop_flag), st), "cl_reduce_partials")
+        if self.deterministic and not _piece:
+            self._det_reduce(obs, st)
 
     def _block_args(self, ma: MlpArgs, obs: ObsData, k: int) -> MlpArgs:
         """Arguments of block k of the chain: its slice of the parameters, its input (metadata or the previous block's output)."""
@@ -820,10 +927,7 @@ class ElboEngine:
         """Device image of another observation set (validation data) for `evaluate_nll`."""
         if BaseModel.is_laue(inputs) != self.laue:
             raise ValueError("validation data and training data differ in kind (mono / Laue)")
-        o = ObsData(self.lib, inputs, 0, None, self.S, self.layout.P, self.device, n_refl=self.R,
-                    n_images=self._max_images(), pack_images=self.imgl is not None,
-                    laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None and not self.wide,
-                    wide=self.wide)
+        o = self._build_obs(inputs, 0, None, None, None)
         if o.d != self.d:
             raise ValueError("validation metadata width differs from the training data")
         if self.blocks is not None:

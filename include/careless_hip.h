@@ -161,6 +161,14 @@ typedef struct cl_mlp_args {
     float* act_out;             /* [cl_mlp_meta_rows(w)][n_pad]                                                        */
     const float* dH_ext;        /* [cl_mlp_meta_rows(w)][n_pad]                                                        */
     float* dX_out;              /* [cl_mlp_meta_rows(d)][n_pad]                                                        */
+    /* Deterministic mode (no reference counterpart: the reference's CPU path is deterministic, fp32 atomics in arbitrary order are
+     * not).  With dzf_obs non-NULL cl_elbo_mono_fwd_bwd (plain layout, width <= 64, no Evans-2011 terms) issues NO atomic: the
+     * amplitude gradient of every (observation, sample) is STORED in dzf_obs, the image-scale gradient of every observation in
+     * dimg_obs, every workgroup's NLL in nll_part; cl_det_reduce then sums them per reflection / per image / per launch in a fixed
+     * order.  Two runs on the same inputs give bit-identical gradients.                                                        */
+    float* dzf_obs;             /* [n_obs][S]                                                                          */
+    float* dimg_obs;            /* [n_obs]                                                                             */
+    double* nll_part;           /* [grid]                                                                              */
 } cl_mlp_args;
 
 enum { CL_LIK_NORMAL_ = 0, CL_LIK_STUDENTT_ = 1 };
@@ -181,6 +189,18 @@ int cl_mlp_backward_ext(const cl_mlp_args* args, int grid, void* stream);
 int cl_mlp_kernel_name(const cl_mlp_args* args, int mode, char* out, size_t n);
 /* grad_mlp[P] += sum over the `nparts` workgroup partials, in index order (deterministic) */
 int cl_reduce_partials(const float* partials, int nparts, int P, float* grad_mlp, const int* stop_flag, void* stream);
+
+/* Deterministic mode, second half: fixed-order sums of what cl_elbo_mono_fwd_bwd stored (dzf_obs / dimg_obs / nll_part).
+ * perm_refl lists the shard's observations sorted by reflection (stable), seg_refl[r] .. seg_refl[r+1] is reflection r's range;
+ * perm_img / seg_img the same by image.  dz_f[r][s] += sum in that order; d_img[m-1] += ... (image 0 is pinned); scalars[NLL] += sum
+ * of nll_part in index order.                                                                                              */
+typedef struct cl_det_args {
+    const float* dzf_obs; const int* perm_refl; const int* seg_refl; int R, S; float* dz_f;
+    const float* dimg_obs; const int* perm_img; const int* seg_img; int n_images; float* d_img;      /* d_img NULL: no image scales */
+    const double* nll_part; int nparts; double* scalars;
+    const int* stop_flag;
+} cl_det_args;
+int cl_det_reduce(const cl_det_args* args, void* stream);
 
 /* --- scalers wider than 64 ---------------------------------------------------------------------------------------------
  * replaces: the Dense stack of MetadataScaler / MLPScaler (careless/models/scaling/nn.py:55-68, 92-120) and its gradient
@@ -277,8 +297,8 @@ int cl_step_finalize(const double* scalars, float kl_weight_or_one, double* hist
 
 /* --- diagnostics -------------------------------------------------------------------------------------------------- */
 const char* cl_version(void);
-/* sizeof(cl_tn_args), sizeof(cl_mlp_args), sizeof(cl_adam_args), sizeof(cl_laue_args): lets a binding verify its mirrors */
-void cl_abi_sizes(size_t out[4]);
+/* sizeof(cl_tn_args), sizeof(cl_mlp_args), sizeof(cl_adam_args), sizeof(cl_laue_args), sizeof(cl_det_args): lets a binding verify its mirrors */
+void cl_abi_sizes(size_t out[5]);
 /* out[n][S]: kind 0 = the uniforms of cl_tn_*, kind 1 = the normals of cl_elbo_mono_fwd_bwd, for (seed, step) */
 int cl_debug_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
                    void* stream);

@@ -199,9 +199,9 @@ def _assert_grads(g_hip, grads, prob, name=""):
                 best = (e, sub)
             if e < RTOL_GRAD:
                 FLIP_CASES.append((name, sub, e))
-                import warnings
-                warnings.warn(f"{name}: gradients match the fp64 oracle at {e:.1e} with the LeakyReLU unit(s) (layer, row, unit) {list(sub)} on the "
-                              f"engine's branch (pre-activation within fp32 rounding of zero; {max(errs):.1e} on the fp64 branch)")
+                # (not a warning: this IS the check passing at full tolerance; `pytest -rP` shows the line, the count is bounded below)
+                print(f"{name}: gradients match the fp64 oracle at {e:.1e} with the LeakyReLU unit(s) (layer, row, unit) {list(sub)} on the "
+                      f"engine's branch (pre-activation within fp32 rounding of zero; {max(errs):.1e} on the fp64 branch)")
                 return
     raise AssertionError(f"gradient errors {errs}; best forced-branch assignment {best[1]} still at {best[0]:.2e} (candidates {cand})")
 
@@ -679,6 +679,16 @@ def test_full_size_properties_1M():
     assert bool(torch.isfinite(eng.grads).all()) and float(eng.grads.abs().max()) > 0
     hist = model.train_model(inputs, 5, progress=False)
     assert len(hist["loss"]) == 5 and all(np.isfinite(hist["loss"])) and hist["loss"][-1] < hist["loss"][0]
+    # ... and in deterministic mode (no atomics: stores + fixed-order sums) nothing differs at all, and it agrees with the default mode
+    from careless_amd.engine import ElboEngine
+    model2, inputs2, _, _ = make_workload("mono_1M_normal_5x64_S1")
+    model2.deterministic = True
+    det = [ElboEngine(model2, inputs2, seed=model.seed) for _ in range(2)]
+    for e in det:
+        e.forward_backward(0)
+    torch.cuda.synchronize()
+    assert torch.equal(det[0].grads, det[1].grads) and det[0].loss_terms() == det[1].loss_terms()
+    assert torch.allclose(det[0].grads, g1, rtol=1e-3, atol=1e-3 * float(g1.abs().max()))
 
 
 def test_full_size_laue_single_pass_equals_two_pass():
@@ -822,6 +832,107 @@ def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch()
     for lo, hi in zip(lay.seg_off[:-1], lay.seg_off[1:]):                      # per trainable tensor (fp32 atomics: summation order only)
         a, b = g_sum[lo:hi], g_full[lo:hi]
         assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6), (lo, hi)
+
+
+@pytest.mark.parametrize("kw", [dict(N=1500, R=60, d0=5, L=5, w=64, S=3, likelihood="studentt", dof=8.0),
+                                dict(N=1300, R=50, d0=5, posenc=True, L=20, w=10, S=2, perturb=0.02),
+                                dict(N=1100, R=50, d0=5, L=12, w=32, S=2)],
+                         ids=["mono_5x64", "cli_default_posenc_d21", "chained_12x32"])
+def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
+    """A shard whose metadata image would pass 4 GiB runs as consecutive launches (engine.ObsChunks; the reference is full-batch at
+    any N, variational.py:255-256).  With the bound lowered to a few hundred rows the same problem runs as 4 - 6 launches: loss,
+    predictions and every gradient equal the oracle's (injected noise) and, with in-kernel noise, the single-launch step's."""
+    from careless_amd.engine import ElboEngine, ObsChunks
+    L, w = kw["L"], kw["w"]
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    inputs = util.reference_inputs(data)
+    d = np.asarray(data["metadata"]).shape[1]
+    monkeypatch.setenv("CARELESS_HIP_MAX_LAUNCH_BYTES", str(4 * ((d + 3) // 4 * 4) * 300))
+    model = util.build_model(data, cfg, params, L, w)
+    ipred = model(inputs, u_f=u_f, eta=eta).cpu().numpy()
+    eng = model._engine
+    assert isinstance(eng.obs, ObsChunks) and len(eng.obs.children) >= 4 and sum(c.N for c in eng.obs.children) == kw["N"]
+    torch.cuda.synchronize()
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64))
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(out["loss"])) <= RTOL_LOSS * abs(float(out["loss"]))
+    assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
+    _assert_grads([g.cpu().numpy() for g in eng.grad_tensors()], grads, (data, cfg, params, u_f, eta), "chunked")
+    # in-kernel noise: the pieces draw what the single launch draws (keyed by the global row)
+    cut = ElboEngine(util.build_model(data, cfg, params, L, w), inputs, seed=31)
+    cut.forward_backward(2)
+    monkeypatch.delenv("CARELESS_HIP_MAX_LAUNCH_BYTES")
+    one = ElboEngine(util.build_model(data, cfg, params, L, w), inputs, seed=31)
+    assert not isinstance(one.obs, ObsChunks)
+    one.forward_backward(2)
+    torch.cuda.synchronize()
+    ta, tb = cut.loss_terms(), one.loss_terms()
+    assert abs(ta["nll"] - tb["nll"]) <= 1e-6 * abs(tb["nll"]) and ta["kl"] == tb["kl"]
+    assert util.rel_err(cut.grads.cpu().numpy(), one.grads.cpu().numpy()) < 2e-5
+    # and the training loop with validation data runs on the cut shard
+    m2 = util.build_model(data, cfg, params, L, w)
+    monkeypatch.setenv("CARELESS_HIP_MAX_LAUNCH_BYTES", str(4 * ((d + 3) // 4 * 4) * 300))
+    tr, te = tuple(a[:900] for a in inputs), tuple(a[900:] for a in inputs)
+    h = m2.train_model(tr, 3, progress=False, validation_data=te, validation_frequency=1)
+    assert len(h["loss"]) == 3 and all(np.isfinite(h["loss"])) and all(np.isfinite(h["NLL_val"]))
+
+
+@pytest.mark.parametrize("kw", [dict(N=1500, R=60, d0=5, L=5, w=64, S=3, likelihood="studentt", dof=8.0, n_images=7),
+                                dict(N=900, R=50, d0=5, L=20, w=10, S=2, perturb=0.02),
+                                dict(N=1300, R=40, d0=5, posenc=True, L=3, w=32, S=8, shuffle_rows=True, n_images=9),
+                                dict(N=700, R=40, d0=5, L=2, w=32, S=1, use_image_scales=False, kl_weight=0.5)],
+                         ids=["mono_5x64", "cli_default_20x10", "rows_in_arbitrary_order_S8", "no_image_scales_klweight"])
+def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypatch):
+    """`model.deterministic = True` (or CARELESS_HIP_DETERMINISTIC=1): the fused kernel stores per-observation contributions instead of
+    issuing float atomics and `cl_det_reduce` sums them in row order (include/careless_hip.h).  Same parity bar against the oracle,
+    and two engines on the same inputs produce bit-identical gradients, loss terms and -- after several Adam steps -- parameters;
+    also with the shard cut into several launches."""
+    from careless_amd.engine import ElboEngine
+    kw = dict(kw)
+    shuffle = kw.pop("shuffle_rows", False)
+    L, w = kw["L"], kw["w"]
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    if shuffle:
+        perm = np.random.default_rng(2).permutation(kw["N"])
+        for k in ("refl_id", "image_id", "file_id", "metadata", "iobs", "sigiobs"):
+            data[k] = np.asarray(data[k])[perm]
+        eta = eta[:, perm]
+        x = O.inputs_from_numpy(data)
+    inputs = util.reference_inputs(data)
+
+    def fresh():
+        m = util.build_model(data, cfg, params, L, w)
+        m.deterministic = True
+        return m
+    model = fresh()
+    ipred = model(inputs, u_f=u_f, eta=eta).cpu().numpy()
+    eng = model._engine
+    assert eng.deterministic and "deterministic" in eng.kernel_name()
+    torch.cuda.synchronize()
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64))
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(out["loss"])) <= RTOL_LOSS * abs(float(out["loss"]))
+    assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
+    _assert_grads([g.cpu().numpy() for g in eng.grad_tensors()], grads, (data, cfg, params, u_f, eta), "deterministic")
+    runs = []
+    for cut in (False, False, True):
+        if cut:
+            d = np.asarray(data["metadata"]).shape[1]
+            monkeypatch.setenv("CARELESS_HIP_MAX_LAUNCH_BYTES", str(4 * ((d + 3) // 4 * 4) * 400))
+        e = ElboEngine(fresh(), inputs, seed=5)
+        e.forward_backward(1)
+        torch.cuda.synchronize()
+        g, terms = e.grads.clone(), e.loss_terms()
+        e.alloc_history(4)
+        for i in range(4):
+            e.train_step(i)
+        torch.cuda.synchronize()
+        runs.append((g, terms, e.params.clone(), e.read_history(4)))
+    (g0, t0, p0, h0), (g1, t1, p1, h1), (g2, t2, p2, h2) = runs
+    assert torch.equal(g0, g1) and t0["nll"] == t1["nll"] and torch.equal(p0, p1) and h0["NLL"] == h1["NLL"]
+    # cut into launches: the per-reflection / per-image sums still run in row order -> the same bits in dz_f and the image scales; the
+    # scaler's weight gradient adds the pieces' partials in a different grouping (same values to rounding)
+    assert util.rel_err(g2.cpu().numpy(), g0.cpu().numpy()) < 2e-5
 
 
 def test_flip_resolutions_stay_rare():
