@@ -31,6 +31,23 @@ HEADERS = ["cl_math.h", "cl_kernels.h", os.path.join("..", "..", "include", "car
 ARCH = "gfx950"
 
 
+LANE_FLAG = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]      # internal LLVM option (validated on ROCm 7.2.0 / AMD clang 22); probed before use
+
+
+def _lane_flag_ok(hipcc: str) -> bool:
+    """The lane kernel asks LLVM to keep 4x4x1 MFMA results in architectural registers.  The option is internal to the AMDGPU
+    backend and may be renamed or dropped by a later ROCm: compile an empty device function with it; without it the kernel still
+    builds (its inline-assembly accumulators do not depend on the option), only slower by a few accumulator-register moves."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "probe.hip")
+        with open(src, "w") as f:
+            f.write("#include <hip/hip_runtime.h>\n__global__ void probe() {}\n")
+        r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-O3", "--cuda-device-only"] + LANE_FLAG + ["-c", src, "-o", os.path.join(d, "probe.o")],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return r.returncode == 0
+
+
 def _hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -61,7 +78,12 @@ def _build(LIB: str, extra, verbose: bool) -> str:
     hipcc = _hipcc()
     objs = []
     procs = []
+    lane_ok = _lane_flag_ok(hipcc)
+    if not lane_ok and verbose:
+        print("hipcc rejects " + " ".join(LANE_FLAG) + ": building elbo_lane.hip without it", flush=True)
     for s, stem, flags in UNITS:
+        if not lane_ok:
+            flags = [f for f in flags if f not in LANE_FLAG]
         o = os.path.join(LIBDIR, stem + ".o" + ("s" if extra else ""))
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + list(extra) + flags + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:

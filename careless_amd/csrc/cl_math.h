@@ -97,7 +97,9 @@ CL_HD float cl_noise_uniform(uint64_t seed, uint32_t step, uint32_t s, uint64_t 
 // fast device forms of the transcendental pieces of the noise generator (1-ulp hardware approximations are ample for
 // Monte-Carlo noise; the oracle is always fed the numbers the device actually drew, via cl_debug_noise)
 #if defined(__HIP_DEVICE_COMPILE__)
-CL_HD float cl_fast_log(float x) { return __logf(x); }
+// (v_log_f32 is log2 to 1 ulp; `__logf` wraps it in ~10 instructions of denormal scaling and error compensation that the arguments here --
+// uniforms >= 2^-24, 1 + x, sigmas -- do not need: every instruction of the sampling epilogue is paid in full by a lone wave)
+CL_HD float cl_fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 CL_HD float cl_fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 CL_HD void cl_fast_sincos_rev(float rev, float* s, float* c) { *s = __builtin_amdgcn_sinf(rev); *c = __builtin_amdgcn_cosf(rev); }
 CL_HD float cl_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -133,7 +133,7 @@ struct LSmem {
     static constexpr int oK = oF + NF * IMG;                  // transposed (dgrad) images, layers 0 .. NL-1 and the head
     static constexpr int oT = oK + (NL + 1) * IMG;            // per wave: sZ[TPAR], sH[TPAR] (by layer parity), sX (not LX)   [16][PIT] each
     static constexpr int oS = (2 * TPAR + (LX ? 0 : 1)) * 16 * PIT;   // (within a wave's region) sS: the lane's SPRE sampled amplitudes / amplitude gradients; sQ
-    static constexpr int oX = oS + (SPRE + 1) * 64;           // LX: two buffers of `xrows` metadata rows [row][PIT]
+    static constexpr int oX = oS + (2 * SPRE + 1) * 64;       // (sS, sQ, sE: the batch's scale noise); LX: two buffers of `xrows` metadata rows [row][PIT]
     static constexpr int TWF = oX;                            // floats of a wave's region without the row buffers
     static constexpr int NACCB = NL + (LX ? 1 : 0);           // 16 x 16 accumulator blocks a wave parks in the flush
     static constexpr int REG = NACCB * 256;
@@ -262,6 +262,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     float* const sX = sH + TPAR * 16 * PIT;            // (not LX) the metadata of the tile (layer 0's input)
     float* const sS = sZ + SM::oS;                     // sampled amplitudes of a batch of SPRE samples, then their gradients   [sample][lane]
     unsigned* const sQ = reinterpret_cast<unsigned*>(sS + SPRE * 64);       // byte offset of the lane's reflection in dz_f (~0: none)
+    float* const sE = sS + (SPRE + 1) * 64;            // the standard normals of the lane's observation for the samples of a batch   [sample][lane]
     float* const sXb = sZ + SM::oX;                    // LX: metadata rows of the current / the next tile: buffer (tile parity) x [xrows][PIT]
     constexpr int PAR = (TPAR - 1) * 16 * PIT;         // second copy of sZ / sH (layers alternate between the two; LX: one copy)
 
@@ -510,7 +511,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         const int lik_kind = A.lik_kind;
         const float dof = A.dof, lik_const = A.lik_const, shift = A.shift;
         const float inv_dof = (lik_kind == CL_LIK_STUDENTT) ? 1.0f / dof : 0.0f;       // wave-uniform
-        float esin[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         const bool act = rid >= 0;
         // (The amplitudes wait in LDS: inside the loop every wait on a global load would also wait for the previous sample's
         //  atomics -- one in-order counter --, a few microseconds each for a lone wave.)
@@ -550,20 +550,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 pda += dzs * tq;
             }
         };
-        auto philox_eta = [&](int s) -> float {      // one Philox block + Box-Muller pair serves samples s and s + 4
-            float eta = 0.0f;
-            if (!act) {
-            } else if (((s >> 2) & 1) == 0) {
-                float sn;
-                cl_noise_normal_pair(A.seed, A.step, (uint32_t)s, (uint64_t)(PACKED ? nkey : A.obs_offset + gobs), &eta, &sn);
-                const int kk = s & 3;
-                if (kk == 0) esin[0] = sn; else if (kk == 1) esin[1] = sn; else if (kk == 2) esin[2] = sn; else esin[3] = sn;
-            } else {
-                const int kk = s & 3;
-                eta = (kk == 0) ? esin[0] : (kk == 1) ? esin[1] : (kk == 2) ? esin[2] : esin[3];
-            }
-            return eta;
-        };
         if (coal) sQ[lane] = (rid >= 0) ? zoff : 0xFFFFFFFFu;
         int sb = 0;                                      // first sample of the batch
         do {
@@ -576,6 +562,20 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(A.z_f) + (zoff + 4u * (unsigned)min(sb + j, S - 1)),
                                                      (__attribute__((address_space(3))) void*)(sS + j * 64), 4, 0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (A.eta == nullptr) {
+                // the batch's in-kernel noise, drawn up front into LDS: one Philox block + Box-Muller pair serves samples s and s + 4
+                // (cl_math.h).  Drawn inside the sample loop, the pair's second half had to be parked in registers selected by
+                // s & 3 -- a dozen scalar branches per sample, each paid in full by a lone wave
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    if (sb + p < S) {                            // wave-uniform
+                        float ec, es;
+                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)(sb + p), (uint64_t)(PACKED ? nkey : A.obs_offset + gobs), &ec, &es);
+                        sE[p * 64 + lane] = ec;
+                        sE[(p + 4) * 64 + lane] = es;
+                    }
+                }
             }
             if (laue || rid >= 0) {
                 // Two loops over the batch (wave-uniform trip counts), so that the common one -- in-kernel noise -- contains no
@@ -590,7 +590,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 } else {
                     for (int s = sb; s < se; ++s) {
                         const float zf = (s > 0) ? sS[(s & (SPRE - 1)) * 64 + lane] : zf0;
-                        sample(s, philox_eta(s), act ? zf : 0.0f);
+                        sample(s, sE[(s & (SPRE - 1)) * 64 + lane], act ? zf : 0.0f);
                     }
                 }
             }
