@@ -191,17 +191,27 @@ def cpu_baseline(workload: str, n_sample: int, steps: int, full: bool = False):
                       f"fp32 PyTorch-CPU restatement of the reference graph (not TensorFlow), torch {torch.__version__}"}
 
 
+def _traffic_from(workload: str, world: int):
+    """Where `roofline.traffic` comes from: the source hash of the kernels the PMC passes ran on and whether it is this build's."""
+    from careless_amd.build import source_hash
+    rec = traffic_bytes(workload, world)[1]
+    if rec is None:
+        return None
+    return {"sources": rec.get("sources"), "this_build": source_hash(), "stale": rec.get("sources") != source_hash(), "file": rec.get("file")}
+
+
 def traffic_bytes(workload: str, world: int):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/traffic.json; collected with
-    scripts/pmc_passes.sh, separate --pmc runs); None for configurations that were not profiled."""
+    """(HBM bytes per launch of the dominant kernel, record) from the committed PMC passes (profiles/traffic.json; collected with
+    scripts/pmc_passes.sh, separate --pmc runs; written by scripts/traffic_json.py together with the source hash of the kernels it
+    was measured on); (None, None) for configurations that were not profiled."""
     try:
         here = os.path.dirname(os.path.abspath(__file__))
         rec = json.load(open(os.path.join(here, "profiles", "traffic.json"))).get(workload)
         if rec and rec.get("n_gpus") == world:
-            return rec["hbm_bytes_per_launch"]
+            return rec["hbm_bytes_per_launch"], rec
     except Exception:
         pass
-    return None
+    return None, None
 
 
 # ----------------------------------------------------------------------------------------------------------------------------
@@ -351,11 +361,16 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
                    "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
         "roofline": {"bound": "mfma", "kernel": (kernel_name + " (" + ("cl_wide_* GEMM launches" if eng.wide else ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd")) + ")"),
                      "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
-                     "traffic": traffic_bytes(name, world), "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
+                     "traffic": traffic_bytes(name, world)[0], "traffic_from": _traffic_from(name, world), "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
                      "achieved_on_step_time": achieved_step, "frac_on_step_time": achieved_step / 157.3,
                      "hbm_secondary": {"achieved_GBps": B * eng.N / (kern_ms * 1e-3) / 1e9, "bytes_per_obs": B}},
         "obs_per_rank": obs_per_rank, "host_peak_rss_gib_per_rank": rss_per_rank,
     }
+
+
+def _build_id():
+    from careless_amd.build import source_hash
+    return source_hash()
 
 
 def worker(args) -> int:
@@ -429,7 +444,7 @@ def worker(args) -> int:
                "n_gpus": world, "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None),
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": res["config"], "roofline": res["roofline"], "obs_per_rank": res["obs_per_rank"],
+               "build": _build_id(), "config": res["config"], "roofline": res["roofline"], "obs_per_rank": res["obs_per_rank"],
                "host_peak_rss_gib_per_rank": res["host_peak_rss_gib_per_rank"]}
         if extras:
             out["extra_configs"] = extras

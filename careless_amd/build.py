@@ -55,6 +55,18 @@ def _hipcc() -> str:
     return exe
 
 
+def source_hash() -> str:
+    """Identity of the kernel sources a library is built from (sha256 over csrc/, include/ and this file, 12 hex digits): profiles
+    and `profiles/traffic.json` record it, `bench.py` prints it, so a figure measured on other sources shows as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(HERE, "..", "include", "careless_hip.h")
+    for f in sorted(os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith((".hip", ".h"))) + [inc, os.path.abspath(__file__)]:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True

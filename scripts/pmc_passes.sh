@@ -13,7 +13,7 @@ for d in "ABCD":
     for f in glob.glob(f"gpurun_out/pmc{d}_{T}/*/*counter_collection.csv"):
         acc=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if any(k in r['Kernel_Name'] for k in ('elbo_mlp', 'elbo_narrow', 'elbo_lane')):
+            if any(k in r['Kernel_Name'] for k in ('elbo_mlp', 'elbo_narrow', 'elbo_lane', 'wide_stream', 'wide_gemm')):
                 acc[r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in acc.items(): print(d,k,len(v),sum(v)/len(v))
 print('# FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request: double it (calibrated on this kernel\'s own access pattern with scripts/calib_fetch.sh: forward-only launch, 960 MB of metadata -> FETCH_SIZE 469117 KiB; WRITE_SIZE exact)')

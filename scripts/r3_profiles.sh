@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-3 evidence on the current sources, one gpurun: for every workload a kernel-trace summary of `bench.py --workload W` (rocprofv3
+# --kernel-trace --stats, program directly after --) and the bench line of the same command; then the PMC passes (separate runs) of the
+# headline workload and of the two default-scaler workloads, and profiles/traffic.json from them (with the source hash).
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+out=gpurun_out/r3p; mkdir -p $out
+python3 -c "from careless_amd.build import source_hash; print(source_hash())" > $out/sources.txt
+WLS=${WLS:-"mono_10M_studentt_posenc_5x64_S8 mono_1M_normal_5x64_S1 laue_5M_normal_5x64_S1 mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_20x10_S8 mono_10M_studentt_posenc_4x64_img1_S8 mono_2M_studentt_3x128_S4 dw_50M_normal_5x64_S1"}
+for wl in $WLS; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$wl -o t -- python3 bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_$wl.json 2> $out/bench_$wl.err
+  f=$(find $out/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_$wl.csv
+  rm -rf $out/prof_$wl
+  python3 - $out/bench_$wl.json $out/kernel_stats_$wl.csv <<'PY'
+import sys, json, csv
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r = d["roofline"]
+    rows = list(csv.DictReader(open(sys.argv[2])))
+    top = rows[0]
+    print("PROF %-40s %.4g refl/s %.3f ms/step | live kernel %.3f ms frac %.3f | rocprof top: %s calls %s avg %.3f ms (%s%%) | build %s" % (
+        d["config"]["workload"], d["value"], d["ms_per_step"], r["kernel_ms"], r["frac"], top["Name"][:60], top["Calls"], float(top["AverageNs"]) / 1e6, top["Percentage"], d.get("build")))
+except Exception as e:
+    print("PROF", sys.argv[1], "FAILED", e)
+PY
+done | tee $out/summary.txt
+for wl in ${PMC_WLS:-"mono_10M_studentt_posenc_5x64_S8 mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_20x10_S8"}; do
+  bash scripts/pmc_passes.sh $wl > $out/pmc_$wl.txt 2>&1
+  tail -30 $out/pmc_$wl.txt | grep -E "^[A-D] " | head -40
+done
+rm -rf gpurun_out/pmc?_* gpurun_out/pmc?.log
