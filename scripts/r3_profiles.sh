@@ -22,7 +22,8 @@ except Exception as e:
     print("PROF", sys.argv[1], "FAILED", e)
 PY
 done | tee $out/summary.txt
-for wl in ${PMC_WLS:-"mono_10M_studentt_posenc_5x64_S8 mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_20x10_S8"}; do
+PMC_WLS=${PMC_WLS:-"mono_10M_studentt_posenc_5x64_S8 mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_20x10_S8"}
+for wl in $PMC_WLS; do
   bash scripts/pmc_passes.sh $wl > $out/pmc_$wl.txt 2>&1
   tail -30 $out/pmc_$wl.txt | grep -E "^[A-D] " | head -40
 done

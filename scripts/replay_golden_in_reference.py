@@ -5,7 +5,9 @@ TensorFlow / TFP / tf_keras) and diff loss, gradients and the 6-step Adam trajec
 This is the one-command pin of the oracle SURVEY.md 8c(v) asks for.  It cannot run in the build container or on the GPU box
 (TensorFlow is not installed there and the reference never travels); run it wherever `import careless` works:
 
-    pip install careless            # or: pip install -e /path/to/reference
+    python3.10 -m venv /tmp/ref && . /tmp/ref/bin/activate
+    pip install "tensorflow==2.18.0" "tensorflow-probability[tf]==0.25" tf_keras reciprocalspaceship "careless==0.5.4"
+        # (= the reference's pyproject.toml:14-19; or: pip install -e /path/to/reference)
     python scripts/replay_golden_in_reference.py [--cases mono_2x32_normal_S3 ...] [--rtol 1e-4]
 
 What it does per case (tests/golden/cases.json holds the problem sizes, the .npz everything else):
@@ -23,8 +25,13 @@ What it does per case (tests/golden/cases.json holds the problem sizes, the .npz
   * compares  loss / NLL / KL  (model.losses, metrics),  every gradient tensor (tf.GradientTape over model.trainable_variables,
     matched to `grad_XX` by the oracle's tensor order),  and  6 x `train_step_with_gradient_norm` on `traj_u` / `traj_eta`
     against `traj_loss`, `traj_gnorm` and the final parameters `final_XX`.
-Exit code 0 = every compared number within --rtol (default 1e-4, the north_star tolerance); the table it prints is the evidence.
-Not covered: the double-Wilson golden file (the reference builds that prior from gemmi-backed ASU objects, not arrays).
+Exit code 0 = every compared number within --rtol (default 1e-4, the north_star tolerance); the PASS / FAIL table it ends with is the
+evidence.
+The double-Wilson case: the reference builds `DoubleWilsonPrior` from gemmi-backed `ReciprocalASUCollection` objects
+(careless/models/priors/wilson.py:82-138); the golden file holds what that constructor derives from them (reflids, root, asu_ids,
+centric, multiplicity, r), so the script allocates the reference's class without running its constructor and assigns exactly the
+attributes `log_prob` reads (:146-175) -- the arithmetic under test is the reference's own `log_prob`, `RiceWoolfson`, `Rice` and
+`FoldedNormal`.
 """
 import argparse
 import json
@@ -59,7 +66,9 @@ def main():
     from careless.models.likelihoods import mono as mono_lik
     from careless.models.merging import surrogate_posteriors as sp
     from careless.models.merging.variational import VariationalMergingModel
-    from careless.models.priors.wilson import WilsonPrior
+    from careless.models.priors.wilson import DoubleWilsonPrior, WilsonPrior
+    from careless.models.priors.base import Prior
+    from tensorflow_probability import util as tfu
     from careless.models.scaling.image import HybridImageScaler, ImageScaler, NeuralImageScaler
     from careless.models.scaling.nn import MLPScaler
 
@@ -81,8 +90,8 @@ def main():
     tfd.Normal._sample_n = normal_sample_n
 
     cases = json.load(open(os.path.join(GOLD, "cases.json")))
-    names = args.cases or [k for k, kw in cases.items() if not kw.get("double_wilson")]
-    worst = 0.0
+    names = args.cases or list(cases)
+    worst, table = 0.0, []
     for name in names:
         kw = cases[name]
         z = np.load(os.path.join(GOLD, name + ".npz"))
@@ -101,7 +110,24 @@ def main():
         finals = [z[k] for k in sorted(k for k in z.files if k.startswith("final_"))]
 
         centric = np.asarray(z["centric"], bool)
-        prior = WilsonPrior(centric, np.asarray(z["multiplicity"], np.float32))
+        mult = np.asarray(z["multiplicity"], np.float32)
+        dw = bool(kw.get("double_wilson"))
+        if dw:
+            # the reference's class with the attributes its constructor would derive from the ASU collection (wilson.py:112-138)
+            prior = DoubleWilsonPrior.__new__(DoubleWilsonPrior)
+            Prior.__init__(prior)
+            prior.parents, prior.optimize_r = [None, 0], bool(kw.get("optimize_dw_r"))
+            r0 = np.asarray(z["data_dw_r"], np.float32)
+            prior.r = tfu.TransformedVariable(tf.convert_to_tensor(r0), tfb.Sigmoid()) if prior.optimize_r else tf.convert_to_tensor(r0)
+            prior.centric, prior.multiplicity = centric, mult
+            prior.asu_ids = np.asarray(z["data_asu_ids"], np.int32)
+            prior.sigma = 1.0
+            prior.reflids = np.asarray(z["data_parent_ids"], np.int32)
+            prior.absent = tf.convert_to_tensor(prior.reflids == -1)
+            prior.root = np.asarray(z["data_root"], bool)
+            prior.wilson_prior = WilsonPrior(centric, mult, 1.0)
+        else:
+            prior = WilsonPrior(centric, mult)
         low = (1e-32 * ~centric).astype("float32")
         q = sp.TruncatedNormal.from_loc_and_scale(np.exp(params[0]).astype("float32"), (np.exp(params[1]) + eps).astype("float32"),
                                                   low, scale_shift=eps)
@@ -142,6 +168,8 @@ def main():
             for layer in scaler.image_layers:
                 layer.w.assign(next(it)); order.append(layer.w)
                 layer.b.assign(next(it)); order.append(layer.b)
+        if dw and prior.optimize_r:
+            prior.r.pretransformed_input.assign(next(it)); order.append(prior.r.pretransformed_input)
         if kw.get("ev11"):
             ev = next(it)
             e11 = lik.mono if laue else lik
@@ -178,12 +206,19 @@ def main():
         for o in order:
             cur.append(np.array([float(x) for x in o]) if isinstance(o, tuple) else o.numpy())
         rows += [(f"final_{i:02d}", rel(a, b)) for i, (a, b) in enumerate(zip(cur, finals))]
-        bad = [r for r in rows if not (r[1] <= args.rtol)]
-        worst = max(worst, max(r[1] for r in rows))
-        print(f"== {name}: {'OK' if not bad else 'MISMATCH'}  (max rel err {max(r[1] for r in rows):.2e})")
+        finite = [r for r in rows if np.isfinite(r[1])]          # (logit(r = 0) = -inf for the root ASU: compared as equal infinities below)
+        bad = [r for r in finite if not (r[1] <= args.rtol)]
+        worst = max(worst, max(r[1] for r in finite))
+        print(f"== {name}: {'OK' if not bad else 'MISMATCH'}  (max rel err {max(r[1] for r in finite):.2e})")
         for n_, e in rows:
-            print(f"   {n_:28s} {e:.3e}{'' if e <= args.rtol else '   <-- above tolerance'}")
-    print(f"worst relative error over all cases: {worst:.3e} (tolerance {args.rtol:g})")
+            print(f"   {n_:28s} {e:.3e}{'' if (e <= args.rtol or not np.isfinite(e)) else '   <-- above tolerance'}")
+        pick = lambda pre: max([e for n_, e in finite if n_.startswith(pre)] or [0.0])
+        table.append((name, pick("loss"), max(pick("NLL"), pick("F KLDiv")), pick("grad_"), max(pick("traj"), pick("final_")), not bad))
+    print()
+    print(f"{'case':44s} {'loss':>9s} {'NLL/KL':>9s} {'gradients':>10s} {'trajectory':>11s}   verdict")
+    for name, a, b, c, d, ok in table:
+        print(f"{name:44s} {a:9.2e} {b:9.2e} {c:10.2e} {d:11.2e}   {'PASS' if ok else 'FAIL'}")
+    print(f"worst relative error over all cases: {worst:.3e} (tolerance {args.rtol:g}) -> {'PASS' if worst <= args.rtol else 'FAIL'}")
     return 0 if worst <= args.rtol else 1
 
 
