@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "cl_math.h"
 #include "cl_kernels.h"
@@ -909,7 +910,9 @@ int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {
         4ull * (unsigned long long)a.R * (unsigned long long)a.S >= (1ull << 32))
         return -4;
     if (grid < 1) return -1;
-    const bool rows = a.d > DMAX_ALL;
+    // (CARELESS_HIP_LANE_ROWS_FROM=k: metadata as LDS rows from k columns on instead of 16 -- A/B runs)
+    static const int rows_from = [] { const char* e = getenv("CARELESS_HIP_LANE_ROWS_FROM"); const int v = e ? atoi(e) : DMAX_ALL + 1; return v < 1 ? 1 : (v > DMAX_ALL + 1 ? DMAX_ALL + 1 : v); }();
+    const bool rows = a.d >= rows_from;
     if (a.row_map != nullptr) {
         if (a.n_obs != a.n_pad || (a.gmeta != nullptr && a.tile_gmax == nullptr)) return -1;
         if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;

@@ -52,6 +52,8 @@ struct GemmArgs {
     int ksplit;                     // EPI_WGRAD: contraction range of a z-block; partial stride (floats)
     long long pstride;
     int n_in;                       // EPI_WGRAD: N = n_in (the bias gradient = column sums of A, taken on the way)
+    const int* seg;                 // EPI_WGRAD, grouped (per-image layers): z-block g contracts rows seg[g] .. seg[g+1] and writes the group's
+    float* Cb; long long bstride;   //   kernel at C + g * pstride, its bias at Cb + g * bstride (NULL: the flat layer layout, bias behind the kernel)
     const int* stop_flag;
 };
 
@@ -116,8 +118,11 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     int kbeg = 0, kend = G.K;
     if (EPI == EPI_WGRAD) {
-        kbeg = (int)min((long long)blockIdx.z * G.ksplit, (long long)G.K);
-        kend = (int)min((long long)kbeg + G.ksplit, (long long)G.K);
+        if (G.seg != nullptr) { kbeg = G.seg[blockIdx.z]; kend = G.seg[blockIdx.z + 1]; }
+        else {
+            kbeg = (int)min((long long)blockIdx.z * G.ksplit, (long long)G.K);
+            kend = (int)min((long long)kbeg + G.ksplit, (long long)G.K);
+        }
     }
     const bool vecA = (G.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(G.A) & 15) == 0);
     const bool vecB = (G.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(G.B) & 15) == 0);
@@ -188,8 +193,10 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     }
 
     // epilogue: accumulator (a, b), element t of lane (j, q) = C[m0 + 32 wv + 16 a + 4 q + t][n0 + 16 b + j]
-    if (EPI == EPI_WGRAD && blockIdx.y == 0 && tid < BM && m0 + tid < G.M)
-        (G.C + (size_t)blockIdx.z * G.pstride)[(size_t)G.M * G.n_in + m0 + tid] = bsum;
+    if (EPI == EPI_WGRAD && blockIdx.y == 0 && tid < BM && m0 + tid < G.M) {
+        if (G.Cb != nullptr) G.Cb[(size_t)blockIdx.z * (size_t)G.bstride + m0 + tid] = bsum;
+        else (G.C + (size_t)blockIdx.z * G.pstride)[(size_t)G.M * G.n_in + m0 + tid] = bsum;
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -337,10 +344,16 @@ struct StreamArgs {
     const float* H; int ldh;         // EPI_DLRELU
     float leak; int act;
     const int* stop_flag;
+    // Grouped form (per-image layers, careless/models/scaling/image.py:90-96): the rows are sorted by image, seg[g] .. seg[g+1] are the
+    // rows of group g, its weights sit at W + g * wstride and its bias at bias + g * bstride.  A workgroup takes whole groups: it
+    // stages the group's weights, its eight waves walk the group's 16-row blocks, then the next group.  seg == NULL: one group = all rows.
+    const int* seg; int n_groups;
+    long long wstride, bstride;
 };
 
-// NAT: 16-column blocks of the output an instance holds (4: N <= 64, 8: N <= 128)
-template <bool WKM, int EPI, int NAT>
+// NAT: 16-column blocks of the output an instance holds (4: N <= 64, 8: N <= 128); GRP: the grouped form (its own instances: the
+// group loop costs the plain ones registers)
+template <bool WKM, int EPI, int NAT, bool GRP>
 __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
     if (S.stop_flag != nullptr && *S.stop_flag != 0) return;
     extern __shared__ __attribute__((aligned(16))) float sW[];      // [16 NA][SKP], zero outside N x K
@@ -348,9 +361,19 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
     const int j = lane & 15, q = lane >> 4;
     const int N = S.N, K = S.K;
     const int NA = (N + 15) >> 4, KC = (K + 15) >> 4;               // 16-column blocks of the output, 16-deep chunks of the contraction
+    const int tot = 16 * NA * SKP;
+    float* const sBias = sW + tot;                                   // [16 NA] (forward), zero past N
+    const bool vec = (S.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.X) & 15) == 0);
+    const float* const wrow = sW + j * SKP + 4 * q;
+    constexpr bool grouped = GRP;
+    const int ngroups = grouped ? S.n_groups : 1;
+  for (int grp = grouped ? (int)blockIdx.x : 0; grp < ngroups; grp += grouped ? (int)gridDim.x : 1) {
+    const long long row0 = grouped ? (long long)S.seg[grp] : 0, rend = grouped ? (long long)S.seg[grp + 1] : S.n;      // the group's rows
+    if (rend <= row0) continue;                                      // (workgroup-uniform)
+    const float* __restrict__ Wg = S.W + (size_t)grp * (size_t)S.wstride;
+    if (grouped && grp != (int)blockIdx.x) __syncthreads();          // every wave is done with the previous group's weights
     // (eight independent loads in flight per thread: a plain loop waits for every load in turn -- a fixed cost per launch; consecutive
     //  threads walk the contiguous axis of the stored weights)
-    const int tot = 16 * NA * SKP;
     for (int base = 0; base < tot; base += 8 * 512) {
         float v[8];
         int at[8];
@@ -362,21 +385,19 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
             else { k = idx / (16 * NA); o = idx - k * (16 * NA); }
             at[u] = (idx < tot && k < SKP) ? o * SKP + k : -1;
             v[u] = 0.0f;
-            if (idx < tot && o < N && k < K) v[u] = WKM ? S.W[(size_t)k * S.ldw + o] : S.W[(size_t)o * S.ldw + k];
+            if (idx < tot && o < N && k < K) v[u] = WKM ? Wg[(size_t)k * S.ldw + o] : Wg[(size_t)o * S.ldw + k];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) if (at[u] >= 0) sW[at[u]] = v[u];
     }
-    float* const sBias = sW + tot;                                   // [16 NA] (forward), zero past N
-    if (EPI == EPI_BIAS_LRELU && tid < 16 * NA) sBias[tid] = (tid < N) ? S.bias[tid] : 0.0f;
+    if (EPI == EPI_BIAS_LRELU && tid < 16 * NA) sBias[tid] = (tid < N) ? S.bias[(size_t)grp * (size_t)S.bstride + tid] : 0.0f;
     __syncthreads();
-    const long long nblk = (S.n + 15) >> 4;
-    const bool vec = (S.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.X) & 15) == 0);
+    const long long nblk = (rend - row0 + 15) >> 4;
     // the rows' operand: lane (row j, k-group q) holds X[row][16 kc + 4 q .. + 3] of chunk kc (MFMA step t contracts k = 16 kc + 4 q + t)
     auto load_x = [&](long long b, int kc) -> f32x4 {
-        const long long row = b * 16 + j;
+        const long long row = row0 + b * 16 + j;
         f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (row < S.n) {
+        if (row < rend) {
             const int k = 16 * kc + 4 * q;
             const float* p = S.X + (size_t)row * S.ldx + k;
             if (vec && k + 3 < K) x = *reinterpret_cast<const f32x4*>(p);
@@ -387,11 +408,10 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
         }
         return x;
     };
-    long long blk = (long long)blockIdx.x * 8 + wv;
-    const long long bstep = (long long)gridDim.x * 8;
+    long long blk = grouped ? (long long)wv : (long long)blockIdx.x * 8 + wv;
+    const long long bstep = grouped ? 8 : (long long)gridDim.x * 8;
     f32x4 xc = {0.0f, 0.0f, 0.0f, 0.0f};
     if (blk < nblk) xc = load_x(blk, 0);
-    const float* const wrow = sW + j * SKP + 4 * q;
     for (; blk < nblk; blk += bstep) {
         f32x4 acc[NAT];
 #pragma unroll
@@ -413,8 +433,8 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
             xc = xnx;
         }
         // accumulator a, element t of lane (j, q) = Y[row = 16 blk + j][column 16 a + 4 q + t]: four consecutive columns of the lane's row
-        const long long row = blk * 16 + j;
-        if (row < S.n) {
+        const long long row = row0 + blk * 16 + j;
+        if (row < rend) {
             const bool vecy = (S.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.Y) & 15) == 0);
             const bool vech = (S.ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.H) & 15) == 0);
             f32x4 hm[NAT];                           // dgrad: the activations whose sign selects the derivative, all requested before the first use
@@ -458,13 +478,14 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
             }
         }
     }
+  }
 }
 
-template <bool WKM, int EPI, int NAT>
+template <bool WKM, int EPI, int NAT, bool GRP>
 int launch_stream_n(const StreamArgs& s, hipStream_t st) {
     const int NA = (s.N + 15) >> 4;
     const size_t sm = (size_t)(16 * NA * SKP + 16 * NA) * sizeof(float);
-    auto kern = wide_stream_kernel<WKM, EPI, NAT>;
+    auto kern = wide_stream_kernel<WKM, EPI, NAT, GRP>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -475,8 +496,9 @@ int launch_stream_n(const StreamArgs& s, hipStream_t st) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const long long nblk = (s.n + 15) >> 4;
-    long long grid = (nblk + 7) / 8;
+    long long grid = s.seg != nullptr ? (long long)s.n_groups : (nblk + 7) / 8;
     if (grid > 2LL * cus) grid = 2LL * cus;          // two 8-wave workgroups per CU (2 x 67.6 KB of LDS at 128 x 128)
+    if (grid < 1) grid = 1;
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sm, st, s);
     return (int)hipGetLastError();
@@ -484,8 +506,9 @@ int launch_stream_n(const StreamArgs& s, hipStream_t st) {
 
 template <bool WKM, int EPI>
 int launch_stream(const StreamArgs& s, hipStream_t st) {
-    if (s.N <= 64) return launch_stream_n<WKM, EPI, 4>(s, st);
-    return launch_stream_n<WKM, EPI, 8>(s, st);
+    if (s.seg != nullptr) return s.N <= 64 ? launch_stream_n<WKM, EPI, 4, true>(s, st) : launch_stream_n<WKM, EPI, 8, true>(s, st);
+    if (s.N <= 64) return launch_stream_n<WKM, EPI, 4, false>(s, st);
+    return launch_stream_n<WKM, EPI, 8, false>(s, st);
 }
 
 template <bool AK, bool BK_, int EPI>
@@ -551,6 +574,41 @@ int cl_wide_dense_wgrad(const float* dZ, int lddz, const float* H, int ldh, long
     g.pstride = (long long)n_out * n_in + n_out;
     g.stop_flag = stop_flag;
     return launch_gemm<true, true, EPI_WGRAD>(g, nsplit, (hipStream_t)stream);
+}
+
+/* per-image layers (grouped): rows sorted by image, seg[g] .. seg[g+1] = rows of image g of this call (n_groups images);
+ * W = the layer's kernels [image][out][in] (w x w each), b = its biases [image][w]; both pointers at the call's first image */
+int cl_wide_image_forward(const float* X, int ldx, const float* W, const float* b, const int* seg, int n_groups, long long n, int w, float leak,
+                          float* Y, int ldy, const int* stop_flag, void* stream) {
+    if (X == nullptr || W == nullptr || b == nullptr || seg == nullptr || Y == nullptr || n_groups < 1 || n < 1 || w < 1 || w > SMAX || ldx < w || ldy < w) return w > SMAX ? -2 : -1;
+    StreamArgs s = {};
+    s.X = X; s.ldx = ldx; s.W = W; s.ldw = w; s.Y = Y; s.ldy = ldy; s.n = n; s.N = w; s.K = w;
+    s.bias = b; s.leak = leak; s.act = 1; s.stop_flag = stop_flag;
+    s.seg = seg; s.n_groups = n_groups; s.wstride = (long long)w * w; s.bstride = w;
+    return launch_stream<false, EPI_BIAS_LRELU>(s, (hipStream_t)stream);
+}
+
+int cl_wide_image_dgrad(const float* dZ, int lddz, const float* W, const int* seg, int n_groups, long long n, int w, const float* Hprev, int ldh, float leak,
+                        float* dX, int ldo, const int* stop_flag, void* stream) {
+    if (dZ == nullptr || W == nullptr || seg == nullptr || dX == nullptr || n_groups < 1 || n < 1 || w < 1 || w > SMAX || lddz < w || ldo < w) return w > SMAX ? -2 : -1;
+    StreamArgs s = {};
+    s.X = dZ; s.ldx = lddz; s.W = W; s.ldw = w; s.Y = dX; s.ldy = ldo; s.n = n; s.N = w; s.K = w;
+    s.H = Hprev; s.ldh = ldh; s.leak = leak; s.stop_flag = stop_flag;
+    s.seg = seg; s.n_groups = n_groups; s.wstride = (long long)w * w;
+    return launch_stream<true, EPI_DLRELU>(s, (hipStream_t)stream);
+}
+
+/* dW[image][out][in] = dZ_rows^T H_rows, db[image][out] = column sums of dZ_rows, written (not added) for the n_groups images of the call */
+int cl_wide_image_wgrad(const float* dZ, int lddz, const float* H, int ldh, const int* seg, int n_groups, long long n, int w, float* dW, float* db,
+                        const int* stop_flag, void* stream) {
+    if (dZ == nullptr || H == nullptr || seg == nullptr || dW == nullptr || db == nullptr || n_groups < 1 || n < 1 || n > 0x7fffffffLL || w < 1 || lddz < w || ldh < w)
+        return -1;
+    GemmArgs g = {};
+    g.A = dZ; g.lda = lddz; g.B = H; g.ldb = ldh; g.C = dW;
+    g.M = w; g.N = w; g.K = (int)n; g.n_in = w;
+    g.pstride = (long long)w * w; g.seg = seg; g.Cb = db; g.bstride = w;
+    g.stop_flag = stop_flag;
+    return launch_gemm<true, true, EPI_WGRAD>(g, n_groups, (hipStream_t)stream);
 }
 
 int cl_wide_head_forward(const float* H, int ldh, const float* Wo, long long n, int w, int bij_kind, float eps, float* loc_out, float* sig_out,

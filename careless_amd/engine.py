@@ -289,7 +289,7 @@ class ObsData:
     layers) the arrays the fused kernel streams are in the packed order of `pack_by_image`."""
 
     def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None,
-                 laue_groups=None, pack_images: bool = False, laue_single_pass: bool = True, wide: bool = False):
+                 laue_groups=None, pack_images: bool = False, laue_single_pass: bool = True, wide: bool = False, sort_images: bool = False):
         # Views of the caller's arrays (possibly memory-mapped files shared by the ranks of a node): only this shard's rows are
         # ever copied / converted -- a rank of an 8-GPU job does not hold eight copies' worth of the 50 M-observation problem
         refl_all = _np(BaseModel.get_refl_id(inputs)).reshape(-1)
@@ -381,6 +381,15 @@ class ObsData:
             self.meta_ld = int(lib.cl_wide_ld(self.d))                 # [rows][ld]: the features, zero padding to a multiple of four
             rm = np.zeros((self.N, self.meta_ld), dtype=np.float32)
             rm[:, : self.d] = metadata[sl]
+            self.perm = None
+            if sort_images:
+                # per-image layers on this path: the rows of an image must be consecutive (grouped GEMM kernels); everything per row
+                # is stored in image order, `perm` maps the local order back to the caller's
+                self.perm = np.argsort(img_l, kind="stable")
+                rid_l, img_l, rm = rid_l[self.perm], img_l[self.perm], rm[self.perm]
+                if not self.laue:                       # (mono: a row is its own slot; Laue keeps iobs / sig per slot)
+                    iobs_l, sig_l = np.asarray(iobs_l)[self.perm], np.asarray(sig_l)[self.perm]
+                self.img_seg = np.concatenate([[0], np.cumsum(np.bincount(img_l, minlength=int(n_images or (img_l.max() + 1))))]).astype(np.int64)
             self.meta_rm = torch.as_tensor(rm, device=device)
         else:
             self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
@@ -402,6 +411,13 @@ class ObsData:
                 self.row_index = torch.as_tensor(self.rows.astype(np.int64), device=device)
         if wide and not self.laue:
             hl = np.arange(self.N)             # every row its own "harmonic group": the slot kernels then ARE the mono likelihood
+        elif wide and getattr(self, "perm", None) is not None:
+            hl = hl[self.perm]
+        if wide and getattr(self, "perm", None) is not None:
+            # global rows in the stored (image) order: the noise key of every row, and which columns of an injected eta are its
+            base_rows = self.rows if self.rows is not None else np.arange(self.start, self.start + self.N)
+            self.rows = np.asarray(base_rows)[self.perm]
+            self.row_index = torch.as_tensor(self.rows.astype(np.int64), device=device)
         if (self.laue and not self.fused_laue) or wide:
             self.harmonic_id = torch.as_tensor(hl.astype(np.int32), device=device)
             self.laue_loc = torch.empty(self.N, dtype=torch.float32, device=device)
@@ -531,16 +547,18 @@ class ElboEngine:
         # blocks, so the scaler runs unfused -- one fp32-MFMA GEMM launch (csrc/wide_gemm.hip) per layer and direction, activations
         # through HBM -- around the same HIP likelihood kernels (_data_term_wide)
         self.wide = self.w > 64 or self.d > 64
+        if imgl is not None and not self.wide and self.L + imgl.n_image_layers > int(self.lib.cl_mlp_max_layers_imgl(self.w)):
+            self.wide = True        # more hidden layers (Dense + per-image) than one fused launch holds: layer by layer as well
         max_plain = 1 if self.wide else int(self.lib.cl_mlp_max_layers(self.w))
-        if self.wide and imgl is not None:
-            raise NotImplementedError(f"per-image layers of width {self.w}: the HIP engine supports them up to width 64")
+        if self.wide and imgl is not None and self.w > 128:
+            raise NotImplementedError(f"per-image layers of width {self.w}: the HIP engine supports them up to width 128")
         if not self.wide and imgl is None and self.L > max_plain:
             # deeper than one launch holds in registers: a chain of layer blocks, activations exchanged through HBM
             self.blocks = chain_plan(self.d, self.w, self.L, max_plain)
         if imgl is not None:
             imgl.build(self.d)
             max_l = int(self.lib.cl_mlp_max_layers_imgl(self.w))
-            if self.L + imgl.n_image_layers > max_l:
+            if not self.wide and self.L + imgl.n_image_layers > max_l:
                 raise NotImplementedError(f"{self.L} Dense + {imgl.n_image_layers} image layers of width {self.w}: the HIP engine "
                                           f"supports {max_l} hidden layers in total at this width")
         # Deterministic mode (`model.deterministic = True` or CARELESS_HIP_DETERMINISTIC=1): no float atomics anywhere in the step --
@@ -610,7 +628,8 @@ class ElboEngine:
     def _build_obs(self, inputs, start, stop, grid, laue_groups):
         """Device image of rows [start, stop) of `inputs`: one `ObsData`, or -- plain layout only -- as many pieces as the 4-GiB
         bound of a launch asks for (`ObsChunks`)."""
-        kw = dict(grid=grid, n_refl=self.R, n_images=self._max_images(), laue_groups=laue_groups, pack_images=self.imgl is not None,
+        kw = dict(grid=grid, n_refl=self.R, n_images=self._max_images(), laue_groups=laue_groups, pack_images=self.imgl is not None and not self.wide,
+                  sort_images=self.imgl is not None and self.wide,
                   laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None and not self.wide, wide=self.wide)
         n_total = int(_np(BaseModel.get_refl_id(inputs)).reshape(-1).shape[0])
         stop = n_total if stop is None else stop
@@ -971,26 +990,59 @@ class ElboEngine:
     WIDE_BUDGET = 1 << 30     # bytes of activation storage a row chunk may take ((L + 2) buffers of chunk x ld floats)
 
     def _wide_setup(self):
-        """Work buffers of the unfused path (csrc/wide_gemm.hip): L activation buffers + two gradient buffers of `chunk` rows, the
-        per-layer weight-gradient partials.  The chunk is sized from the layer count and width so the buffers stay inside
-        WIDE_BUDGET (and, with it, inside the device memory next to the shard)."""
+        """Work buffers of the unfused path (csrc/wide_gemm.hip): one activation buffer per hidden layer (Dense + per-image) + two
+        gradient buffers of `chunk` rows, the per-layer weight-gradient partials.  The chunk is sized from the layer count and
+        width so the buffers stay inside WIDE_BUDGET (and, with it, inside the device memory next to the shard)."""
         if getattr(self, "_wide", None) is not None:
             return self._wide
         lib, dev = self.lib, self.device
         ldw = int(lib.cl_wide_ld(self.w))
-        per_row = 4 * (self.L + 2) * ldw
+        nh = self.L + (self.imgl.n_image_layers if self.imgl is not None else 0)
+        per_row = 4 * (nh + 2) * ldw
         free = torch.cuda.mem_get_info(dev)[0]
         budget = min(self.WIDE_BUDGET, max(free // 4, 64 << 20))
         chunk = max(128, min(budget // per_row, 1 << 20) // 128 * 128)
-        acts = [torch.zeros(chunk * ldw, dtype=torch.float32, device=dev) for _ in range(max(2, self.L))]
-        dz = [torch.empty(chunk * ldw, dtype=torch.float32, device=dev) for _ in range(2)]
-        nsplit = int(lib.cl_wide_wgrad_splits(chunk))
-        pmax = max(self.w * self.d + self.w, self.w * self.w + self.w)
-        nblk = int(lib.cl_wide_head_blocks(chunk))
-        self._wide = dict(ldw=ldw, chunk=chunk, acts=acts, dz=dz, nsplit=nsplit, nblk=nblk,
-                          wpart=torch.empty(nsplit * pmax, dtype=torch.float32, device=dev),
-                          hpart=torch.empty(nblk * (2 * self.w + 2), dtype=torch.float32, device=dev))
+        self._wide = dict(ldw=ldw, chunk=chunk, nh=nh, rows=0, acts=[], dz=[])
+        self._wide_buffers(chunk)
         return self._wide
+
+    def _wide_buffers(self, rows: int):
+        """(Re)allocate the row buffers for chunks of up to `rows` rows (an image larger than the default chunk needs its own size)."""
+        W, lib, dev = self._wide, self.lib, self.device
+        if rows <= W["rows"]:
+            return
+        ldw = W["ldw"]
+        W["acts"] = [torch.zeros(rows * ldw, dtype=torch.float32, device=dev) for _ in range(max(2, W["nh"]))]
+        W["dz"] = [torch.zeros(rows * ldw, dtype=torch.float32, device=dev) for _ in range(2)]
+        W["nsplit"], W["nblk"] = int(lib.cl_wide_wgrad_splits(rows)), int(lib.cl_wide_head_blocks(rows))
+        pmax = max(self.w * self.d + self.w, self.w * self.w + self.w)
+        W["wpart"] = torch.empty(W["nsplit"] * pmax, dtype=torch.float32, device=dev)
+        W["hpart"] = torch.empty(W["nblk"] * (2 * self.w + 2), dtype=torch.float32, device=dev)
+        W["rows"] = rows
+
+    def _wide_chunks(self, obs: ObsData):
+        """Row chunks [a, b) of `obs` for the layer-by-layer path.  With per-image layers a chunk holds whole images (their rows are
+        consecutive: ObsData sort_images) and carries (first image, device array of the images' row starts relative to a)."""
+        if getattr(obs, "wide_chunks", None) is not None:
+            return obs.wide_chunks
+        W = self._wide_setup()
+        chunks = []
+        if self.imgl is None:
+            chunks = [(a, min(obs.N, a + W["chunk"]), 0, None) for a in range(0, obs.N, W["chunk"])]
+        else:
+            seg, M = obs.img_seg, len(obs.img_seg) - 1
+            m0 = 0
+            while m0 < M:
+                m1 = m0 + 1
+                while m1 < M and seg[m1 + 1] - seg[m0] <= W["chunk"]:
+                    m1 += 1
+                if seg[m1] > seg[m0]:
+                    rel = torch.as_tensor((seg[m0:m1 + 1] - seg[m0]).astype(np.int32), device=self.device)
+                    chunks.append((int(seg[m0]), int(seg[m1]), m0, rel))
+                m0 = m1
+            self._wide_buffers(max(b - a for a, b, _, _ in chunks))
+        obs.wide_chunks = chunks
+        return chunks
 
     def _wide_layers(self):
         """(offset of Wt, offset of b, fan-in) of every Dense layer inside the scaler's flat W^T layout, then the head's offset."""
@@ -1001,46 +1053,72 @@ class ElboEngine:
             fan_in = self.w
         return out, off
 
-    def _wide_forward(self, obs: ObsData, a: int, b: int, keep: bool, st):
-        """Dense stack on rows [a, b) of `obs`: layer l's output lands in acts[l] when `keep` (else two buffers alternate); returns
-        the (buffer, ld) pairs of h_0 .. h_L."""
+    def _imgl_ptrs(self, flat: torch.Tensor, k: int, m0: int):
+        """Device pointers of (kernel, bias) of image m0 in per-image layer k inside `flat` (params or grads): the layer's block is
+        [W: n_images x (w x w) | b: n_images x w] (include/careless_hip.h)."""
+        M, w = self.imgl.max_images, self.w
+        base = flat.data_ptr() + 4 * (self.layout.off_imgl + k * M * (w * w + w))
+        return base + 4 * m0 * w * w, base + 4 * (M * w * w + m0 * w)
+
+    def _wide_forward(self, obs: ObsData, chunk, keep: bool, st):
+        """Hidden layers on one row chunk of `obs`: layer l's output lands in acts[l] when `keep` (else two buffers alternate);
+        returns the (buffer, ld) pairs of h_0 .. h_(L + K)."""
+        a, b, m0, seg = chunk
         lib, W = self.lib, self._wide_setup()
         n, ldw, base = b - a, W["ldw"], self.params.data_ptr() + 4 * self.layout.off_mlp
         layers, _ = self._wide_layers()
+        sf, leak = ptr(self.stop_flag), self.mlp.leakiness
         hs = [(obs.meta_rm.data_ptr() + 4 * a * obs.meta_ld, obs.meta_ld)]
         for l, (ow, ob, fan_in) in enumerate(layers):
             dst = W["acts"][l if keep else l & 1]
-            check(lib.cl_wide_dense_forward(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, self.mlp.leakiness, 1,
-                                            ptr(dst), ldw, ptr(self.stop_flag), st), "cl_wide_dense_forward")
+            check(lib.cl_wide_dense_forward(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, 1,
+                                            ptr(dst), ldw, sf, st), "cl_wide_dense_forward")
+            hs.append((dst.data_ptr(), ldw))
+        for k in range(self.imgl.n_image_layers if self.imgl is not None else 0):       # image.py:116-125
+            l = self.L + k
+            dst = W["acts"][l if keep else l & 1]
+            wk, bk = self._imgl_ptrs(self.params, k, m0)
+            check(lib.cl_wide_image_forward(hs[-1][0], hs[-1][1], wk, bk, ptr(seg), seg.numel() - 1, n, self.w, leak, ptr(dst), ldw, sf, st),
+                  "cl_wide_image_forward")
             hs.append((dst.data_ptr(), ldw))
         return hs
 
     def _data_term_wide(self, obs: ObsData, step: int, eta, ipred_out, st):
-        """Hidden / metadata width > 64: unfused scaler on the GEMM kernels of csrc/wide_gemm.hip.  Forward (row chunks) -> (loc,
-        sigma) per row -> the HIP slot likelihood kernels (mono rows are their own groups) -> dL/d(loc, sigma) -> per chunk: forward
-        again (activations kept), head backward, then weight gradient and dgrad layer by layer, top down.  8 P_mm flops per
-        observation; every product in exact fp32."""
+        """Hidden / metadata width > 64 (or more hidden layers with per-image layers than one fused launch holds): unfused scaler on
+        the GEMM kernels of csrc/wide_gemm.hip.  Forward (row chunks) -> (loc, sigma) per row -> the HIP slot likelihood kernels (mono
+        rows are their own groups) -> dL/d(loc, sigma) -> per chunk: forward again (activations kept), head backward, then weight
+        gradient and dgrad layer by layer, top down.  8 P_mm flops per observation; every product in exact fp32."""
         lib, lay, W = self.lib, self.layout, self._wide_setup()
+        chunks = self._wide_chunks(obs)
         ma = self._mlp_args(step, eta, ipred_out, obs)
         layers, off_head = self._wide_layers()
         pbase = self.params.data_ptr() + 4 * lay.off_mlp
         gbase = self.grads.data_ptr() + 4 * lay.off_mlp
         sf, leak, w, ldw = ptr(self.stop_flag), self.mlp.leakiness, self.w, W["ldw"]
-        for a in range(0, obs.N, W["chunk"]):
-            b = min(obs.N, a + W["chunk"])
-            hs = self._wide_forward(obs, a, b, False, st)
+        K = self.imgl.n_image_layers if self.imgl is not None else 0
+        for ch in chunks:
+            a, b = ch[0], ch[1]
+            hs = self._wide_forward(obs, ch, False, st)
             check(lib.cl_wide_head_forward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, b - a, w, self.bij_kind, self.mlp.epsilon,
                                            obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a, sf, st), "cl_wide_head_forward")
         self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
-        for a in range(0, obs.N, W["chunk"]):
-            b = min(obs.N, a + W["chunk"])
+        for ch in chunks:
+            a, b, m0, seg = ch
             n = b - a
-            hs = self._wide_forward(obs, a, b, True, st)
+            hs = self._wide_forward(obs, ch, True, st)
             dz, dzn = W["dz"]
             nblk = min(W["nblk"], int(lib.cl_wide_head_blocks(n)))
             check(lib.cl_wide_head_backward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, obs.laue_dO.data_ptr() + 8 * a, n, w, self.bij_kind,
                                             self.mlp.epsilon, leak, ptr(dz), ldw, ptr(W["hpart"]), nblk, sf, st), "cl_wide_head_backward")
             check(lib.cl_reduce_partials(ptr(W["hpart"]), nblk, 2 * w + 2, gbase + 4 * off_head, sf, st), "cl_reduce_partials")
+            for k in range(K - 1, -1, -1):          # per-image layers: each image's gradient is written once (its rows sit in one chunk)
+                l = self.L + k
+                gw, gb = self._imgl_ptrs(self.grads, k, m0)
+                wk, _ = self._imgl_ptrs(self.params, k, m0)
+                check(lib.cl_wide_image_wgrad(ptr(dz), ldw, hs[l][0], hs[l][1], ptr(seg), seg.numel() - 1, n, w, gw, gb, sf, st), "cl_wide_image_wgrad")
+                check(lib.cl_wide_image_dgrad(ptr(dz), ldw, wk, ptr(seg), seg.numel() - 1, n, w, hs[l][0], hs[l][1], leak, ptr(dzn), ldw, sf, st),
+                      "cl_wide_image_dgrad")
+                dz, dzn = dzn, dz
             nsplit = min(W["nsplit"], int(lib.cl_wide_wgrad_splits(n)))
             for l in range(self.L - 1, -1, -1):
                 ow, ob, fan_in = layers[l]
@@ -1201,30 +1279,66 @@ def scaler_forward(mlp, metadata, imgl=None, image_id=None):
     mlp.build(d)
     if mlp.flat.device != dev:
         mlp.flat = mlp.flat.to(dev)
-    if mlp.width > 64 or d > 64:
-        # wider than the fused kernel holds: the layer-by-layer GEMM kernels (see ElboEngine._data_term_wide), forward only
-        if imgl is not None:
-            raise NotImplementedError(f"per-image layers of width {mlp.width}: the HIP engine supports them up to width 64")
+    too_deep = imgl is not None and mlp.n_layers + imgl.n_image_layers > int(lib.cl_mlp_max_layers_imgl(mlp.width))
+    if mlp.width > 64 or d > 64 or too_deep:
+        # wider (or, with per-image layers, deeper) than the fused kernel holds: the layer-by-layer GEMM kernels (see
+        # ElboEngine._data_term_wide), forward only; per-image layers run grouped on the rows sorted by image
         w, L, st = mlp.width, mlp.n_layers, _stream()
+        order = seg = None
+        if imgl is not None:
+            if w > 128:
+                raise NotImplementedError(f"per-image layers of width {w}: the HIP engine supports them up to width 128")
+            imgl.build(d)
+            if imgl.flat.device != dev:
+                imgl.flat = imgl.flat.to(dev)
+            ids = _np(image_id).reshape(-1).astype(np.int64)
+            if ids.size != N or (ids.size and (ids.min() < 0 or ids.max() >= imgl.max_images)):
+                raise ValueError("image_id does not match the metadata / exceeds max_images")
+            order = np.argsort(ids, kind="stable")
+            md = md[order]
+            seg = np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=imgl.max_images))]).astype(np.int64)
         ld0, ldw = int(lib.cl_wide_ld(d)), int(lib.cl_wide_ld(w))
         chunk = max(128, min(N, ((256 << 20) // (8 * max(ld0, ldw))) // 128 * 128))
+        if seg is None:
+            chunks = [(a, min(N, a + chunk), 0, None) for a in range(0, N, chunk)]
+        else:                                   # whole images per chunk
+            chunks, m0, M = [], 0, imgl.max_images
+            while m0 < M:
+                m1 = m0 + 1
+                while m1 < M and seg[m1 + 1] - seg[m0] <= chunk:
+                    m1 += 1
+                if seg[m1] > seg[m0]:
+                    chunks.append((int(seg[m0]), int(seg[m1]), m0, torch.as_tensor((seg[m0:m1 + 1] - seg[m0]).astype(np.int32), device=dev)))
+                m0 = m1
+            chunk = max(b - a for a, b, _, _ in chunks)
         loc = torch.empty(N, dtype=torch.float32, device=dev)
         sig = torch.empty(N, dtype=torch.float32, device=dev)
         x = torch.zeros(chunk * ld0, dtype=torch.float32, device=dev)
-        hb = [torch.empty(chunk * ldw, dtype=torch.float32, device=dev) for _ in range(2)]
+        hb = [torch.zeros(chunk * ldw, dtype=torch.float32, device=dev) for _ in range(2)]
         bij = _lib.CL_BIJ_EXP if mlp.scale_bijector == "exp" else _lib.CL_BIJ_SOFTPLUS
         base = mlp.flat.data_ptr()
-        for a in range(0, N, chunk):
-            b = min(N, a + chunk)
+        for a, b, m0, sg in chunks:
             x.view(chunk, ld0)[: b - a, :d] = torch.as_tensor(md[a:b], device=dev)
-            src, off, fan_in = (x.data_ptr(), ld0), 0, d
+            src, off, fan_in, nl = (x.data_ptr(), ld0), 0, d, 0
             for l in range(L):
-                dst = hb[l & 1]
+                dst = hb[nl & 1]
                 check(lib.cl_wide_dense_forward(src[0], src[1], base + 4 * off, base + 4 * (off + w * fan_in), b - a, fan_in, w, mlp.leakiness, 1,
                                                 ptr(dst), ldw, None, st), "cl_wide_dense_forward")
-                src, off, fan_in = (dst.data_ptr(), ldw), off + w * fan_in + w, w
+                src, off, fan_in, nl = (dst.data_ptr(), ldw), off + w * fan_in + w, w, nl + 1
+            for k in range(imgl.n_image_layers if imgl is not None else 0):
+                dst = hb[nl & 1]
+                M = imgl.max_images
+                kb = imgl.flat.data_ptr() + 4 * k * M * (w * w + w)
+                check(lib.cl_wide_image_forward(src[0], src[1], kb + 4 * m0 * w * w, kb + 4 * (M * w * w + m0 * w), ptr(sg), sg.numel() - 1, b - a, w,
+                                                mlp.leakiness, ptr(dst), ldw, None, st), "cl_wide_image_forward")
+                src, nl = (dst.data_ptr(), ldw), nl + 1
             check(lib.cl_wide_head_forward(src[0], src[1], base + 4 * off, b - a, w, bij, mlp.epsilon, loc.data_ptr() + 4 * a,
                                            sig.data_ptr() + 4 * a, None, st), "cl_wide_head_forward")
+        if order is not None:                   # back to the caller's row order
+            inv = torch.as_tensor(order, device=dev)
+            loc_c, sig_c = torch.empty_like(loc), torch.empty_like(sig)
+            loc_c[inv], sig_c[inv] = loc, sig
+            return loc_c, sig_c
         return loc, sig
     keep = []
     if imgl is not None:

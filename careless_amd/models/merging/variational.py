@@ -77,6 +77,11 @@ class VariationalMergingModel(BaseModel):
         du, de = eng._noise_to_device(u_f, eta)
         ipred = torch.empty(eng.N * eng.S, dtype=torch.float32, device=eng.device)
         eng.forward_backward(eng.t, du, de, ipred_out=ipred)
+        perm = getattr(eng.obs, "perm", None)
+        if perm is not None:                    # rows stored in image order (per-image layers on the layer-by-layer path): back to the caller's
+            out = torch.empty_like(ipred).view(eng.N, eng.S)
+            out[torch.as_tensor(perm, device=eng.device)] = ipred.view(eng.N, eng.S)
+            return out.t()
         return ipred.view(eng.N, eng.S).t()
 
     # -- training ------------------------------------------------------------------------------------------

@@ -222,6 +222,15 @@ int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n,
 int cl_wide_wgrad_splits(long long n);
 int cl_wide_dense_wgrad(const float* dZ, int lddz, const float* H, int ldh, long long n, int n_out, int n_in, float* partials, int nsplit,
                         const int* stop_flag, void* stream);
+/* Per-image layers of NeuralImageScaler (careless/models/scaling/image.py:66-125) on this path: rows sorted by image, seg[g] ..
+ * seg[g+1] = the rows of the g-th image of the call; W / b / dW / db point at that first image's kernel (w x w, (out, in)) and bias.
+ * Width <= 128 (-2 beyond).  cl_wide_image_wgrad WRITES the images' gradients (the caller keeps an image's rows in one call). */
+int cl_wide_image_forward(const float* X, int ldx, const float* W, const float* b, const int* seg, int n_groups, long long n, int w, float leak,
+                          float* Y, int ldy, const int* stop_flag, void* stream);
+int cl_wide_image_dgrad(const float* dZ, int lddz, const float* W, const int* seg, int n_groups, long long n, int w, const float* Hprev, int ldh, float leak,
+                        float* dX, int ldo, const int* stop_flag, void* stream);
+int cl_wide_image_wgrad(const float* dZ, int lddz, const float* H, int ldh, const int* seg, int n_groups, long long n, int w, float* dW, float* db,
+                        const int* stop_flag, void* stream);
 /* Dense(2) head: Wo = [Wo^T (2 x w) | bo (2)]; forward writes loc and sigma = bijector(raw) + eps per row; backward takes
  * dO[n][2] = dL/d(loc, sigma), writes dZ of the top layer and partials[nblocks][2 w + 2] of the head's gradient              */
 int cl_wide_head_forward(const float* H, int ldh, const float* Wo, long long n, int w, int bij_kind, float eps, float* loc_out, float* sig_out,

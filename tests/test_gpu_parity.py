@@ -111,6 +111,14 @@ CASES = {
     "wide_2x128_softplus_noimg": dict(N=400, R=40, d0=5, L=2, w=128, S=2, bijector="softplus", shift=1.5, use_image_scales=False),
     "wide_metadata_d70_2x32": dict(N=300, R=30, d0=70, L=2, w=32, S=2),
     "wide_laue_2x80_ev11": dict(N=500, R=40, L=2, w=80, S=2, laue=True, ev11=True),
+    # per-image layers beyond one fused launch: wider than 64, or more hidden layers (Dense + per-image) than a launch holds at the
+    # width -- layer by layer on the grouped GEMM kernels (csrc/wide_gemm.hip), rows stored in image order
+    "wide_image_layers1_2x96_S3": dict(N=700, R=40, d0=5, L=2, w=96, S=3, n_images=5, image_layers=1),
+    "wide_image_layers2_1x128_studentt_rows_in_arbitrary_order": dict(N=900, R=50, d0=5, L=1, w=128, S=2, n_images=7, image_layers=2, likelihood="studentt",
+                                                                      dof=6.0, shuffle_rows=True),
+    "deep_image_layers2_5x64_S2": dict(N=800, R=40, d0=5, L=5, w=64, S=2, n_images=6, image_layers=2),
+    "deep_image_layers3_9x32_softplus": dict(N=600, R=40, d0=5, L=9, w=32, S=2, n_images=4, image_layers=3, bijector="softplus", shift=0.5, perturb=0.03),
+    "wide_laue_image_layers1_2x80": dict(N=600, R=50, L=2, w=80, S=2, laue=True, n_images=4, image_layers=1),
     "double_wilson_trainable_r_S4": dict(N=400, R=60, d0=5, L=2, w=32, S=4, double_wilson=True, optimize_dw_r=True),
     "double_wilson_5x64_S8_studentt": dict(N=600, R=80, d0=5, L=5, w=64, S=8, double_wilson=True, likelihood="studentt", dof=8.0),
 }
@@ -570,6 +578,40 @@ def _np(t):
     return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
 
 
+def test_wide_image_layers_adam_trajectory_and_scaler_call():
+    """--image-layers on a scaler wider than 64 (layer-by-layer path, grouped per-image GEMMs): `scaler(inputs)`, an 8-step Adam
+    trajectory and the prediction path against the oracle; rows arrive in arbitrary image order."""
+    kw = dict(N=500, R=40, d0=5, L=2, w=72, S=2, n_images=5, image_layers=2)
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    perm = np.random.default_rng(3).permutation(kw["N"])
+    for k in ("refl_id", "image_id", "file_id", "metadata", "iobs", "sigiobs"):
+        data[k] = np.asarray(data[k])[perm]
+    x = O.inputs_from_numpy(data)
+    steps = 8
+    rng = np.random.default_rng(11)
+    noises = [(rng.random((2, 40)).astype(np.float32), rng.normal(size=(2, 500)).astype(np.float32)) for _ in range(steps)]
+    model = util.build_model(data, cfg, params, 2, 72)
+    inputs = util.reference_inputs(data)
+    dist = model.scaling_model(inputs)
+    o = O.mlp_forward(x.metadata, params.mlp_w, params.mlp_b, cfg.leakiness, x.image_id, params.imgl_w, params.imgl_b)
+    assert util.rel_err(dist.loc.cpu().numpy(), o[:, 0].numpy()) < 1e-5
+    assert util.rel_err(dist.scale.cpu().numpy(), O.scale_bijector(o[:, 1], "exp", cfg.epsilon).numpy()) < 1e-5
+    hist = model.train_model(inputs, steps, progress=False, noise=lambda i: noises[i])
+    assert model._engine.wide and model._engine.imgl is not None
+    p = params.clone()
+    st = O.AdamState.zeros_like(p.tensors())
+    ref = [O.train_step(p, x, cfg, st, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+           for u, e in noises]
+    for k in ("loss", "NLL", "F KLDiv", "Grad Norm"):
+        a = np.array(hist[k]); b = np.array([r[k] for r in ref])
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)) < 2e-4, (k, a, b)
+    for a, b in zip(model.scaling_model.image_weights, [t for pair in zip(p.imgl_w, p.imgl_b) for t in pair]):
+        assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
+    mean, std = model.scale_mean_stddev(inputs)
+    o = O.mlp_forward(x.metadata, p.mlp_w, p.mlp_b, cfg.leakiness, x.image_id, p.imgl_w, p.imgl_b)
+    assert util.rel_err(_np(mean).reshape(-1), o[:, 0].detach().numpy()) < 2e-4
+
+
 def test_chained_deep_scaler_trajectory_validation_and_predictions():
     """13 layers of width 32 = two launches per pass (10 is the most one launch holds): Adam trajectory against the oracle,
     NLL_val, and the prediction path (`scaler(inputs)` chains its forward the same way)."""
@@ -773,9 +815,10 @@ def test_freeze_flags_and_early_stop():
                                 dict(N=600, R=40, d0=5, L=2, w=32, S=3, ev11=True, likelihood="studentt", dof=6.0),
                                 dict(N=500, R=60, d0=5, L=2, w=32, S=2, double_wilson=True, optimize_dw_r=True),
                                 dict(N=600, R=40, d0=5, L=2, w=96, S=2),
-                                dict(N=600, R=50, L=2, w=32, S=2, laue=True, ev11=True)],
+                                dict(N=600, R=50, L=2, w=32, S=2, laue=True, ev11=True),
+                                dict(N=700, R=40, d0=5, L=2, w=96, S=2, n_images=6, image_layers=1)],
                          ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers", "cli_default_20x10",
-                              "cli_default_posenc_d21_S9", "ev11", "trainable_double_wilson_r", "wide_2x96", "laue_ev11"])
+                              "cli_default_posenc_d21_S9", "ev11", "trainable_double_wilson_r", "wide_2x96", "laue_ev11", "wide_image_layers"])
 def test_rank_shards_sum_to_full_batch_on_gpu(kw):
     """Data-parallel decomposition on ONE GPU: the engines of rank 0 and rank 1 of a 2-rank world (all-reduce skipped) produce
     partial losses / gradients that add up to the single-rank result; in-kernel noise is keyed by global indices, so the shards
