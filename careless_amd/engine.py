@@ -987,7 +987,8 @@ class ElboEngine:
         check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")
 
     # -- scalers wider than 64 ---------------------------------------------------------------------------------------------
-    WIDE_BUDGET = 1 << 30     # bytes of activation storage a row chunk may take ((L + 2) buffers of chunk x ld floats)
+    WIDE_BUDGET = 4 << 30     # bytes of activation storage a row chunk may take ((L + 2) buffers of chunk x ld floats), and never more
+                              # than a quarter of the free device memory: longer chunks = fewer launches and a better-balanced last round of row blocks
 
     def _wide_setup(self):
         """Work buffers of the unfused path (csrc/wide_gemm.hip): one activation buffer per hidden layer (Dense + per-image) + two
@@ -1001,7 +1002,7 @@ class ElboEngine:
         per_row = 4 * (nh + 2) * ldw
         free = torch.cuda.mem_get_info(dev)[0]
         budget = min(self.WIDE_BUDGET, max(free // 4, 64 << 20))
-        chunk = max(128, min(budget // per_row, 1 << 20) // 128 * 128)
+        chunk = max(128, min(budget // per_row, 1 << 21) // 128 * 128)
         self._wide = dict(ldw=ldw, chunk=chunk, nh=nh, rows=0, acts=[], dz=[])
         self._wide_buffers(chunk)
         return self._wide
