@@ -42,6 +42,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CL_LANE_SCHED
 #define CL_LANE_SCHED 1
 #endif
+#ifndef CL_LANE_PKDZ
+#define CL_LANE_PKDZ 0          /* LeakyReLU derivative on packed fp32: step(h) as a clamped multiply, slope = leak + (1 - leak) step, dZ = dH slope (three packed instructions per feature pair instead of a multiply, two compares and two selects) */
+#endif
 #ifndef CL_LANE_FAST_DIV
 #define CL_LANE_FAST_DIV 1      /* Student-T: 1/nu hoisted, the per-sample division as reciprocal + Newton step (a lone wave pays ~8 cycles per instruction of the two IEEE divisions) */
 #endif
@@ -337,6 +340,11 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     if (wt_begin < n_wt) prefetch(wt_begin, 0);
 
     const float ones = 1.0f;
+#if CL_LANE_PKDZ
+    const f32x2 inf2 = {__builtin_inff(), __builtin_inff()}, oml2 = {1.0f - leak, 1.0f - leak};
+    f32x2 leak2 = {leak, leak};
+    asm volatile("" : "+v"(leak2));          // (a register pair: a packed instruction reads one scalar-register operand)
+#endif
     const int rr16 = lane & 15, kq = lane >> 4;
     const float* const rdZ = sZ + rr16 * PIT + 4 * kq;       // wgrad operands: row (lane & 15), observations 16 c + 4 kq .. + 3
     const float* const rdH = sH + rr16 * PIT + 4 * kq;
@@ -394,7 +402,10 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         }
         LSTAMP(0);
         // ================= forward ==========================================================================================
-        float hs[NL][W];
+        // (activations and dZ in aligned register pairs: the packed fp32 instructions of the backward pass take them as they stand)
+        static_assert(W % 2 == 0, "feature pairs");
+        f32x2 hsp[NL][W / 2];
+#define HS(l, f) hsp[l][(f) >> 1][(f) & 1]
         float wan[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) wan[c] = sF[c * 64];
@@ -449,7 +460,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     static_for<0, W>([&](auto kc) {
                         constexpr int k = decltype(kc)::value;
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) acc[c] = mfma_bk<k>(wa[c], hs[l > 0 ? l - 1 : 0][k], acc[c]);
+                        for (int c = 0; c < NC; ++c) acc[c] = mfma_bk<k>(wa[c], HS(l > 0 ? l - 1 : 0, k), acc[c]);
                     });
                 }
 #pragma unroll
@@ -459,11 +470,11 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #pragma unroll
                     for (int c = 0; c < NC; ++c) lk[c] = acc[c] * leak;
 #pragma unroll
-                    for (int f = 0; f < W; ++f) hs[l][f] = lrelu2(acc[f >> 2][f & 3], lk[f >> 2][f & 3]);
+                    for (int f = 0; f < W; ++f) HS(l, f) = lrelu2(acc[f >> 2][f & 3], lk[f >> 2][f & 3]);
                 }
             }
         }
-        const float (&top)[W] = hs[NL - 1];              // the head's input
+#define TOP(k) HS(NL - 1, k)                             /* the head's input */
         LSTAMP(1);
         // Dense(2) head: outputs 0, 1 of one more chunk
         float o0, o1;
@@ -472,7 +483,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
             static_for<0, W>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                a = mfma_bk<k>(wh, top[k], a);
+                a = mfma_bk<k>(wh, TOP(k), a);
             });
             a = mfma_bk<ONE>(wh, ones, a);
             o0 = a[0];
@@ -628,7 +639,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         {
             const f32x2 dd2 = {dloc, draw};
 #pragma unroll
-            for (int k = 0; k < W; ++k) hacc[k] += dd2 * f32x2{top[k], top[k]};
+            for (int k = 0; k < W; ++k) hacc[k] += dd2 * f32x2{TOP(k), TOP(k)};
             hacc[W] += dd2;
         }
         f32x4 dH[NC];
@@ -644,7 +655,19 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             // dZ of a layer: dH where the activation is positive, leak dH otherwise.  As the compiler writes the select (compare
             // into VCC, wait states, select, per element) a lone wave pays ~9 cycles per instruction; compares into scalar
             // register pairs first and the selects after them issue back to back (scripts/probe/pkfma_probe.hip: 5.4 cycles).
-            auto dz_of = [&](float (&dz)[W], const float (&h)[W], const f32x4 (&dh)[NC]) {
+            auto dz_of = [&](f32x2 (&dzp)[W / 2], const f32x2 (&hp)[W / 2], const f32x4 (&dh)[NC]) {
+#if CL_LANE_PKDZ
+                // step(h) = clamp(h * inf) (h > 0 -> 1; h < 0 -> 0; h = 0 -> NaN -> 0 under the code object's clamp mode), slope = leak +
+                // (1 - leak) step (exactly 1 or leak for the reference's 0.01), dZ = dH * slope: packed, two features per instruction
+#pragma unroll
+                for (int p = 0; p < W / 2; ++p) {
+                    f32x2 st, sl;
+                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(st) : "v"(hp[p]), "s"(inf2));
+                    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(sl) : "v"(st), "s"(oml2), "v"(leak2));
+                    const f32x2 d2 = {dh[p >> 1][2 * (p & 1)], dh[p >> 1][2 * (p & 1) + 1]};
+                    dzp[p] = d2 * sl;
+                }
+#else
                 f32x4 lk[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) lk[c] = dh[c] * leak;
@@ -653,32 +676,34 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     unsigned long long m[SELG];
 #pragma unroll
                     for (int i = 0; i < SELG; ++i)
-                        if (f0 + i < W) asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[i]) : "v"(h[f0 + i < W ? f0 + i : 0]));
+                        if (f0 + i < W) asm volatile("v_cmp_lt_f32_e64 %0, 0, %1" : "=s"(m[i]) : "v"(hp[(f0 + i < W ? f0 + i : 0) >> 1][(f0 + i < W ? f0 + i : 0) & 1]));
 #pragma unroll
                     for (int i = 0; i < SELG; ++i) {
                         const int f = f0 + i < W ? f0 + i : 0;
                         if (f0 + i < W)
-                            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dz[f]) : "v"(lk[f >> 2][f & 3]), "v"(dh[f >> 2][f & 3]), "s"(m[i]));
+                            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dzp[f >> 1][f & 1]) : "v"(lk[f >> 2][f & 3]), "v"(dh[f >> 2][f & 3]), "s"(m[i]));
                     }
                 }
+#endif
             };
             // LDS operation number i of layer ll: staging writes (dZ, the layer's input: feature pairs) into the tiles of the
             // layer's parity, then the transposed reads of its weight-gradient operands; past those, the dgrad weights of the
             // layer below.  One wave's LDS operations execute in order and a wave only touches its own tiles.
             constexpr int WP = (W + 1) / 2, NOPS = 2 * WP + 8;
             f32x4 pa[2][4], pb[2][4];
-            float dz[2][W];
+            f32x2 dzp[2][W / 2];
+#define DZ(q, f) dzp[q][(f) >> 1][(f) & 1]
             float wk[2][NC];
             auto lds_op = [&](auto llc, auto ic_) {
                 constexpr int ll = decltype(llc)::value, i = decltype(ic_)::value, q = ll & 1;
                 if constexpr (i < WP) {
-                    sZ[q * PAR + (2 * i) * PIT + lane] = dz[q][2 * i];
-                    if constexpr (2 * i + 1 < W) sZ[q * PAR + (2 * i + 1) * PIT + lane] = dz[q][2 * i + 1];
+                    sZ[q * PAR + (2 * i) * PIT + lane] = DZ(q, 2 * i);
+                    if constexpr (2 * i + 1 < W) sZ[q * PAR + (2 * i + 1) * PIT + lane] = DZ(q, 2 * i + 1);
                 } else if constexpr (i < 2 * WP) {
                     constexpr int f = 2 * (i - WP);
                     if constexpr (ll > 0) {
-                        sH[q * PAR + f * PIT + lane] = hs[ll > 0 ? ll - 1 : 0][f];
-                        if constexpr (f + 1 < W) sH[q * PAR + (f + 1) * PIT + lane] = hs[ll > 0 ? ll - 1 : 0][f + 1];
+                        sH[q * PAR + f * PIT + lane] = HS(ll > 0 ? ll - 1 : 0, f);
+                        if constexpr (f + 1 < W) sH[q * PAR + (f + 1) * PIT + lane] = HS(ll > 0 ? ll - 1 : 0, f + 1);
                     }
                 } else if constexpr (i < NOPS) {
                     constexpr int j = i - 2 * WP, c = j >> 1;
@@ -689,7 +714,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 }
             };
             // top layer: nothing to hide behind
-            dz_of(dz[(NL - 1) & 1], hs[NL - 1], dH);
+            dz_of(dzp[(NL - 1) & 1], hsp[NL - 1], dH);
             static_for<0, NOPS + NC>([&](auto ic_) { lds_op(std::integral_constant<int, NL - 1>{}, ic_); });
             static_for<0, NL>([&](auto lc) {
                 constexpr int l = NL - 1 - decltype(lc)::value, q = l & 1;
@@ -700,9 +725,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     static_for<0, W>([&](auto oc_) {
                         constexpr int o = decltype(oc_)::value;
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) dH[c] = mfma_bk<o>(wk[q][c], dz[q][o], dH[c]);
+                        for (int c = 0; c < NC; ++c) dH[c] = mfma_bk<o>(wk[q][c], DZ(q, o), dH[c]);
                     });
-                    dz_of(dz[q ^ 1], hs[l > 0 ? l - 1 : 0], dH);
+                    dz_of(dzp[q ^ 1], hsp[l > 0 ? l - 1 : 0], dH);
                 }
                 LFENCE();
                 // weight gradient of layer l; in the shadow of its MFMAs (two LDS instructions each are free for a lone wave) the

@@ -4,8 +4,8 @@ name=$1; shift
 cd /root/repo/careless_amd/csrc
 B=/tmp/t/lbase; mkdir -p $B /tmp/t/lexp
 if [ ! -f $B/cl_api.o ] || [ -n "$REBASE" ]; then
-for u in "cl_api: " "elbo_mlp:-DCL_IMGL=0" "elbo_mlp_imgl:-DCL_IMGL=1" "elbo_mlp_packed:-DCL_IMGL=2" "elbo_mlp_chain:-DCL_CHAIN=1" "elbo_elem: " "elbo_laue: " "elbo_narrow:-fno-slp-vectorize"; do
-  stem=${u%%:*}; fl=${u#*:}; src=${stem%_imgl}; src=${src%_packed}; src=${src%_chain}.hip
+for u in "cl_api: " "elbo_mlp:-DCL_IMGL=0" "elbo_mlp_imgl:-DCL_IMGL=1" "elbo_mlp_packed:-DCL_IMGL=2" "elbo_mlp_chain:-DCL_CHAIN=1" "elbo_mlp_det:-DCL_DET=1" "wide_gemm: " "elbo_elem: " "elbo_laue: " "elbo_narrow:-fno-slp-vectorize"; do
+  stem=${u%%:*}; fl=${u#*:}; src=${stem%_imgl}; src=${src%_packed}; src=${src%_chain}; src=${src%_det}.hip
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $fl -c $src -o $B/$stem.o &
 done
 wait
