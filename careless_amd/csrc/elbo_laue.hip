@@ -82,37 +82,51 @@ __global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args
     }
 }
 
+// One thread per (row, sample): the S samples of a row are consecutive lanes, so the amplitude-gradient atomics of a row hit S
+// consecutive floats of dz_f (one request) -- with a thread per row and a loop over the samples every instruction sent 64 lanes to 64
+// different lines, the pattern the memory side serialises (0.52 ms per step at 2 M rows x 4 samples; csrc/elbo_lane.hip has the same
+// story).  The row's sums over its samples (dL/dloc, dL/dsigma, image-scale gradient) are segmented lane reductions; the first lane
+// of a row's segment inside a wave adds them into dO (zeroed by the caller side of this launch: see cl_launch_laue_backward).
 __global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool act = i < A.n_obs;                    // no early return: the image-scale reduction below is wave-wide
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool act = p < (long long)A.n_obs * A.S;   // no early return: the reductions below are wave-wide
+    const int i = act ? (int)(p / A.S) : -1, s = act ? (int)(p - (long long)i * A.S) : 0;
     int im = 0;
-    float da = 0.0f;
+    float dloc = 0.0f, dsig = 0.0f, da = 0.0f;
     if (act) {
         const int rid = A.refl_id[i], hid = A.harmonic_id[i];
         float aim = 1.0f;
         if (A.use_img) { im = A.image_id[i]; if (im > 0) aim = A.img[im - 1]; }
         const float loc = A.loc[i], sigma = A.sigma[i];
-        float dloc = 0.0f, dsig = 0.0f;
-        for (int s = 0; s < A.S; ++s) {
-            const float eta = laue_eta(A, i, s);
-            const float tq = loc + sigma * eta + A.shift;
-            const float zf = A.z_f[(size_t)rid * A.S + s];
-            const float gi = A.iconv[(size_t)hid * A.S + s];
-            const float dzs = gi * zf * zf;
-            atomicAdd(A.dz_f + (size_t)rid * A.S + s, gi * aim * tq * 2.0f * zf);
-            const float dt = dzs * aim;
-            dloc += dt;
-            dsig += dt * eta;
-            da += dzs * tq;
-        }
-        A.dO[2 * (size_t)i] = dloc;
-        A.dO[2 * (size_t)i + 1] = dsig;
+        const float eta = laue_eta(A, i, s);
+        const float tq = loc + sigma * eta + A.shift;
+        const float zf = A.z_f[(size_t)rid * A.S + s];
+        const float gi = A.iconv[(size_t)hid * A.S + s];
+        const float dzs = gi * zf * zf;
+        atomicAdd(A.dz_f + (size_t)rid * A.S + s, gi * aim * tq * 2.0f * zf);
+        const float dt = dzs * aim;
+        dloc = dt;
+        dsig = dt * eta;
+        da = dzs * tq;
+    }
+    // segmented sums over the lanes of one row (they are consecutive)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int r2 = __shfl_down(i, off);
+        const float a = __shfl_down(dloc, off), b = __shfl_down(dsig, off), c = __shfl_down(da, off);
+        if (lane + off < 64 && r2 == i) { dloc += a; dsig += b; da += c; }
+    }
+    const int prev = __shfl_up(i, 1);
+    const bool head = act && (lane == 0 || prev != i);
+    if (head) {
+        atomicAdd(A.dO + 2 * (size_t)i, dloc);       // (a row that straddles two waves has two heads)
+        atomicAdd(A.dO + 2 * (size_t)i + 1, dsig);
     }
     if (A.use_img) {
-        // rows are (nearly) ordered by image, so a wave usually holds one image: 64 same-address atomics would serialise in the
-        // L2 atomic unit -- reduce in the wave and issue one
-        const int key = (act && im > 0) ? im : 0;    // 0: nothing to add (image 0 is pinned to 1, image.py:23-25)
+        // rows are (nearly) ordered by image, so a wave usually holds one image: reduce the row heads' sums in the wave and issue one atomic
+        const int key = (head && im > 0) ? im : 0;   // 0: nothing to add (image 0 is pinned to 1, image.py:23-25)
         int kmax = key;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, __shfl_xor(kmax, off));
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A
             float v = key ? da : 0.0f;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if ((threadIdx.x & 63) == 0 && kmax > 0) atomicAdd(A.d_img + (kmax - 1), v);
+            if (lane == 0 && kmax > 0) atomicAdd(A.d_img + (kmax - 1), v);
         } else if (key > 0) {
             atomicAdd(A.d_img + (key - 1), da);
         }
@@ -156,6 +170,10 @@ int cl_launch_laue_backward(const cl_laue_args& a, hipStream_t st) {
     if (int e = laue_check(a)) return e;
     if (a.dz_f == nullptr || a.dO == nullptr || (a.use_img && a.d_img == nullptr)) return -1;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(laue_backward_kernel, dim3((a.n_obs + 255) / 256), dim3(256), 0, st, a);
+    // dO receives the rows' sums by atomics: cleared here, on the same stream (part of the call)
+    hipError_t e = hipMemsetAsync(a.dO, 0, sizeof(float) * 2 * (size_t)a.n_obs, st);
+    if (e != hipSuccess) return (int)e;
+    const long long n = (long long)a.n_obs * a.S;
+    hipLaunchKernelGGL(laue_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
