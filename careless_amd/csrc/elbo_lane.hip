@@ -186,6 +186,10 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;   // a previous step hit a non-finite gradient norm
+#ifdef CL_STAMPS
+    unsigned long long st_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -239,18 +243,21 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         // staging tiles: rows that are never written hold their constants (zero; row 15 of the input tiles = the ones)
         static_assert(SM::oT % 4 == 0 && SM::TWF % 4 == 0 && PIT % 4 == 0 && SM::oS % PIT == 0, "16-byte fill");
         const int TWr = SM::tw(d), xrows = SM::xrows(d);
-        for (int idx = 4 * tid; idx < NWV * TWr; idx += 4 * NT) {
-            const int off = idx % TWr;
-            bool one;
-            if (off < SM::oS) {
-                const int row = off / PIT;                              // sZ[TPAR], sH[TPAR], (not LX) sX: 16 rows each
-                one = row >= TPAR * 16 && (row & 15) == ONE;
-            } else {
-                const int xo = off - SM::oX;                            // LX: the two row buffers
-                one = LX && xo >= 0 && (xo / PIT) % (xrows > 0 ? xrows : 1) == ONE;
+        // (wave region by wave region: no division by the run-time region size)
+        for (int wr = 0; wr < NWV; ++wr) {
+            float* const reg = smem + SM::oT + wr * TWr;
+            for (int off = 4 * tid; off < TWr; off += 4 * NT) {
+                bool one;
+                if (off < SM::oS) {
+                    const int row = off / PIT;                          // sZ[TPAR], sH[TPAR], (not LX) sX: 16 rows each
+                    one = row >= TPAR * 16 && (row & 15) == ONE;
+                } else {
+                    const int xr = (off - SM::oX) / PIT;                // LX: the two row buffers (negative before them: sS / sQ / sE)
+                    one = LX && off >= SM::oX && (xr == ONE || xr == xrows + ONE);
+                }
+                const float v = one ? 1.0f : 0.0f;
+                *reinterpret_cast<f32x4*>(reg + off) = f32x4{v, v, v, v};
             }
-            const float v = one ? 1.0f : 0.0f;
-            *reinterpret_cast<f32x4*>(smem + SM::oT + idx) = f32x4{v, v, v, v};
         }
         if (LX) {                                                       // (tail that the upper-block reads of the last wave's second buffer touch)
             for (int idx = 4 * tid; idx < (32 - xrows) * PIT; idx += 4 * NT) *reinterpret_cast<f32x4*>(smem + SM::oT + NWV * TWr + idx) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -354,6 +361,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+    st_acc[6] = st_last - st_t0;                                  // launch prologue: weight images, tile fill, first prefetch issue
 #endif
     int xcur = 0;                                             // LX: buffer of the current tile's metadata rows
     for (int wt = wt_begin; wt < n_wt; wt += wt_step, xcur ^= 1) {
@@ -758,14 +766,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             });
         LSTAMP(5);
     }
-#ifdef CL_STAMPS
-    if (A.loc_out != nullptr && lane == 0) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.loc_out) + ((size_t)blockIdx.x * NWV + wv) * 8;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dbg[k] = st_acc[k];
-    }
-#endif
-
     // ================= flush: sum the waves' accumulators, scatter into the flat W^T layout of this workgroup's partial ====
 #if CL_LANE_ASM_ACC
     asm volatile("s_nop 15\n\ts_nop 15");     // (the compiler does not know that the inline-assembly MFMAs' results take eight passes to land)
@@ -855,6 +855,18 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             }
         }
     }
+#ifdef CL_STAMPS
+    {
+        unsigned long long t_;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        st_acc[7] = t_ - st_last;                                 // flush (st_last: end of the last tile)
+        if (A.loc_out != nullptr && lane == 0) {
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(A.loc_out) + ((size_t)blockIdx.x * NWV + wv) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dbg[k] = st_acc[k];
+        }
+    }
+#endif
 }
 
 // The instances are spread over four compilations of this file (build.py: -DCL_LANE_PART=0 .. 3, in parallel; a part takes 25 - 50 s):

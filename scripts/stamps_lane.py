@@ -23,10 +23,10 @@ for i in range(3):
     eng.train_step(i)
 torch.cuda.synchronize()
 d = dbg.view(eng.grid, NWV, 8).cpu().numpy().astype(np.float64)
-names = ["tile prologue (inputs, gathers)", "forward layers", "head + epilogue", "prefetch issue", "backward head", "backward layers", "-", "-"]
+names = ["tile prologue (inputs, gathers)", "forward layers", "head + epilogue", "prefetch issue", "backward head", "backward layers", "LAUNCH prologue (images, fill)", "LAUNCH flush"]
 tot = d.sum(-1).mean()
 tiles = -(-nobs // 64) / (eng.grid * NWV)
 print(f"{eng.kernel_name()} workload {wl} nobs {nobs}: wave tiles per wave {tiles:.1f}, mean ticks per wave {tot:.0f}, per wave tile {tot / tiles / 3:.0f} (3 launches accumulated)")
-for k, n in enumerate(names[:6]):
+for k, n in enumerate(names):
     v = d[:, :, k].mean()
-    print(f"  {n:34s} {v / tiles / 3:10.1f} /tile  {100 * v / tot:5.1f}%")
+    print(f"  {n:34s} {v / tiles / 3:10.1f} /tile  {100 * v / tot:5.1f}%   per launch {v / 3:10.0f} ticks")
