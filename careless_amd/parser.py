@@ -12,8 +12,8 @@ from careless_amd.manager import default_args
 def _common(p: argparse.ArgumentParser):
     d = default_args()
     p.add_argument("metadata_keys", type=str, help="comma separated metadata column names, e.g. dHKL,Hobs,Kobs,Lobs,BATCH")
-    p.add_argument("reflection_files", nargs="+", metavar="reflections.{mtz,npz}")
-    p.add_argument("output_base", metavar="out")
+    p.add_argument("reflection_files", type=str, nargs="+", metavar="reflections.{mtz,npz}")
+    p.add_argument("output_base", type=str, metavar="out")
     # args/common.py
     p.add_argument("--mc-samples", type=int, default=d.mc_samples)
     p.add_argument("--structure-factor-file", type=str, default=None)
