@@ -357,7 +357,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
                    "prior": "double-wilson (2 ASUs, r=0.9)" if spec.get("kind") == "double_wilson" else "wilson",
                    "kind": spec.get("kind", "mono"), "image_scales": spec.get("image_layers", 0) == 0,
                    "image_layers": spec.get("image_layers", 0), "noise": "in-kernel philox",
-                   "parallelism": f"obs-shard x{world}" if world > 1 else "single",
+                   "parallelism": (("reflection-owner shard" if eng.owner else "obs-shard") + f" x{eng.shard.world}") if eng.shard.world > 1 else "single",
                    "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
         "roofline": {"bound": "mfma", "kernel": (kernel_name + " (" + ("cl_wide_* GEMM launches" if eng.wide else ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd")) + ")"),
                      "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,

@@ -30,6 +30,7 @@ class TnArgs(C.Structure):
         ("high", C.c_float), ("eps", C.c_float),
         ("w_kl", C.c_float), ("kl_grad_mult", C.c_float),
         ("kl_begin", C.c_int), ("kl_end", C.c_int),
+        ("r_begin", C.c_int), ("r_end", C.c_int),
         ("u_f", _vp),
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("z_f", _vp), ("dz_f", _vp), ("d_loc_raw", _vp), ("d_scale_raw", _vp),
@@ -107,6 +108,8 @@ class AdamArgs(C.Structure):
         ("seg_off", _vp),
         ("nseg", C.c_int),
         ("seg_sq", _vp), ("frozen", _vp), ("scalars", _vp), ("stop_flag", _vp), ("norm_out", _vp),
+        ("n_ranges", C.c_int), ("range_begin", C.c_int * 3), ("range_end", C.c_int * 3), ("norm_skip_ranges", C.c_int),
+        ("norm_extra", _vp),
     ]
 
 
@@ -144,6 +147,7 @@ EXPORTS = {
     "cl_reduce_partials": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "cl_grad_sqnorm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "cl_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
+    "cl_owner_qnorm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "cl_step_finalize": (C.c_int, [_vp, C.c_float, _vp, C.c_int, _vp, _vp]),
     "cl_debug_noise": (C.c_int, [C.c_ulonglong, C.c_uint, C.c_int, C.c_longlong, C.c_longlong, C.c_int, _vp, _vp]),
 }

@@ -95,6 +95,9 @@ static int check_tn(const cl_tn_args* a) {
     if (a->prior_kind == CL_PRIOR_DOUBLE_WILSON_ && (a->parent_ids == nullptr || a->root == nullptr)) return -1;
     if (a->prior_kind == CL_PRIOR_DOUBLE_WILSON_ && a->dw_r == nullptr && (a->dw_r_raw == nullptr || a->asu_ids == nullptr)) return -1;
     if (a->prior_kind != CL_PRIOR_DOUBLE_WILSON_ && a->prior_kind != CL_PRIOR_WILSON_) return -1;
+    if (a->r_end > a->r_begin && (a->r_begin < 0 || a->r_end > a->R)) return -1;
+    // an owned reflection range and the double-Wilson prior do not go together: a child's parent may belong to another rank
+    if (a->r_end > a->r_begin && a->prior_kind == CL_PRIOR_DOUBLE_WILSON_) return -2;
     return 0;
 }
 
@@ -129,7 +132,15 @@ int cl_adam_step(const cl_adam_args* a, void* stream) {
     if ((a->clipnorm > 0.0f || a->frozen != nullptr) && (a->seg_off == nullptr || a->nseg < 1)) return -1;
     if (a->clipnorm > 0.0f && a->seg_sq == nullptr) return -1;
     if (a->global_clipnorm > 0.0f && a->scalars == nullptr) return -1;
+    if (a->n_ranges < 0 || a->n_ranges > 3 || a->norm_skip_ranges < 0 || a->norm_skip_ranges > a->n_ranges) return -1;
+    for (int k = 0; k < a->n_ranges; ++k)
+        if (a->range_begin[k] < 0 || a->range_end[k] > a->n || a->range_end[k] < a->range_begin[k]) return -1;
     return cl_launch_adam(*a, (hipStream_t)stream);
+}
+
+int cl_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* out, double* scratch, const int* stop_flag, void* stream) {
+    if (g == nullptr || out == nullptr || scratch == nullptr || R < 1 || r_begin < 0 || r_end > R || r_end <= r_begin) return -1;
+    return cl_launch_owner_qnorm(g, R, r_begin, r_end, out, scratch, stop_flag, (hipStream_t)stream);
 }
 
 int cl_step_finalize(const double* scalars, float kl_weight_or_one, double* history, int step_index, int* stop_flag,

@@ -60,9 +60,10 @@ __device__ __forceinline__ float prior_lp(const cl_tn_args& A, int h, float z, f
 
 __global__ __launch_bounds__(256) void tn_forward_kernel(const cl_tn_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool part = A.r_end > A.r_begin;               // an owned reflection range (reflection-owner data parallelism)
+    const int h = (part ? A.r_begin : 0) + blockIdx.x * blockDim.x + threadIdx.x;
     double kl = 0.0;
-    if (h < A.R) {
+    if (h < (part ? A.r_end : A.R)) {
         const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
         const bool in_kl = (h >= A.kl_begin && h < A.kl_end);
         const bool dw_child = (A.prior_kind == CL_PRIOR_DOUBLE_WILSON_) && (A.root[h] == 0);
@@ -84,8 +85,9 @@ __global__ __launch_bounds__(256) void tn_forward_kernel(const cl_tn_args A) {
 
 __global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= A.R) return;
+    const bool part = A.r_end > A.r_begin;
+    const int h = (part ? A.r_begin : 0) + blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= (part ? A.r_end : A.R)) return;
     const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
     const bool in_kl = (h >= A.kl_begin && h < A.kl_end);
     const float wkl = in_kl ? A.w_kl * A.kl_grad_mult : 0.0f;
@@ -188,6 +190,44 @@ __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restric
     block_atomic_add_d(sane, scalars + CL_SC_GNORM2_SANE);
 }
 
+// Reflection-owner data parallelism: squared norm of this rank's own part of the surrogate-posterior gradient -- d a and d b of
+// reflections [r0, r1) -- as four floats of the step's message (raw, sanitised, sanitised per tensor).  Double accumulation through
+// scratch[0..3]; the last workgroup to arrive (ticket in scratch[4]) converts.  The caller zeroes scratch once per step.
+__global__ __launch_bounds__(256) void owner_qnorm_kernel(const float* __restrict__ g, int R, int r0, int r1, float* __restrict__ out,
+                                                          double* scratch, const int* stop_flag) {
+    if (stop_flag != nullptr && *stop_flag != 0) return;
+    const int nr = r1 - r0;
+    double raw = 0.0, sa = 0.0, sb = 0.0;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < 2 * nr; t += gridDim.x * blockDim.x) {
+        const bool isb = t >= nr;
+        const float v = g[isb ? R + r0 + (t - nr) : r0 + t];
+        const double v2 = (double)v * (double)v;
+        raw += v2;
+        const double s2 = isfinite(v) ? v2 : 0.0;
+        if (isb) sb += s2; else sa += s2;
+    }
+    block_atomic_add_d(raw, scratch + 0);
+    __syncthreads();
+    block_atomic_add_d(sa, scratch + 2);
+    __syncthreads();
+    block_atomic_add_d(sb, scratch + 3);
+    __shared__ unsigned last;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(reinterpret_cast<unsigned*>(scratch + 4), 1u);
+    }
+    __syncthreads();
+    if (last == gridDim.x - 1 && threadIdx.x == 0) {
+        __threadfence();
+        const double qa = atomicAdd(scratch + 2, 0.0), qb = atomicAdd(scratch + 3, 0.0), qr = atomicAdd(scratch + 0, 0.0);
+        scratch[1] = qa + qb;
+        out[0] = (float)qr;
+        out[1] = (float)(qa + qb);
+        out[2] = (float)qa;
+        out[3] = (float)qb;
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(const cl_adam_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
     float gscale = 1.0f;
@@ -197,9 +237,25 @@ __global__ __launch_bounds__(256) void adam_kernel(const cl_adam_args A) {
         gscale = A.global_clipnorm / fmaxf(nrm, A.global_clipnorm);
     }
     double acc = 0.0, sane = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += gridDim.x * blockDim.x) {
+    // the indices this call updates: the whole vector, or (reflection-owner data parallelism) up to three ranges -- the rank's own
+    // reflections' a and b, whose norm over all ranks arrives in norm_extra, and the replicated tail
+    const int len0 = A.n_ranges > 0 ? A.range_end[0] - A.range_begin[0] : A.n;
+    const int len1 = A.n_ranges > 1 ? A.range_end[1] - A.range_begin[1] : 0;
+    const int len2 = A.n_ranges > 2 ? A.range_end[2] - A.range_begin[2] : 0;
+    const int total = len0 + len1 + len2;
+    if (A.norm_out != nullptr && A.norm_extra != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        acc = (double)A.norm_extra[0];
+        sane = (double)A.norm_extra[1];
+    }
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        int i = t, rk = 0;
+        if (A.n_ranges > 0) {
+            if (t < len0) { i = A.range_begin[0] + t; }
+            else if (t < len0 + len1) { i = A.range_begin[1] + (t - len0); rk = 1; }
+            else { i = A.range_begin[2] + (t - len0 - len1); rk = 2; }
+        }
         float g = A.g[i];
-        if (A.norm_out != nullptr) {                                   // fused tf.linalg.global_norm (variational.py:205)
+        if (A.norm_out != nullptr && rk >= A.norm_skip_ranges) {       // fused tf.linalg.global_norm (variational.py:205)
             const double v2 = (double)g * (double)g;
             acc += v2;
             sane += isfinite(g) ? v2 : 0.0;
@@ -262,13 +318,15 @@ __global__ void noise_kernel(unsigned long long seed, unsigned step, int S, long
 int cl_launch_tn_forward(const cl_tn_args& a, hipStream_t st) {
     if (a.R <= 0 || a.S <= 0) return -1;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
-    hipLaunchKernelGGL(tn_forward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    const int nr = a.r_end > a.r_begin ? a.r_end - a.r_begin : a.R;
+    hipLaunchKernelGGL(tn_forward_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st) {
     if (a.R <= 0 || a.S <= 0) return -1;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
-    hipLaunchKernelGGL(tn_backward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    const int nr = a.r_end > a.r_begin ? a.r_end - a.r_begin : a.R;
+    hipLaunchKernelGGL(tn_backward_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int cl_launch_dw_forward(const cl_tn_args& a, hipStream_t st) {
@@ -288,7 +346,13 @@ int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, d
 }
 int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
     if (a.n <= 0) return -1;
-    int grid = (a.n + 255) / 256;
+    int work = a.n;
+    if (a.n_ranges > 0) {
+        work = 0;
+        for (int k = 0; k < a.n_ranges; ++k) work += a.range_end[k] - a.range_begin[k];
+        if (work < 1) work = 1;
+    }
+    int grid = (work + 255) / 256;
     // two same-address fp64 atomics per workgroup (fused gradient norm), ~12 ns each and serialised: few workgroups for the usual
     // ~1e6 parameters (18.5 -> 15.6 us against 512), more when the vector is long enough for streaming to dominate (per-image
     // layers: 4e7 parameters)
@@ -296,6 +360,14 @@ int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
     if (grid > cap) grid = cap;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+int cl_launch_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* out, double* scratch, const int* stop_flag, hipStream_t st) {
+    int grid = (2 * (r_end - r_begin) + 1023) / 1024;
+    if (grid > 64) grid = 64;
+    if (grid < 1) grid = 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(owner_qnorm_kernel, dim3(grid), dim3(256), 0, st, g, R, r_begin, r_end, out, scratch, stop_flag);
     return (int)hipGetLastError();
 }
 int cl_launch_finalize(const double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,

@@ -406,6 +406,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 rme = ld_uo(A.row_map, pb);
                 if (A.gmeta != nullptr) gm = ld_uo(A.gmeta, pb);
                 nkey = (A.noise_row != nullptr) ? (long long)ld_uo(A.noise_row, pb) : A.obs_offset + rme;
+            } else if (A.noise_row != nullptr) {
+                // plain layout over rows that are not a contiguous range of the caller's (reflection-owner shard): the row's global number
+                nkey = (long long)ld_uo(A.noise_row, 4u * (unsigned)(wt * WT + lane));
             }
         }
         LSTAMP(0);
@@ -591,7 +594,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 for (int p = 0; p < 4; ++p) {
                     if (sb + p < S) {                            // wave-uniform
                         float ec, es;
-                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)(sb + p), (uint64_t)(PACKED ? nkey : A.obs_offset + gobs), &ec, &es);
+                        cl_noise_normal_pair(A.seed, A.step, (uint32_t)(sb + p), (uint64_t)((PACKED || A.noise_row != nullptr) ? nkey : A.obs_offset + gobs), &ec, &es);
                         sE[p * 64 + lane] = ec;
                         sE[(p + 4) * 64 + lane] = es;
                     }

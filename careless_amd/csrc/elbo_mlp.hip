@@ -554,6 +554,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             if (eta_t != nullptr) {
                 if (qe < S) et0 = ld_uo(eta_t, eoff + 4u * qe);
                 if (qe + 4 < S) et1 = ld_uo(eta_t, eoff + 4u * (qe + 4));
+            } else if (!IMGL && E0->noise_row != nullptr) {
+                // plain layout over rows that are not a contiguous range of the caller's (a rank that owns a reflection range takes
+                // every observation of those reflections): the row's GLOBAL number, the key of the in-kernel noise, rides in the
+                // register the injected noise would use
+                et0 = __builtin_bit_cast(float, ld_uo(E0->noise_row, 4u * (unsigned)gobs_e));
             }
         }
         STAMP_VM(0);
@@ -751,7 +756,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     if (eta_t != nullptr) {
                         eta = (k == 0) ? et0 : ((k == 1) ? et1 : ld_uo(eta_t, eoff + 4u * s));
                     } else if ((k & 1) == 0) {       // one Philox block + Box-Muller pair serves samples s and s + 4
-                        cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)(IMGL ? nkey : E->obs_offset + gobs_e), &eta, &eta_sin);
+                        const long long key_plain = (E->noise_row != nullptr) ? (long long)__builtin_bit_cast(int, et0) : E->obs_offset + gobs_e;
+                        cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)(IMGL ? nkey : key_plain), &eta, &eta_sin);
                     } else {
                         eta = eta_sin;
                     }

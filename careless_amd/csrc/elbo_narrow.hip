@@ -325,6 +325,9 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     rme = ld_uo(E0->row_map, pb);
                     if (E0->gmeta != nullptr) gm = ld_uo(E0->gmeta, pb);
                     nkey = (E0->noise_row != nullptr) ? (long long)ld_uo(E0->noise_row, pb) : E0->obs_offset + rme;
+                } else if (E0->noise_row != nullptr) {
+                    // plain layout over rows that are not a contiguous range of the caller's (reflection-owner shard): the row's global number
+                    nkey = (long long)ld_uo(E0->noise_row, 4u * (unsigned)(wt * WT + (lane & (WT - 1))));
                 }
             }
         }
@@ -426,7 +429,7 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     eta = eta_p[s];
                 } else if (((s >> 2) & 1) == 0) {        // one Philox block + Box-Muller pair serves samples s and s + 4
                     float sn;
-                    cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)(PACKED ? nkey : E->obs_offset + gobs), &eta, &sn);
+                    cl_noise_normal_pair(E->seed, E->step, (uint32_t)s, (uint64_t)((PACKED || E->noise_row != nullptr) ? nkey : E->obs_offset + gobs), &eta, &sn);
                     const int kk = s & 3;
                     if (kk == 0) esin[0] = sn; else if (kk == 1) esin[1] = sn; else if (kk == 2) esin[2] = sn; else esin[3] = sn;
                 } else {

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -61,6 +62,8 @@ class Shard:
     stop: int
     kl_begin: int     # reflections whose KL term this rank owns
     kl_end: int
+    owner: bool = False          # reflection-owner sharding: the rank holds EVERY observation of reflections [kl_begin, kl_end) and
+    rows: Optional[np.ndarray] = None   # nothing else (`rows`: their global row numbers, ascending); start / stop are then 0 / len(rows)
 
 
 def make_shard(n_obs: int, n_refl: int, rank: int = 0, world: int = 1) -> Shard:
@@ -80,6 +83,34 @@ def make_shard(n_obs: int, n_refl: int, rank: int = 0, world: int = 1) -> Shard:
     start, stop = min(rank * per, n_obs), min((rank + 1) * per, n_obs)
     rper = (n_refl + world - 1) // world
     return Shard(rank, world, start, stop, min(rank * rper, n_refl), min((rank + 1) * rper, n_refl))
+
+
+def owner_bounds(refl_id: np.ndarray, n_refl: int, world: int) -> Optional[np.ndarray]:
+    """Reflection ranges of a reflection-owner split: world + 1 boundaries in [0, n_refl] such that the ranges hold about the same
+    number of OBSERVATIONS (the work) and every rank gets at least one reflection with at least one observation.  None when no such
+    split exists (fewer observed reflections than ranks) -- the same answer on every rank, which then all use the row split."""
+    counts = np.bincount(np.asarray(refl_id).reshape(-1).astype(np.int64), minlength=n_refl)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    n = int(cum[-1])
+    b = np.array([int(np.searchsorted(cum, n * r / world, side="left")) for r in range(world)] + [n_refl], dtype=np.int64)
+    b[0] = 0
+    b = np.clip(b, 0, n_refl)
+    if np.any(np.diff(b) <= 0) or np.any(np.diff(cum[b]) <= 0):
+        return None
+    return b
+
+
+def owner_shard(refl_id: np.ndarray, n_refl: int, rank: int, world: int) -> Optional[Shard]:
+    """The shard of `rank` in a reflection-owner split: reflections [r0, r1) and every observation of theirs.  All the
+    terms of the loss that touch q(F_h) of an owned reflection -- its KL, its observations' likelihoods -- are then local: no other
+    rank samples it, adds to its gradient or updates it, and the step's all-reduce carries the scaler's gradient only."""
+    b = owner_bounds(refl_id, n_refl, world)
+    if b is None:
+        return None
+    r0, r1 = int(b[rank]), int(b[rank + 1])
+    rid = np.asarray(refl_id).reshape(-1)
+    rows = np.nonzero((rid >= r0) & (rid < r1))[0]
+    return Shard(rank, world, 0, int(len(rows)), r0, r1, True, rows)
 
 
 def laue_group_shard(harmonic_id: np.ndarray, rank: int, world: int):
@@ -289,7 +320,8 @@ class ObsData:
     layers) the arrays the fused kernel streams are in the packed order of `pack_by_image`."""
 
     def __init__(self, lib, inputs, start: int, stop: int, S: int, P: int, device, grid=None, n_refl=None, n_images=None,
-                 laue_groups=None, pack_images: bool = False, laue_single_pass: bool = True, wide: bool = False, sort_images: bool = False):
+                 laue_groups=None, pack_images: bool = False, laue_single_pass: bool = True, wide: bool = False, sort_images: bool = False,
+                 rows: Optional[np.ndarray] = None):
         # Views of the caller's arrays (possibly memory-mapped files shared by the ranks of a node): only this shard's rows are
         # ever copied / converted -- a rank of an 8-GPU job does not hold eight copies' worth of the 50 M-observation problem
         refl_all = _np(BaseModel.get_refl_id(inputs)).reshape(-1)
@@ -312,6 +344,15 @@ class ObsData:
             slot_idx = np.concatenate([np.arange(g0, g1), np.arange(pad0, pad1)])
             assert len(slot_idx) == len(self.rows)
             iobs_l, sig_l = iobs_all[slot_idx].astype(np.float32), sig_all[slot_idx].astype(np.float32)
+        elif rows is not None:
+            # monochromatic rows that are not a contiguous range (reflection-owner shard): stored in ascending row order; the global
+            # row numbers key the in-kernel noise (noise_row) and pick the columns of injected noise
+            if self.laue:
+                raise ValueError("explicit rows are for monochromatic data (Laue shards go by harmonic group)")
+            self.rows = np.asarray(rows, dtype=np.int64)
+            sl = self.rows
+            start, stop = 0, len(self.rows)
+            iobs_l, sig_l = iobs_all[sl].astype(np.float32), sig_all[sl].astype(np.float32)
         else:
             sl = slice(start, stop)
             iobs_l, sig_l = iobs_all[sl].astype(np.float32), sig_all[sl].astype(np.float32)
@@ -324,7 +365,7 @@ class ObsData:
             raise ValueError("image_id exceeds ImageScaler.max_images")
         metadata = _ShardRows(meta_all, sl)       # metadata[sl] -> this shard's rows as float32
         self.d = int(metadata.shape[1])
-        self.tile_img = self.row_map = self.gmeta = self.tile_gmax = None
+        self.tile_img = self.row_map = self.gmeta = self.tile_gmax = self.noise_row = None
         self.fused_laue = False
         rid_l, img_l = refl_all[sl].astype(np.int32), image_all[sl].astype(np.int32)
         lp = None
@@ -395,6 +436,10 @@ class ObsData:
             self.n_pad = ((self.N + TILE - 1) // TILE) * TILE
             meta_t = np.zeros((int(lib.cl_mlp_meta_rows(self.d)), self.n_pad), dtype=np.float32)
             meta_t[: self.d, : self.N] = metadata[sl].T
+            if rows is not None:             # (every plain-layout kernel reads the per-row noise key when it is given)
+                nr = np.zeros(self.n_pad, dtype=np.int32)
+                nr[: self.N] = self.rows.astype(np.int32)
+                self.noise_row = torch.as_tensor(nr, device=device)
         self.refl_id = torch.as_tensor(rid_l, device=device)
         self.image_id = torch.as_tensor(img_l, device=device)
         self.meta_t = torch.as_tensor(meta_t, device=device)
@@ -450,12 +495,20 @@ class ObsChunks:
         self.n_pad, self.grid, self.partials = sum(c.n_pad for c in children), c0.grid, c0.partials
         self.laue, self.fused_laue, self.rows, self.row_map, self.row0 = False, False, None, None, 0
         for c in children:
-            c.row0 = c.start - self.start           # first row of the piece inside the shard's eta / ipred arrays
+            if getattr(c, "rows", None) is None:
+                c.row0 = c.start - self.start       # first row of the piece inside the shard's eta / ipred arrays
 
     def alloc_chain(self, lib, blocks, w, device):
         self.children[0].alloc_chain(lib, blocks, w, device)         # the pieces run one after the other: one set of buffers
         for c in self.children[1:]:
             c.chain_act, c.chain_dact = self.children[0].chain_act, self.children[0].chain_dact
+
+
+class _EmptyObs:
+    """An owner-mode rank's share of a validation set in which none of its reflections occurs: nothing to launch."""
+
+    def __init__(self, n_total: int):
+        self.N, self.N_total, self.rows, self.empty = 0, n_total, np.zeros(0, dtype=np.int64), True
 
 
 def launch_row_limit(d: int) -> int:
@@ -563,7 +616,6 @@ class ElboEngine:
                                           f"supports {max_l} hidden layers in total at this width")
         # Deterministic mode (`model.deterministic = True` or CARELESS_HIP_DETERMINISTIC=1): no float atomics anywhere in the step --
         # per-observation stores + fixed-order sums (cl_det_reduce) -- so two runs give bit-identical gradients and parameters
-        import os
         self.deterministic = bool(getattr(model, "deterministic", False)) or os.environ.get("CARELESS_HIP_DETERMINISTIC", "0") == "1"
         if self.deterministic and (self.laue or self.wide or imgl is not None or self.ev11 or self.double_wilson or self.blocks is not None):
             raise NotImplementedError("deterministic mode covers monochromatic data, the Wilson prior, Normal / Student-T likelihoods and "
@@ -604,20 +656,41 @@ class ElboEngine:
         self.S = int(model.mc_sample_size)
         if self.S < 1:
             raise ValueError("mc_sample_size must be >= 1")
-        self.obs = self._build_obs(inputs, self.shard.start, self.shard.stop, grid, self.laue_groups)
+        # Reflection-owner sharding: with more than one rank, monochromatic data and the Wilson prior, a rank takes a
+        # RANGE OF REFLECTIONS and every observation of theirs instead of a range of rows.  Sampling q(F), its KL, its gradient and
+        # its Adam update are then local to the owner (1 / world of the replicated work of the row split), and the step's all-reduce
+        # carries the scaler's gradient and four norm terms instead of 2 R floats.  Laue data (a harmonic group mixes reflections),
+        # the double-Wilson prior (a child's parent may live on another rank), per-image layers, wide scalers and the deterministic
+        # mode keep the row split.  `model.owner_shard = False` / CARELESS_HIP_OWNER_SHARD=0: the row split (A/B runs).
+        self.owner = False
+        want = getattr(model, "owner_shard", None)
+        if want is None:
+            want = os.environ.get("CARELESS_HIP_OWNER_SHARD", "1") != "0"
+        if (want and self.shard.world > 1 and not self.laue and not self.double_wilson and not self.wide and imgl is None
+                and not self.deterministic and not self.shard.owner):
+            osh = owner_shard(_np(BaseModel.get_refl_id(inputs)).reshape(-1), self.R, self.shard.rank, self.shard.world)
+            if osh is not None:
+                self.shard = osh
+        self.owner = bool(self.shard.owner)
+        self.obs = self._build_obs(inputs, self.shard.start, self.shard.stop, grid, self.laue_groups, rows=self.shard.rows if self.owner else None)
         if self.blocks is not None:
             self.obs.alloc_chain(self.lib, self.blocks, self.w, dev)
         RS = self.R * self.S
         o_dz = 0
         o_g = (RS + 3) // 4 * 4
-        o_sc = (o_g + lay.n + 4 + 3) // 4 * 4           # 4 doubles = 8 floats, 16-byte aligned
-        o_seg = o_sc + 8
-        tot = o_seg + 2 * self.nseg
+        o_sc = (o_g + lay.n + 8 + 3) // 4 * 4           # 4 floats of slack, then the 4 norm terms of the owner-mode message; 16-byte aligned
+        o_seg = o_sc + 8                                # 4 doubles = 8 floats
+        o_own = o_seg + 2 * self.nseg                   # owner mode: 4 double accumulators + the block ticket of cl_owner_qnorm
+        tot = o_own + 10
         self.ws = torch.zeros(tot, dtype=torch.float32, device=dev)
         self.dz_f = self.ws[o_dz:o_dz + RS]
         self.grads = self.ws[o_g:o_g + lay.n]
         self.scalars = self.ws[o_sc:o_sc + 8].view(torch.float64)
         self.seg_sq = self.ws[o_seg:o_seg + 2 * self.nseg].view(torch.float64)
+        self.own_scratch = self.ws[o_own:o_own + 10].view(torch.float64)
+        self.msg_norm = self.ws[o_g + lay.n + 4:o_g + lay.n + 8]                # [raw, sanitised, sanitised a, sanitised b]
+        self.msg = self.ws[o_g + 2 * self.R:o_g + lay.n + 8]                    # what an owner-mode step all-reduces
+        self.ws_step = self.ws[o_g:]                                            # owner mode zeroes this and its own slice of dz_f per step
         self.z_f = torch.empty(RS, dtype=torch.float32, device=dev)
         self.stop_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.frozen = torch.zeros(self.nseg, dtype=torch.uint8, device=dev)
@@ -625,7 +698,7 @@ class ElboEngine:
         self._keep = None
         self.refresh_config()
 
-    def _build_obs(self, inputs, start, stop, grid, laue_groups):
+    def _build_obs(self, inputs, start, stop, grid, laue_groups, rows=None):
         """Device image of rows [start, stop) of `inputs`: one `ObsData`, or -- plain layout only -- as many pieces as the 4-GiB
         bound of a launch asks for (`ObsChunks`)."""
         kw = dict(grid=grid, n_refl=self.R, n_images=self._max_images(), laue_groups=laue_groups, pack_images=self.imgl is not None and not self.wide,
@@ -634,18 +707,24 @@ class ElboEngine:
         n_total = int(_np(BaseModel.get_refl_id(inputs)).reshape(-1).shape[0])
         stop = n_total if stop is None else stop
         per = launch_row_limit(self.d)
+        if rows is not None:
+            start, stop = 0, len(rows)
         if self.laue or self.imgl is not None or self.wide or stop - start <= per:
-            o = ObsData(self.lib, inputs, start, stop, self.S, self.layout.P, self.device, **kw)
+            o = ObsData(self.lib, inputs, start, stop, self.S, self.layout.P, self.device, rows=rows, **kw)
             if self.deterministic:
                 self._det_attach(o, [o])
             return o
         pieces = []
         for a in range(start, stop, per):
-            pieces.append(ObsData(self.lib, inputs, a, min(stop, a + per), self.S, self.layout.P, self.device, **kw))
+            b = min(stop, a + per)
+            pieces.append(ObsData(self.lib, inputs, a, b, self.S, self.layout.P, self.device, rows=None if rows is None else rows[a:b], **kw))
+            pieces[-1].row0 = a - start                   # first row of the piece inside the shard's eta / ipred arrays
             kw["n_refl"] = kw["n_images"] = None          # (the id ranges were checked over the whole input by the first piece)
             if len(pieces) > 1:
                 pieces[-1].partials = pieces[0].partials  # launches are serialised on one stream: one partial buffer
         o = ObsChunks(pieces)
+        if rows is not None:
+            o.rows = np.asarray(rows, dtype=np.int64)
         if self.deterministic:
             self._det_attach(o, pieces)
         return o
@@ -723,6 +802,8 @@ class ElboEngine:
         a.high, a.eps = self.q.high, self.q.scale_shift
         a.w_kl, a.kl_grad_mult = self.w_kl, self.kl_mult
         a.kl_begin, a.kl_end = self.shard.kl_begin, self.shard.kl_end
+        if self.owner:
+            a.r_begin, a.r_end = self.shard.kl_begin, self.shard.kl_end      # the reflections this rank owns: nobody else touches them
         a.u_f = ptr(u_f)
         a.seed, a.step = self.seed, step & 0xFFFFFFFF
         a.z_f = ptr(self.z_f); a.dz_f = ptr(self.dz_f)
@@ -753,6 +834,7 @@ class ElboEngine:
             a.row_map = ptr(obs.row_map)
         if obs.fused_laue:
             a.gmeta, a.tile_gmax = ptr(obs.gmeta), ptr(obs.tile_gmax)
+        if getattr(obs, "noise_row", None) is not None:
             a.noise_row = ptr(obs.noise_row)
         if self.imgl is not None:
             a.imgl = self.params.data_ptr() + 4 * lay.off_imgl
@@ -830,16 +912,31 @@ class ElboEngine:
     def forward_backward(self, step: int, u_f=None, eta=None, ipred_out=None):
         """Enqueue the loss + gradient part of a step (everything up to, not including, the optimizer)."""
         lib, st = self.lib, _stream()
-        self.ws.zero_()
+        self._zero_step()
         tn = self._tn_args(step, u_f)
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
         if self.double_wilson:
             check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")
         self._data_term(self.obs, step, eta, ipred_out, st)
         check(lib.cl_tn_backward(C.byref(tn), st), "cl_tn_backward")
+        if self.owner:
+            # this rank's share of |d a|^2 + |d b|^2 into the message, next to the scaler's gradient
+            check(lib.cl_owner_qnorm(ptr(self.grads), self.R, self.shard.kl_begin, self.shard.kl_end, ptr(self.msg_norm),
+                                     ptr(self.own_scratch), ptr(self.stop_flag), st), "cl_owner_qnorm")
         if (self.shard.world > 1 and not getattr(self, "local_only", False)) or getattr(self, "force_allreduce", False):
             self._allreduce()        # local_only: a test hook that leaves the per-rank partial gradient in place
         self._keep = (u_f, eta, ipred_out)
+
+    def _zero_step(self):
+        """Clear the step's accumulators: dz_f, the flat gradient, the scalars.  An owner-mode rank only ever touches the dz_f rows and
+        the q gradients of its own reflections (those gradients are rewritten, not accumulated, by nobody else): it clears its slice
+        of dz_f and everything from the gradients on."""
+        if not self.owner:
+            self.ws.zero_()
+            return
+        r0, r1 = self.shard.kl_begin, self.shard.kl_end
+        self.dz_f[r0 * self.S:r1 * self.S].zero_()
+        self.ws_step.zero_()
 
     def _det_reduce(self, obs, st):
         det, lay = obs.det, self.layout
@@ -856,6 +953,8 @@ class ElboEngine:
     def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st, _piece: bool = False):
         """NLL of `obs` into scalars[NLL] and its gradient into dz_f / the flat gradient (scaler + image scales)."""
         lib, lay = self.lib, self.layout
+        if getattr(obs, "empty", False):
+            return
         if isinstance(obs, ObsChunks):
             for piece in obs.children:
                 self._data_term(piece, step, eta, ipred_out, st, _piece=True)
@@ -935,10 +1034,16 @@ class ElboEngine:
         (S, N_val) inject the noise (parity tests).  Uses the step workspace (call it between steps); synchronises."""
         lib, st = self.lib, _stream()
         u_f, eta = self._noise_to_device(u_f, eta, obs)
-        self.ws.zero_()
+        self._zero_step()
         tn = self._tn_args(key, u_f)
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
         self._data_term(obs, key, eta, None, st)
+        if self.owner and self.shard.world > 1 and not getattr(self, "local_only", False):
+            # an owner-mode rank holds the validation rows of ITS reflections (make_obs): the set's NLL is the sum over the ranks
+            import torch.distributed as dist
+            t = self.scalars[0:1].clone()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+            return float(t.item())
         torch.cuda.synchronize()
         return float(self.scalars[0].item())
 
@@ -946,7 +1051,15 @@ class ElboEngine:
         """Device image of another observation set (validation data) for `evaluate_nll`."""
         if BaseModel.is_laue(inputs) != self.laue:
             raise ValueError("validation data and training data differ in kind (mono / Laue)")
-        o = self._build_obs(inputs, 0, None, None, None)
+        rows = None
+        if self.owner:
+            # validation rows follow their reflections' owner (only the owner samples them); a rank none of whose reflections occurs
+            # in the set launches nothing and contributes 0 to the sum
+            rid = _np(BaseModel.get_refl_id(inputs)).reshape(-1)
+            rows = np.nonzero((rid >= self.shard.kl_begin) & (rid < self.shard.kl_end))[0]
+            if len(rows) == 0:
+                return _EmptyObs(int(len(rid)))
+        o = self._build_obs(inputs, 0, None, None, None, rows=rows)
         if o.d != self.d:
             raise ValueError("validation metadata width differs from the training data")
         if self.blocks is not None:
@@ -1132,7 +1245,21 @@ class ElboEngine:
 
     def _allreduce(self):
         from careless_amd.distributed import allreduce_flat_
-        allreduce_flat_(self.grads, self.process_group)
+        # row split: the whole flat gradient (2 R + P + ... floats); reflection-owner split: the scaler's part and the norm terms
+        allreduce_flat_(self.msg if self.owner else self.grads, self.process_group)
+
+    def sync_owned(self):
+        """Reflection-owner mode: every rank has updated a and b of its own reflections only; after training all ranks need all of
+        them (the output step, saved weights, a later `train_model` call).  One sum all-reduce of a vector that is zero outside the
+        rank's own ranges -- once per training run, not per step.  Adam's moments stay with the owner (ownership is fixed for the
+        engine's lifetime)."""
+        if not self.owner or self.shard.world <= 1 or getattr(self, "local_only", False):
+            return
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return
+        from careless_amd.distributed import gather_owned_
+        gather_owned_(self.params, self.R, self.shard.kl_begin, self.shard.kl_end, self.process_group)
 
     def optimizer_step(self, step_index: int):
         lib, st, opt = self.lib, _stream(), self.opt
@@ -1144,6 +1271,15 @@ class ElboEngine:
         if norm_first:
             check(lib.cl_grad_sqnorm(ptr(self.grads), n, ptr(self.seg_off), self.nseg, ptr(self.seg_sq) if use_seg else None,
                                      ptr(self.scalars), ptr(self.stop_flag), st), "cl_grad_sqnorm")
+            if self.owner:
+                # the pass above saw this rank's own q gradients (the others' entries are zero here) and the all-reduced tail: trade
+                # the own share (cl_owner_qnorm's double accumulators) for the sum over the ranks that came back in the message
+                tot, own = self.msg_norm.double(), self.own_scratch
+                self.scalars[2] += tot[0] - own[0]
+                self.scalars[3] += tot[1] - own[1]
+                if use_seg:
+                    self.seg_sq[0] += tot[2] - own[2]
+                    self.seg_sq[1] += tot[3] - own[3]
         self.t += 1
         t = self.t
         a = AdamArgs()
@@ -1159,6 +1295,16 @@ class ElboEngine:
         a.scalars = ptr(self.scalars)
         a.stop_flag = ptr(self.stop_flag)
         a.norm_out = None if norm_first else ptr(self.scalars)
+        if self.owner:
+            # update what this rank owns -- a and b of its reflections -- and the replicated tail; the norm fused into the call covers
+            # the tail, the q part over all ranks arrives in the message
+            r0, r1, R = self.shard.kl_begin, self.shard.kl_end, self.R
+            a.n_ranges = 3
+            a.range_begin[0], a.range_end[0] = r0, r1
+            a.range_begin[1], a.range_end[1] = R + r0, R + r1
+            a.range_begin[2], a.range_end[2] = 2 * R, n
+            a.norm_skip_ranges = 2
+            a.norm_extra = None if norm_first else ptr(self.msg_norm)
         check(lib.cl_adam_step(C.byref(a), st), "cl_adam_step")
         check(lib.cl_step_finalize(ptr(self.scalars), self.kl_mult, ptr(self.history_buf), step_index,
                                    ptr(self.stop_flag), st), "cl_step_finalize")

@@ -126,6 +126,7 @@ class VariationalMergingModel(BaseModel):
                 break
         if bar is not None:
             bar.close()
+        eng.sync_owned()              # reflection-owner data parallelism: every rank gets the other owners' q(F) parameters
         history = eng.read_history(done)
         if val_obs is not None:
             history["NLL_val"] = val_hist[: len(history["loss"])]

@@ -64,6 +64,9 @@ typedef struct cl_tn_args {
     float w_kl;                 /* weight of every KL element in the reported KL: 1/S (sum) or 1/(S R) (mean)   */
     float kl_grad_mult;         /* extra weight of the KL in the loss: 1, or --kl-weight                        */
     int kl_begin, kl_end;       /* reflection range whose KL this rank owns (data-parallel: counted once)       */
+    int r_begin, r_end;         /* cl_tn_forward / cl_tn_backward work on reflections [r_begin, r_end) only -- a rank that OWNS a
+                                 * reflection range (all observations of those reflections are its own: no other rank reads their
+                                 * samples or adds to their gradients); r_end <= r_begin means all of [0, R)                     */
     const float* u_f;           /* [R][S] injected uniforms or NULL                                             */
     unsigned long long seed; unsigned step;
     float* z_f;                 /* [R][S] out (forward)                                                          */
@@ -294,11 +297,24 @@ typedef struct cl_adam_args {
     const int* stop_flag;
     double* norm_out;           /* optional [CL_SC_COUNT]: also accumulate the squared gradient norm here (replaces a separate
                                    cl_grad_sqnorm launch when no norm-dependent clipping is configured)                      */
+    /* Reflection-owner data parallelism: a rank updates only the index ranges it owns (its reflections' a and b, then the replicated
+     * tail) and learns the other ranks' share of the gradient norm from the step's message.  n_ranges = 0: the whole vector.      */
+    int n_ranges;               /* 0..3 */
+    int range_begin[3], range_end[3];   /* absolute index ranges [begin, end) of p / g / m / v this call updates                 */
+    int norm_skip_ranges;       /* the first k ranges stay out of the norm fused into this call (norm_out) ...                     */
+    const float* norm_extra;    /* ... because their squared norm over ALL ranks arrives here: [2] = raw, sanitised (cl_owner_qnorm
+                                   + the all-reduce); NULL = nothing to add                                                       */
 } cl_adam_args;
 
 int cl_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
                    const int* stop_flag, void* stream);
 int cl_adam_step(const cl_adam_args* args, void* stream);
+/* Reflection-owner data parallelism (no reference counterpart; the reference is single-process): the squared norm of THIS rank's
+ * part of the surrogate-posterior gradient -- g[r_begin .. r_end) (d a) and g[R + r_begin .. R + r_end) (d b) -- as four floats the
+ * step's all-reduce sums over the ranks next to the replicated tail: out[0] = raw (NaN / inf propagate, variational.py:205),
+ * out[1] = sanitised (what the optimizer's clipping sees, :208), out[2] / out[3] = sanitised, per tensor (clipnorm).  Accumulated in
+ * double in scratch[0..3] (scratch[4] is the block ticket; the caller zeroes all five per step).                               */
+int cl_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* out, double* scratch, const int* stop_flag, void* stream);
 /* history[step_index] = {loss, F KLDiv, NLL, Grad Norm, skipped}; sets *stop_flag when the norm is not finite
  * (careless/models/merging/variational.py:262-274) */
 int cl_step_finalize(const double* scalars, float kl_weight_or_one, double* history, int step_index, int* stop_flag,

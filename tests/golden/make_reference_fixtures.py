@@ -6,8 +6,8 @@ container, so the ELBO golden vectors come from the oracle (make_golden.py).  Tw
 Python / numpy and ARE executed here, loaded by file path (the package's own `__init__` asks setuptools for an installed
 `careless` distribution):
 
-  * `careless/utils/positional_encoding.py: positional_encoding`  -> ref_positional_encoding.npz (inputs + the reference's outputs)
-  * `careless/args/*.py` (the argparse tables behind `careless mono|poly`) -> ref_cli_flags.json (flag -> dest/default/type/action/...)
+  * `careless/utils/positional_encoding.py: positional_encoding`  -> reference/positional_encoding.npz (inputs + the reference's outputs)
+  * `careless/args/*.py` (the argparse tables behind `careless mono|poly`) -> reference/cli_flags.json (flag -> dest/default/type/action/...)
 
 The fixtures are data (inputs and expected outputs); nothing of the reference's source text is stored.  Run in the build container:
 
@@ -47,7 +47,7 @@ def positional_encoding_fixture(ref):
         out[f"{k}__x"] = x
         out[f"{k}__L"] = np.int64(L)
         out[f"{k}__y"] = pe(x, L)
-    np.savez_compressed(os.path.join(HERE, "ref_positional_encoding.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, "reference", "positional_encoding.npz"), **out)
     return len(cases)
 
 
@@ -75,7 +75,7 @@ def cli_flags_fixture(ref):
                                 action=type(act).__name__, nargs=act.nargs, choices=list(act.choices) if act.choices else None,
                                 const=act.const if isinstance(act.const, (type(None), bool, int, float, str)) else repr(act.const)))
         table[g] = entries
-    with open(os.path.join(HERE, "ref_cli_flags.json"), "w") as f:
+    with open(os.path.join(HERE, "reference", "cli_flags.json"), "w") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     return sum(len(v) for v in table.values())
 

@@ -133,3 +133,97 @@ def test_make_shard_never_hands_out_an_empty_range():
     assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == 5
     with pytest.raises(ValueError):
         laue_group_shard(np.zeros(8, dtype=np.int64), 0, 2)          # one group cannot be split over two ranks
+
+
+def _owner_worker(rank, world, port, q):
+    from careless_amd.distributed import allreduce_flat_, gather_owned_
+    from careless_amd.engine import owner_shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    kw = dict(N=203, R=21, d0=5, L=2, w=16, S=3)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    R = kw["R"]
+    sh = owner_shard(np.asarray(data["refl_id"]), R, rank, world)
+    rows = torch.as_tensor(sh.rows)
+    xs = O.ElboInputs(refl_id=x.refl_id[rows], image_id=x.image_id[rows], metadata=x.metadata[rows], iobs=x.iobs[rows],
+                      sigiobs=x.sigiobs[rows], centric=x.centric, multiplicity=x.multiplicity, low=x.low, sigma=x.sigma)
+    kl_mask = torch.zeros(R, dtype=torch.bool)
+    kl_mask[sh.kl_begin:sh.kl_end] = True
+    u, e = torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta[:, sh.rows], dtype=torch.float64)
+    out, grads = O.elbo_value_and_grads(params, xs, cfg, u, e, kl_mask=kl_mask)
+    flat = torch.cat([g.reshape(-1) for g in grads]).to(torch.float32)
+    own = torch.zeros(2 * R, dtype=torch.bool)
+    own[sh.kl_begin:sh.kl_end] = True
+    own[R + sh.kl_begin:R + sh.kl_end] = True
+    foreign = float(flat[: 2 * R][~own].abs().max())             # nothing of another rank's reflections in this rank's gradient
+    # the step's message: the replicated tail and this rank's share of |d a|^2 + |d b|^2 (engine.ElboEngine.msg)
+    msg = torch.cat([flat[2 * R:], (flat[: 2 * R].double() ** 2).sum().float().reshape(1)])
+    allreduce_flat_(msg)
+    # after "training": a parameter vector of which the rank changed its own entries only
+    p = torch.arange(2 * R + 5, dtype=torch.float32)
+    p[: 2 * R][own] += 100.0 * (rank + 1)
+    gather_owned_(p, R, sh.kl_begin, sh.kl_end)
+    q.put((rank, sh.kl_begin, sh.kl_end, sh.rows, flat[: 2 * R].numpy(), msg.numpy(), foreign, p.numpy(), float(out["nll"]), float(out["kl"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_reflection_owner_shards_sum_to_full_batch():
+    """The reflection-owner split on CPU (gloo, world size 2; the ORACLE stands in for the kernels): the ranks' q gradients are
+    disjoint and concatenate to the full-batch one, the all-reduced message holds the full scaler gradient and the q gradient's
+    squared norm, and `gather_owned_` leaves every rank with every owner's parameters."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kw = dict(N=203, R=21, d0=5, L=2, w=16, S=3)
+    R = kw["R"]
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64),
+                                        torch.as_tensor(eta, dtype=torch.float64))
+    full = torch.cat([g.reshape(-1) for g in grads]).numpy()
+    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == R
+    rows = np.concatenate([g[3] for g in got])
+    assert len(rows) == kw["N"] and len(np.unique(rows)) == kw["N"]
+    qsum = got[0][4] + got[1][4]
+    tol = dict(rtol=2e-5, atol=1e-6 * np.abs(full).max())
+    assert np.allclose(qsum, full[: 2 * R], **tol)
+    for g in got:
+        assert g[6] == 0.0
+        assert np.allclose(g[5][:-1], full[2 * R:], **tol)
+        assert np.isclose(g[5][-1], (full[: 2 * R].astype(np.float64) ** 2).sum(), rtol=1e-5)
+        want = np.arange(2 * R + 5, dtype=np.float32)
+        for o in got:
+            want[o[1]:o[2]] += 100.0 * (o[0] + 1)
+            want[R + o[1]:R + o[2]] += 100.0 * (o[0] + 1)
+        assert np.array_equal(g[7], want)
+    assert np.isclose(got[0][8] + got[1][8], float(out["nll"]), rtol=1e-10) and np.isclose(got[0][9] + got[1][9], float(out["kl"]), rtol=1e-10)
+
+
+def test_owner_bounds_balance_observations_and_fall_back_when_impossible():
+    from careless_amd.engine import owner_bounds, owner_shard
+    rng = np.random.default_rng(3)
+    rid = rng.integers(0, 5000, size=160_000)
+    for world in (2, 3, 4, 8):
+        b = owner_bounds(rid, 5000, world)
+        assert b[0] == 0 and b[-1] == 5000 and np.all(np.diff(b) > 0)
+        cnt = [int(((rid >= b[r]) & (rid < b[r + 1])).sum()) for r in range(world)]
+        assert sum(cnt) == len(rid) and max(cnt) - min(cnt) <= 4 * np.bincount(rid).max()          # balanced to a few reflections' worth
+        sh = [owner_shard(rid, 5000, r, world) for r in range(world)]
+        assert all(s.owner and s.start == 0 and s.stop == len(s.rows) for s in sh)
+        assert all(np.all(np.diff(s.rows) > 0) for s in sh)                                       # ascending: the caller's order is kept
+        assert all(np.all((rid[s.rows] >= s.kl_begin) & (rid[s.rows] < s.kl_end)) for s in sh)
+    # reflections without observations are owned too (their KL term and update are somebody's); skewed counts still balance
+    rid = np.concatenate([np.zeros(1000, dtype=np.int64), rng.integers(10, 20, size=1000)])
+    b = owner_bounds(rid, 40, 2)
+    assert b.tolist() == [0, 1, 40] or (b[0] == 0 and b[-1] == 40)
+    assert owner_bounds(np.array([0, 0, 0, 1]), 5, 3) is None and owner_shard(np.array([0, 0, 0, 1]), 5, 0, 3) is None   # -> row split

@@ -982,3 +982,111 @@ def test_flip_resolutions_stay_rare():
     """Runs after the parity cases of this module (pytest keeps file order): the forced-branch resolution is for measure-zero events,
     not a habit -- a handful of cases among the few hundred at most."""
     assert len(FLIP_CASES) <= 6, FLIP_CASES
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# reflection-owner data parallelism (DESIGN 5.2): a rank takes a range of reflections and every observation of theirs
+# --------------------------------------------------------------------------------------------------------------------------
+OWNER_CASES = {
+    "mono_2x32": dict(N=517, R=41, d0=5, L=2, w=32, S=3),
+    "headline_shape_5x64_posenc_S8": dict(N=900, R=60, d0=5, posenc=True, L=5, w=64, S=8, likelihood="studentt", dof=16.0),
+    "cli_default_20x10": dict(N=900, R=40, d0=5, L=20, w=10, S=2, perturb=0.02),
+    "cli_default_posenc_d21_S9": dict(N=700, R=40, d0=5, posenc=True, L=20, w=10, S=9, likelihood="studentt", dof=8.0, perturb=0.02),
+    "narrow_20x13": dict(N=800, R=40, d0=5, L=20, w=13, S=2, perturb=0.02),
+    "chained_12x32": dict(N=600, R=40, d0=5, L=12, w=32, S=2),
+    "ev11": dict(N=600, R=40, d0=5, L=2, w=32, S=3, ev11=True, likelihood="studentt", dof=6.0),
+    "klweight_noimg": dict(N=500, R=40, d0=5, L=3, w=20, S=2, kl_weight=0.5, use_image_scales=False),
+    "global_clipnorm": dict(N=400, R=40, d0=5, L=2, w=32, S=2, global_clipnorm=1.0),
+    "clipnorm": dict(N=400, R=40, d0=5, L=2, w=32, S=2, clipnorm=0.5),
+}
+
+
+@pytest.mark.parametrize("name", list(OWNER_CASES))
+@pytest.mark.parametrize("world", [2, 3])
+def test_reflection_owner_shards_reproduce_the_full_batch_step(name, world):
+    """The engines of all ranks of a reflection-owner split, run one after the other on this GPU with the all-reduce replaced by a
+    sum of their messages: loss terms and gradients add up to the single-rank step's (in-kernel noise: keyed by the GLOBAL row and
+    reflection, so the shards draw what the full batch draws), and after the optimizer step the owners' a / b and everybody's copy
+    of the replicated tail equal the single-rank parameters; the logged gradient norm is the full-batch one on every rank."""
+    from careless_amd.engine import ElboEngine, make_shard
+    kw = OWNER_CASES[name]
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    inputs = util.reference_inputs(data)
+    L, w, R = kw["L"], kw["w"], kw["R"]
+    full = ElboEngine(util.build_model(data, cfg, params, L, w), inputs, seed=99)
+    full.alloc_history(1)
+    full.forward_backward(0)
+    torch.cuda.synchronize()
+    g_full, t_full = full.grads.clone(), full.loss_terms()
+    full.optimizer_step(0)
+    h_full = full.read_history(1)
+    engs = []
+    for r in range(world):
+        eng = ElboEngine(util.build_model(data, cfg, params, L, w), inputs, seed=99, shard=make_shard(kw["N"], R, r, world))
+        assert eng.owner and eng.shard.owner and eng.shard.rank == r
+        eng.local_only = True
+        eng.alloc_history(1)
+        eng.forward_backward(0)
+        engs.append(eng)
+    torch.cuda.synchronize()
+    # the shards partition reflections and rows
+    rows = np.concatenate([e.shard.rows for e in engs])
+    assert len(rows) == kw["N"] and len(np.unique(rows)) == kw["N"]
+    assert engs[0].shard.kl_begin == 0 and engs[-1].shard.kl_end == R and all(a.shard.kl_end == b.shard.kl_begin for a, b in zip(engs, engs[1:]))
+    g_sum = sum(e.grads for e in engs)
+    nll, kl = sum(e.loss_terms()["nll"] for e in engs), sum(e.loss_terms()["kl"] for e in engs)
+    assert abs(nll - t_full["nll"]) <= 1e-5 * abs(t_full["nll"]) and abs(kl - t_full["kl"]) <= 1e-5 * max(abs(t_full["kl"]), 1.0)
+    assert util.rel_err(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 2e-5
+    for e in engs:                                   # a rank's q gradient lives on its own reflections only
+        own = torch.zeros(2 * R, dtype=torch.bool)
+        own[e.shard.kl_begin:e.shard.kl_end] = True
+        own[R + e.shard.kl_begin:R + e.shard.kl_end] = True
+        assert float(e.grads[:2 * R][~own.to(e.grads.device)].abs().max()) == 0.0
+    # the all-reduce: every rank gets the sum of the messages (scaler gradient + the four norm terms)
+    msg = sum(e.msg for e in engs).clone()
+    for e in engs:
+        e.msg.copy_(msg)
+        e.optimizer_step(0)
+    torch.cuda.synchronize()
+    p_full = full.params.cpu().numpy()
+    for e in engs:
+        p = e.params.cpu().numpy()
+        r0, r1 = e.shard.kl_begin, e.shard.kl_end
+        for lo, hi in ((r0, r1), (R + r0, R + r1), (2 * R, len(p))):
+            assert util.rel_err(p[lo:hi], p_full[lo:hi]) < 2e-5, (e.shard.rank, lo, hi)
+        h = e.read_history(1)
+        assert abs(h["Grad Norm"][0] - h_full["Grad Norm"][0]) <= 2e-5 * h_full["Grad Norm"][0]
+    # the others' reflections were not touched (they arrive with sync_owned at the end of training)
+    p0 = engs[0].params.cpu().numpy()
+    init = np.concatenate([params.q_loc_raw.numpy(), params.q_scale_raw.numpy()]).astype(np.float32)
+    r1 = engs[0].shard.kl_end
+    assert np.array_equal(p0[r1:R], init[r1:R])
+
+
+def test_reflection_owner_shards_with_injected_noise_match_the_oracle():
+    """Owner shards on injected noise (the columns of eta follow the shard's rows): the summed loss and gradients equal the fp64
+    oracle's, so the decomposition is checked against the reference restatement and not only against the engine itself; the
+    validation NLL of an owner-sharded validation set sums to the single-rank value."""
+    from careless_amd.engine import ElboEngine, make_shard
+    kw = dict(N=640, R=48, d0=5, L=5, w=64, S=4, likelihood="studentt", dof=8.0)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    inputs = util.reference_inputs(data)
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64))
+    full = ElboEngine(util.build_model(data, cfg, params, 5, 64), inputs, seed=5)
+    vfull = full.evaluate_nll(full.make_obs(inputs), 77)
+    gs, nll, kl, vsum = None, 0.0, 0.0, 0.0
+    for r in range(3):
+        eng = ElboEngine(util.build_model(data, cfg, params, 5, 64), inputs, seed=5, shard=make_shard(kw["N"], kw["R"], r, 3))
+        eng.local_only = True
+        du, de = eng._noise_to_device(u_f, eta)
+        eng.forward_backward(0, du, de)
+        torch.cuda.synchronize()
+        gt = [g.clone() for g in eng.grad_tensors()]
+        gs = gt if gs is None else [a + b for a, b in zip(gs, gt)]
+        t = eng.loss_terms()
+        nll += t["nll"]; kl += t["kl"]
+        vsum += eng.evaluate_nll(eng.make_obs(inputs), 77)
+    assert abs(nll - float(out["nll"])) <= 1e-4 * abs(float(out["nll"])) and abs(kl - float(out["kl"])) <= 1e-4 * abs(float(out["kl"]))
+    for a, b in zip(gs, grads):
+        assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
+    assert abs(vsum - vfull) <= 1e-5 * abs(vfull)

@@ -11,7 +11,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _pe_cases():
-    z = np.load(os.path.join(GOLD, "ref_positional_encoding.npz"))
+    z = np.load(os.path.join(GOLD, "reference", "positional_encoding.npz"))
     names = sorted({k.split("__")[0] for k in z.files})
     return [(n, z[f"{n}__x"], int(z[f"{n}__L"]), z[f"{n}__y"]) for n in names]
 
@@ -29,7 +29,7 @@ def test_positional_encoding_equals_the_reference_output(name, x, L, y):
 
 
 def _ref_flags():
-    return json.load(open(os.path.join(GOLD, "ref_cli_flags.json")))
+    return json.load(open(os.path.join(GOLD, "reference", "cli_flags.json")))
 
 
 def _our_actions(sub):
