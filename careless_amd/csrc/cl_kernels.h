@@ -65,9 +65,27 @@ __device__ __forceinline__ float cl_wave_sum(float v) {
     v = CL_DPP_ADD(v, 0x143, 0xC);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Image-scale gradients of a wave whose observations belong to MORE than one image (the rows of an image end inside the wave:
+// stills with a few dozen reflections per image, or a reflection-owner shard that holds an eighth of every image's rows).  Image ids
+// are sorted, so a wave holds a few images: one wave reduction and ONE atomic per image, image by image (up to four; a wave with more
+// -- unsorted input -- finishes lane by lane).  `take`: this lane carries a term of a trainable image (img > 0); d_img[img - 1] += v.
+__device__ __forceinline__ void cl_image_grad_segments(float* __restrict__ d_img, int img, float v, bool take, int lane) {
+    unsigned long long m = __ballot(take);
+    for (int it = 0; it < 4 && m != 0ull; ++it) {                      // wave-uniform
+        const int first = __builtin_ctzll(m);
+        const int im = __builtin_amdgcn_readlane(img, first);
+        const bool mine = take && img == im;
+        const float s = cl_wave_sum(mine ? v : 0.0f);
+        if (lane == 0) atomicAdd(d_img + (im - 1), s);
+        take = take && !mine;
+        m = __ballot(take);
+    }
+    if (take) atomicAdd(d_img + (img - 1), v);
+}
 #else
 typedef const cl_mlp_args* cl_args_p;                                        // (host pass over the kernel bodies: never executed)
 __host__ __device__ inline cl_args_p kernargs_again() { return nullptr; }
 __host__ __device__ inline float cl_quad_sum(float v) { return v; }
 __host__ __device__ inline float cl_wave_sum(float v) { return v; }
+__host__ __device__ inline void cl_image_grad_segments(float*, int, float, bool, int) {}
 #endif

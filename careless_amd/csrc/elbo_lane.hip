@@ -634,8 +634,8 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             if (__all(img == img0 || rid < 0)) {
                 const float v = cl_wave_sum(rid >= 0 ? pda : 0.0f);
                 if (lane == 0 && img0 > 0) atomicAdd(A.d_img + (img0 - 1), v);
-            } else if (rid >= 0 && img > 0) {
-                atomicAdd(A.d_img + (img - 1), pda);
+            } else {
+                cl_image_grad_segments(A.d_img, img, pda, rid >= 0 && img > 0, lane);
             }
         }
         const float dloc = pdl, draw = pds * dsig_draw;              // zero for padding observations
