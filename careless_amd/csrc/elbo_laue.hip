@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0 && kmax > 0) atomicAdd(A.d_img + (kmax - 1), v);
-        } else if (key > 0) {
-            atomicAdd(A.d_img + (key - 1), da);
+        } else {
+            cl_image_grad_segments(A.d_img, key, da, key > 0, lane);       // the wave spans several images: one reduction + atomic per image
         }
     }
 }
