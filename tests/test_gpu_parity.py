@@ -819,11 +819,16 @@ def test_freeze_flags_and_early_stop():
                                 dict(N=700, R=40, d0=5, L=2, w=96, S=2, n_images=6, image_layers=1)],
                          ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers", "cli_default_20x10",
                               "cli_default_posenc_d21_S9", "ev11", "trainable_double_wilson_r", "wide_2x96", "laue_ev11", "wide_image_layers"])
-def test_rank_shards_sum_to_full_batch_on_gpu(kw):
+@pytest.mark.parametrize("split", ["auto", "rows"])
+def test_rank_shards_sum_to_full_batch_on_gpu(kw, split):
     """Data-parallel decomposition on ONE GPU: the engines of rank 0 and rank 1 of a 2-rank world (all-reduce skipped) produce
     partial losses / gradients that add up to the single-rank result; in-kernel noise is keyed by global indices, so the shards
-    draw exactly the numbers the full batch draws."""
+    draw exactly the numbers the full batch draws.  `auto`: the split the engine picks (reflection owners for monochromatic data
+    with the Wilson prior, rows otherwise); `rows`: the row split forced where `auto` would pick owners."""
     from careless_amd.engine import ElboEngine, make_shard
+    owner_eligible = not (kw.get("laue") or kw.get("double_wilson") or kw.get("image_layers") or kw["w"] > 64)
+    if split == "rows" and not owner_eligible:
+        pytest.skip("the row split is what `auto` runs for this configuration")
     data, cfg, params, x, u_f, eta = util.make_problem(**kw)
     if kw.get("laue"):                                  # rows of a harmonic group are not contiguous in real inputs
         perm = np.random.default_rng(1).permutation(kw["N"])
@@ -837,7 +842,11 @@ def test_rank_shards_sum_to_full_batch_on_gpu(kw):
     g_full, t_full = full.grads.clone(), full.loss_terms()
     g_sum, nll, kl = torch.zeros_like(g_full), 0.0, 0.0
     for r in range(2):
-        eng = ElboEngine(util.build_model(data, cfg, params, L, w), inputs, seed=99, shard=make_shard(kw["N"], kw["R"], r, 2))
+        m = util.build_model(data, cfg, params, L, w)
+        if split == "rows":
+            m.owner_shard = False
+        eng = ElboEngine(m, inputs, seed=99, shard=make_shard(kw["N"], kw["R"], r, 2))
+        assert eng.owner == (owner_eligible and split == "auto")
         eng.local_only = True
         eng.forward_backward(3)
         torch.cuda.synchronize()
@@ -848,13 +857,16 @@ def test_rank_shards_sum_to_full_batch_on_gpu(kw):
     assert util.rel_err(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 2e-5
 
 
-def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch():
+@pytest.mark.parametrize("owner", [True, False], ids=["reflection_owners", "rows"])
+def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch(owner):
     """1 M observations on the careless CLI's default scaler (20 x 10: the narrow kernel instance), in-kernel noise: the eight
-    rank shards of an 8-GPU job, run one after the other on this GPU without the all-reduce, add up to the single-GPU step --
-    a size-independent property (every workgroup walks dozens of tiles, the accumulators carry over in registers and LDS)."""
+    rank shards of an 8-GPU job -- reflection-owner split and row split --, run one after the other on this GPU without the
+    all-reduce, add up to the single-GPU step: a size-independent property (every workgroup walks dozens of tiles, the accumulators
+    carry over in registers and LDS)."""
     from careless_amd.engine import ElboEngine, make_shard
     from careless_amd.workloads import make_workload
     model, inputs, data, spec = make_workload("mono_10M_cli_default_20x10_S1", N=1_000_000)
+    model.owner_shard = owner
     n, r = 1_000_000, int(model.surrogate_posterior.loc_raw.numel())
     full = ElboEngine(model, inputs, seed=7)
     full.forward_backward(1)
@@ -863,6 +875,7 @@ def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch()
     g_sum, nll, kl = torch.zeros_like(g_full), 0.0, 0.0
     for rank in range(8):
         eng = ElboEngine(model, inputs, seed=7, shard=make_shard(n, r, rank, 8))
+        assert eng.owner == owner
         eng.local_only = True
         eng.forward_backward(1)
         torch.cuda.synchronize()
