@@ -249,33 +249,53 @@ __global__ __launch_bounds__(256) void adam_kernel(const cl_adam_args A) {
         acc = (double)A.norm_extra[0];
         sane = (double)A.norm_extra[1];
     }
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        int i = t, rk = 0;
-        if (A.n_ranges > 0) {
-            if (t < len0) { i = A.range_begin[0] + t; }
-            else if (t < len0 + len1) { i = A.range_begin[1] + (t - len0); rk = 1; }
-            else { i = A.range_begin[2] + (t - len0 - len1); rk = 2; }
+    // Four elements per thread and round, all their loads issued before the first store: p / m / v / g may alias as far as the compiler
+    // knows, so the one-element loop was a chain of dependent memory round trips (15 - 23 us for 6.4e5 parameters; the arithmetic is
+    // nothing).  Elements of a round are a grid stride apart: coalesced as before.
+    const int stride = gridDim.x * blockDim.x;
+    constexpr int U = 4;
+    for (int t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < total; t0 += U * stride) {
+        int ii[U], rk[U];
+        float g_[U], m_[U], v_[U], p_[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * stride;
+            on[u] = t < total;
+            int i = on[u] ? t : 0, r = 0;
+            if (A.n_ranges > 0 && on[u]) {
+                if (t < len0) { i = A.range_begin[0] + t; }
+                else if (t < len0 + len1) { i = A.range_begin[1] + (t - len0); r = 1; }
+                else { i = A.range_begin[2] + (t - len0 - len1); r = 2; }
+            }
+            ii[u] = i; rk[u] = r;
+            g_[u] = A.g[i]; m_[u] = A.m[i]; v_[u] = A.v[i]; p_[u] = A.p[i];
         }
-        float g = A.g[i];
-        if (A.norm_out != nullptr && rk >= A.norm_skip_ranges) {       // fused tf.linalg.global_norm (variational.py:205)
-            const double v2 = (double)g * (double)g;
-            acc += v2;
-            sane += isfinite(g) ? v2 : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const int i = ii[u];
+            float g = g_[u];
+            if (A.norm_out != nullptr && rk[u] >= A.norm_skip_ranges) {    // fused tf.linalg.global_norm (variational.py:205)
+                const double v2 = (double)g * (double)g;
+                acc += v2;
+                sane += isfinite(g) ? v2 : 0.0;
+            }
+            if (A.frozen != nullptr && A.frozen[seg_of(A.seg_off, A.nseg, i)] != 0) continue;
+            if (!isfinite(g)) g = 0.0f;                                   // variational.py:208
+            if (A.clipnorm > 0.0f) {                                      // per-tensor tf.clip_by_norm [3P]
+                const float nrm = (float)sqrt(A.seg_sq[seg_of(A.seg_off, A.nseg, i)]);
+                if (nrm > A.clipnorm) g *= A.clipnorm / nrm;
+            }
+            g *= gscale;
+            if (A.clipvalue > 0.0f) g = fminf(fmaxf(g, -A.clipvalue), A.clipvalue);
+            float m = m_[u], v = v_[u];
+            m += (g - m) * (1.0f - A.beta1);
+            v += (g * g - v) * (1.0f - A.beta2);
+            A.m[i] = m;
+            A.v[i] = v;
+            A.p[i] = p_[u] - m * A.alpha / (sqrtf(v) + A.adam_eps);
         }
-        if (A.frozen != nullptr && A.frozen[seg_of(A.seg_off, A.nseg, i)] != 0) continue;
-        if (!isfinite(g)) g = 0.0f;                                   // variational.py:208
-        if (A.clipnorm > 0.0f) {                                      // per-tensor tf.clip_by_norm [3P]
-            const float nrm = (float)sqrt(A.seg_sq[seg_of(A.seg_off, A.nseg, i)]);
-            if (nrm > A.clipnorm) g *= A.clipnorm / nrm;
-        }
-        g *= gscale;
-        if (A.clipvalue > 0.0f) g = fminf(fmaxf(g, -A.clipvalue), A.clipvalue);
-        float m = A.m[i], v = A.v[i];
-        m += (g - m) * (1.0f - A.beta1);
-        v += (g * g - v) * (1.0f - A.beta2);
-        A.m[i] = m;
-        A.v[i] = v;
-        A.p[i] -= m * A.alpha / (sqrtf(v) + A.adam_eps);
     }
     if (A.norm_out != nullptr) {
         block_atomic_add_d(acc, A.norm_out + CL_SC_GNORM2);
@@ -354,7 +374,7 @@ int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
         for (int k = 0; k < a.n_ranges; ++k) work += a.range_end[k] - a.range_begin[k];
         if (work < 1) work = 1;
     }
-    int grid = (work + 255) / 256;
+    int grid = (work + 1023) / 1024;          // four elements per thread and round (every workgroup ends in two same-address fp64 atomics: no more of them than the work needs)
     // two same-address fp64 atomics per workgroup (fused gradient norm), ~12 ns each and serialised: few workgroups for the usual
     // ~1e6 parameters (18.5 -> 15.6 us against 512), more when the vector is long enough for streaming to dominate (per-image
     // layers: 4e7 parameters)

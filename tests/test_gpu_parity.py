@@ -1103,3 +1103,38 @@ def test_reflection_owner_shards_with_injected_noise_match_the_oracle():
     for a, b in zip(gs, grads):
         assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
     assert abs(vsum - vfull) <= 1e-5 * abs(vfull)
+
+
+def test_reflection_owner_shard_cut_into_several_launches(monkeypatch):
+    """An owner shard whose metadata would pass the 4-GiB bound of a launch runs as consecutive launches like any other shard
+    (engine.ObsChunks over the shard's row list): with the bound lowered to a few hundred rows, the ranks' gradients -- in-kernel
+    noise keyed by the global row, injected noise picked by it -- still add up to the single-rank, single-launch step."""
+    from careless_amd.engine import ElboEngine, ObsChunks, make_shard
+    kw = dict(N=1400, R=60, d0=5, posenc=True, L=5, w=64, S=3, likelihood="studentt", dof=8.0)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    inputs = util.reference_inputs(data)
+    full = ElboEngine(util.build_model(data, cfg, params, 5, 64), inputs, seed=11)
+    full.forward_backward(2)
+    torch.cuda.synchronize()
+    g_full, t_full = full.grads.clone(), full.loss_terms()
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64))
+    d = np.asarray(data["metadata"]).shape[1]
+    monkeypatch.setenv("CARELESS_HIP_MAX_LAUNCH_BYTES", str(4 * ((d + 3) // 4 * 4) * 256))        # 256 rows per launch
+    g_sum, nll, gs = torch.zeros_like(g_full), 0.0, None
+    for r in range(2):
+        eng = ElboEngine(util.build_model(data, cfg, params, 5, 64), inputs, seed=11, shard=make_shard(kw["N"], kw["R"], r, 2))
+        assert eng.owner and isinstance(eng.obs, ObsChunks) and len(eng.obs.children) >= 2
+        eng.local_only = True
+        eng.forward_backward(2)
+        torch.cuda.synchronize()
+        g_sum += eng.grads
+        nll += eng.loss_terms()["nll"]
+        du, de = eng._noise_to_device(u_f, eta)
+        eng.forward_backward(0, du, de)
+        torch.cuda.synchronize()
+        gt = [g.clone() for g in eng.grad_tensors()]
+        gs = gt if gs is None else [a + b for a, b in zip(gs, gt)]
+    assert abs(nll - t_full["nll"]) <= 1e-5 * abs(t_full["nll"])
+    assert util.rel_err(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 2e-5
+    for a, b in zip(gs, grads):
+        assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
