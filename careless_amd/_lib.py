@@ -34,7 +34,7 @@ class TnArgs(C.Structure):
         ("u_f", _vp),
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("z_f", _vp), ("dz_f", _vp), ("d_loc_raw", _vp), ("d_scale_raw", _vp),
-        ("scalars", _vp), ("stop_flag", _vp),
+        ("scalars", _vp), ("kl_part", _vp), ("stop_flag", _vp),
         ("prior_kind", C.c_int),
         ("parent_ids", _vp), ("root", _vp), ("dw_r", _vp), ("dz_f_out", _vp),
         ("dw_r_raw", _vp), ("asu_ids", _vp), ("d_dw_r_raw", _vp), ("n_asu", C.c_int),
@@ -109,7 +109,7 @@ class AdamArgs(C.Structure):
         ("nseg", C.c_int),
         ("seg_sq", _vp), ("frozen", _vp), ("scalars", _vp), ("stop_flag", _vp), ("norm_out", _vp),
         ("n_ranges", C.c_int), ("range_begin", C.c_int * 3), ("range_end", C.c_int * 3), ("norm_skip_ranges", C.c_int),
-        ("norm_extra", _vp),
+        ("norm_extra", _vp), ("norm_part", _vp),
     ]
 
 
@@ -148,7 +148,8 @@ EXPORTS = {
     "cl_grad_sqnorm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "cl_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
     "cl_owner_qnorm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
-    "cl_step_finalize": (C.c_int, [_vp, C.c_float, _vp, C.c_int, _vp, _vp]),
+    "cl_step_finalize": (C.c_int, [_vp, C.c_float, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "cl_adam_grid": (C.c_int, [C.POINTER(AdamArgs)]),
     "cl_debug_noise": (C.c_int, [C.c_ulonglong, C.c_uint, C.c_int, C.c_longlong, C.c_longlong, C.c_int, _vp, _vp]),
 }
 

@@ -143,11 +143,14 @@ int cl_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* out, do
     return cl_launch_owner_qnorm(g, R, r_begin, r_end, out, scratch, stop_flag, (hipStream_t)stream);
 }
 
-int cl_step_finalize(const double* scalars, float kl_weight_or_one, double* history, int step_index, int* stop_flag,
-                     void* stream) {
+int cl_step_finalize(double* scalars, float kl_weight_or_one, double* history, int step_index, int* stop_flag,
+                     const double* norm_part, int n_norm_part, void* stream) {
     if (scalars == nullptr || history == nullptr || step_index < 0) return -1;
-    return cl_launch_finalize(scalars, kl_weight_or_one, history, step_index, CL_HIST_STRIDE, stop_flag, (hipStream_t)stream);
+    if (norm_part != nullptr && n_norm_part < 1) return -1;
+    return cl_launch_finalize(scalars, kl_weight_or_one, history, step_index, CL_HIST_STRIDE, stop_flag, norm_part, n_norm_part, (hipStream_t)stream);
 }
+
+int cl_adam_grid(const cl_adam_args* a) { return a == nullptr ? -1 : cl_adam_grid_of(*a); }
 
 int cl_debug_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
                    void* stream) {

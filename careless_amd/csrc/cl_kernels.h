@@ -26,8 +26,9 @@ int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, d
                           const int* stop_flag, hipStream_t st);
 int cl_launch_adam(const cl_adam_args& a, hipStream_t st);
 int cl_launch_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* out, double* scratch, const int* stop_flag, hipStream_t st);
-int cl_launch_finalize(const double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,
-                       hipStream_t st);
+int cl_launch_finalize(double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,
+                       const double* norm_part, int n_norm_part, hipStream_t st);
+int cl_adam_grid_of(const cl_adam_args& a);
 int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
                     hipStream_t st);
 int cl_launch_laue_predict(const cl_laue_args& a, hipStream_t st);

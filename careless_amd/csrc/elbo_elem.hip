@@ -80,12 +80,32 @@ __global__ __launch_bounds__(256) void tn_forward_kernel(const cl_tn_args A) {
             }
         }
     }
-    block_atomic_add_d(kl * (double)A.w_kl, A.scalars + CL_SC_KL);
+    if (A.kl_part != nullptr) {
+        // one store per workgroup; the step's cl_tn_backward adds the parts up (no atomics, fixed order)
+        __shared__ double sh[4];
+        const double w = wave_sum_d(kl * (double)A.w_kl);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) A.kl_part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    } else {
+        block_atomic_add_d(kl * (double)A.w_kl, A.scalars + CL_SC_KL);
+    }
 }
 
 __global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
     const bool part = A.r_end > A.r_begin;
+    if (A.kl_part != nullptr && blockIdx.x == 0) {
+        // the KL sums the forward launch left per workgroup (same grid): added up here, in index order
+        const int nb = gridDim.x;
+        double t = 0.0;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) t += A.kl_part[i];
+        __shared__ double sh[4];
+        const double w = wave_sum_d(t);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) A.scalars[CL_SC_KL] += (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    }
     const int h = (part ? A.r_begin : 0) + blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= (part ? A.r_end : A.R)) return;
     const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
@@ -297,25 +317,45 @@ __global__ __launch_bounds__(256) void adam_kernel(const cl_adam_args A) {
             A.p[i] = p_[u] - m * A.alpha / (sqrtf(v) + A.adam_eps);
         }
     }
-    if (A.norm_out != nullptr) {
+    if (A.norm_out != nullptr && A.norm_part != nullptr) {
+        // one store pair per workgroup; cl_step_finalize adds them up (the whole grid is resident at once: its same-address atomics
+        // would queue up at the end of the kernel)
+        __shared__ double sh[2][4];
+        const double wa = wave_sum_d(acc), ws = wave_sum_d(sane);
+        if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = wa; sh[1][threadIdx.x >> 6] = ws; }
+        __syncthreads();
+        if (threadIdx.x < 2) A.norm_part[2 * blockIdx.x + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+    } else if (A.norm_out != nullptr) {
         block_atomic_add_d(acc, A.norm_out + CL_SC_GNORM2);
         __syncthreads();
         block_atomic_add_d(sane, A.norm_out + CL_SC_GNORM2_SANE);
     }
 }
 
-// one thread: write the history record of this step and update the sticky stop flag
-__global__ void finalize_kernel(const double* scalars, float kl_weight_or_one, double* history, int step_index,
-                                int hist_stride, int* stop_flag) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one wave: add up what cl_adam_step left per workgroup (norm_part), then lane 0 writes the history record of this step and updates
+// the sticky stop flag
+__global__ void finalize_kernel(double* scalars, float kl_weight_or_one, double* history, int step_index,
+                                int hist_stride, int* stop_flag, const double* __restrict__ norm_part, int n_norm_part) {
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
     double* rec = history + (size_t)step_index * hist_stride;
     if (stop_flag != nullptr && *stop_flag != 0) {
-        rec[0] = rec[1] = rec[2] = rec[3] = 0.0;
-        rec[4] = 1.0;                      // skipped
+        if (threadIdx.x == 0) {
+            rec[0] = rec[1] = rec[2] = rec[3] = 0.0;
+            rec[4] = 1.0;                  // skipped
+        }
         return;
     }
+    double gn2 = scalars[CL_SC_GNORM2];
+    if (norm_part != nullptr) {
+        double a = 0.0, b = 0.0;
+        for (int i = threadIdx.x; i < n_norm_part; i += 64) { a += norm_part[2 * i]; b += norm_part[2 * i + 1]; }
+        a = wave_sum_d(a); b = wave_sum_d(b);
+        gn2 += a;
+        if (threadIdx.x == 0) { scalars[CL_SC_GNORM2] = gn2; scalars[CL_SC_GNORM2_SANE] += b; }
+    }
+    if (threadIdx.x != 0) return;
     const double nll = scalars[CL_SC_NLL], kl = scalars[CL_SC_KL];
-    const double gn = sqrt(scalars[CL_SC_GNORM2]);
+    const double gn = sqrt(gn2);
     rec[0] = nll + (double)kl_weight_or_one * kl;   // loss
     rec[1] = kl;                                    // "F KLDiv"
     rec[2] = nll;                                   // "NLL"
@@ -366,7 +406,7 @@ int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, d
     hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, seg_off, nseg, seg_sq, scalars, stop_flag);
     return (int)hipGetLastError();
 }
-int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
+int cl_adam_grid_of(const cl_adam_args& a) {
     if (a.n <= 0) return -1;
     int work = a.n;
     if (a.n_ranges > 0) {
@@ -374,12 +414,17 @@ int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
         for (int k = 0; k < a.n_ranges; ++k) work += a.range_end[k] - a.range_begin[k];
         if (work < 1) work = 1;
     }
-    int grid = (work + 1023) / 1024;          // four elements per thread and round (every workgroup ends in two same-address fp64 atomics: no more of them than the work needs)
-    // two same-address fp64 atomics per workgroup (fused gradient norm), ~12 ns each and serialised: few workgroups for the usual
-    // ~1e6 parameters (18.5 -> 15.6 us against 512), more when the vector is long enough for streaming to dominate (per-image
-    // layers: 4e7 parameters)
-    const int cap = (a.n >= (1 << 22)) ? 1024 : 256;
+    int grid = (work + 1023) / 1024;          // four elements per thread and round
+    // without norm_part a workgroup ends in two same-address fp64 atomics (fused gradient norm), ~12 ns each and serialised: few
+    // workgroups then for the usual ~1e6 parameters, more when the vector is long enough for streaming to dominate (per-image layers:
+    // 4e7 parameters)
+    const int cap = (a.n >= (1 << 22) || a.norm_out == nullptr || a.norm_part != nullptr) ? 1024 : 256;
     if (grid > cap) grid = cap;
+    return grid;
+}
+int cl_launch_adam(const cl_adam_args& a, hipStream_t st) {
+    const int grid = cl_adam_grid_of(a);
+    if (grid < 1) return -1;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, a);
     return (int)hipGetLastError();
@@ -392,10 +437,10 @@ int cl_launch_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* 
     hipLaunchKernelGGL(owner_qnorm_kernel, dim3(grid), dim3(256), 0, st, g, R, r_begin, r_end, out, scratch, stop_flag);
     return (int)hipGetLastError();
 }
-int cl_launch_finalize(const double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,
-                       hipStream_t st) {
+int cl_launch_finalize(double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,
+                       const double* norm_part, int n_norm_part, hipStream_t st) {
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, scalars, klw, history, step_index, hist_stride, stop_flag);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, scalars, klw, history, step_index, hist_stride, stop_flag, norm_part, n_norm_part);
     return (int)hipGetLastError();
 }
 int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,

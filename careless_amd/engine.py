@@ -691,6 +691,8 @@ class ElboEngine:
         self.msg_norm = self.ws[o_g + lay.n + 4:o_g + lay.n + 8]                # [raw, sanitised, sanitised a, sanitised b]
         self.msg = self.ws[o_g + 2 * self.R:o_g + lay.n + 8]                    # what an owner-mode step all-reduces
         self.ws_step = self.ws[o_g:]                                            # owner mode zeroes this and its own slice of dz_f per step
+        self.norm_part = torch.zeros(2 * 1024, dtype=torch.float64, device=dev)                  # per-workgroup norm sums of cl_adam_step (<= 1024 workgroups)
+        self.kl_part = torch.zeros((self.R + 255) // 256, dtype=torch.float64, device=dev)      # per-workgroup KL sums of cl_tn_forward
         self.z_f = torch.empty(RS, dtype=torch.float32, device=dev)
         self.stop_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.frozen = torch.zeros(self.nseg, dtype=torch.uint8, device=dev)
@@ -914,6 +916,7 @@ class ElboEngine:
         lib, st = self.lib, _stream()
         self._zero_step()
         tn = self._tn_args(step, u_f)
+        tn.kl_part = ptr(self.kl_part)       # the forward launch stores its workgroups' KL sums, the backward launch of this step adds them up
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
         if self.double_wilson:
             check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")
@@ -1305,9 +1308,14 @@ class ElboEngine:
             a.range_begin[2], a.range_end[2] = 2 * R, n
             a.norm_skip_ranges = 2
             a.norm_extra = None if norm_first else ptr(self.msg_norm)
+        n_part = 0
+        if not norm_first:
+            # the norm fused into the update leaves one pair of sums per workgroup; cl_step_finalize adds them up
+            a.norm_part = ptr(self.norm_part)
+            n_part = int(lib.cl_adam_grid(C.byref(a)))
         check(lib.cl_adam_step(C.byref(a), st), "cl_adam_step")
         check(lib.cl_step_finalize(ptr(self.scalars), self.kl_mult, ptr(self.history_buf), step_index,
-                                   ptr(self.stop_flag), st), "cl_step_finalize")
+                                   ptr(self.stop_flag), ptr(self.norm_part) if n_part else None, n_part, st), "cl_step_finalize")
 
     def alloc_history(self, steps: int):
         self.history_buf = torch.zeros(max(1, steps) * _lib.CL_HIST_STRIDE, dtype=torch.float64, device=self.device)

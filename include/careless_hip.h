@@ -74,6 +74,10 @@ typedef struct cl_tn_args {
     float* d_loc_raw;           /* [R] += (backward)                                                             */
     float* d_scale_raw;         /* [R] += (backward)                                                             */
     double* scalars;            /* [CL_SC_COUNT]: forward adds the weighted KL into scalars[CL_SC_KL]            */
+    double* kl_part;            /* optional [ceil(R / 256)] workspace: cl_tn_forward then STORES every workgroup's KL sum here instead of
+                                 * adding it to scalars[CL_SC_KL] (a 312 k-reflection launch is resident all at once: its 1 200 same-address
+                                 * fp64 atomics queue up at the end, 9 of the kernel's 19 us), and the cl_tn_backward of the same step adds
+                                 * them up, in index order, into scalars[CL_SC_KL]                                                       */
     const int* stop_flag;       /* optional device int: non-zero => skip (numerical failure in an earlier step)  */
     /* double-Wilson prior (careless/models/priors/wilson.py:82-175); all NULL / 0 for the plain Wilson prior        */
     int prior_kind;             /* CL_PRIOR_WILSON_ | CL_PRIOR_DOUBLE_WILSON_                                       */
@@ -304,6 +308,8 @@ typedef struct cl_adam_args {
     int norm_skip_ranges;       /* the first k ranges stay out of the norm fused into this call (norm_out) ...                     */
     const float* norm_extra;    /* ... because their squared norm over ALL ranks arrives here: [2] = raw, sanitised (cl_owner_qnorm
                                    + the all-reduce); NULL = nothing to add                                                       */
+    double* norm_part;          /* optional [2 * cl_adam_grid(args)] workspace: the workgroups' two norm sums are STORED here (raw, sanitised per
+                                   workgroup) instead of added to norm_out by same-address atomics, and cl_step_finalize adds them up     */
 } cl_adam_args;
 
 int cl_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
@@ -316,9 +322,12 @@ int cl_adam_step(const cl_adam_args* args, void* stream);
  * double in scratch[0..3] (scratch[4] is the block ticket; the caller zeroes all five per step).                               */
 int cl_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* out, double* scratch, const int* stop_flag, void* stream);
 /* history[step_index] = {loss, F KLDiv, NLL, Grad Norm, skipped}; sets *stop_flag when the norm is not finite
- * (careless/models/merging/variational.py:262-274) */
-int cl_step_finalize(const double* scalars, float kl_weight_or_one, double* history, int step_index, int* stop_flag,
-                     void* stream);
+ * (careless/models/merging/variational.py:262-274).  norm_part (optional, n_norm_part workgroups' pairs left by cl_adam_step) is added,
+ * in index order, to scalars[CL_SC_GNORM2 / _SANE] first. */
+int cl_step_finalize(double* scalars, float kl_weight_or_one, double* history, int step_index, int* stop_flag,
+                     const double* norm_part, int n_norm_part, void* stream);
+/* workgroups cl_adam_step launches for these arguments (the length / 2 of norm_part) */
+int cl_adam_grid(const cl_adam_args* args);
 
 /* --- diagnostics -------------------------------------------------------------------------------------------------- */
 const char* cl_version(void);
