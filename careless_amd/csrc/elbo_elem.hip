@@ -96,10 +96,13 @@ __global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
     const bool part = A.r_end > A.r_begin;
     if (A.kl_part != nullptr && blockIdx.x == 0) {
-        // the KL sums the forward launch left per workgroup (same grid): added up here, in index order
+        // the KL sums the forward launch(es) left per workgroup (same grid; the double-Wilson pass always covers all R): added up
+        // here, in index order
         const int nb = gridDim.x;
         double t = 0.0;
         for (int i = threadIdx.x; i < nb; i += blockDim.x) t += A.kl_part[i];
+        if (A.kl_part_dw != nullptr && A.prior_kind == CL_PRIOR_DOUBLE_WILSON_)
+            for (int i = threadIdx.x; i < (A.R + 255) / 256; i += blockDim.x) t += A.kl_part_dw[i];
         __shared__ double sh[4];
         const double w = wave_sum_d(t);
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
@@ -177,7 +180,15 @@ __global__ __launch_bounds__(256) void dw_forward_kernel(const cl_tn_args A) {
             atomicAdd(A.d_dw_r_raw + asu, gr);
         }
     }
-    block_atomic_add_d(kl * (double)A.w_kl, A.scalars + CL_SC_KL);
+    if (A.kl_part_dw != nullptr && A.kl_part != nullptr) {          // (kl_part: the step's cl_tn_backward will add the parts up)
+        __shared__ double sh[4];
+        const double w = wave_sum_d(kl * (double)A.w_kl);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) A.kl_part_dw[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    } else {
+        block_atomic_add_d(kl * (double)A.w_kl, A.scalars + CL_SC_KL);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

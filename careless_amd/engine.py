@@ -693,6 +693,7 @@ class ElboEngine:
         self.ws_step = self.ws[o_g:]                                            # owner mode zeroes this and its own slice of dz_f per step
         self.norm_part = torch.zeros(2 * 1024, dtype=torch.float64, device=dev)                  # per-workgroup norm sums of cl_adam_step (<= 1024 workgroups)
         self.kl_part = torch.zeros((self.R + 255) // 256, dtype=torch.float64, device=dev)      # per-workgroup KL sums of cl_tn_forward
+        self.kl_part_dw = torch.zeros_like(self.kl_part) if self.double_wilson else None        # ... and of cl_dw_prior_forward
         self.z_f = torch.empty(RS, dtype=torch.float32, device=dev)
         self.stop_flag = torch.zeros(1, dtype=torch.int32, device=dev)
         self.frozen = torch.zeros(self.nseg, dtype=torch.uint8, device=dev)
@@ -917,6 +918,8 @@ class ElboEngine:
         self._zero_step()
         tn = self._tn_args(step, u_f)
         tn.kl_part = ptr(self.kl_part)       # the forward launch stores its workgroups' KL sums, the backward launch of this step adds them up
+        if self.double_wilson:
+            tn.kl_part_dw = ptr(self.kl_part_dw)
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
         if self.double_wilson:
             check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")

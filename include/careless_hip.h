@@ -78,6 +78,7 @@ typedef struct cl_tn_args {
                                  * adding it to scalars[CL_SC_KL] (a 312 k-reflection launch is resident all at once: its 1 200 same-address
                                  * fp64 atomics queue up at the end, 9 of the kernel's 19 us), and the cl_tn_backward of the same step adds
                                  * them up, in index order, into scalars[CL_SC_KL]                                                       */
+    double* kl_part_dw;         /* optional [ceil(R / 256)]: the same for cl_dw_prior_forward (also summed by cl_tn_backward)               */
     const int* stop_flag;       /* optional device int: non-zero => skip (numerical failure in an earlier step)  */
     /* double-Wilson prior (careless/models/priors/wilson.py:82-175); all NULL / 0 for the plain Wilson prior        */
     int prior_kind;             /* CL_PRIOR_WILSON_ | CL_PRIOR_DOUBLE_WILSON_                                       */
