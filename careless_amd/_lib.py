@@ -34,7 +34,10 @@ class TnArgs(C.Structure):
         ("u_f", _vp),
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("z_f", _vp), ("dz_f", _vp), ("d_loc_raw", _vp), ("d_scale_raw", _vp),
-        ("scalars", _vp), ("kl_part", _vp), ("kl_part_dw", _vp), ("stop_flag", _vp),
+        ("scalars", _vp), ("kl_part", _vp), ("kl_part_dw", _vp),
+        ("zero_ptr", _vp), ("zero_n", C.c_longlong), ("zero_dzf", _vp),
+        ("red_partials", _vp), ("red_nparts", C.c_int), ("red_P", C.c_int), ("red_out", _vp),
+        ("stop_flag", _vp),
         ("prior_kind", C.c_int),
         ("parent_ids", _vp), ("root", _vp), ("dw_r", _vp), ("dz_f_out", _vp),
         ("dw_r_raw", _vp), ("asu_ids", _vp), ("d_dw_r_raw", _vp), ("n_asu", C.c_int),

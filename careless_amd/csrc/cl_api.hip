@@ -104,12 +104,16 @@ static int check_tn(const cl_tn_args* a) {
 int cl_tn_forward(const cl_tn_args* a, void* stream) {
     if (int e = check_tn(a)) return e;
     if (a->z_f == nullptr || a->scalars == nullptr) return -1;
+    if (a->zero_ptr != nullptr && (a->zero_n < 1 || (reinterpret_cast<uintptr_t>(a->zero_ptr) & 15) != 0)) return -1;
+    // the KL must not be added into a block this launch is clearing: the parts go to kl_part then
+    if (a->zero_ptr != nullptr && a->kl_part == nullptr) return -1;
     return cl_launch_tn_forward(*a, (hipStream_t)stream);
 }
 
 int cl_tn_backward(const cl_tn_args* a, void* stream) {
     if (int e = check_tn(a)) return e;
     if (a->dz_f == nullptr || a->d_loc_raw == nullptr || a->d_scale_raw == nullptr) return -1;
+    if (a->red_partials != nullptr && (a->red_out == nullptr || a->red_nparts < 1 || a->red_P < 1)) return -1;
     return cl_launch_tn_backward(*a, (hipStream_t)stream);
 }
 

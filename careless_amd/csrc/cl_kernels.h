@@ -66,6 +66,38 @@ __device__ __forceinline__ float cl_wave_sum(float v) {
     v = CL_DPP_ADD(v, 0x143, 0xC);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// out[i] += sum over the `nparts` per-workgroup partials of element i, in index order (deterministic): the work of ONE 256-thread
+// workgroup -- 32 consecutive elements x 8 chunks of the partial list; a thread sums its chunk (coalesced 128-B rows, eight rows in
+// flight: a one-at-a-time loop is a chain of dependent HBM / MALL latencies), the 8 chunk sums are combined through LDS in chunk order.
+// Shared by reduce_partials_kernel (elbo_mlp.hip) and the extra workgroups of tn_backward_kernel (elbo_elem.hip).
+__device__ __forceinline__ void cl_reduce_partials_block(const float* __restrict__ partials, int nparts, int P, float* __restrict__ out, int block) {
+    __shared__ float sh[8][33];
+    const int e = threadIdx.x & 31, c = threadIdx.x >> 5;
+    const int i = block * 32 + e;
+    const int per = (nparts + 7) / 8;
+    float s = 0.0f;
+    if (i < P) {
+        const int g1 = min(nparts, (c + 1) * per);
+        int g = c * per;
+        for (; g + 8 <= g1; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partials[(size_t)(g + k) * P + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; g < g1; ++g) s += partials[(size_t)g * P + i];
+    }
+    sh[c][e] = s;
+    __syncthreads();
+    if (c == 0 && i < P) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][e];
+        out[i] += t;
+    }
+}
+
 // Image-scale gradients of a wave whose observations belong to MORE than one image (the rows of an image end inside the wave:
 // stills with a few dozen reflections per image, or a reflection-owner shard that holds an eighth of every image's rows).  Image ids
 // are sorted, so a wave holds a few images: one wave reduction and ONE atomic per image, image by image (up to four; a wave with more
@@ -89,4 +121,5 @@ __host__ __device__ inline cl_args_p kernargs_again() { return nullptr; }
 __host__ __device__ inline float cl_quad_sum(float v) { return v; }
 __host__ __device__ inline float cl_wave_sum(float v) { return v; }
 __host__ __device__ inline void cl_image_grad_segments(float*, int, float, bool, int) {}
+__host__ __device__ inline void cl_reduce_partials_block(const float*, int, int, float*, int) {}
 #endif

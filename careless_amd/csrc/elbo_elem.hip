@@ -16,6 +16,8 @@
 
 namespace {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -62,8 +64,18 @@ __global__ __launch_bounds__(256) void tn_forward_kernel(const cl_tn_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
     const bool part = A.r_end > A.r_begin;               // an owned reflection range (reflection-owner data parallelism)
     const int h = (part ? A.r_begin : 0) + blockIdx.x * blockDim.x + threadIdx.x;
+    // the step's accumulators, cleared on the way (instead of a memset launch in front of this one): the flat gradient + scalar block
+    // by all threads, the dz_f rows of this launch's reflections by their threads
+    if (A.zero_ptr != nullptr) {
+        const long long n4 = A.zero_n >> 2;              // (16-byte aligned, a multiple of four floats: the caller's workspace layout)
+        f32x4_t* z4 = reinterpret_cast<f32x4_t*>(A.zero_ptr);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) z4[i] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        for (long long i = 4 * n4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.zero_n; i += (long long)gridDim.x * blockDim.x) A.zero_ptr[i] = 0.0f;
+    }
     double kl = 0.0;
     if (h < (part ? A.r_end : A.R)) {
+        if (A.zero_dzf != nullptr)
+            for (int s = 0; s < A.S; ++s) A.zero_dzf[(size_t)h * A.S + s] = 0.0f;
         const float a = A.q_loc_raw[h], b = A.q_scale_raw[h], low = A.low[h];
         const bool in_kl = (h >= A.kl_begin && h < A.kl_end);
         const bool dw_child = (A.prior_kind == CL_PRIOR_DOUBLE_WILSON_) && (A.root[h] == 0);
@@ -95,10 +107,15 @@ __global__ __launch_bounds__(256) void tn_forward_kernel(const cl_tn_args A) {
 __global__ __launch_bounds__(256) void tn_backward_kernel(const cl_tn_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
     const bool part = A.r_end > A.r_begin;
+    const int nb_tn = ((part ? A.r_end - A.r_begin : A.R) + 255) / 256;      // workgroups of the reflections; the rest carry the reduction
+    if ((int)blockIdx.x >= nb_tn) {
+        cl_reduce_partials_block(A.red_partials, A.red_nparts, A.red_P, A.red_out, (int)blockIdx.x - nb_tn);
+        return;
+    }
     if (A.kl_part != nullptr && blockIdx.x == 0) {
         // the KL sums the forward launch(es) left per workgroup (same grid; the double-Wilson pass always covers all R): added up
         // here, in index order
-        const int nb = gridDim.x;
+        const int nb = nb_tn;
         double t = 0.0;
         for (int i = threadIdx.x; i < nb; i += blockDim.x) t += A.kl_part[i];
         if (A.kl_part_dw != nullptr && A.prior_kind == CL_PRIOR_DOUBLE_WILSON_)
@@ -399,7 +416,8 @@ int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st) {
     if (a.R <= 0 || a.S <= 0) return -1;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     const int nr = a.r_end > a.r_begin ? a.r_end - a.r_begin : a.R;
-    hipLaunchKernelGGL(tn_backward_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, a);
+    const int nred = (a.red_partials != nullptr) ? (a.red_P + 31) / 32 : 0;
+    hipLaunchKernelGGL(tn_backward_kernel, dim3((nr + 255) / 256 + nred), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int cl_launch_dw_forward(const cl_tn_args& a, hipStream_t st) {

@@ -1305,39 +1305,12 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 // ---------------------------------------------------------------------------------------------------------
 // sum of the per-workgroup partials in a fixed order -> MLP slice of the flat gradient buffer
 // ---------------------------------------------------------------------------------------------------------
-// block = 32 consecutive elements x 8 chunks of the partial list; a thread sums its chunk (coalesced 128-B rows), the 8 chunk
-// sums are combined through LDS in chunk order => the result does not depend on scheduling
+// (the work of a workgroup is cl_reduce_partials_block, cl_kernels.h: shared with the step's cl_tn_backward launch, which can carry it)
 #if !CL_IMGL && !CL_CHAIN && !CL_DET
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partials, int nparts, int P,
                                                                float* __restrict__ out, const int* stop_flag) {
     if (stop_flag != nullptr && *stop_flag != 0) return;
-    __shared__ float sh[8][33];
-    const int e = threadIdx.x & 31, c = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + e;
-    const int per = (nparts + 7) / 8;
-    float s = 0.0f;
-    if (i < P) {
-        const int g1 = min(nparts, (c + 1) * per);
-        int g = c * per;
-        // eight rows in flight per thread (a one-at-a-time loop is a chain of dependent HBM / MALL latencies: 12.4 us for 256 partials of
-        // the 5 x 64 scaler); the additions keep the row order
-        for (; g + 8 <= g1; g += 8) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = partials[(size_t)(g + k) * P + i];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s += v[k];
-        }
-        for (; g < g1; ++g) s += partials[(size_t)g * P + i];
-    }
-    sh[c][e] = s;
-    __syncthreads();
-    if (c == 0 && i < P) {
-        float t = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][e];
-        out[i] += t;
-    }
+    cl_reduce_partials_block(partials, nparts, P, out, (int)blockIdx.x);
 }
 #endif
 

@@ -915,15 +915,23 @@ class ElboEngine:
     def forward_backward(self, step: int, u_f=None, eta=None, ipred_out=None):
         """Enqueue the loss + gradient part of a step (everything up to, not including, the optimizer)."""
         lib, st = self.lib, _stream()
-        self._zero_step()
         tn = self._tn_args(step, u_f)
         tn.kl_part = ptr(self.kl_part)       # the forward launch stores its workgroups' KL sums, the backward launch of this step adds them up
         if self.double_wilson:
             tn.kl_part_dw = ptr(self.kl_part_dw)
+        # the step's accumulators are cleared by the forward launch itself (no memset launch in front of it): the flat gradient and
+        # the scalars by all its threads, the dz_f rows of the reflections it samples by their threads
+        tn.zero_ptr, tn.zero_n, tn.zero_dzf = self.ws_step.data_ptr(), int(self.ws_step.numel()), ptr(self.dz_f)
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
         if self.double_wilson:
             check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")
-        self._data_term(self.obs, step, eta, ipred_out, st)
+        self._pending_reduce = None
+        self._data_term(self.obs, step, eta, ipred_out, st, defer_reduce=True)
+        if self._pending_reduce is not None:
+            # ... and the reduction of the fused kernel's per-workgroup scaler-gradient partials rides in extra workgroups of the
+            # backward launch (independent work: one launch instead of two)
+            tn.red_partials, tn.red_nparts, tn.red_P, tn.red_out = self._pending_reduce
+            self._pending_reduce = None
         check(lib.cl_tn_backward(C.byref(tn), st), "cl_tn_backward")
         if self.owner:
             # this rank's share of |d a|^2 + |d b|^2 into the message, next to the scaler's gradient
@@ -956,8 +964,10 @@ class ElboEngine:
         a.stop_flag = ptr(self.stop_flag)
         check(self.lib.cl_det_reduce(C.byref(a), st), "cl_det_reduce")
 
-    def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st, _piece: bool = False):
-        """NLL of `obs` into scalars[NLL] and its gradient into dz_f / the flat gradient (scaler + image scales)."""
+    def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st, _piece: bool = False, defer_reduce: bool = False):
+        """NLL of `obs` into scalars[NLL] and its gradient into dz_f / the flat gradient (scaler + image scales).  `defer_reduce`:
+        a single fused launch leaves its partial reduction to the caller (`self._pending_reduce`: forward_backward hands it to the
+        step's cl_tn_backward launch)."""
         lib, lay = self.lib, self.layout
         if getattr(obs, "empty", False):
             return
@@ -993,8 +1003,11 @@ class ElboEngine:
             if self.deterministic:
                 obs.det_parent.det["nll"][obs.det_index * obs.grid:(obs.det_index + 1) * obs.grid].zero_()
             check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
-        check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
-                                     ptr(self.stop_flag), st), "cl_reduce_partials")
+        if defer_reduce and not _piece and not self.deterministic:
+            self._pending_reduce = (ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp)
+        else:
+            check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
+                                         ptr(self.stop_flag), st), "cl_reduce_partials")
         if self.deterministic and not _piece:
             self._det_reduce(obs, st)
 

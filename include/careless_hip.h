@@ -79,6 +79,14 @@ typedef struct cl_tn_args {
                                  * fp64 atomics queue up at the end, 9 of the kernel's 19 us), and the cl_tn_backward of the same step adds
                                  * them up, in index order, into scalars[CL_SC_KL]                                                       */
     double* kl_part_dw;         /* optional [ceil(R / 256)]: the same for cl_dw_prior_forward (also summed by cl_tn_backward)               */
+    /* Fewer launches per step (each small kernel costs ~4.5 us of launch + drain, a quarter of the step of a 250 k-observation data set):
+     * cl_tn_forward can clear the step's accumulators on its way, cl_tn_backward can carry the scaler-gradient reduction.            */
+    float* zero_ptr;            /* optional: cl_tn_forward zeroes zero_ptr[0 .. zero_n) (the caller's flat gradient + scalar block) ...     */
+    long long zero_n;
+    float* zero_dzf;            /* ... and, non-NULL, the rows [R][S] of this dz_f buffer that belong to the reflections it works on        */
+    const float* red_partials;  /* optional: cl_tn_backward also runs cl_reduce_partials(red_partials, red_nparts, red_P, red_out) in extra   */
+    int red_nparts, red_P;      /*           workgroups of the same launch                                                                 */
+    float* red_out;
     const int* stop_flag;       /* optional device int: non-zero => skip (numerical failure in an earlier step)  */
     /* double-Wilson prior (careless/models/priors/wilson.py:82-175); all NULL / 0 for the plain Wilson prior        */
     int prior_kind;             /* CL_PRIOR_WILSON_ | CL_PRIOR_DOUBLE_WILSON_                                       */

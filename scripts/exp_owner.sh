@@ -11,4 +11,4 @@ for wl in mono_10M_studentt_posenc_5x64_S8 mono_10M_cli_default_20x10_S1 mono_1M
   done
 done
 CARELESS_HIP_OWNER_SHARD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_sim8 -o t -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --force-dist --sim-world 8 > $out/sim8.json 2> $out/sim8.err
-f=$(find $out/prof_sim8 -name "*kernel_stats.csv" | head -1); cut -d, -f1-4 $f | cut -c1-110 | head -14
+f=$(find $out/prof_sim8 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] || { echo "no kernel_stats.csv (the profiled command failed)"; continue 2>/dev/null || exit 1; }; cut -d, -f1-4 $f | cut -c1-110 | head -14

@@ -8,6 +8,6 @@ for spec in "mono_10M_cli_default_20x10_S1 128" "mono_10M_cli_default_20x10_S1 1
   set -- $spec
   rm -rf $out/p_$1_$2
   ${PRE:-} rocprofv3 --kernel-trace --stats --output-format csv -d $out/p_$1_$2 -o t -- python3 bench.py --workload $1 --nobs $2 --steps 50 --warmup 5 --no-cpu-baseline > $out/b.json 2> $out/b.err
-  f=$(find $out/p_$1_$2 -name "*kernel_stats.csv" | head -1)
+  f=$(find $out/p_$1_$2 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] || { echo "no kernel_stats.csv (the profiled command failed)"; continue 2>/dev/null || exit 1; }
   echo "$1 nobs=$2: $(sed -n 2,12p $f | grep -E "elbo_(lane|mlp|narrow)" | head -1 | awk -F'",' '{print $2}' | cut -d, -f1,3,5,6)  (calls, avg ns, min, max)"
 done

@@ -8,7 +8,7 @@ python3 -c "from careless_amd.build import source_hash; print(source_hash())" > 
 WLS=${WLS:-"mono_10M_studentt_posenc_5x64_S8 mono_1M_normal_5x64_S1 laue_5M_normal_5x64_S1 mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_20x10_S8 mono_10M_studentt_posenc_4x64_img1_S8 mono_2M_studentt_3x128_S4 dw_50M_normal_5x64_S1"}
 for wl in $WLS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$wl -o t -- python3 bench.py --workload $wl --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_$wl.json 2> $out/bench_$wl.err
-  f=$(find $out/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats_$wl.csv
+  f=$(find $out/prof_$wl -name "*kernel_stats.csv" | head -1); [ -n "$f" ] || { echo "no kernel_stats.csv (the profiled command failed)"; continue 2>/dev/null || exit 1; }; [ -n "$f" ] && cp $f $out/kernel_stats_$wl.csv
   rm -rf $out/prof_$wl
   python3 - $out/bench_$wl.json $out/kernel_stats_$wl.csv <<'PY'
 import sys, json, csv
