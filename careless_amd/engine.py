@@ -921,7 +921,11 @@ class ElboEngine:
             tn.kl_part_dw = ptr(self.kl_part_dw)
         # the step's accumulators are cleared by the forward launch itself (no memset launch in front of it): the flat gradient and
         # the scalars by all its threads, the dz_f rows of the reflections it samples by their threads
-        tn.zero_ptr, tn.zero_n, tn.zero_dzf = self.ws_step.data_ptr(), int(self.ws_step.numel()), ptr(self.dz_f)
+        n_own = (self.shard.kl_end - self.shard.kl_begin) if self.owner else self.R
+        if self.ws_step.numel() <= max(1 << 20, 64 * n_own * self.S):
+            tn.zero_ptr, tn.zero_n, tn.zero_dzf = self.ws_step.data_ptr(), int(self.ws_step.numel()), ptr(self.dz_f)
+        else:                                # (per-image layers over many images: a gradient vector far longer than the launch: memset)
+            self._zero_step()
         check(lib.cl_tn_forward(C.byref(tn), st), "cl_tn_forward")
         if self.double_wilson:
             check(lib.cl_dw_prior_forward(C.byref(tn), st), "cl_dw_prior_forward")
