@@ -5,13 +5,14 @@ What one step replaces in the reference: `train_step_with_gradient_norm` (carele
 = forward (`call`, :141-183), `tape.gradient`, `tf.linalg.global_norm`, non-finite sanitise, Adam.
 
 Step schedule (all on one HIP stream, no host synchronisation):
-    zero workspace -> cl_tn_forward -> cl_elbo_mono_fwd_bwd -> cl_reduce_partials -> cl_tn_backward
-    -> [all-reduce of the flat gradient, data-parallel only] -> cl_grad_sqnorm -> cl_adam_step -> cl_step_finalize
+    cl_tn_forward (clears the step's accumulators on its way) -> cl_elbo_mono_fwd_bwd -> cl_tn_backward (carries cl_reduce_partials)
+    -> [cl_owner_qnorm + all-reduce, data-parallel only: the flat gradient (row split) or its tail + 4 norm terms (reflection-owner
+    split)] -> [cl_grad_sqnorm: clip modes only] -> cl_adam_step -> cl_step_finalize
 
 HBM layout owned by the engine (see include/careless_hip.h):
-    params / m / v / grads : one flat fp32 vector  [ q_loc_raw (R) | q_scale_raw (R) | scaler W^T layout (P) | image scales (M-1) ]
-    workspace              : [ dz_f (R*S) | grads (n) | scalars (4 doubles) | per-tensor norms ]  -- one memset per step
-    observation shard      : refl_id i32, image_id i32, meta_t [d][n_pad], iobs, sig   (immutable)
+    params / m / v / grads : one flat fp32 vector  [ q_loc_raw (R) | q_scale_raw (R) | scaler W^T layout (P) | image scales (M-1) | ... ]
+    workspace              : [ dz_f (R*S) | grads (n) + message tail | scalars (4 doubles) | per-tensor norms | owner-mode scratch ]
+    observation shard      : refl_id i32, image_id i32, meta_t [d][n_pad], iobs, sig [, noise_row]   (immutable)
 PyTorch is used for device memory, streams and torch.distributed only.
 """
 from __future__ import annotations
