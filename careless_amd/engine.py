@@ -662,11 +662,15 @@ class ElboEngine:
         # its Adam update are then local to the owner (1 / world of the replicated work of the row split), and the step's all-reduce
         # carries the scaler's gradient and four norm terms instead of 2 R floats.  Laue data (a harmonic group mixes reflections),
         # the double-Wilson prior (a child's parent may live on another rank), per-image layers, wide scalers and the deterministic
-        # mode keep the row split.  `model.owner_shard = False` / CARELESS_HIP_OWNER_SHARD=0: the row split (A/B runs).
+        # mode keep the row split.  By default from four ranks on: an owner shard holds 1 / world of every image's rows, so more waves
+        # span two images -- on one device that costs the lane kernel 2.7 % at two ranks, more than the smaller message
+        # can win back there, 0.4 % at four, nothing at eight.  `model.owner_shard = True / False` or CARELESS_HIP_OWNER_SHARD=1 / 0
+        # force the choice (tests, A/B runs).
         self.owner = False
         want = getattr(model, "owner_shard", None)
         if want is None:
-            want = os.environ.get("CARELESS_HIP_OWNER_SHARD", "1") != "0"
+            env = os.environ.get("CARELESS_HIP_OWNER_SHARD", "")
+            want = (env == "1") if env in ("0", "1") else self.shard.world >= 4
         if (want and self.shard.world > 1 and not self.laue and not self.double_wilson and not self.wide and imgl is None
                 and not self.deterministic and not self.shard.owner):
             osh = owner_shard(_np(BaseModel.get_refl_id(inputs)).reshape(-1), self.R, self.shard.rank, self.shard.world)

@@ -176,10 +176,13 @@ def test_preformatted_npz_input(tmp_path):
     assert len(hist["loss"]) == 5 and read_mtz(out + "_0.mtz").spacegroup_number == 173
 
 
-def test_data_parallel_cli_two_ranks_match_one(tmp_path):
+@pytest.mark.parametrize("split", ["rows", "owners"])
+def test_data_parallel_cli_two_ranks_match_one(tmp_path, split):
     """`python -m careless_amd mono ...` as two one-process-per-GPU ranks (here: both on this GPU, gloo backend) writes the same
-    merged amplitudes and history as the single-process run: observations sharded, one gradient all-reduce per step, in-kernel
-    noise keyed by global indices, rank 0 writes the files (careless_amd/careless.py: _data_parallel)."""
+    merged amplitudes and history as the single-process run: observations sharded, one all-reduce per step, in-kernel noise keyed
+    by global indices, rank 0 writes the files (careless_amd/careless.py: _data_parallel).  Both splits: rows (what two ranks run
+    by default) and reflection owners (the default from four ranks on: every rank updates its own reflections' q(F) only, the ranks
+    exchange them after training, the validation rows follow their reflection's owner)."""
     import socket
     import subprocess
     import sys
@@ -192,7 +195,7 @@ def test_data_parallel_cli_two_ranks_match_one(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   CARELESS_DIST_BACKEND="gloo", PYTHONPATH=root)
+                   CARELESS_DIST_BACKEND="gloo", PYTHONPATH=root, CARELESS_HIP_OWNER_SHARD="1" if split == "owners" else "0")
         procs.append(subprocess.Popen([sys.executable, "-m", "careless_amd"] + flags + [PYP, two], env=env, cwd=root))
     assert [p.wait(timeout=600) for p in procs] == [0, 0]
     a, b = read_mtz(one + "_0.mtz"), read_mtz(two + "_0.mtz")

@@ -819,16 +819,16 @@ def test_freeze_flags_and_early_stop():
                                 dict(N=700, R=40, d0=5, L=2, w=96, S=2, n_images=6, image_layers=1)],
                          ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers", "cli_default_20x10",
                               "cli_default_posenc_d21_S9", "ev11", "trainable_double_wilson_r", "wide_2x96", "laue_ev11", "wide_image_layers"])
-@pytest.mark.parametrize("split", ["auto", "rows"])
+@pytest.mark.parametrize("split", ["rows", "owners"])
 def test_rank_shards_sum_to_full_batch_on_gpu(kw, split):
     """Data-parallel decomposition on ONE GPU: the engines of rank 0 and rank 1 of a 2-rank world (all-reduce skipped) produce
     partial losses / gradients that add up to the single-rank result; in-kernel noise is keyed by global indices, so the shards
-    draw exactly the numbers the full batch draws.  `auto`: the split the engine picks (reflection owners for monochromatic data
-    with the Wilson prior, rows otherwise); `rows`: the row split forced where `auto` would pick owners."""
+    draw exactly the numbers the full batch draws.  `rows`: the row split (what every configuration runs at two ranks); `owners`:
+    the reflection-owner split forced (monochromatic data with the Wilson prior: the default from four ranks on)."""
     from careless_amd.engine import ElboEngine, make_shard
     owner_eligible = not (kw.get("laue") or kw.get("double_wilson") or kw.get("image_layers") or kw["w"] > 64)
-    if split == "rows" and not owner_eligible:
-        pytest.skip("the row split is what `auto` runs for this configuration")
+    if split == "owners" and not owner_eligible:
+        pytest.skip("this configuration always runs the row split")
     data, cfg, params, x, u_f, eta = util.make_problem(**kw)
     if kw.get("laue"):                                  # rows of a harmonic group are not contiguous in real inputs
         perm = np.random.default_rng(1).permutation(kw["N"])
@@ -843,10 +843,10 @@ def test_rank_shards_sum_to_full_batch_on_gpu(kw, split):
     g_sum, nll, kl = torch.zeros_like(g_full), 0.0, 0.0
     for r in range(2):
         m = util.build_model(data, cfg, params, L, w)
-        if split == "rows":
-            m.owner_shard = False
+        if split == "owners":
+            m.owner_shard = True
         eng = ElboEngine(m, inputs, seed=99, shard=make_shard(kw["N"], kw["R"], r, 2))
-        assert eng.owner == (owner_eligible and split == "auto")
+        assert eng.owner == (split == "owners")
         eng.local_only = True
         eng.forward_backward(3)
         torch.cuda.synchronize()
@@ -1035,7 +1035,9 @@ def test_reflection_owner_shards_reproduce_the_full_batch_step(name, world):
     h_full = full.read_history(1)
     engs = []
     for r in range(world):
-        eng = ElboEngine(util.build_model(data, cfg, params, L, w), inputs, seed=99, shard=make_shard(kw["N"], R, r, world))
+        m = util.build_model(data, cfg, params, L, w)
+        m.owner_shard = True                    # (the automatic choice takes the owner split from four ranks on)
+        eng = ElboEngine(m, inputs, seed=99, shard=make_shard(kw["N"], R, r, world))
         assert eng.owner and eng.shard.owner and eng.shard.rank == r
         eng.local_only = True
         eng.alloc_history(1)
@@ -1089,7 +1091,10 @@ def test_reflection_owner_shards_with_injected_noise_match_the_oracle():
     vfull = full.evaluate_nll(full.make_obs(inputs), 77)
     gs, nll, kl, vsum = None, 0.0, 0.0, 0.0
     for r in range(3):
-        eng = ElboEngine(util.build_model(data, cfg, params, 5, 64), inputs, seed=5, shard=make_shard(kw["N"], kw["R"], r, 3))
+        m = util.build_model(data, cfg, params, 5, 64)
+        m.owner_shard = True
+        eng = ElboEngine(m, inputs, seed=5, shard=make_shard(kw["N"], kw["R"], r, 3))
+        assert eng.owner
         eng.local_only = True
         du, de = eng._noise_to_device(u_f, eta)
         eng.forward_backward(0, du, de)
@@ -1122,7 +1127,9 @@ def test_reflection_owner_shard_cut_into_several_launches(monkeypatch):
     monkeypatch.setenv("CARELESS_HIP_MAX_LAUNCH_BYTES", str(4 * ((d + 3) // 4 * 4) * 256))        # 256 rows per launch
     g_sum, nll, gs = torch.zeros_like(g_full), 0.0, None
     for r in range(2):
-        eng = ElboEngine(util.build_model(data, cfg, params, 5, 64), inputs, seed=11, shard=make_shard(kw["N"], kw["R"], r, 2))
+        m = util.build_model(data, cfg, params, 5, 64)
+        m.owner_shard = True
+        eng = ElboEngine(m, inputs, seed=11, shard=make_shard(kw["N"], kw["R"], r, 2))
         assert eng.owner and isinstance(eng.obs, ObsChunks) and len(eng.obs.children) >= 2
         eng.local_only = True
         eng.forward_backward(2)
