@@ -1145,3 +1145,55 @@ def test_reflection_owner_shard_cut_into_several_launches(monkeypatch):
     assert util.rel_err(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 2e-5
     for a, b in zip(gs, grads):
         assert util.rel_err(a.cpu().numpy(), b.numpy()) < 2e-4
+
+
+# seeded random sweep over what the reflection-owner split takes: monochromatic configurations of the engine sweep above, cut over a
+# random number of ranks (OWNER_RANDOM_N=60 OWNER_RANDOM_SEED=5 python -m pytest tests/test_gpu_parity.py -k random_owner)
+def _random_owner_cases(n, seed):
+    pool = {k: v for k, v in _random_engine_cases(6 * n + 12, seed).items() if "_mono_" in k and v["w"] <= 64 and v["R"] >= 12}
+    rng = np.random.default_rng(seed + 1)
+    out = {}
+    for k, v in list(pool.items())[:n]:
+        out[f"{k}_ranks{int(rng.integers(2, 6))}"] = v
+    return out
+
+
+RANDOM_OWNER_CASES = _random_owner_cases(int(os.environ.get("OWNER_RANDOM_N", "6")), int(os.environ.get("OWNER_RANDOM_SEED", "21")))
+
+
+@pytest.mark.parametrize("name", list(RANDOM_OWNER_CASES))
+def test_random_owner_shards_match_the_oracle(name):
+    """The ranks' loss terms and gradients of a reflection-owner split, on injected noise, add up to the fp64 oracle's (same gate as
+    every other case: 2e-4 on every tensor)."""
+    from careless_amd.engine import ElboEngine, make_shard, owner_bounds
+    kw = dict(RANDOM_OWNER_CASES[name])
+    world = int(name.rsplit("ranks", 1)[1])
+    shuffle, grid = kw.pop("shuffle_rows", False), kw.pop("grid", None)
+    L, w = kw["L"], kw["w"]
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    if shuffle:
+        perm = np.random.default_rng(2).permutation(kw["N"])
+        for k in ("refl_id", "image_id", "file_id", "metadata", "iobs", "sigiobs"):
+            data[k] = np.asarray(data[k])[perm]
+        eta = eta[:, perm]
+        x = O.inputs_from_numpy(data)
+    if owner_bounds(np.asarray(data["refl_id"]), kw["R"], world) is None:
+        pytest.skip("fewer observed reflections than ranks: the engine keeps the row split")
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64))
+    inputs = util.reference_inputs(data)
+    gs, nll, kl = None, 0.0, 0.0
+    for r in range(world):
+        m = util.build_model(data, cfg, params, L, w)
+        m.owner_shard, m.kernel_grid = True, grid
+        eng = ElboEngine(m, inputs, seed=3, shard=make_shard(kw["N"], kw["R"], r, world), grid=grid)
+        assert eng.owner
+        eng.local_only = True
+        du, de = eng._noise_to_device(u_f, eta)
+        eng.forward_backward(0, du, de)
+        torch.cuda.synchronize()
+        gt = [g.cpu().numpy().copy() for g in eng.grad_tensors()]
+        gs = gt if gs is None else [a + b for a, b in zip(gs, gt)]
+        t = eng.loss_terms()
+        nll += t["nll"]; kl += t["kl"]
+    assert abs(nll - float(out["nll"])) <= RTOL_LOSS * abs(float(out["nll"])) and abs(kl - float(out["kl"])) <= RTOL_LOSS * max(abs(float(out["kl"])), 1.0)
+    _assert_grads(gs, grads, (data, cfg, params, u_f, eta), name)
