@@ -1202,34 +1202,52 @@ class ElboEngine:
         base = flat.data_ptr() + 4 * (self.layout.off_imgl + k * M * (w * w + w))
         return base + 4 * m0 * w * w, base + 4 * (M * w * w + m0 * w)
 
-    def _wide_forward(self, obs: ObsData, chunk, keep: bool, st):
-        """Hidden layers on one row chunk of `obs`: layer l's output lands in acts[l] when `keep` (else two buffers alternate);
-        returns the (buffer, ld) pairs of h_0 .. h_(L + K)."""
+    WIDE_KEEP_BUDGET = 64 << 30     # bytes of activations of a whole observation set the forward pass may keep for the backward pass
+
+    def _wide_keep_all(self, obs: ObsData):
+        """Per-layer activation buffers over ALL rows of `obs` (list of tensors), or None when they do not fit: then the backward pass
+        recomputes each chunk's forward into the chunk-sized buffers."""
+        W = self._wide_setup()
+        need = 4 * W["nh"] * W["ldw"] * obs.N
+        have = getattr(obs, "wide_full", None)
+        if have is not None:
+            return have
+        free = torch.cuda.mem_get_info(self.device)[0]
+        if need > min(self.WIDE_KEEP_BUDGET, free // 4):
+            return None
+        obs.wide_full = [torch.zeros(obs.N * W["ldw"], dtype=torch.float32, device=self.device) for _ in range(W["nh"])]
+        return obs.wide_full
+
+    def _wide_forward(self, obs: ObsData, chunk, keep: bool, st, full=None):
+        """Hidden layers on one row chunk of `obs`: layer l's output lands in acts[l] when `keep` (else two buffers alternate), or
+        in the chunk's rows of the whole-set buffers `full`; returns the (buffer, ld) pairs of h_0 .. h_(L + K)."""
         a, b, m0, seg = chunk
         lib, W = self.lib, self._wide_setup()
         n, ldw, base = b - a, W["ldw"], self.params.data_ptr() + 4 * self.layout.off_mlp
         layers, _ = self._wide_layers()
         sf, leak = ptr(self.stop_flag), self.mlp.leakiness
+        dst_of = (lambda l: full[l].data_ptr() + 4 * a * ldw) if full is not None else (lambda l: W["acts"][l if keep else l & 1].data_ptr())
         hs = [(obs.meta_rm.data_ptr() + 4 * a * obs.meta_ld, obs.meta_ld)]
         for l, (ow, ob, fan_in) in enumerate(layers):
-            dst = W["acts"][l if keep else l & 1]
+            dst = dst_of(l)
             check(lib.cl_wide_dense_forward(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, 1,
-                                            ptr(dst), ldw, sf, st), "cl_wide_dense_forward")
-            hs.append((dst.data_ptr(), ldw))
+                                            dst, ldw, sf, st), "cl_wide_dense_forward")
+            hs.append((dst, ldw))
         for k in range(self.imgl.n_image_layers if self.imgl is not None else 0):       # image.py:116-125
             l = self.L + k
-            dst = W["acts"][l if keep else l & 1]
+            dst = dst_of(l)
             wk, bk = self._imgl_ptrs(self.params, k, m0)
-            check(lib.cl_wide_image_forward(hs[-1][0], hs[-1][1], wk, bk, ptr(seg), seg.numel() - 1, n, self.w, leak, ptr(dst), ldw, sf, st),
+            check(lib.cl_wide_image_forward(hs[-1][0], hs[-1][1], wk, bk, ptr(seg), seg.numel() - 1, n, self.w, leak, dst, ldw, sf, st),
                   "cl_wide_image_forward")
-            hs.append((dst.data_ptr(), ldw))
+            hs.append((dst, ldw))
         return hs
 
     def _data_term_wide(self, obs: ObsData, step: int, eta, ipred_out, st):
         """Hidden / metadata width > 64 (or more hidden layers with per-image layers than one fused launch holds): unfused scaler on
         the GEMM kernels of csrc/wide_gemm.hip.  Forward (row chunks) -> (loc, sigma) per row -> the HIP slot likelihood kernels (mono
-        rows are their own groups) -> dL/d(loc, sigma) -> per chunk: forward again (activations kept), head backward, then weight
-        gradient and dgrad layer by layer, top down.  8 P_mm flops per observation; every product in exact fp32."""
+        rows are their own groups) -> dL/d(loc, sigma) -> per chunk: forward again unless the one chunk's activations were kept, head
+        backward, then weight gradient and dgrad layer by layer, top down.  6 (one chunk) or 8 P_mm flops per observation; every
+        product in exact fp32."""
         lib, lay, W = self.lib, self.layout, self._wide_setup()
         chunks = self._wide_chunks(obs)
         ma = self._mlp_args(step, eta, ipred_out, obs)
@@ -1238,16 +1256,23 @@ class ElboEngine:
         gbase = self.grads.data_ptr() + 4 * lay.off_mlp
         sf, leak, w, ldw = ptr(self.stop_flag), self.mlp.leakiness, self.w, W["ldw"]
         K = self.imgl.n_image_layers if self.imgl is not None else 0
+        # The activations of ALL rows are kept by the forward pass when they fit (WIDE_KEEP_BUDGET, a quarter of the free memory at
+        # most: 15 GB for 10 M rows of a 3 x 128 scaler on a 288-GB device) and the backward pass starts from them -- 6 P_mm flops per
+        # observation.  Otherwise the buffers hold one chunk at a time and each chunk's forward is recomputed when its turn in the
+        # backward pass comes (8 P_mm).
+        full = self._wide_keep_all(obs)
+        kept = []
         for ch in chunks:
             a, b = ch[0], ch[1]
-            hs = self._wide_forward(obs, ch, False, st)
+            hs = self._wide_forward(obs, ch, True, st, full=full) if full is not None else self._wide_forward(obs, ch, False, st)
+            kept.append(hs)
             check(lib.cl_wide_head_forward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, b - a, w, self.bij_kind, self.mlp.epsilon,
                                            obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a, sf, st), "cl_wide_head_forward")
         self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
-        for ch in chunks:
+        for ic, ch in enumerate(chunks):
             a, b, m0, seg = ch
             n = b - a
-            hs = self._wide_forward(obs, ch, True, st)
+            hs = kept[ic] if full is not None else self._wide_forward(obs, ch, True, st)
             dz, dzn = W["dz"]
             nblk = min(W["nblk"], int(lib.cl_wide_head_blocks(n)))
             check(lib.cl_wide_head_backward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, obs.laue_dO.data_ptr() + 8 * a, n, w, self.bij_kind,
