@@ -204,8 +204,9 @@ def check(code: int, what: str) -> None:
             f"{what}: scaler geometry not supported by the fused gfx950 kernel "
             "(needs mlp_width <= 64, metadata width <= 64 and mlp_layers <= 20 / 10 / 5 for width <= 15 / 32 / 64)")
     if code == -4:
-        raise ValueError(f"{what}: observation shard too large for one launch (metadata image or z_f >= 4 GiB): "
-                         "shard the observations over more GPUs")
+        raise ValueError(f"{what}: one launch addresses < 4 GiB of metadata, z_f and per-(row, sample) arrays (32-bit lane offsets); the "
+                         "engine cuts plain-layout shards into several launches (engine.ObsChunks) -- a packed layout (Laue, per-image "
+                         "layers) or R x S amplitudes past the bound need more ranks")
     if code < 0:
         raise ValueError(f"{what}: invalid argument (code {code})")
     raise CarelessHipError(f"{what}: HIP error {code}")

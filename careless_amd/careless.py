@@ -51,7 +51,9 @@ def _data_parallel():
     import torch.distributed as dist
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    global _CREATED_GROUP
     if not dist.is_initialized():
+        _CREATED_GROUP = True                   # (an embedding caller's own process group is left alone at the end)
         backend = os.environ.get("CARELESS_DIST_BACKEND", "nccl")        # nccl = RCCL on ROCm; gloo rehearses on a single GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29534")
@@ -62,15 +64,35 @@ def _data_parallel():
     return rank, world
 
 
+_CREATED_GROUP = False
+
+
+def _all_ranks_ok(ok: bool, world: int) -> bool:
+    """Rank 0's output step has no collective of its own: all ranks learn whether it went through (one MIN all-reduce of a flag, as
+    bench.py's `agree`), so a failed write ends every rank with an error instead of leaving the others in a barrier until the RCCL
+    watchdog fires."""
+    if world <= 1:
+        return ok
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
 def _leave_data_parallel(world: int) -> None:
-    """End of a one-process-per-GPU run: wait for rank 0's output step, then tear the process group down (RCCL otherwise warns --
-    or hangs -- at interpreter exit)."""
+    """End of a one-process-per-GPU run: tear down the process group this module created (RCCL otherwise warns -- or hangs -- at
+    interpreter exit); a group the embedding caller had initialised is the caller's to destroy."""
+    global _CREATED_GROUP
     if world <= 1:
         return
     import torch.distributed as dist
     if dist.is_initialized():
         dist.barrier()
-        dist.destroy_process_group()
+        if _CREATED_GROUP:
+            dist.destroy_process_group()
+            _CREATED_GROUP = False
 
 
 def run_careless(parser):
@@ -105,7 +127,7 @@ def run_careless(parser):
     asus = list(rac)
     # The output step has no collective and the parameters are identical on every rank: rank 0 alone computes and writes it (the
     # other ranks skip the result tables and the full-size prediction pass instead of computing them for no-op writers)
-    if rank == 0:
+    def output_step():
         for i, table in enumerate(results_tables(dm.get_results(model.surrogate_posterior, inputs=train), rac)):
             write_table_mtz(parser.output_base + f"_{i}.mtz", table, asus[i])
         write_history_csv(parser.output_base + "_history.csv", history)
@@ -121,6 +143,18 @@ def run_careless(parser):
             tables = [{k: np.concatenate([a[k], b[k]]) for k in a} for a, b in zip(tables, _prediction_tables(dm, model, test, 1))]
         for i, table in enumerate(tables):
             write_table_mtz(parser.output_base + f"_predictions_{i}.mtz", table, asus[i], PREDICTION_TYPES)
+
+    out_err = None
+    if rank == 0:
+        try:
+            output_step()
+        except Exception as e:                                  # noqa: BLE001  (reported on every rank below)
+            out_err = e
+    if not _all_ranks_ok(out_err is None, world):
+        _leave_data_parallel(world)
+        if out_err is not None:
+            raise out_err
+        raise RuntimeError("careless_amd: rank 0 failed in the output step (see its traceback); nothing was left waiting")
 
     if parser.merge_half_datasets:
         scaling_model = model.scaling_model

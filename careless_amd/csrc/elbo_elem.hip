@@ -261,11 +261,11 @@ __global__ __launch_bounds__(256) void owner_qnorm_kernel(const float* __restric
     block_atomic_add_d(sb, scratch + 3);
     __shared__ unsigned last;
     if (threadIdx.x == 0) {
-        // the block's atomics are acknowledged (performed at the memory side) before it takes its ticket.  Not __threadfence(): a
-        // device-scope release on this multi-XCD part writes the L2's dirty lines back (measured on the same pattern in tn_forward:
-        // 20 -> 30 us)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last = atomicAdd(reinterpret_cast<unsigned*>(scratch + 4), 1u);
+        // release / acquire at agent scope on the ticket: the block's three sums are visible to whoever draws the last ticket (on a
+        // multi-XCD part relaxed ordering guarantees nothing across L2s).  At most 64 workgroups take a ticket, so the L2 write-back
+        // the release implies costs microseconds at worst (the same fence per workgroup of a 1 221-workgroup launch: tn_forward
+        // 20 -> 30 us, which is why the big launches store per-workgroup parts instead)
+        last = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(scratch + 4), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (last == gridDim.x - 1 && threadIdx.x == 0) {

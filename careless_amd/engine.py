@@ -512,12 +512,15 @@ class _EmptyObs:
         self.N, self.N_total, self.rows, self.empty = 0, n_total, np.zeros(0, dtype=np.int64), True
 
 
-def launch_row_limit(d: int) -> int:
+def launch_row_limit(d: int, S: int = 0) -> int:
     """Most rows of the plain layout one launch takes: 4 * cl_mlp_meta_rows(d) * n_pad bytes of metadata must stay below 4 GiB
-    (include/careless_hip.h: return code -4).  CARELESS_HIP_MAX_LAUNCH_BYTES lowers the bound (tests of the chunked path)."""
+    (include/careless_hip.h: return code -4), and -- `S` given: launches that address per-(row, sample) arrays with 32-bit lane
+    offsets (the deterministic mode's dzf_obs) -- 4 * S * n_pad bytes as well.  CARELESS_HIP_MAX_LAUNCH_BYTES lowers the bound
+    (tests of the chunked path)."""
     import os
     lim = int(os.environ.get("CARELESS_HIP_MAX_LAUNCH_BYTES", str((1 << 32) - (1 << 24))))
-    return max(TILE, lim // (4 * ((d + 3) // 4 * 4)) // TILE * TILE)
+    per_row = 4 * max((d + 3) // 4 * 4, int(S))
+    return max(TILE, lim // per_row // TILE * TILE)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -714,7 +717,7 @@ class ElboEngine:
                   laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None and not self.wide, wide=self.wide)
         n_total = int(_np(BaseModel.get_refl_id(inputs)).reshape(-1).shape[0])
         stop = n_total if stop is None else stop
-        per = launch_row_limit(self.d)
+        per = launch_row_limit(self.d, self.S if self.deterministic else 0)
         if rows is not None:
             start, stop = 0, len(rows)
         if self.laue or self.imgl is not None or self.wide or stop - start <= per:
@@ -1009,8 +1012,8 @@ class ElboEngine:
         elif self.laue:
             self._laue_passes(ma, obs, step, eta, ipred_out, st)
         else:
-            if self.deterministic:
-                obs.det_parent.det["nll"][obs.det_index * obs.grid:(obs.det_index + 1) * obs.grid].zero_()
+            # (deterministic mode: every workgroup of the launch STORES its NLL slot, det["grid"] slots per piece -- nothing to clear;
+            #  the slots a short last piece leaves unwritten were zero-initialised and are never touched)
             check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
         if defer_reduce and not _piece and not self.deterministic:
             self._pending_reduce = (ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp)
@@ -1340,8 +1343,11 @@ class ElboEngine:
         a.n = n
         a.alpha = opt.learning_rate * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
         a.beta1, a.beta2, a.adam_eps = opt.beta_1, opt.beta_2, opt.epsilon
-        a.clipnorm, a.clipvalue = clipnorm, float(opt.clipvalue or 0.0)
-        a.global_clipnorm = float(opt.global_clipnorm or 0.0)
+        # tf_keras applies the FIRST active clip mode only -- clipnorm, else global_clipnorm, else clipvalue
+        # (`_BaseOptimizer._clip_gradients` [3P-recall]; oracle.clip_grads): the kernel sees one mode
+        a.global_clipnorm = 0.0 if clipnorm > 0.0 else float(opt.global_clipnorm or 0.0)
+        a.clipnorm = clipnorm
+        a.clipvalue = 0.0 if (clipnorm > 0.0 or a.global_clipnorm > 0.0) else float(opt.clipvalue or 0.0)
         a.seg_off, a.nseg = ptr(self.seg_off), self.nseg
         a.seg_sq = ptr(self.seg_sq)
         a.frozen = ptr(self.frozen) if self.any_frozen else None

@@ -513,20 +513,25 @@ def global_norm(grads: Sequence[torch.Tensor]) -> torch.Tensor:
 
 
 def clip_grads(grads: List[torch.Tensor], cfg: ElboConfig) -> List[torch.Tensor]:
-    """tf_keras optimizer gradient clipping [3P]: clipnorm = per-tensor tf.clip_by_norm, clipvalue = clip_by_value,
-    global_clipnorm = tf.clip_by_global_norm (manager.py:498-500)."""
-    if cfg.clipnorm is not None:
+    """tf_keras optimizer gradient clipping (manager.py:498-500 hands all three to `tfk.optimizers.Adam`) [3P-recall]:
+    `_BaseOptimizer._clip_gradients` applies the FIRST active mode and returns -- clipnorm (per-tensor `tf.clip_by_norm`), else
+    global_clipnorm (`tf.clip_by_global_norm`), else clipvalue (`tf.clip_by_value`); the constructor refuses clipnorm together with
+    global_clipnorm.  So `--clipnorm X --clipvalue Y` clips by norm only.  (Rounds 1-3 applied the modes cumulatively; the
+    two-flag case of scripts/replay_golden_in_reference.py settles it on the first machine with TensorFlow.)"""
+    if cfg.clipnorm is not None and cfg.global_clipnorm is not None:
+        raise ValueError("At most one of `clipnorm` and `global_clipnorm` can be set")
+    if cfg.clipnorm is not None and cfg.clipnorm > 0:
         out = []
         for g in grads:
             n = torch.sqrt((g * g).sum())
             out.append(torch.where(n > cfg.clipnorm, g * (cfg.clipnorm / n), g))
-        grads = out
-    if cfg.global_clipnorm is not None:
+        return out
+    if cfg.global_clipnorm is not None and cfg.global_clipnorm > 0:
         n = global_norm(grads)
         sc = cfg.global_clipnorm / torch.maximum(n, torch.as_tensor(cfg.global_clipnorm, dtype=n.dtype))
-        grads = [g * sc for g in grads]
-    if cfg.clipvalue is not None:
-        grads = [torch.clamp(g, -cfg.clipvalue, cfg.clipvalue) for g in grads]
+        return [g * sc for g in grads]
+    if cfg.clipvalue is not None and cfg.clipvalue > 0:
+        return [torch.clamp(g, -cfg.clipvalue, cfg.clipvalue) for g in grads]
     return grads
 
 

@@ -25,6 +25,14 @@ What it does per case (tests/golden/cases.json holds the problem sizes, the .npz
   * compares  loss / NLL / KL  (model.losses, metrics),  every gradient tensor (tf.GradientTape over model.trainable_variables,
     matched to `grad_XX` by the oracle's tensor order),  and  6 x `train_step_with_gradient_norm` on `traj_u` / `traj_eta`
     against `traj_loss`, `traj_gnorm` and the final parameters `final_XX`.
+Two cases exist to make the first TensorFlow run decisive on the two [3P-recall] items the oracle carries: `mono_2x16_clipnorm_and_
+clipvalue_S2` (both clip flags: tf_keras applies the first active mode only -- the trajectory differs from a cumulative clip in the
+first step) and `mono_2x16_extreme_uniforms_S4` (injected uniforms at 1 - 2^-24 and 1e-30, where the [tiny, 1 - eps] clip of TFP's
+sample gradient is active; with loc = exp(a) > 0 >= low the truncation point cannot sit in the upper tail, so the ends of u are the
+only way to reach the clip).  NOTE for the second one: patch 1 below differentiates the inverse CDF exactly and does NOT reproduce
+TFP's clip; its `grad_00 / grad_01` rows therefore show the clip's effect as a mismatch there if and only if the oracle's
+recollection of the clip is right -- compare those two rows with `--no-tn-patch`, which leaves TFP's own sampler gradient in place
+and checks d z / d(loc, scale) on TFP's own draws against the oracle's formula evaluated at the same draws.
 Exit code 0 = every compared number within --rtol (default 1e-4, the north_star tolerance); the PASS / FAIL table it ends with is the
 evidence.
 The double-Wilson case: the reference builds `DoubleWilsonPrior` from gemmi-backed `ReciprocalASUCollection` objects
@@ -49,10 +57,44 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-30))
 
 
+def tn_gradient_check(tf, tfd, cases, names, rtol):
+    """TFP's own sampler, TFP's own implicit gradient: sum_s dz/dloc and sum_s dz/dscale per reflection against the formula the
+    oracle and the HIP kernels use (oracle._TNStdSample.backward): cdf = clip((Phi(e) - Phi(alpha)) / Z, tiny, 1 - eps),
+    dl = exp((e^2 - alpha^2) / 2 + log1p(-cdf)), du = exp((e^2 - beta^2) / 2 + log cdf), dz/dloc = 1 - dl - du,
+    dz/dscale = e - alpha dl - beta du -- evaluated in float64 at the draws TFP made.  The draws themselves are TF's (no injected
+    noise), so extreme cdf values occur with their natural probability only: run it with many samples."""
+    from scipy.special import ndtr
+    worst = 0.0
+    for name in names:
+        z = np.load(os.path.join(GOLD, name + ".npz"))
+        a, b = z["param_00"].astype(np.float32), z["param_01"].astype(np.float32)
+        centric = np.asarray(z["centric"], bool)
+        low = (1e-32 * ~centric).astype("float32")
+        loc, scale = tf.Variable(np.exp(a)), tf.Variable(np.exp(b) + np.float32(1e-7))
+        with tf.GradientTape() as tape:
+            zs = tfd.TruncatedNormal(loc, scale, low, 1e10).sample(4096, seed=1)
+            tot = tf.reduce_sum(zs)
+        gl, gs = [g.numpy().astype(np.float64) for g in tape.gradient(tot, [loc, scale])]
+        L, Sc, zs = loc.numpy().astype(np.float64), scale.numpy().astype(np.float64), zs.numpy().astype(np.float64)
+        e, al, be = (zs - L) / Sc, (low - L) / Sc, (1e10 - L) / Sc
+        Z = ndtr(be) - ndtr(al)
+        cdf = np.clip((ndtr(e) - ndtr(al)) / Z, np.finfo(np.float32).tiny, 1.0 - np.finfo(np.float32).eps)
+        dl = np.exp(0.5 * (e * e - al * al) + np.log1p(-cdf))
+        du = np.exp(0.5 * (e * e - be * be) + np.log(cdf))
+        want_l, want_s = (1.0 - dl - du).sum(0), (e - al * dl - be * du).sum(0)
+        el, es = rel(gl, want_l), rel(gs, want_s)
+        worst = max(worst, el, es)
+        print(f"{name:44s} sum_s dz/dloc {el:.2e}   sum_s dz/dscale {es:.2e}")
+    print(f"worst: {worst:.3e} (tolerance {rtol:g}) -> {'PASS' if worst <= rtol else 'FAIL'}")
+    return 0 if worst <= rtol else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", nargs="*", default=None)
     ap.add_argument("--rtol", type=float, default=1e-4)
+    ap.add_argument("--no-tn-patch", action="store_true", help="leave TFP's truncated-normal sampler (and its implicit sample gradient) "
+                    "in place and check d z / d(loc, scale) of TFP's own draws against the oracle's closed form, clip included")
     args = ap.parse_args()
 
     import tensorflow as tf
@@ -91,6 +133,8 @@ def main():
 
     cases = json.load(open(os.path.join(GOLD, "cases.json")))
     names = args.cases or list(cases)
+    if args.no_tn_patch:
+        return tn_gradient_check(tf, tfd, cases, names, args.rtol)
     worst, table = 0.0, []
     for name in names:
         kw = cases[name]
@@ -148,7 +192,10 @@ def main():
             mlp = MLPScaler(L, w, epsilon=eps, scale_bijector=bij, scale_multiplier=shift)
             scaler = HybridImageScaler(mlp, ImageScaler(n_images)) if use_img else mlp
         model = VariationalMergingModel(q, prior, lik, scaler, S, kl_weight=kw.get("kl_weight"))
-        model.compile(tfk.optimizers.Adam(1e-3, 0.9, 0.99), run_eagerly=True)
+        # (clip flags as DataManager.build_model passes them, io/manager.py:494-501: the two-flag case pins the precedence of
+        #  tf_keras' `_clip_gradients` -- first active mode only -- that oracle.clip_grads restates from memory)
+        model.compile(tfk.optimizers.Adam(1e-3, 0.9, 0.99, clipnorm=kw.get("clipnorm"), clipvalue=kw.get("clipvalue"),
+                                          global_clipnorm=kw.get("global_clipnorm")), run_eagerly=True)
 
         noise["u"], noise["eta"] = z["u_f"], z["eta"]
         model(inputs)                                        # builds every variable

@@ -26,13 +26,29 @@ FROZEN = ("mono_2x32_normal_S3", "mono_5x64_studentt_posenc_S8", "mono_3x20_soft
 STEPS = 6
 
 
+def extreme_uniforms(u_f):
+    """A few injected uniforms at the ends of (0, 1): the largest float32 below one (cdf > 1 - eps_f32) and 1e-30, so that the
+    [tiny, 1 - eps] clip of TFP's truncated-normal sample gradient (oracle._TNStdSample, [3P-recall]) is ACTIVE in the case -- with
+    loc = exp(a) > 0 >= low the truncation point never lies in the upper tail, so the ends of u are the only way to reach the clip."""
+    u = np.array(u_f, dtype=np.float32)
+    u[0, ::5] = np.nextafter(np.float32(1.0), np.float32(0.0))
+    u[-1, 1::5] = np.float32(1e-30)
+    return u
+
+
 def make(name, kw):
+    kw = dict(kw)
+    extreme = kw.pop("extreme_u", False)
     data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    if extreme:
+        u_f = extreme_uniforms(u_f)
     out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64),
                                         torch.as_tensor(eta, dtype=torch.float64))
     rng = np.random.default_rng(99)
     S, R, N = kw["S"], kw["R"], kw["N"]
     noises_u = rng.random((STEPS, S, R)).astype(np.float32)
+    if extreme:
+        noises_u = np.stack([extreme_uniforms(u) for u in noises_u])
     noises_e = rng.normal(size=(STEPS, S, N)).astype(np.float32)
     p = params.clone()
     st = O.AdamState.zeros_like(p.tensors())

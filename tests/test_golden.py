@@ -30,7 +30,8 @@ def load_case(path):
                        scale_bijector=kw.get("bijector", "exp"), scale_shift=kw.get("shift", 0.0),
                        use_image_scales=kw.get("use_image_scales", True) and image_layers == 0, kl_weight=kw.get("kl_weight"),
                        prior="double_wilson" if kw.get("double_wilson") else "wilson", laue=kw.get("laue", False),
-                       ev11=kw.get("ev11", False), optimize_dw_r=kw.get("optimize_dw_r", False), image_layers=image_layers)
+                       ev11=kw.get("ev11", False), optimize_dw_r=kw.get("optimize_dw_r", False), image_layers=image_layers,
+                       clipnorm=kw.get("clipnorm"), clipvalue=kw.get("clipvalue"), global_clipnorm=kw.get("global_clipnorm"))
     n_t = len([k for k in z.files if k.startswith("param_")])
     ts = [torch.as_tensor(z[f"param_{i:02d}"].astype(np.float64)) for i in range(n_t)]
     n_layers = kw["L"] + 1

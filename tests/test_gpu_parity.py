@@ -106,7 +106,7 @@ CASES = {
     "deep_11x32_noimg": dict(N=400, R=40, d0=5, L=11, w=32, S=3, use_image_scales=False),
     "deep_laue_7x64": dict(N=500, R=50, L=7, w=64, S=2, laue=True, two_pass=True),
     "deep_double_wilson_6x64": dict(N=400, R=60, d0=5, L=6, w=64, S=2, double_wilson=True),
-    # hidden / metadata width beyond 64: unfused scaler on library GEMMs around the same HIP likelihood kernels
+    # hidden / metadata width beyond 64: unfused scaler on the engine's own fp32-MFMA GEMM kernels (csrc/wide_gemm.hip) around the same HIP likelihood kernels
     "wide_3x96_studentt_S3": dict(N=700, R=50, d0=5, L=3, w=96, S=3, likelihood="studentt", dof=6.0),
     "wide_2x128_softplus_noimg": dict(N=400, R=40, d0=5, L=2, w=128, S=2, bijector="softplus", shift=1.5, use_image_scales=False),
     "wide_metadata_d70_2x32": dict(N=300, R=30, d0=70, L=2, w=32, S=2),
@@ -312,7 +312,7 @@ def test_random_shapes_on_the_lane_kernel(name):
 
 def _random_engine_cases(n=12, seed=11):
     """Seeded random draws over everything the engine routes: widths 1 .. 100 (lane / narrow / 32- and 64-wide fused instances,
-    chains of launches for deep scalers, library GEMMs beyond width 64), depths 1 .. 24, 1 .. 40 metadata columns, 1 .. 12 MC samples,
+    chains of launches for deep scalers, the own GEMM kernels of csrc/wide_gemm.hip beyond width 64), depths 1 .. 24, 1 .. 40 metadata columns, 1 .. 12 MC samples,
     mono / Laue / double-Wilson / per-image layers, every likelihood, bijector and reduction switch."""
     rng = np.random.default_rng(seed)
     cases = {}
@@ -756,7 +756,8 @@ def test_full_size_laue_single_pass_equals_two_pass():
         assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6), (lo, hi)
 
 
-@pytest.mark.parametrize("clip", [dict(clipnorm=0.5), dict(clipvalue=0.01), dict(global_clipnorm=1.0)])
+@pytest.mark.parametrize("clip", [dict(clipnorm=0.5), dict(clipvalue=0.01), dict(global_clipnorm=1.0), dict(clipnorm=0.5, clipvalue=0.01),
+                                  dict(global_clipnorm=1.0, clipvalue=0.01)])
 def test_clipping_modes_match_oracle(clip):
     """tfk.optimizers.Adam(clipnorm= / clipvalue= / global_clipnorm=) (reference io/manager.py:494-501, tests/test_cli.py:196-208)"""
     kw = dict(N=300, R=40, d0=5, L=2, w=32, S=2, **clip)

@@ -190,6 +190,13 @@ def test_adam_first_step_and_clipping():
     assert torch.allclose(c[0], T([3.0, 4.0]) / n) and torch.allclose(c[1], T([0.3]) / n)
     c = O.clip_grads(gs, O.ElboConfig(clipvalue=0.5))
     assert torch.allclose(c[0], T([0.5, 0.5])) and torch.allclose(c[1], T([0.3]))
+    # tf_keras `_clip_gradients` returns after the first active mode: with two flags the value clip never runs [3P-recall]
+    c = O.clip_grads(gs, O.ElboConfig(clipnorm=1.0, clipvalue=0.5))
+    assert torch.allclose(c[0], T([0.6, 0.8])) and torch.allclose(c[1], T([0.3]))
+    c = O.clip_grads(gs, O.ElboConfig(global_clipnorm=1.0, clipvalue=0.1))
+    assert torch.allclose(c[0], T([3.0, 4.0]) / n)
+    with pytest.raises(ValueError):
+        O.clip_grads(gs, O.ElboConfig(clipnorm=1.0, global_clipnorm=1.0))
 
 
 def test_adam_trajectory_vs_an_independent_implementation():
