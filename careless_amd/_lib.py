@@ -18,6 +18,7 @@ CL_SC_NLL, CL_SC_KL, CL_SC_GNORM2, CL_SC_GNORM2_SANE, CL_SC_COUNT = 0, 1, 2, 3, 
 CL_LIK_NORMAL, CL_LIK_STUDENTT = 0, 1
 CL_BIJ_EXP, CL_BIJ_SOFTPLUS = 0, 1
 CL_PRIOR_WILSON, CL_PRIOR_DOUBLE_WILSON = 0, 1
+CL_LAUE_LIK_MAX_BLOCKS = 2048
 
 _vp = C.c_void_p
 
@@ -96,7 +97,7 @@ class LaueArgs(C.Structure):
         ("eta", _vp),
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("iconv", _vp), ("dz_f", _vp), ("d_img", _vp), ("dO", _vp), ("scalars", _vp), ("ipred_out", _vp), ("stop_flag", _vp),
-        ("ev11", _vp), ("d_ev11", _vp), ("row_index", _vp),
+        ("ev11", _vp), ("d_ev11", _vp), ("row_index", _vp), ("nll_part", _vp),
     ]
 
 

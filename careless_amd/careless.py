@@ -18,6 +18,45 @@ def _format(parser):
     return fmt.format_files(files)
 
 
+def _format_once_per_node(parser, rank: int, world: int):
+    """Data-parallel launch: rank 0 alone reads and formats the reflection files (MTZ parsing, ASU mapping, metadata standardisation:
+    host work of the order of the file size) and leaves the formatted arrays as `.npy` files in /dev/shm; after a flag all-reduce
+    (so that a formatting error ends every rank instead of leaving them in a barrier) the ranks map the files read-only -- the node
+    holds ONE copy of the inputs, the engine of a rank copies only its shard's rows (engine.ObsData) -- and rank 0 removes them (the
+    maps keep the pages alive).  The ASU collection (small) travels as a pickle.  One node is what the launch supports (bench.py uses
+    the same scheme for its synthetic problems)."""
+    if world <= 1:
+        return _format(parser)
+    import os
+    import pickle
+    import shutil
+    import torch.distributed as dist
+    path = f"/dev/shm/careless_amd_{os.environ.get('MASTER_ADDR', 'local')}_{os.environ.get('MASTER_PORT', '0')}"
+    err = None
+    if rank == 0:
+        try:
+            shutil.rmtree(path, ignore_errors=True)
+            os.makedirs(path)
+            inputs, rac = _format(parser)
+            for i, a in enumerate(inputs):
+                np.save(os.path.join(path, f"input_{i:02d}.npy"), np.ascontiguousarray(a))
+            with open(os.path.join(path, "rac.pickle"), "wb") as f:
+                pickle.dump((len(inputs), rac), f)
+        except Exception as e:                                  # noqa: BLE001  (every rank raises below)
+            err = e
+    if not _all_ranks_ok(err is None, world):
+        if rank == 0:
+            shutil.rmtree(path, ignore_errors=True)
+        raise err if err is not None else RuntimeError("careless_amd: rank 0 could not format the reflection files (see its traceback)")
+    with open(os.path.join(path, "rac.pickle"), "rb") as f:
+        n, rac = pickle.load(f)
+    inputs = tuple(np.load(os.path.join(path, f"input_{i:02d}.npy"), mmap_mode="r") for i in range(n))
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(path, ignore_errors=True)
+    return inputs, rac
+
+
 def _prediction_tables(dm, model, inputs, test_value):
     """Per-ASU prediction tables (reference manager.py:89-161): one row per observation (per harmonic group for Laue data)."""
     from careless_amd.models.base import BaseModel
@@ -42,7 +81,8 @@ def _data_parallel():
     """(rank, world) of a one-process-per-GPU launch (`python -m torch.distributed.run --nproc-per-node N -m careless_amd mono ...`):
     RANK / LOCAL_RANK / WORLD_SIZE in the environment select the data-parallel engine -- observations sharded over the ranks,
     one all-reduce of the flat gradient per step (careless_amd/distributed.py).  The reference has no counterpart (it pins one
-    GPU, careless/parser.py:26-40).  Every rank formats the same files and draws the same splits; rank 0 writes the outputs."""
+    GPU, careless/parser.py:26-40).  Rank 0 formats the files once for the node (`_format_once_per_node`), every rank draws the same
+    splits from the shared arrays; rank 0 writes the outputs."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
@@ -101,7 +141,7 @@ def run_careless(parser):
 
     rank, world = _data_parallel()
     np.random.seed(parser.seed)                                    # reference parser.py:22-23
-    inputs, rac = _format(parser)
+    inputs, rac = _format_once_per_node(parser, rank, world)
     dm = DataManager(inputs, rac, parser=parser)
     if parser.test_fraction is not None:
         train, test = dm.split_data_by_refl(parser.test_fraction)

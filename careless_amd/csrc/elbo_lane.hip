@@ -45,6 +45,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CL_LANE_PKDZ
 #define CL_LANE_PKDZ 0          /* LeakyReLU derivative on packed fp32: step(h) as a clamped multiply, slope = leak + (1 - leak) step, dZ = dH slope (three packed instructions per feature pair instead of a multiply, two compares and two selects) */
 #endif
+#ifndef CL_LANE_NO_DZF
+#define CL_LANE_NO_DZF 0        /* diagnostic builds only (WRONG gradients): 1 drops the amplitude-gradient atomics -- what is left of WRITE_SIZE is everything else the kernel writes */
+#endif
+#ifndef CL_LANE_PAIRS
+#define CL_LANE_PAIRS 0         /* 1: the sampling epilogue takes two MC samples at a time on packed fp32 (monochromatic data, S >= 2, production instance) */
+#endif
 #ifndef CL_LANE_FAST_DIV
 #define CL_LANE_FAST_DIV 1      /* Student-T: 1/nu hoisted, the per-sample division as reciprocal + Newton step (a lone wave pays ~8 cycles per instruction of the two IEEE divisions) */
 #endif
@@ -81,6 +87,9 @@ __device__ __forceinline__ f32x4 mfma_bk(float a, float b, f32x4 c) { return __b
 // wait states between them; the only other reader is the flush, a barrier later.)
 #ifndef CL_LANE_ASM_ACC
 #define CL_LANE_ASM_ACC 1
+#endif
+#ifndef CL_LANE_ACC2
+#define CL_LANE_ACC2 1          /* 1: two accumulators per layer (consecutive weight-gradient MFMAs never depend on each other); 0: one */
 #endif
 __device__ __forceinline__ void mfma16_acc(f32x4& acc, float a, float b) {
 #if CL_LANE_ASM_ACC
@@ -168,7 +177,11 @@ struct LSmem {
 // weight-gradient MFMAs.
 // DMAX: metadata columns the instance holds in registers (8 or 15: the registers of seven more columns cost the common narrow case
 // 8 %); 0 = the LDS-row instance (LX, see LSmem) for 16 .. 31 columns.
-template <int W, int DMAX, bool PACKED>
+// FULL: every optional input / output of the launch (injected scale noise `eta`, `ipred_out`, the Evans-2011 error model).  The
+// training step of a production run uses none of them: its instance (FULL = false) carries neither their branches -- a lone wave
+// pays every one -- nor their scalar registers (the kernel spills ~90 of them into lanes of a vector register and reads them back
+// with v_readlane at the use).
+template <int W, int DMAX, bool PACKED, bool FULL>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void elbo_lane_kernel(const cl_mlp_args A) {
     constexpr bool LX = (DMAX == 0);
@@ -201,44 +214,55 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     //      transposed weights W_l[b][4 c + i] ---------------------------------------------------------------------------------
     {
         const float* __restrict__ P = A.mlp;
-        constexpr int NIMG = (SM::NF + NL + 1) * IMG, NIT = (NIMG + NT - 1) / NT;
+        // One "row" of the images = the 64 lanes of one register (image, chunk): rows * 64 floats in all, row rho at smem[64 rho].
+        // Wave `sub` of the workgroup takes rows sub, sub + NWV, ...; what depends on the lane -- block b, feature-in-chunk -- is
+        // computed once, what depends on the row is wave-uniform.  No branch around a load: every lane loads from a valid address
+        // (offset 0 when its element is padding) and selects afterwards -- with a branch per condition the compiler built ~150
+        // exec-mask regions here, a third of the launch's fixed cost for this one-wave-per-SIMD kernel.
+        constexpr int NROW = (SM::NF + NL + 1) * NC, NIT = (NROW + NWV - 1) / NWV;
+        static_assert(NT == 64 * NWV, "one wave per image row");
         float v_[NIT];
-        const int offWo = w * d + w + (L - 1) * (w * w + w);
+        const int offWo = w * d + w + (NL - 1) * (w * w + w);         // (cl_lane_supports: the scaler has exactly NL layers)
+        const int b = lane >> 2, fq = lane & 3;
         // (all loads of a thread are issued before the first LDS store: see elbo_narrow.hip)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = it * NT + tid;
-            const int tr = idx >= SM::NF * IMG ? 1 : 0, r = idx - tr * (SM::NF * IMG);
-            const int l = r / IMG, c = (r - l * IMG) >> 6, ln = r & 63;
-            const int b = ln >> 2, f = 4 * c + (ln & 3);
-            float v = 0.0f;
-            if (idx < NIMG) {
-                if (LX && tr == 0 && l == NL + 1) {                 // layer 0, second input block: block b = metadata column 15 + b
-                    if (f < w && 15 + b < d) v = P[f * d + 15 + b];
-                } else if (l < L) {
-                    const int in_dim = (l == 0) ? d : w;
-                    const int base = (l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w));
-                    if (tr == 0) {
-                        if (f < w && b < in_dim && b < ONE) v = P[base + f * in_dim + b];
-                        else if (f < w && b == ONE) v = P[base + w * in_dim + f];
-                    } else if (l > 0) {
-                        if (b < w && f < w) v = P[base + b * w + f];
-                    }
-                } else if (l == NL) {
-                    if (tr == 0) {
-                        if (f < 2 && b < w) v = P[offWo + f * w + b];
-                        else if (f < 2 && b == ONE) v = P[offWo + 2 * w + f];
-                    } else {
-                        if (b < 2 && f < w) v = P[offWo + b * w + f];
-                    }
+            const int rho = it * NWV + wv;                            // wave-uniform
+            const int img = rho / NC, c = rho - img * NC;
+            const int tr = img >= SM::NF ? 1 : 0, l = img - tr * SM::NF;
+            const int f = 4 * c + fq;
+            const int in_dim = (l == 0) ? d : w;
+            const int base = (l == 0) ? 0 : (w * d + w + (l - 1) * (w * w + w));
+            int off;
+            bool ok;
+            if (tr == 0) {                                            // (wave-uniform selects: scalar code)
+                if (LX && l == NL + 1) {                              // layer 0, second input block: block b = metadata column 15 + b
+                    off = f * d + 15 + b;
+                    ok = f < w && 15 + b < d;
+                } else if (l < NL) {
+                    off = b == ONE ? base + w * in_dim + f : base + f * in_dim + b;
+                    ok = f < w && (b == ONE || b < in_dim);
+                } else {                                              // the Dense(2) head
+                    off = b == ONE ? offWo + 2 * w + f : offWo + f * w + b;
+                    ok = f < 2 && (b == ONE || b < w);
+                }
+            } else {
+                if (l < NL) {
+                    off = base + b * w + f;
+                    ok = l > 0 && b < w && f < w;
+                } else {
+                    off = offWo + b * w + f;
+                    ok = b < 2 && f < w;
                 }
             }
-            v_[it] = v;
+            ok = ok && rho < NROW;
+            const float v = P[ok ? off : 0];
+            v_[it] = ok ? v : 0.0f;
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = it * NT + tid;
-            if (idx < NIMG) smem[SM::oF + idx] = v_[it];
+            const int rho = it * NWV + wv;
+            if (rho < NROW) smem[SM::oF + rho * 64 + lane] = v_[it];
         }
         // staging tiles: rows that are never written hold their constants (zero; row 15 of the input tiles = the ones)
         static_assert(SM::oT % 4 == 0 && SM::TWF % 4 == 0 && PIT % 4 == 0 && SM::oS % PIT == 0, "16-byte fill");
@@ -278,9 +302,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     constexpr int PAR = (TPAR - 1) * 16 * PIT;         // second copy of sZ / sH (layers alternate between the two; LX: one copy)
 
     // ---- accumulators that live across all tiles of this wave ----------------------------------------------------------
-    f32x4 wacc[NL], wacd[NL];           // dW_l = wacc + wacd: lane (j, q), element t = dW_l[out 4 q + t][in j]  (in 15: the bias)
+    f32x4 wacc[NL], wacd[CL_LANE_ACC2 ? NL : 1];           // dW_l = wacc + wacd: lane (j, q), element t = dW_l[out 4 q + t][in j]  (in 15: the bias)
 #pragma unroll
-    for (int l = 0; l < NL; ++l) { wacc[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; wacd[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    for (int l = 0; l < NL; ++l) { wacc[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; if (CL_LANE_ACC2) wacd[CL_LANE_ACC2 ? l : 0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
     f32x4 wacc0b = {0.0f, 0.0f, 0.0f, 0.0f}, wacd0b = {0.0f, 0.0f, 0.0f, 0.0f};      // LX: layer 0's second input block (columns 15 .. 30)
     f32x2 hacc[W + 1];                  // head: per-lane sums of (dloc, draw) x top activation k; [W]: the bias
 #pragma unroll
@@ -288,7 +312,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     float nll_acc = 0.0f;
     cl_ev11 ev = {1.0f, 0.0f, 0.0f};
     float ev_g0 = 0.0f, ev_g1 = 0.0f, ev_g2 = 0.0f;
-    const bool use_ev11 = A.ev11 != nullptr;
+    const bool use_ev11 = FULL && A.ev11 != nullptr;
+    const bool has_eta = FULL && A.eta != nullptr;          // injected scale noise (parity tests)
+    const bool det = FULL && A.dzf_obs != nullptr;          // deterministic mode: stores per (observation, sample) instead of float atomics
     if (use_ev11) { ev.sdfac = cl_softplus(A.ev11[0]); ev.sdadd = cl_softplus(A.ev11[1]); ev.sdb = cl_softplus(A.ev11[2]); }
 
     const int n_wt = (A.n_obs + WT - 1) / WT;                        // wave tiles
@@ -542,7 +568,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             const float tq = o0 + sigma * eta + shift;
             const float zs = aim * tq;
             const float ipred = act ? zs * zf * zf : 0.0f;
-            if (A.ipred_out != nullptr && act) A.ipred_out[(size_t)gobs * S + s] = ipred;
+            if (FULL && A.ipred_out != nullptr && act) A.ipred_out[(size_t)gobs * S + s] = ipred;
             float lin = ipred;                                   // what the likelihood sees: the prediction, or its group's total
             if (laue) {
                 lin = 0.0f;
@@ -566,14 +592,55 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
                 const float dzs = gi * zf * zf;
                 if (coal) sS[(s & (SPRE - 1)) * 64 + lane] = gi * zs * 2.0f * zf;      // (the sample's slot: its amplitude was read at the start of this sample)
-                else atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
+                else if (det) *reinterpret_cast<float*>(reinterpret_cast<char*>(A.dzf_obs) + 4u * ((unsigned)gobs * (unsigned)S + (unsigned)s)) = gi * zs * 2.0f * zf;
+                else if (!CL_LANE_NO_DZF) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
                 const float dt = dzs * aim;
                 pdl += dt;
                 pds += dt * eta;
                 pda += dzs * tq;
             }
         };
-        if (coal) sQ[lane] = (rid >= 0) ? zoff : 0xFFFFFFFFu;
+#if CL_LANE_PAIRS
+        // Two MC samples of this lane's observation at once, as the halves of packed fp32 registers (v_pk_fma / mul / add_f32): a lone
+        // wave pays ~8 cycles per instruction whatever it does, so the ~75 instructions of a sample are halved in number, the hardware
+        // reciprocal / logarithm alone stay per sample.  Production instance only (monochromatic data, in-kernel noise, no Evans-2011
+        // terms, no prediction output), gradients through LDS (coal); arithmetic of cl_lik_log_prob3.
+        f32x2 nll2 = {0.0f, 0.0f}, pdl2 = {0.0f, 0.0f}, pds2 = {0.0f, 0.0f}, pda2 = {0.0f, 0.0f};
+        const bool pairs = !FULL && !PACKED && coal;        // wave-uniform
+        auto sample2 = [&](int s, f32x2 eta, f32x2 zf) {
+            const f32x2 tq = (sigma * eta + o0) + shift;
+            const f32x2 zs = aim * tq;
+            const f32x2 zz = zf * zf;
+            const f32x2 ipred = zs * zz;
+            const f32x2 y = (ipred - io) * inv_sg;
+            f32x2 dll, ll;
+            if (lik_kind == CL_LIK_NORMAL) {
+                dll = -y * inv_sg;
+                ll = (-0.5f * y) * y - (0.5f * CL_LOG_2PI_F + log_sg);
+            } else {
+                const f32x2 y2 = y * y;
+                const f32x2 den = y2 + dof;
+                f32x2 r = {cl_fast_rcp(den[0]), cl_fast_rcp(den[1])};
+                r = r * (2.0f - den * r);
+                dll = ((-(dof + 1.0f) * inv_sg) * y) * r;
+                const f32x2 xx = y2 * inv_dof, u = xx + 1.0f;
+                const f32x2 lg = {cl_fast_log(u[0]), cl_fast_log(u[1])}, ru = {cl_fast_rcp(u[0]), cl_fast_rcp(u[1])};
+                ll = (-0.5f * (dof + 1.0f)) * (lg + (xx - (u - 1.0f)) * ru) + (lik_const - log_sg);
+            }
+            nll2 -= ll * w_ll;
+            const f32x2 gi = -dll * w_ll;
+            const f32x2 dzs = gi * zz;
+            const f32x2 ga = (gi * zs) * (2.0f * zf);
+            sS[(s & (SPRE - 1)) * 64 + lane] = ga[0];
+            sS[((s + 1) & (SPRE - 1)) * 64 + lane] = ga[1];
+            const f32x2 dt = dzs * aim;
+            pdl2 += dt;
+            pds2 += dt * eta;
+            pda2 += dzs * tq;
+        };
+#endif
+        // (deterministic mode: the observation's own record in dzf_obs instead of its reflection's row of dz_f)
+        if (coal) sQ[lane] = (rid >= 0) ? (det ? 4u * (unsigned)gobs * (unsigned)S : zoff) : 0xFFFFFFFFu;
         int sb = 0;                                      // first sample of the batch
         do {
             const int se = (sb + SPRE < S) ? sb + SPRE : S;
@@ -586,7 +653,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                                                      (__attribute__((address_space(3))) void*)(sS + j * 64), 4, 0, 0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (A.eta == nullptr) {
+            if (!has_eta) {
                 // the batch's in-kernel noise, drawn up front into LDS: one Philox block + Box-Muller pair serves samples s and s + 4
                 // (cl_math.h).  Drawn inside the sample loop, the pair's second half had to be parked in registers selected by
                 // s & 3 -- a dozen scalar branches per sample, each paid in full by a lone wave
@@ -604,14 +671,24 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 // Two loops over the batch (wave-uniform trip counts), so that the common one -- in-kernel noise -- contains no
                 // global load at all: any load in the loop makes the compiler wait on the one in-order memory counter, i.e.
                 // for the previous sample's atomics, a few microseconds each for a lone wave.
-                if (A.eta != nullptr) {
+                if (has_eta) {
                     const float* __restrict__ eta_p = A.eta + (size_t)gobs * S;
                     for (int s = sb; s < se; ++s) {
                         const float zf = (s > 0) ? sS[(s & (SPRE - 1)) * 64 + lane] : zf0;
                         sample(s, act ? eta_p[s] : 0.0f, act ? zf : 0.0f);
                     }
                 } else {
-                    for (int s = sb; s < se; ++s) {
+                    int s = sb;
+#if CL_LANE_PAIRS
+                    if (pairs) {                                 // (not Laue: this lane's row is a real observation here)
+                        for (; s + 2 <= se; s += 2) {
+                            const f32x2 zf = {(s > 0) ? sS[(s & (SPRE - 1)) * 64 + lane] : zf0, sS[((s + 1) & (SPRE - 1)) * 64 + lane]};
+                            const f32x2 et = {sE[(s & (SPRE - 1)) * 64 + lane], sE[((s + 1) & (SPRE - 1)) * 64 + lane]};
+                            sample2(s, et, zf);
+                        }
+                    }
+#endif
+                    for (; s < se; ++s) {
                         const float zf = (s > 0) ? sS[(s & (SPRE - 1)) * 64 + lane] : zf0;
                         sample(s, sE[(s & (SPRE - 1)) * 64 + lane], act ? zf : 0.0f);
                     }
@@ -623,12 +700,23 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 for (int j = 0; j < 8; ++j) {
                     const unsigned zq = sQ[8 * j + oj];
                     const float g = sS[ss * 64 + 8 * j + oj];
-                    if (sb + ss < S && zq != 0xFFFFFFFFu) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(A.dz_f) + zq + 4u * (unsigned)(sb + ss)), g);
+                    if (sb + ss < S && zq != 0xFFFFFFFFu) {
+                        if (det) *reinterpret_cast<float*>(reinterpret_cast<char*>(A.dzf_obs) + zq + 4u * (unsigned)(sb + ss)) = g;
+                        else if (!CL_LANE_NO_DZF) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(A.dz_f) + zq + 4u * (unsigned)(sb + ss)), g);
+                    }
                 }
             }
             sb += SPRE;
         } while (sb < S);
-        if (A.use_img) {
+#if CL_LANE_PAIRS
+        nll_acc += nll2[0] + nll2[1];
+        pdl += pdl2[0] + pdl2[1];
+        pds += pds2[0] + pds2[1];
+        pda += pda2[0] + pda2[1];
+#endif
+        if (A.use_img && det) {
+            if (rid >= 0) A.dimg_obs[gobs] = pda;                        // summed per image, in row order, by cl_det_reduce
+        } else if (A.use_img) {
             // image ids are sorted: the observations of a wave tile almost always share one image -> ONE atomic per wave
             const int img0 = uniform(img);
             if (__all(img == img0 || rid < 0)) {
@@ -746,7 +834,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 static_for<0, 16>([&](auto ic_) {
                     constexpr int i = decltype(ic_)::value, c = (i >> 3) * 2, t = (i >> 1) & 3;
                     if constexpr ((i & 1) == 0) mfma16_acc(wacc[l], pa[q][c][t], pb[q][c][t]);
-                    else mfma16_acc(wacd[l], pa[q][c + 1][t], pb[q][c + 1][t]);
+                    else mfma16_acc(CL_LANE_ACC2 ? wacd[CL_LANE_ACC2 ? l : 0] : wacc[l], pa[q][c + 1][t], pb[q][c + 1][t]);
                     if constexpr (l > 0) {
                         lds_op(std::integral_constant<int, (l > 0 ? l - 1 : 0)>{}, std::integral_constant<int, 2 * i>{});
                         lds_op(std::integral_constant<int, (l > 0 ? l - 1 : 0)>{}, std::integral_constant<int, 2 * i + 1>{});
@@ -762,7 +850,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     static_for<0, 16>([&](auto ic_) {
                         constexpr int i = decltype(ic_)::value, c = (i >> 3) * 2, t = (i >> 1) & 3;
                         if constexpr ((i & 1) == 0) mfma16_acc(wacc0b, pa[0][c][t], pb[1][c][t]);
-                        else mfma16_acc(wacd0b, pa[0][c + 1][t], pb[1][c + 1][t]);
+                        else mfma16_acc(CL_LANE_ACC2 ? wacd0b : wacc0b, pa[0][c + 1][t], pb[1][c + 1][t]);
                         LFENCE();
                     });
                 }
@@ -779,9 +867,11 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     // fixed binary tree over the waves (deterministic): at stride s the waves with (wv & (2s - 1)) == s park their sums in the
     // region of wave wv - s, which adds them to its own
     constexpr int REG = SM::REG;
+#if CL_LANE_ACC2
 #pragma unroll
     for (int l = 0; l < NL; ++l) wacc[l] += wacd[l];
     wacc0b += wacd0b;
+#endif
     float* const sHead = smem + (NWV / 2) * REG;            // [wave][2 * 16]: the head's sums of every wave
     {
         // head: wave sums of the per-lane sums
@@ -847,7 +937,8 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         if (tid == 0) {
             double t = 0.0;
             for (int k = 0; k < NWV; ++k) t += (double)smem[k];
-            atomicAdd(A.scalars + CL_SC_NLL, t);
+            if (det) A.nll_part[blockIdx.x] = t;            // every workgroup stores its slot, cl_det_reduce adds them in index order
+            else atomicAdd(A.scalars + CL_SC_NLL, t);
         }
         if (use_ev11) {
             ev_g0 = cl_wave_sum(ev_g0); ev_g1 = cl_wave_sum(ev_g1); ev_g2 = cl_wave_sum(ev_g2);
@@ -878,12 +969,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #define CL_LANE_PART 0
 #endif
 
-template <int W, int DMAX, bool PACKED>
-static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
+template <int W, int DMAX, bool PACKED, bool FULL>
+static int launch_lane_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SM = LSmem<W, DMAX == 0>;
     const size_t sm = (size_t)SM::total(a.d) * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_lane_kernel<W, DMAX, PACKED>;
+    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -894,6 +985,15 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), sm, st, a);
     return (int)hipGetLastError();
+}
+
+// the plain layout has a second instance without the optional inputs / outputs (the training step of a production run); the packed
+// layout (single-pass Laue) keeps the one full instance
+static inline bool lane_wants_full(const cl_mlp_args& a) { return a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr || a.dzf_obs != nullptr; }
+template <int W, int DMAX, bool PACKED>
+static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
+    if constexpr (PACKED) return launch_lane_inst<W, DMAX, true, true>(a, grid, st);
+    else return lane_wants_full(a) ? launch_lane_inst<W, DMAX, false, true>(a, grid, st) : launch_lane_inst<W, DMAX, false, false>(a, grid, st);
 }
 
 #ifndef CL_LANE_WMAX
@@ -940,7 +1040,9 @@ int cl_lane_supports(const cl_mlp_args& a) {
 int cl_lane_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
     const int W = a.w <= 4 ? 4 : (a.w <= 6 ? 6 : (a.w <= 8 ? 8 : 10));
     const int DM = a.d <= 8 ? 8 : (a.d <= DMAX_ALL ? DMAX_ALL : 0);
-    return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s>", W, DM, a.row_map != nullptr ? "true" : "false");
+    const bool packed = a.row_map != nullptr;
+    return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s>%s", W, DM, packed ? "true" : "false", (packed || lane_wants_full(a)) ? "true" : "false",
+                    a.dzf_obs != nullptr ? " (deterministic stores)" : "");
 }
 
 int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {
@@ -950,6 +1052,11 @@ int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {
         4ull * (unsigned long long)a.R * (unsigned long long)a.S >= (1ull << 32))
         return -4;
     if (grid < 1) return -1;
+    if (a.dzf_obs != nullptr) {          // deterministic mode: stores per (observation, sample) / observation / workgroup, no Evans-2011 terms
+        if (a.ev11 != nullptr) return -2;
+        if (a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
+        if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+    }
     // (CARELESS_HIP_LANE_ROWS_FROM=k: metadata as LDS rows from k columns on instead of 16 -- A/B runs)
     static const int rows_from = [] { const char* e = getenv("CARELESS_HIP_LANE_ROWS_FROM"); const int v = e ? atoi(e) : DMAX_ALL + 1; return v < 1 ? 1 : (v > DMAX_ALL + 1 ? DMAX_ALL + 1 : v); }();
     const bool rows = a.d >= rows_from;

@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args
     nll = wave_sum_d2(nll);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = nll;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(A.scalars + CL_SC_NLL, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) {
+        if (A.nll_part != nullptr) A.nll_part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];      // deterministic mode: summed in index order by cl_det_reduce
+        else atomicAdd(A.scalars + CL_SC_NLL, sh[0] + sh[1] + sh[2] + sh[3]);
+    }
     if (A.ev11 != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { g0 += __shfl_xor(g0, off); g1 += __shfl_xor(g1, off); g2 += __shfl_xor(g2, off); }
@@ -162,7 +165,7 @@ int cl_launch_laue_likelihood(const cl_laue_args& a, hipStream_t st) {
     const long long n = (long long)a.n_obs * a.S;
     (void)hipGetLastError();
     long long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > CL_LAUE_LIK_MAX_BLOCKS) blocks = CL_LAUE_LIK_MAX_BLOCKS;
     hipLaunchKernelGGL(laue_likelihood_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }

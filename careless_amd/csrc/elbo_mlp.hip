@@ -1413,7 +1413,16 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
-    if (a.dzf_obs != nullptr) return cl_launch_mlp_det(a, mode, grid, st);      // deterministic mode: every width <= 64 on the fused kernel of this file
+    if (a.dzf_obs != nullptr) {
+        // deterministic mode: the default scaler's shapes keep their own kernels (round 4: elbo_lane.hip / elbo_narrow.hip store per
+        // observation when dzf_obs is given), every other width <= 64 runs the deterministic compilation of this file
+        if (mode == 0 && a.ev11 == nullptr && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1) {
+            const int g = grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid;
+            if (cl_lane_supports(a) && lane_enabled()) return cl_launch_lane(a, g, st);
+            if (cl_narrow_supports(a) && narrow_enabled()) return cl_launch_narrow(a, g, st);
+        }
+        return cl_launch_mlp_det(a, mode, grid, st);
+    }
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
     if (a.n_imgl > 0) return cl_launch_mlp_imgl(a, mode, grid, st);            // packed layout + per-image layers
     if (a.row_map != nullptr && !(mode == 0 && ((cl_narrow_supports(a) && narrow_enabled()) || (cl_lane_supports(a) && lane_enabled()))))
@@ -1446,8 +1455,11 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
 int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     const char* unit = "";
     bool packed = false;
-    if (a.dzf_obs != nullptr) unit = ", deterministic";
-    else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
+    if (a.dzf_obs != nullptr) {
+        if (mode == 0 && a.ev11 == nullptr && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
+        if (mode == 0 && a.ev11 == nullptr && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
+        unit = ", deterministic";
+    } else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
     else if (a.n_imgl > 0) unit = ", image layers";
     else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }
     if (a.dzf_obs == nullptr && (unit[0] == 0 || packed)) {

@@ -394,6 +394,8 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         const int half = lane >> 5;
         const long long gobs = PACKED ? (long long)rme : (long long)wt * WT + (lane & (WT - 1));      // this lane's observation in the caller's order
         const unsigned zoff = 4u * (unsigned)(rid < 0 ? 0 : rid) * (unsigned)S;
+        const bool det = E->dzf_obs != nullptr;                            // wave-uniform: deterministic mode (stores instead of float atomics)
+        const unsigned dob = 4u * (unsigned)gobs * (unsigned)S;            // this observation's record in dzf_obs (< 4 GiB: cl_launch_narrow)
         float o0 = acc_h[0], o1 = acc_h[1];
         if (S > 1) {                                     // wave-uniform
             o0 = __shfl(o0, lane & 31);
@@ -462,7 +464,10 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     if (counts) nll_acc -= ll * w_ll;
                     const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
                     const float dzs = gi * zf * zf;
-                    atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
+                    // deterministic mode (include/careless_hip.h: dzf_obs): the contribution is STORED per (observation, sample) and
+                    // cl_det_reduce sums the observations of a reflection in row order; otherwise a float atomic
+                    if (det) *reinterpret_cast<float*>(reinterpret_cast<char*>(E->dzf_obs) + dob + 4u * s) = gi * zs * 2.0f * zf;
+                    else atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
                     const float dt = dzs * aim;
                     pdl += dt;
                     pds += dt * eta;
@@ -475,7 +480,9 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
             pds += __shfl_xor(pds, 32);
             pda += __shfl_xor(pda, 32);
         }
-        if (E->use_img) {
+        if (E->use_img && det) {
+            if (rid >= 0 && lane < WT) E->dimg_obs[gobs] = pda;          // summed per image, in row order, by cl_det_reduce
+        } else if (E->use_img) {
             // image ids are sorted: the observations of a wave tile almost always share one image -> ONE atomic per wave
             const int img0 = uniform(img);
             if (__all(img == img0 || rid < 0)) {
@@ -681,7 +688,8 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         if (tid == 0) {
             double t = 0.0;
             for (int k = 0; k < NWAVES; ++k) t += (double)smem[k];
-            atomicAdd(A.scalars + CL_SC_NLL, t);
+            if (A.nll_part != nullptr) A.nll_part[blockIdx.x] = t;       // deterministic mode: every workgroup stores its slot, cl_det_reduce adds them in index order
+            else atomicAdd(A.scalars + CL_SC_NLL, t);
         }
         if (use_ev11) {
 #pragma unroll
@@ -724,7 +732,8 @@ int cl_narrow_supports(const cl_mlp_args& a) {
 // name of the instance cl_launch_narrow runs (cl_mlp_kernel_name)
 int cl_narrow_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
     const int m = a.w > a.d ? a.w : a.d;
-    return snprintf(out, n, "elbo_narrow_kernel<2, %d, 8, %s>", m <= 8 ? 2 : (m <= 12 ? 3 : 4), a.row_map != nullptr ? "true" : "false");
+    return snprintf(out, n, "elbo_narrow_kernel<2, %d, 8, %s>%s", m <= 8 ? 2 : (m <= 12 ? 3 : 4), a.row_map != nullptr ? "true" : "false",
+                    a.dzf_obs != nullptr ? " (deterministic stores)" : "");
 }
 
 template <bool PACKED>
@@ -746,6 +755,11 @@ int cl_launch_narrow(const cl_mlp_args& a, int grid, hipStream_t st) {
         4ull * (unsigned long long)a.R * (unsigned long long)a.S >= (1ull << 32))
         return -4;
     if (grid < 1) return -1;
+    if (a.dzf_obs != nullptr) {          // deterministic mode: stores per (observation, sample) / observation / workgroup, no Evans-2011 terms
+        if (a.ev11 != nullptr) return -2;
+        if (a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
+        if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+    }
     if (a.row_map != nullptr) {
         if (a.n_obs != a.n_pad || (a.gmeta != nullptr && a.tile_gmax == nullptr)) return -1;
         if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;

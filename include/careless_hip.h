@@ -287,7 +287,10 @@ typedef struct cl_laue_args {
     float* d_ev11;              /* [3] +=                                     */
     const long long* row_index; /* optional [n_obs]: global row number of every local row (noise key) when the shard is not a
                                    contiguous range (data-parallel Laue keeps harmonic groups on one rank); NULL = obs_offset + i */
+    double* nll_part;           /* optional [CL_LAUE_LIK_MAX_BLOCKS] (deterministic mode): cl_laue_likelihood STORES every workgroup's NLL
+                                   here -- slots past its grid are left alone -- instead of adding it to scalars with an atomic       */
 } cl_laue_args;
+#define CL_LAUE_LIK_MAX_BLOCKS 2048
 
 int cl_laue_predict(const cl_laue_args* args, void* stream);
 int cl_laue_likelihood(const cl_laue_args* args, void* stream);

@@ -27,7 +27,7 @@ What it does per case (tests/golden/cases.json holds the problem sizes, the .npz
     against `traj_loss`, `traj_gnorm` and the final parameters `final_XX`.
 Two cases exist to make the first TensorFlow run decisive on the two [3P-recall] items the oracle carries: `mono_2x16_clipnorm_and_
 clipvalue_S2` (both clip flags: tf_keras applies the first active mode only -- the trajectory differs from a cumulative clip in the
-first step) and `mono_2x16_extreme_uniforms_S4` (injected uniforms at 1 - 2^-24 and 1e-30, where the [tiny, 1 - eps] clip of TFP's
+first step) and `mono_2x16_extreme_uniforms_S4` (injected uniforms at 1 - 2^-24, where the [tiny, 1 - eps] clip of TFP's
 sample gradient is active; with loc = exp(a) > 0 >= low the truncation point cannot sit in the upper tail, so the ends of u are the
 only way to reach the clip).  NOTE for the second one: patch 1 below differentiates the inverse CDF exactly and does NOT reproduce
 TFP's clip; its `grad_00 / grad_01` rows therefore show the clip's effect as a mismatch there if and only if the oracle's

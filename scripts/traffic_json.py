@@ -9,16 +9,18 @@ out_path = "profiles/traffic.json"
 out = {}
 for arg in sys.argv[1:]:
     wl, path = arg.split("=", 1)
-    vals = {}
+    vals, launches = {}, {}
     for ln in open(path):
         m = re.match(r"^[A-D] (\w+) (\d+) ([0-9.eE+-]+)$", ln.strip())
         if m:
             vals[m.group(1)] = float(m.group(3))
+            launches[m.group(1)] = int(m.group(2))
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         print("no FETCH_SIZE / WRITE_SIZE in", path); continue
     out[wl] = {"n_gpus": 1, "hbm_bytes_per_launch": 1024.0 * (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]),
                "fetch_kib_reported": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "atomic_requests": vals.get("TCC_EA0_ATOMIC_sum"),
                "sources": source_hash(), "file": path,
-               "method": "2 x FETCH_SIZE + WRITE_SIZE per launch of the dominant kernel, separate rocprofv3 --pmc passes (scripts/pmc_passes.sh)"}
+               "launches_per_step": launches.get("FETCH_SIZE"),
+               "method": "2 x FETCH_SIZE + WRITE_SIZE summed over the dominant kernel(s)' launches of one step, separate rocprofv3 --pmc passes (scripts/r4_pmc_passes.sh)"}
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -27,12 +27,15 @@ STEPS = 6
 
 
 def extreme_uniforms(u_f):
-    """A few injected uniforms at the ends of (0, 1): the largest float32 below one (cdf > 1 - eps_f32) and 1e-30, so that the
+    """A few injected uniforms at the upper end of (0, 1): the largest float32 below one, 1 - 2^-24 > 1 - eps_f32, so that the
     [tiny, 1 - eps] clip of TFP's truncated-normal sample gradient (oracle._TNStdSample, [3P-recall]) is ACTIVE in the case -- with
-    loc = exp(a) > 0 >= low the truncation point never lies in the upper tail, so the ends of u are the only way to reach the clip."""
+    loc = exp(a) > 0 >= low the truncation point never lies in the upper tail, so the end of u is the only way to reach the clip.
+    (The lower end is left alone: a uniform of 1e-30 or 2^-24 puts the sample within 1e-6 of the truncation point, where
+    z = loc + scale e cancels in float32 and log p(z) ~ log z is singular -- an fp32 engine and an fp64 oracle differ there by
+    rounding alone, as fp32 TensorFlow would; `tiny` is out of reach of any float32 uniform anyway.)"""
     u = np.array(u_f, dtype=np.float32)
     u[0, ::5] = np.nextafter(np.float32(1.0), np.float32(0.0))
-    u[-1, 1::5] = np.float32(1e-30)
+    u[-1, 1::5] = np.nextafter(np.float32(1.0), np.float32(0.0))
     return u
 
 

@@ -176,13 +176,14 @@ def test_preformatted_npz_input(tmp_path):
     assert len(hist["loss"]) == 5 and read_mtz(out + "_0.mtz").spacegroup_number == 173
 
 
-@pytest.mark.parametrize("split", ["rows", "owners"])
+@pytest.mark.parametrize("split", ["rows", "owners", "rows_two_piece_message"])
 def test_data_parallel_cli_two_ranks_match_one(tmp_path, split):
     """`python -m careless_amd mono ...` as two one-process-per-GPU ranks (here: both on this GPU, gloo backend) writes the same
     merged amplitudes and history as the single-process run: observations sharded, one all-reduce per step, in-kernel noise keyed
     by global indices, rank 0 writes the files (careless_amd/careless.py: _data_parallel).  Both splits: rows (what two ranks run
     by default) and reflection owners (the default from four ranks on: every rank updates its own reflections' q(F) only, the ranks
-    exchange them after training, the validation rows follow their reflection's owner)."""
+    exchange them after training, the validation rows follow their reflection's owner); and the row split with its message in two
+    pieces (round 4: the scaler's part all-reduced beside cl_tn_backward, a and b after it)."""
     import socket
     import subprocess
     import sys
@@ -195,7 +196,8 @@ def test_data_parallel_cli_two_ranks_match_one(tmp_path, split):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   CARELESS_DIST_BACKEND="gloo", PYTHONPATH=root, CARELESS_HIP_OWNER_SHARD="1" if split == "owners" else "0")
+                   CARELESS_DIST_BACKEND="gloo", PYTHONPATH=root, CARELESS_HIP_OWNER_SHARD="1" if split == "owners" else "0",
+                   CARELESS_HIP_SPLIT_MESSAGE="1" if split == "rows_two_piece_message" else "0")
         procs.append(subprocess.Popen([sys.executable, "-m", "careless_amd"] + flags + [PYP, two], env=env, cwd=root))
     assert [p.wait(timeout=600) for p in procs] == [0, 0]
     a, b = read_mtz(one + "_0.mtz"), read_mtz(two + "_0.mtz")
@@ -225,3 +227,17 @@ def test_deterministic_command_line_runs_write_identical_files(tmp_path, monkeyp
     ha = np.genfromtxt(outs[0] + "_history.csv", delimiter=",", names=True)
     hb = np.genfromtxt(outs[1] + "_history.csv", delimiter=",", names=True)
     assert np.array_equal(ha["NLL"], hb["NLL"]) and np.allclose(ha["loss"], hb["loss"], rtol=1e-12)
+    # ... and a `poly` command (single-pass Laue: packed layout, per-observation stores by the caller's row; round 4)
+    monkeypatch.delenv("CARELESS_HIP_MAX_LAUNCH_BYTES")
+    flags = f"poly --iterations={niter} --disable-progress-bar --mlp-layers 3 --mc-samples 2 dHKL,image_id"
+    outs = []
+    for k in range(2):
+        out = str(tmp_path / f"poly{k}")
+        _run(flags, [PYP], out, False)
+        outs.append(out)
+    a, b = read_mtz(outs[0] + "_0.mtz"), read_mtz(outs[1] + "_0.mtz")
+    for col in ("F", "SigF", "I", "SigI"):
+        assert np.array_equal(a.columns[col], b.columns[col]), col
+    ha = np.genfromtxt(outs[0] + "_history.csv", delimiter=",", names=True)
+    hb = np.genfromtxt(outs[1] + "_history.csv", delimiter=",", names=True)
+    assert np.array_equal(ha["NLL"], hb["NLL"])

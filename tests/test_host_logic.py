@@ -298,10 +298,12 @@ def test_kernel_name_follows_the_librarys_routing():
         assert n == len(buf.value)
         return buf.value.decode()
 
-    assert name(d=5, w=10, L=20, S=1) == "elbo_lane_kernel<10, 8, false>"
-    assert name(d=12, w=7, L=20, S=3) == "elbo_lane_kernel<8, 15, false>"
-    assert name(d=21, w=10, L=20, S=8) == "elbo_lane_kernel<10, 0, false>"          # positional encodings: rows of an LDS buffer
-    assert name(d=31, w=4, L=20, S=40, row_map=1) == "elbo_lane_kernel<4, 0, true>"
+    # (last argument: the instance with / without the optional inputs and outputs -- injected noise, ipred_out, Ev11)
+    assert name(d=5, w=10, L=20, S=1) == "elbo_lane_kernel<10, 8, false, false>"
+    assert name(d=5, w=10, L=20, S=1, eta=1) == "elbo_lane_kernel<10, 8, false, true>"
+    assert name(d=12, w=7, L=20, S=3) == "elbo_lane_kernel<8, 15, false, false>"
+    assert name(d=21, w=10, L=20, S=8) == "elbo_lane_kernel<10, 0, false, false>"   # positional encodings: rows of an LDS buffer
+    assert name(d=31, w=4, L=20, S=40, row_map=1) == "elbo_lane_kernel<4, 0, true, true>"
     assert name(d=32, w=10, L=20, S=1).startswith("elbo_mlp_kernel<16, 32, 20, 0")
     assert name(d=5, w=13, L=12, S=8) == "elbo_narrow_kernel<2, 4, 8, false>"
     assert name(d=21, w=64, L=5, S=8) == "elbo_mlp_kernel<64, 32, 5, 0, KS=4>"
