@@ -42,6 +42,7 @@ class TnArgs(C.Structure):
         ("prior_kind", C.c_int),
         ("parent_ids", _vp), ("root", _vp), ("dw_r", _vp), ("dz_f_out", _vp),
         ("dw_r_raw", _vp), ("asu_ids", _vp), ("d_dw_r_raw", _vp), ("n_asu", C.c_int),
+        ("dw_child_seg", _vp), ("dw_child_ids", _vp),
     ]
 
 
@@ -135,6 +136,7 @@ EXPORTS = {
     "cl_mlp_kernel_name": (C.c_int, [C.POINTER(MlpArgs), C.c_int, C.c_char_p, C.c_size_t]),
     "cl_wide_ld": (C.c_int, [C.c_int]),
     "cl_wide_dense_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_dense_forward_head": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
     "cl_wide_dense_dgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
     "cl_wide_wgrad_splits": (C.c_int, [C.c_longlong]),
     "cl_wide_dense_wgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),

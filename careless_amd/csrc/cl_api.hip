@@ -121,6 +121,8 @@ int cl_dw_prior_forward(const cl_tn_args* a, void* stream) {
     if (int e = check_tn(a)) return e;
     if (a->prior_kind != CL_PRIOR_DOUBLE_WILSON_ || a->z_f == nullptr || a->dz_f_out == nullptr || a->scalars == nullptr) return -1;
     if (a->dw_r_raw != nullptr && (a->d_dw_r_raw == nullptr || a->n_asu < 1)) return -1;
+    if ((a->dw_child_seg != nullptr) != (a->dw_child_ids != nullptr)) return -1;
+    if (a->dw_child_seg != nullptr && a->dw_r_raw != nullptr) return -2;          // deterministic mode: fixed r only
     return cl_launch_dw_forward(*a, (hipStream_t)stream);
 }
 

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void dw_forward_kernel(const cl_tn_args A) {
             const float lp = cl_dw_log_prob(z, zp, par >= 0, r, c, es, &dz, &dzp, &dr);
             kl -= (double)lp;
             gr -= wg * dr;
-            if (par >= 0) atomicAdd(A.dz_f_out + (size_t)par * A.S + s, -wg * dzp);
+            if (par >= 0 && A.dw_child_seg == nullptr) atomicAdd(A.dz_f_out + (size_t)par * A.S + s, -wg * dzp);      // (deterministic mode: dw_parent_pull_kernel)
         }
         if (A.dw_r_raw) { asu = A.asu_ids[h]; gr *= r * (1.0f - r); }      // d sigmoid(raw) / d raw
     }
@@ -420,10 +420,35 @@ int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st) {
     hipLaunchKernelGGL(tn_backward_kernel, dim3((nr + 255) / 256 + nred), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
+// Deterministic mode of the double-Wilson prior: what dw_forward_kernel's children scatter into their parents with float atomics, pulled
+// by the parent instead -- thread p walks its children (CSR list, ascending) and adds -w dlogp(z_child | z_p) / dz_p to dz_f[p][s] in
+// list order (recomputed: the term needs both samples, which are final).  Only children whose KL this rank owns count (row split).
+__global__ __launch_bounds__(256) void dw_parent_pull_kernel(const cl_tn_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= A.R) return;
+    const int k0 = A.dw_child_seg[p], k1 = A.dw_child_seg[p + 1];
+    if (k1 <= k0) return;
+    const float wg = A.w_kl * A.kl_grad_mult;
+    for (int s = 0; s < A.S; ++s) {
+        const float zp = A.z_f[(size_t)p * A.S + s];
+        float acc = 0.0f;
+        for (int k = k0; k < k1; ++k) {
+            const int h = A.dw_child_ids[k];
+            if (A.root[h] != 0 || h < A.kl_begin || h >= A.kl_end) continue;
+            float dz, dzp, dr;
+            (void)cl_dw_log_prob(A.z_f[(size_t)h * A.S + s], zp, true, dw_r_of(A, h), A.centric[h] != 0, A.es[h], &dz, &dzp, &dr);
+            acc += -wg * dzp;
+        }
+        A.dz_f_out[(size_t)p * A.S + s] += acc;
+    }
+}
+
 int cl_launch_dw_forward(const cl_tn_args& a, hipStream_t st) {
     if (a.R <= 0 || a.S <= 0) return -1;
     (void)hipGetLastError();
     hipLaunchKernelGGL(dw_forward_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
+    if (a.dw_child_seg != nullptr) hipLaunchKernelGGL(dw_parent_pull_kernel, dim3((a.R + 255) / 256), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,

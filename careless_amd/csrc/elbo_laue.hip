@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void laue_predict_kernel(const cl_laue_args A)
     const float zf = A.z_f[(size_t)rid * A.S + s];
     const float ipred = aim * tq * zf * zf;
     if (A.ipred_out) A.ipred_out[p] = ipred;
-    atomicAdd(A.iconv + (size_t)A.harmonic_id[i] * A.S + s, ipred);
+    // harmonic_id NULL: every row is its own slot (monochromatic rows on this path: scalers wider than 64) -- a plain store into a
+    // buffer the caller need not clear; otherwise the group's sum (laue.py:24: duplicates add up)
+    if (A.harmonic_id == nullptr) A.iconv[p] = ipred;
+    else atomicAdd(A.iconv + (size_t)A.harmonic_id[i] * A.S + s, ipred);
 }
 
 __global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args A) {
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A
     int im = 0;
     float dloc = 0.0f, dsig = 0.0f, da = 0.0f;
     if (act) {
-        const int rid = A.refl_id[i], hid = A.harmonic_id[i];
+        const int rid = A.refl_id[i], hid = A.harmonic_id != nullptr ? A.harmonic_id[i] : i;
         float aim = 1.0f;
         if (A.use_img) { im = A.image_id[i]; if (im > 0) aim = A.img[im - 1]; }
         const float loc = A.loc[i], sigma = A.sigma[i];
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A
 }
 
 static int laue_check(const cl_laue_args& a) {
-    if (a.n_obs <= 0 || a.S <= 0 || a.refl_id == nullptr || a.harmonic_id == nullptr || a.loc == nullptr || a.sigma == nullptr ||
+    if (a.n_obs <= 0 || a.S <= 0 || a.refl_id == nullptr || a.loc == nullptr || a.sigma == nullptr ||
         a.z_f == nullptr || a.iconv == nullptr)
         return -1;
     if (a.use_img && (a.image_id == nullptr || a.img == nullptr)) return -1;

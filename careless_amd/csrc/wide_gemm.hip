@@ -349,6 +349,11 @@ struct StreamArgs {
     // stages the group's weights, its eight waves walk the group's 16-row blocks, then the next group.  seg == NULL: one group = all rows.
     const int* seg; int n_groups;
     long long wstride, bstride;
+    // Dense(2) head fused into the forward epilogue of the top layer (EPI_BIAS_LRELU, N <= 128): the rows' activations are in
+    // registers there -- loc / sigma come out of the same pass instead of a launch that reads them back (nn.py:22-25, 84-87)
+    const float* head_W;             // [2][N] then [2] biases (the head's flat layout) or NULL
+    int bij_kind; float eps;
+    float* loc_out; float* sig_out;  // [n]
 };
 
 // NAT: 16-column blocks of the output an instance holds (4: N <= 64, 8: N <= 128); GRP: the grouped form (its own instances: the
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
     const int NA = (N + 15) >> 4, KC = (K + 15) >> 4;               // 16-column blocks of the output, 16-deep chunks of the contraction
     const int tot = 16 * NA * SKP;
     float* const sBias = sW + tot;                                   // [16 NA] (forward), zero past N
+    float* const sHead = sBias + 16 * NA;                            // [2][16 NA] (forward with the fused head), zero past N
     const bool vec = (S.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.X) & 15) == 0);
     const float* const wrow = sW + j * SKP + 4 * q;
     constexpr bool grouped = GRP;
@@ -391,6 +397,10 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
         for (int u = 0; u < 8; ++u) if (at[u] >= 0) sW[at[u]] = v[u];
     }
     if (EPI == EPI_BIAS_LRELU && tid < 16 * NA) sBias[tid] = (tid < N) ? S.bias[(size_t)grp * (size_t)S.bstride + tid] : 0.0f;
+    if (EPI == EPI_BIAS_LRELU && S.head_W != nullptr && tid < 32 * NA) {
+        const int r = tid / (16 * NA), c = tid - r * 16 * NA;
+        sHead[tid] = (c < N) ? S.head_W[r * N + c] : 0.0f;
+    }
     __syncthreads();
     const long long nblk = (rend - row0 + 15) >> 4;
     // the rows' operand: lane (row j, k-group q) holds X[row][16 kc + 4 q .. + 3] of chunk kc (MFMA step t contracts k = 16 kc + 4 q + t)
@@ -453,6 +463,7 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
                     }
                 }
             }
+            float ho0 = 0.0f, ho1 = 0.0f;            // fused head: this lane's share of the row's two dot products
 #pragma unroll
             for (int a = 0; a < NAT; ++a) {
                 const int c = 16 * a + 4 * q;
@@ -463,6 +474,11 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
                         if (S.act) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], S.leak * v[t]);
+                        }
+                        if (S.head_W != nullptr) {      // (zero weights past N: padding columns add nothing)
+                            const f32x4 h0 = *reinterpret_cast<const f32x4*>(sHead + c), h1 = *reinterpret_cast<const f32x4*>(sHead + 16 * NA + c);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) { ho0 = fmaf(v[t], h0[t], ho0); ho1 = fmaf(v[t], h1[t], ho1); }
                         }
                     } else if (S.H != nullptr) {
 #pragma unroll
@@ -476,6 +492,17 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
                     }
                 }
             }
+            if (EPI == EPI_BIAS_LRELU && S.head_W != nullptr) {
+                // the four lanes (q = 0 .. 3) of a row add up their shares; all 64 lanes are inside this branch or none of a row's is
+                // (row < rend depends on j only) -- the shuffles stay among lanes of the same row
+                ho0 += __shfl_xor(ho0, 16); ho1 += __shfl_xor(ho1, 16);
+                ho0 += __shfl_xor(ho0, 32); ho1 += __shfl_xor(ho1, 32);
+                if (q == 0) {
+                    float d;
+                    S.loc_out[row] = ho0 + S.head_W[2 * N];
+                    S.sig_out[row] = cl_scale_bij(ho1 + S.head_W[2 * N + 1], S.bij_kind, S.eps, &d);
+                }
+            }
         }
     }
   }
@@ -484,7 +511,7 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
 template <bool WKM, int EPI, int NAT, bool GRP>
 int launch_stream_n(const StreamArgs& s, hipStream_t st) {
     const int NA = (s.N + 15) >> 4;
-    const size_t sm = (size_t)(16 * NA * SKP + 16 * NA) * sizeof(float);
+    const size_t sm = (size_t)(16 * NA * SKP + 3 * 16 * NA) * sizeof(float);          // weights, bias, the fused head's two rows
     auto kern = wide_stream_kernel<WKM, EPI, NAT, GRP>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
@@ -539,6 +566,23 @@ int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float*
     g.A = X; g.lda = ldx; g.B = Wt; g.ldb = n_in; g.C = Y; g.ldc = ldy;
     g.M = (int)n; g.N = n_out; g.K = n_in; g.bias = b; g.leak = leak; g.act = act; g.stop_flag = stop_flag;
     return launch_gemm<false, false, EPI_BIAS_LRELU>(g, 1, (hipStream_t)stream);
+}
+
+/* the top Dense layer with the Dense(2) head in its epilogue: Y as cl_wide_dense_forward (the backward pass needs it), and
+ * loc = Y . Wo[0] + bo[0], sigma = bijector(Y . Wo[1] + bo[1]) + eps per row (`head` = the head's flat layout [Wo (2 x n_out) | bo (2)]).
+ * Layers up to 128 x 128 (the streaming kernel); -2 otherwise: the caller then runs cl_wide_dense_forward + cl_wide_head_forward.      */
+int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak,
+                               float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out,
+                               const int* stop_flag, void* stream) {
+    if (X == nullptr || Wt == nullptr || b == nullptr || Y == nullptr || head == nullptr || loc_out == nullptr || sig_out == nullptr || n < 1 ||
+        n > 0x7fffffffLL || n_in < 1 || n_out < 1 || ldx < n_in || ldy < n_out)
+        return -1;
+    if (n_in > SMAX || n_out > SMAX) return -2;
+    StreamArgs s = {};
+    s.X = X; s.ldx = ldx; s.W = Wt; s.ldw = n_in; s.Y = Y; s.ldy = ldy; s.n = n; s.N = n_out; s.K = n_in;
+    s.bias = b; s.leak = leak; s.act = 1; s.stop_flag = stop_flag;
+    s.head_W = head; s.bij_kind = bij_kind; s.eps = eps; s.loc_out = loc_out; s.sig_out = sig_out;
+    return launch_stream<false, EPI_BIAS_LRELU>(s, (hipStream_t)stream);
 }
 
 int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* Hprev, int ldh, float leak,

@@ -214,6 +214,7 @@ class ElboEngine(WidePath):
             self.parent_ids = torch.as_tensor(prior.reflids.astype(np.int32), device=dev)
             self.root = torch.as_tensor(prior.root.astype(np.uint8), device=dev)
             self.dw_r = torch.as_tensor(prior.r_per_reflection, device=dev)
+            self.dw_children = None         # deterministic mode: the children of every reflection as a CSR list (built below)
 
         # ---- flat parameters; the plugin objects become views into them ----------------------------------
         mlp.build(self.d)
@@ -247,10 +248,18 @@ class ElboEngine(WidePath):
         # per-observation stores + fixed-order sums (cl_det_reduce) -- so two runs give bit-identical gradients and parameters
         self.deterministic = bool(getattr(model, "deterministic", False)) or os.environ.get("CARELESS_HIP_DETERMINISTIC", "0") == "1"
         two_pass = self.laue and bool(getattr(model, "laue_two_pass", False))
-        if self.deterministic and (two_pass or self.wide or imgl is not None or self.ev11 or self.double_wilson or self.blocks is not None):
-            raise NotImplementedError("deterministic mode covers monochromatic and single-pass Laue data, the Wilson prior, Normal / Student-T "
-                                      "likelihoods and scalers of one launch (width <= 64); the two-pass Laue path, double-Wilson, Evans-2011, "
-                                      "per-image layers, chained and wide scalers keep their float atomics")
+        if self.deterministic and (two_pass or self.wide or imgl is not None or self.ev11 or self.blocks is not None or
+                                   (self.double_wilson and prior.r_raw is not None)):
+            raise NotImplementedError("deterministic mode covers monochromatic and single-pass Laue data, the Wilson and the double-Wilson prior "
+                                      "(fixed r), Normal / Student-T likelihoods and scalers of one launch (width <= 64); the two-pass Laue path, "
+                                      "a trainable double-Wilson r, Evans-2011, per-image layers, chained and wide scalers keep their float atomics")
+        if self.deterministic and self.double_wilson:
+            # parents pull their children's terms in list order instead of children scattering with atomics (cl_dw_prior_forward)
+            par = np.asarray(prior.reflids).astype(np.int64)
+            kids = np.nonzero(par >= 0)[0]
+            kids = kids[np.argsort(par[kids], kind="stable")]
+            seg = np.concatenate([[0], np.cumsum(np.bincount(par[kids], minlength=self.R))]).astype(np.int32)
+            self.dw_children = (torch.as_tensor(seg, device=dev), torch.as_tensor(kids.astype(np.int32) if len(kids) else np.zeros(1, np.int32), device=dev))
         self.layout = make_layout(self.R, self.d, self.w, self.L, n_img, 3 if self.ev11 else 0, n_dwr,
                                   imgl=(imgl.n_image_layers, imgl.max_images) if imgl is not None else None)
         lay = self.layout
@@ -463,6 +472,8 @@ class ElboEngine(WidePath):
             a.prior_kind = _lib.CL_PRIOR_DOUBLE_WILSON
             a.parent_ids, a.root, a.dw_r = ptr(self.parent_ids), ptr(self.root), ptr(self.dw_r)
             a.dz_f_out = ptr(self.dz_f)
+            if self.dw_children is not None:
+                a.dw_child_seg, a.dw_child_ids = ptr(self.dw_children[0]), ptr(self.dw_children[1])
             if self.dw_trainable:
                 a.dw_r_raw = self.params.data_ptr() + 4 * lay.off_dwr
                 a.d_dw_r_raw = self.grads.data_ptr() + 4 * lay.off_dwr
@@ -772,8 +783,9 @@ class ElboEngine(WidePath):
         """From (loc, sigma) per row in obs.laue_loc / laue_sig: sample, predict, group sums, slot likelihood (NLL into the
         scalars), its gradient back on the rows -> dz_f, d(image scales), obs.laue_dO = dL/d(loc, sigma) per row."""
         lib = self.lib
-        obs.laue_iconv.zero_()
         la = LaueArgs()
+        if obs.harmonic_id is not None:
+            obs.laue_iconv.zero_()          # (group sums accumulate by atomics; rows that are their own slot -- harmonic_id None -- store)
         la.refl_id, la.image_id, la.harmonic_id = ptr(obs.refl_id), ptr(obs.image_id), ptr(obs.harmonic_id)
         la.loc, la.sigma, la.iobs, la.sig = ptr(obs.laue_loc), ptr(obs.laue_sig), ptr(obs.iobs), ptr(obs.sig)
         la.n_obs, la.obs_offset = obs.N, obs.start

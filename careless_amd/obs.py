@@ -337,7 +337,7 @@ class ObsData:
                 hl = hl - laue_groups[0]
                 self.row_index = torch.as_tensor(self.rows.astype(np.int64), device=device)
         if wide and not self.laue:
-            hl = np.arange(self.N)             # every row its own "harmonic group": the slot kernels then ARE the mono likelihood
+            hl = None                          # every row its own "harmonic group" (harmonic_id NULL): the slot kernels then ARE the mono likelihood
         elif wide and getattr(self, "perm", None) is not None:
             hl = hl[self.perm]
         if wide and getattr(self, "perm", None) is not None:
@@ -346,7 +346,7 @@ class ObsData:
             self.rows = np.asarray(base_rows)[self.perm]
             self.row_index = torch.as_tensor(self.rows.astype(np.int64), device=device)
         if (self.laue and not self.fused_laue) or wide:
-            self.harmonic_id = torch.as_tensor(hl.astype(np.int32), device=device)
+            self.harmonic_id = torch.as_tensor(hl.astype(np.int32), device=device) if hl is not None else None
             self.laue_loc = torch.empty(self.N, dtype=torch.float32, device=device)
             self.laue_sig = torch.empty(self.N, dtype=torch.float32, device=device)
             self.laue_iconv = torch.empty(self.N * S, dtype=torch.float32, device=device)

@@ -106,7 +106,7 @@ class WidePath:
         obs.wide_full = [torch.zeros(obs.N * W["ldw"], dtype=torch.float32, device=self.device) for _ in range(W["nh"])]
         return obs.wide_full
 
-    def _wide_forward(self, obs: ObsData, chunk, keep: bool, st, full=None):
+    def _wide_forward(self, obs: ObsData, chunk, keep: bool, st, full=None, head=None):
         """Hidden layers on one row chunk of `obs`: layer l's output lands in acts[l] when `keep` (else two buffers alternate), or
         in the chunk's rows of the whole-set buffers `full`; returns the (buffer, ld) pairs of h_0 .. h_(L + K)."""
         a, b, m0, seg = chunk
@@ -116,10 +116,19 @@ class WidePath:
         sf, leak = ptr(self.stop_flag), self.mlp.leakiness
         dst_of = (lambda l: full[l].data_ptr() + 4 * a * ldw) if full is not None else (lambda l: W["acts"][l if keep else l & 1].data_ptr())
         hs = [(obs.meta_rm.data_ptr() + 4 * a * obs.meta_ld, obs.meta_ld)]
+        self._head_fused = False
         for l, (ow, ob, fan_in) in enumerate(layers):
             dst = dst_of(l)
-            check(lib.cl_wide_dense_forward(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, 1,
-                                            dst, ldw, sf, st), "cl_wide_dense_forward")
+            if head is not None and l == self.L - 1 and self.imgl is None and fan_in <= 128 and self.w <= 128:
+                # the top layer carries the Dense(2) head in its epilogue: (loc, sigma) come out of the same pass
+                off_head, loc_ptr, sig_ptr = head
+                check(lib.cl_wide_dense_forward_head(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, dst, ldw,
+                                                     base + 4 * off_head, self.bij_kind, self.mlp.epsilon, loc_ptr, sig_ptr, sf, st),
+                      "cl_wide_dense_forward_head")
+                self._head_fused = True
+            else:
+                check(lib.cl_wide_dense_forward(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, 1,
+                                                dst, ldw, sf, st), "cl_wide_dense_forward")
             hs.append((dst, ldw))
         for k in range(self.imgl.n_image_layers if self.imgl is not None else 0):       # image.py:116-125
             l = self.L + k
@@ -152,10 +161,12 @@ class WidePath:
         kept = []
         for ch in chunks:
             a, b = ch[0], ch[1]
-            hs = self._wide_forward(obs, ch, True, st, full=full) if full is not None else self._wide_forward(obs, ch, False, st)
+            head = (off_head, obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a)
+            hs = self._wide_forward(obs, ch, True, st, full=full, head=head) if full is not None else self._wide_forward(obs, ch, False, st, head=head)
             kept.append(hs)
-            check(lib.cl_wide_head_forward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, b - a, w, self.bij_kind, self.mlp.epsilon,
-                                           obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a, sf, st), "cl_wide_head_forward")
+            if not self._head_fused:
+                check(lib.cl_wide_head_forward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, b - a, w, self.bij_kind, self.mlp.epsilon,
+                                               obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a, sf, st), "cl_wide_head_forward")
         self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
         for ic, ch in enumerate(chunks):
             a, b, m0, seg = ch

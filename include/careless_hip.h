@@ -99,6 +99,12 @@ typedef struct cl_tn_args {
     const int* asu_ids;         /* [R] ASU of every reflection                                                      */
     float* d_dw_r_raw;          /* [n_asu] += dL/d raw (cl_dw_prior_forward)                                        */
     int n_asu;
+    /* Deterministic mode (round 4): with the children of every reflection given as a CSR list -- child_ids[child_seg[p] ..
+     * child_seg[p+1]) are the reflections whose parent is p, ascending -- cl_dw_prior_forward issues NO atomic: a second launch of the
+     * call lets every parent add up its children's -w dlogp/dz_parent itself, in list order (the term is recomputed there).
+     * Fixed r only (the trainable r's gradient is a per-wave atomic).  NULL: children scatter with float atomics.                      */
+    const int* dw_child_seg;    /* [R + 1] */
+    const int* dw_child_ids;    /* [number of reflections with a parent] */
 } cl_tn_args;
 enum { CL_PRIOR_WILSON_ = 0, CL_PRIOR_DOUBLE_WILSON_ = 1 };
 
@@ -231,6 +237,13 @@ int cl_wide_ld(int width);
 /* Y[n][n_out] = act(X[n][n_in] Wt^T + b), act = LeakyReLU(leak) or identity */
 int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak, int act,
                           float* Y, int ldy, const int* stop_flag, void* stream);
+/* The TOP Dense layer with the Dense(2) head in its epilogue (round 4; replaces cl_wide_dense_forward + cl_wide_head_forward for layers up
+ * to 128 x 128, -2 beyond): Y as above -- the backward pass needs it -- and loc = Y . Wo[0] + bo[0], sigma = bijector(Y . Wo[1] + bo[1]) + eps
+ * per row from the registers the activations are in (reference: NormalLayer, careless/models/scaling/nn.py:10-25, 84-87).
+ * head = [Wo^T (2 x n_out) | bo (2)].                                                                                                */
+int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak,
+                               float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out,
+                               const int* stop_flag, void* stream);
 /* dX[n][n_in] = (dZ[n][n_out] Wt) * LeakyReLU'(Hprev[n][n_in])   (Hprev = the layer's input = the previous layer's output; NULL: no mask) */
 int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* Hprev, int ldh, float leak,
                         float* dX, int ldo, const int* stop_flag, void* stream);
@@ -262,7 +275,7 @@ int cl_wide_head_backward(const float* H, int ldh, const float* Wo, const float*
 typedef struct cl_laue_args {
     const int* refl_id;         /* [n_obs]                                   */
     const int* image_id;        /* [n_obs]                                   */
-    const int* harmonic_id;     /* [n_obs] in [0, n_obs)                     */
+    const int* harmonic_id;     /* [n_obs] in [0, n_obs); NULL: row i is slot i (monochromatic rows), iconv needs no clearing */
     const float* loc;           /* [n_obs] scaler mean  (cl_mlp_forward)     */
     const float* sigma;         /* [n_obs] scaler sigma (cl_mlp_forward)     */
     const float* iobs;          /* [n_obs] per slot                          */
