@@ -137,6 +137,11 @@ EXPORTS = {
     "cl_wide_ld": (C.c_int, [C.c_int]),
     "cl_wide_dense_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int, _vp, _vp]),
     "cl_wide_dense_forward_head": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
+    "cl_wide_pre_supported": (C.c_int, [C.c_int, C.c_int]),
+    "cl_wide_dense2_forward": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, C.c_int, C.c_float,
+                                         _vp, _vp, _vp, _vp]),
+    "cl_wide_dense_dgrad_pre": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_dense_wgrad_pre": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_float, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "cl_wide_dense_dgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
     "cl_wide_wgrad_splits": (C.c_int, [C.c_longlong]),
     "cl_wide_dense_wgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),

@@ -508,16 +508,23 @@ int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, 
 // ---------------------------------------------------------------------------------------------------------
 // deterministic mode (include/careless_hip.h: cl_det_args): fixed-order sums of the per-observation stores of elbo_mlp.hip (-DCL_DET=1)
 // ---------------------------------------------------------------------------------------------------------
-// dz_f[r][s] += sum over the observations of reflection r, in row order.  One thread per (r, s): the S threads of a reflection read
-// S consecutive floats of an observation's record.
+// dz_f[r][s] += sum over the observations of reflection r in a FIXED order: sixteen lanes share a reflection -- lane l takes the rows
+// l, l + 16, ... of its (row-ordered) list, the sixteen lane sums combine in a fixed butterfly.  (Round 3 walked the list with one
+// thread per (reflection, sample): ~30 dependent random 4-byte gathers per thread, 0.39 ms per step at 10 M observations -- a fifth of
+// the default scaler's step; the order of the sum is as fixed this way, and the gathers of a reflection are in flight together.)
 __global__ __launch_bounds__(256) void det_refl_kernel(const cl_det_args A) {
     if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)A.R * A.S) return;
-    const int r = (int)(t / A.S), s = (int)(t - (long long)r * A.S);
-    float acc = 0.0f;
-    for (int k = A.seg_refl[r]; k < A.seg_refl[r + 1]; ++k) acc += A.dzf_obs[(size_t)A.perm_refl[k] * A.S + s];
-    A.dz_f[t] += acc;
+    const int sub = threadIdx.x & 15;
+    const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool on = r < A.R;
+    const int k0 = on ? A.seg_refl[r] : 0, k1 = on ? A.seg_refl[r + 1] : 0;
+    for (int s = 0; s < A.S; ++s) {
+        float acc = 0.0f;
+        for (int k = k0 + sub; k < k1; k += 16) acc += A.dzf_obs[(size_t)A.perm_refl[k] * A.S + s];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (on && sub == 0) A.dz_f[(size_t)r * A.S + s] += acc;
+    }
 }
 
 // d_img[m - 1] += sum over the observations of image m (m >= 1), one wave per image: lane l takes the rows l, l + 64, ... of the
@@ -545,8 +552,7 @@ __global__ __launch_bounds__(64) void det_nll_kernel(const cl_det_args A) {
 
 int cl_launch_det_reduce(const cl_det_args& a, hipStream_t st) {
     (void)hipGetLastError();
-    const long long n = (long long)a.R * a.S;
-    hipLaunchKernelGGL(det_refl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(det_refl_kernel, dim3((unsigned)((a.R + 15) / 16)), dim3(256), 0, st, a);
     if (a.d_img != nullptr && a.n_images > 1) hipLaunchKernelGGL(det_img_kernel, dim3((a.n_images - 1 + 3) / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(det_nll_kernel, dim3(1), dim3(64), 0, st, a);
     return (int)hipGetLastError();

@@ -40,6 +40,19 @@ constexpr int SA = (BM * PK > BK * PMA) ? BM * PK : BK * PMA;
 
 enum { EPI_BIAS_LRELU = 0, EPI_DLRELU = 1, EPI_WGRAD = 2 };
 
+// The FIRST Dense layer of the stack, h_0 = LeakyReLU(X_0 Wt_0^T + b_0) on the metadata rows (careless/models/scaling/nn.py:55-68), recomputed
+// wherever its output is needed instead of being stored (round 4): it is a (rows x <= 16) x (<= 16 x w) product -- an eighth of a
+// 128 x 128 layer's work -- against 4 w bytes per row written once and read three times (the second layer's forward, its weight
+// gradient, the mask of its dgrad).  X0 == NULL: not in use.
+constexpr int K0MAX = 16;            // metadata columns the fused forms take in the forward / dgrad kernels (one 16-deep chunk) ...
+constexpr int K0WG = 8;              // ... and in the weight-gradient kernel (the thread's four weight rows live in registers)
+constexpr int S0P = K0MAX + 4;       // pitch of the first layer's weight image [N0][K0MAX]
+struct PreArgs {
+    const float* X0; int ldx0; int K0;      // metadata rows [n][ldx0], K0 columns in use
+    const float* W0; const float* b0;       // Wt_0[N0][K0], b_0[N0]
+    int N0;
+};
+
 struct GemmArgs {
     const float* A; int lda;        // not AK: A[m][k] at A[m * lda + k];  AK: A[k][m] at A[k * lda + m]
     const float* B; int ldb;        // not BK_: B[n][k] at B[n * ldb + k]; BK_: B[k][n] at B[k * ldb + n]
@@ -55,6 +68,7 @@ struct GemmArgs {
     const int* seg;                 // EPI_WGRAD, grouped (per-image layers): z-block g contracts rows seg[g] .. seg[g+1] and writes the group's
     float* Cb; long long bstride;   //   kernel at C + g * pstride, its bias at Cb + g * bstride (NULL: the flat layer layout, bias behind the kernel)
     const int* stop_flag;
+    PreArgs pre;                    // EPI_WGRAD: the B operand (the layer's input) is the recomputed first layer (pre.X0 != NULL; B, ldb unused)
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -135,10 +149,46 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     float bsum = 0.0f;              // EPI_WGRAD: bias gradient of output unit m0 + tid = column sum of the A operand (dZ)
 
     f32x4 ra[BM * BK / 1024], rb[BN * BK / 1024];
+    // EPI_WGRAD with the recomputed first layer as B operand: the thread's four columns of the tile are fixed (BN / 4 threads per
+    // contraction index, 256 a multiple of it), so their weight rows and biases sit in registers for the whole launch
+    const bool pre = EPI == EPI_WGRAD && BK_ && G.pre.X0 != nullptr;
+    float w0r[4][K0WG], b0r[4];
+    const int pcol = n0 + 4 * (tid % (BN / 4));
+    if (pre) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b0r[e] = (pcol + e < G.pre.N0) ? G.pre.b0[pcol + e] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < K0WG; ++i) w0r[e][i] = (pcol + e < G.pre.N0 && i < G.pre.K0) ? G.pre.W0[(size_t)(pcol + e) * G.pre.K0 + i] : 0.0f;
+        }
+    }
+    auto load_b = [&](int kk0, f32x4 (&r)[BN * BK / 1024]) {
+        if (!pre) { load_tile<BN, BK_>(G.B, G.ldb, n0, kk0, G.N, kend, vecB, r, tid); return; }
+#pragma unroll
+        for (int v = 0; v < BN * BK / 1024; ++v) {
+            const int k = kk0 + (v * 256 + tid) / (BN / 4);          // observation (contraction index)
+            f32x4 xa = {0.0f, 0.0f, 0.0f, 0.0f}, xb = {0.0f, 0.0f, 0.0f, 0.0f}, out = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (k < kend) {
+                const float* x = G.pre.X0 + (size_t)k * G.pre.ldx0;      // (ldx0 is a multiple of four, the padding columns are zero)
+                xa = *reinterpret_cast<const f32x4*>(x);
+                if (G.pre.ldx0 > 4) xb = *reinterpret_cast<const f32x4*>(x + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // the contraction order of the forward kernels' MFMAs (step t takes k = t, 4 + t), the bias after it: the same bits
+                    float z = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { z = fmaf(w0r[e][t], xa[t], z); z = fmaf(w0r[e][4 + t], xb[t], z); }
+                    z += b0r[e];
+                    out[e] = fmaxf(z, G.leak * z);
+                }
+            }
+            r[v] = out;
+        }
+    };
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
         load_tile<BM, AK>(G.A, G.lda, m0, kbeg, G.M, kend, vecA, ra, tid);
-        load_tile<BN, BK_>(G.B, G.ldb, n0, kbeg, G.N, kend, vecB, rb, tid);
+        load_b(kbeg, rb);
         store_tile<BM, AK>(sA[0], ra, tid);
         store_tile<BN, BK_>(sB[0], rb, tid);
     }
@@ -147,7 +197,7 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
         const int cur = it & 1;
         if (it + 1 < nk) {           // the next chunk's global loads fly under this chunk's MFMAs
             load_tile<BM, AK>(G.A, G.lda, m0, kbeg + (it + 1) * BK, G.M, kend, vecA, ra, tid);
-            load_tile<BN, BK_>(G.B, G.ldb, n0, kbeg + (it + 1) * BK, G.N, kend, vecB, rb, tid);
+            load_b(kbeg + (it + 1) * BK, rb);
         }
         const float* a_s = sA[cur];
         const float* b_s = sB[cur];
@@ -354,11 +404,12 @@ struct StreamArgs {
     const float* head_W;             // [2][N] then [2] biases (the head's flat layout) or NULL
     int bij_kind; float eps;
     float* loc_out; float* sig_out;  // [n]
+    PreArgs pre;                     // EPI_DLRELU: the activations whose sign selects the derivative are the recomputed first layer (H unused)
 };
 
 // NAT: 16-column blocks of the output an instance holds (4: N <= 64, 8: N <= 128); GRP: the grouped form (its own instances: the
 // group loop costs the plain ones registers)
-template <bool WKM, int EPI, int NAT, bool GRP>
+template <bool WKM, int EPI, int NAT, bool GRP, bool PRE = false>
 __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
     if (S.stop_flag != nullptr && *S.stop_flag != 0) return;
     extern __shared__ __attribute__((aligned(16))) float sW[];      // [16 NA][SKP], zero outside N x K
@@ -369,6 +420,9 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
     const int tot = 16 * NA * SKP;
     float* const sBias = sW + tot;                                   // [16 NA] (forward), zero past N
     float* const sHead = sBias + 16 * NA;                            // [2][16 NA] (forward with the fused head), zero past N
+    float* const sW0 = sHead + 32 * NA;                              // [16 NA][S0P], [16 NA]: the recomputed first layer (dgrad mask), zero outside N x K0
+    float* const sB0 = sW0 + 16 * NA * S0P;
+    constexpr bool premask = PRE && EPI == EPI_DLRELU && !GRP;        // (its own instance: the recomputation costs the plain one registers)
     const bool vec = (S.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.X) & 15) == 0);
     const float* const wrow = sW + j * SKP + 4 * q;
     constexpr bool grouped = GRP;
@@ -397,6 +451,13 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
         for (int u = 0; u < 8; ++u) if (at[u] >= 0) sW[at[u]] = v[u];
     }
     if (EPI == EPI_BIAS_LRELU && tid < 16 * NA) sBias[tid] = (tid < N) ? S.bias[(size_t)grp * (size_t)S.bstride + tid] : 0.0f;
+    if (premask) {
+        for (int idx = tid; idx < 16 * NA * S0P; idx += 512) {
+            const int o = idx / S0P, k = idx - o * S0P;
+            sW0[idx] = (o < N && k < S.pre.K0) ? S.pre.W0[(size_t)o * S.pre.K0 + k] : 0.0f;
+        }
+        if (tid < 16 * NA) sB0[tid] = (tid < N) ? S.pre.b0[tid] : 0.0f;
+    }
     if (EPI == EPI_BIAS_LRELU && S.head_W != nullptr && tid < 32 * NA) {
         const int r = tid / (16 * NA), c = tid - r * 16 * NA;
         sHead[tid] = (c < N) ? S.head_W[r * N + c] : 0.0f;
@@ -444,11 +505,33 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
         }
         // accumulator a, element t of lane (j, q) = Y[row = 16 blk + j][column 16 a + 4 q + t]: four consecutive columns of the lane's row
         const long long row = row0 + blk * 16 + j;
+        f32x4 hpre[NAT];                         // dgrad with the recomputed first layer: its pre-activations of this lane's row and columns
+        if (premask) {
+            // as the forward pass made them: one 16-deep chunk of metadata, four MFMAs per block.  ALL lanes take part (an MFMA reads its
+            // A operand -- the weights of feature 16 a + j -- from every lane): rows past the end read the last row
+            const long long rr = row < rend ? row : rend - 1;
+            f32x4 x0 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (4 * q < S.pre.ldx0) x0 = *reinterpret_cast<const f32x4*>(S.pre.X0 + (size_t)rr * S.pre.ldx0 + 4 * q);
+#pragma unroll
+            for (int a = 0; a < NAT; ++a) {
+                hpre[a] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+                if (a < NA) {
+                    const f32x4 wf = *reinterpret_cast<const f32x4*>(sW0 + (16 * a + j) * S0P + 4 * q);
+                    f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z = mfma4(wf[t], x0[t], z);
+                    hpre[a] = z + *reinterpret_cast<const f32x4*>(sB0 + 16 * a + 4 * q);      // (its sign is the sign of LeakyReLU of it)
+                }
+            }
+        }
         if (row < rend) {
             const bool vecy = (S.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.Y) & 15) == 0);
             const bool vech = (S.ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.H) & 15) == 0);
             f32x4 hm[NAT];                           // dgrad: the activations whose sign selects the derivative, all requested before the first use
-            if (EPI == EPI_DLRELU && S.H != nullptr) {
+            if (premask) {
+#pragma unroll
+                for (int a = 0; a < NAT; ++a) hm[a] = hpre[a];
+            } else if (EPI == EPI_DLRELU && S.H != nullptr) {
 #pragma unroll
                 for (int a = 0; a < NAT; ++a) {
                     const int c = 16 * a + 4 * q;
@@ -480,7 +563,7 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) { ho0 = fmaf(v[t], h0[t], ho0); ho1 = fmaf(v[t], h1[t], ho1); }
                         }
-                    } else if (S.H != nullptr) {
+                    } else if (S.H != nullptr || premask) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) v[t] = (hm[a][t] > 0.0f) ? v[t] : S.leak * v[t];
                     }
@@ -508,11 +591,163 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
   }
 }
 
-template <bool WKM, int EPI, int NAT, bool GRP>
+// The first two Dense layers in one launch: h_0 = LeakyReLU(X_0 Wt_0^T + b_0) of a wave's 16 rows comes out of four MFMAs per 16-column
+// block IN the B-operand layout of the second layer (accumulator a, element t of lane (j, q) = h_0[row j][16 a + 4 q + t] = operand
+// chunk a, element t: the property the fused kernels of elbo_mlp.hip chain their layers with) and never leaves the registers.
+// Optionally the Dense(2) head in the epilogue (a two-layer scaler).  N0, N1 <= 16 NAT.
+struct Stream2Args {
+    PreArgs pre;
+    const float* W1; const float* b1; int N1;      // Wt_1[N1][N0], b_1[N1]
+    float* Y; int ldy; long long n; float leak;
+    const float* head_W; int bij_kind; float eps; float* loc_out; float* sig_out;
+    const int* stop_flag;
+};
+
+// NA: 16-column blocks of BOTH layers' outputs (the hidden widths of a scaler are equal), compile-time: the loops below are straight-line code
+// (run-time block counts inside the unrolled loops cost ~1000 spilled registers)
+template <int NA>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8)))      // (two 8-wave workgroups per CU, as the one-layer kernel: <= 128 registers)
+void wide_stream2_kernel(const Stream2Args S) {
+    if (S.stop_flag != nullptr && *S.stop_flag != 0) return;
+    extern __shared__ __attribute__((aligned(16))) float sm2[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int N0 = S.pre.N0, N1 = S.N1, K0 = S.pre.K0;
+    constexpr int NA0 = NA, NA1 = NA, NAT = NA;
+    float* const sW1 = sm2;                                   // [16 NA1][SKP], zero outside N1 x N0
+    float* const sB1 = sW1 + 16 * NA1 * SKP;                  // [16 NA1]
+    float* const sHead = sB1 + 16 * NA1;                      // [2][16 NA1]
+    float* const sW0 = sHead + 32 * NA1;                      // [16 NA0][S0P], zero outside N0 x K0
+    float* const sB0 = sW0 + 16 * NA0 * S0P;                  // [16 NA0]
+    for (int base = 0; base < 16 * NA1 * SKP; base += 8 * 512) {       // (eight loads in flight per thread, as in wide_stream_kernel)
+        float v[8];
+        int at[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 512 + tid;
+            const int o = idx / SKP, k = idx - o * SKP;
+            at[u] = idx < 16 * NA1 * SKP ? idx : -1;
+            v[u] = (idx < 16 * NA1 * SKP && o < N1 && k < N0) ? S.W1[(size_t)o * N0 + k] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (at[u] >= 0) sW1[at[u]] = v[u];
+    }
+    for (int idx = tid; idx < 16 * NA0 * S0P; idx += 512) {
+        const int o = idx / S0P, k = idx - o * S0P;
+        sW0[idx] = (o < N0 && k < K0) ? S.pre.W0[(size_t)o * K0 + k] : 0.0f;
+    }
+    if (tid < 16 * NA1) sB1[tid] = (tid < N1) ? S.b1[tid] : 0.0f;
+    if (tid < 16 * NA0) sB0[tid] = (tid < N0) ? S.pre.b0[tid] : 0.0f;
+    if (S.head_W != nullptr && tid < 32 * NA1) {
+        const int r = tid / (16 * NA1), c = tid - r * 16 * NA1;
+        sHead[tid] = (c < N1) ? S.head_W[r * N1 + c] : 0.0f;
+    }
+    __syncthreads();
+    const long long nblk = (S.n + 15) >> 4;
+    auto load_x0 = [&](long long b) -> f32x4 {                // lane (row j, k-group q): X_0[row][4 q .. + 3] (the row is zero-padded to ldx0)
+        const long long row = b * 16 + j;
+        f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row < S.n && 4 * q < S.pre.ldx0) x = *reinterpret_cast<const f32x4*>(S.pre.X0 + (size_t)row * S.pre.ldx0 + 4 * q);
+        return x;
+    };
+    long long blk = (long long)blockIdx.x * 8 + wv;
+    const long long bstep = (long long)gridDim.x * 8;
+    f32x4 xc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (blk < nblk) xc = load_x0(blk);
+    for (; blk < nblk; blk += bstep) {
+        f32x4 xn = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (blk + bstep < nblk) xn = load_x0(blk + bstep);
+        f32x4 h0[NAT];
+#pragma unroll
+        for (int a = 0; a < NAT; ++a) {
+            const f32x4 wf = *reinterpret_cast<const f32x4*>(sW0 + (16 * a + j) * S0P + 4 * q);
+            f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) z = mfma4(wf[t], xc[t], z);
+            z += *reinterpret_cast<const f32x4*>(sB0 + 16 * a + 4 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) h0[a][t] = fmaxf(z[t], S.leak * z[t]);
+        }
+        f32x4 acc[NAT];
+#pragma unroll
+        for (int a = 0; a < NAT; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kc = 0; kc < NAT; ++kc) {
+#pragma unroll
+            for (int a = 0; a < NAT; ++a) {
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(sW1 + (16 * a + j) * SKP + 16 * kc + 4 * q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[a] = mfma4(wf[t], h0[kc][t], acc[a]);
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (unrolled for the register-resident h_0: the fence keeps the weight reads of later chunks from being hoisted)
+        }
+        const long long row = blk * 16 + j;
+        if (row < S.n) {
+            const bool vecy = (S.ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.Y) & 15) == 0);
+            float ho0 = 0.0f, ho1 = 0.0f;
+#pragma unroll
+            for (int a = 0; a < NAT; ++a) {
+                const int c = 16 * a + 4 * q;
+                if (c < N1) {
+                    f32x4 v = acc[a] + *reinterpret_cast<const f32x4*>(sB1 + c);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], S.leak * v[t]);
+                    if (S.head_W != nullptr) {
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sHead + c), g1 = *reinterpret_cast<const f32x4*>(sHead + 16 * NA1 + c);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { ho0 = fmaf(v[t], g0[t], ho0); ho1 = fmaf(v[t], g1[t], ho1); }
+                    }
+                    float* y = S.Y + (size_t)row * S.ldy + c;
+                    if (c + 3 < N1 && vecy) *reinterpret_cast<f32x4*>(y) = v;
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (c + t < N1) y[t] = v[t];
+                    }
+                }
+            }
+            if (S.head_W != nullptr) {
+                ho0 += __shfl_xor(ho0, 16); ho1 += __shfl_xor(ho1, 16);
+                ho0 += __shfl_xor(ho0, 32); ho1 += __shfl_xor(ho1, 32);
+                if (q == 0) {
+                    float d;
+                    S.loc_out[row] = ho0 + S.head_W[2 * N1];
+                    S.sig_out[row] = cl_scale_bij(ho1 + S.head_W[2 * N1 + 1], S.bij_kind, S.eps, &d);
+                }
+            }
+        }
+        xc = xn;
+    }
+}
+
+template <int NA>
+int launch_stream2(const Stream2Args& s, hipStream_t st) {
+    constexpr int NA0 = NA, NA1 = NA;
+    const size_t sm = (size_t)(16 * NA1 * SKP + 3 * 16 * NA1 + 16 * NA0 * (S0P + 1)) * sizeof(float);
+    auto kern = wide_stream2_kernel<NA>;
+    static std::atomic<size_t> configured{0};
+    size_t have = configured.load(std::memory_order_acquire);
+    if (have < sm) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        while (have < sm && !configured.compare_exchange_weak(have, sm, std::memory_order_release, std::memory_order_acquire)) {}
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long nblk = (s.n + 15) >> 4;
+    long long grid = (nblk + 7) / 8;
+    if (grid > 2LL * cus) grid = 2LL * cus;
+    if (grid < 1) grid = 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sm, st, s);
+    return (int)hipGetLastError();
+}
+
+template <bool WKM, int EPI, int NAT, bool GRP, bool PRE = false>
 int launch_stream_n(const StreamArgs& s, hipStream_t st) {
     const int NA = (s.N + 15) >> 4;
-    const size_t sm = (size_t)(16 * NA * SKP + 3 * 16 * NA) * sizeof(float);          // weights, bias, the fused head's two rows
-    auto kern = wide_stream_kernel<WKM, EPI, NAT, GRP>;
+    // weights, bias, the fused head's two rows; the dgrad with a recomputed mask adds the first layer's image and bias
+    const size_t sm = (size_t)(16 * NA * SKP + 3 * 16 * NA + (PRE ? 16 * NA * (S0P + 1) : 0)) * sizeof(float);
+    auto kern = wide_stream_kernel<WKM, EPI, NAT, GRP, PRE>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -598,6 +833,68 @@ int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n,
     g.A = dZ; g.lda = lddz; g.B = Wt; g.ldb = n_in; g.C = dX; g.ldc = ldo;
     g.M = (int)n; g.N = n_in; g.K = n_out; g.H = Hprev; g.ldh = ldh; g.leak = leak; g.stop_flag = stop_flag;
     return launch_gemm<false, true, EPI_DLRELU>(g, 1, (hipStream_t)stream);
+}
+
+/* 1: the first Dense layer of a (n_in0 -> w -> w ...) stack can be recomputed instead of stored (cl_wide_dense2_forward,
+ * cl_wide_dense_dgrad_pre, cl_wide_dense_wgrad_pre): metadata of at most 8 columns, hidden width at most 128 */
+int cl_wide_pre_supported(int n_in0, int w) { return n_in0 >= 1 && n_in0 <= K0WG && w >= 1 && w <= SMAX; }
+
+static int pre_check(const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, int w) {
+    if (X0 == nullptr || Wt0 == nullptr || b0 == nullptr) return -1;
+    if (!cl_wide_pre_supported(n_in0, w)) return -2;
+    if (ldx0 < n_in0 || ldx0 % 4 != 0 || ldx0 > K0WG || (reinterpret_cast<uintptr_t>(X0) & 15) != 0) return -1;
+    return 0;
+}
+
+int cl_wide_dense2_forward(const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, const float* Wt1, const float* b1, long long n,
+                           int w0, int w1, float leak, float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out,
+                           const int* stop_flag, void* stream) {
+    if (int e = pre_check(X0, ldx0, n_in0, Wt0, b0, w0)) return e;
+    if (Wt1 == nullptr || b1 == nullptr || Y == nullptr || n < 1 || n > 0x7fffffffLL || w1 < 1 || ldy < w1) return -1;
+    if (w1 > SMAX) return -2;
+    if (head != nullptr && (loc_out == nullptr || sig_out == nullptr)) return -1;
+    Stream2Args s = {};
+    s.pre.X0 = X0; s.pre.ldx0 = ldx0; s.pre.K0 = n_in0; s.pre.W0 = Wt0; s.pre.b0 = b0; s.pre.N0 = w0;
+    s.W1 = Wt1; s.b1 = b1; s.N1 = w1; s.Y = Y; s.ldy = ldy; s.n = n; s.leak = leak;
+    s.head_W = head; s.bij_kind = bij_kind; s.eps = eps; s.loc_out = loc_out; s.sig_out = sig_out; s.stop_flag = stop_flag;
+    hipStream_t st = (hipStream_t)stream;
+    switch (((w0 > w1 ? w0 : w1) + 15) >> 4) {         // exact block count: zero-padded blocks would cost real MFMAs
+        case 1: return launch_stream2<1>(s, st);
+        case 2: return launch_stream2<2>(s, st);
+        case 3: return launch_stream2<3>(s, st);
+        case 4: return launch_stream2<4>(s, st);
+        case 5: return launch_stream2<5>(s, st);
+        case 6: return launch_stream2<6>(s, st);
+        case 7: return launch_stream2<7>(s, st);
+        default: return launch_stream2<8>(s, st);
+    }
+}
+
+int cl_wide_dense_dgrad_pre(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* X0, int ldx0, int n_in0,
+                            const float* Wt0, const float* b0, float leak, float* dX, int ldo, const int* stop_flag, void* stream) {
+    if (int e = pre_check(X0, ldx0, n_in0, Wt0, b0, n_in)) return e;
+    if (dZ == nullptr || Wt == nullptr || dX == nullptr || n < 1 || n > 0x7fffffffLL || n_out < 1 || lddz < n_out || ldo < n_in) return -1;
+    if (n_out > SMAX) return -2;
+    StreamArgs s = {};
+    s.X = dZ; s.ldx = lddz; s.W = Wt; s.ldw = n_in; s.Y = dX; s.ldy = ldo; s.n = n; s.N = n_in; s.K = n_out;
+    s.leak = leak; s.stop_flag = stop_flag;
+    s.pre.X0 = X0; s.pre.ldx0 = ldx0; s.pre.K0 = n_in0; s.pre.W0 = Wt0; s.pre.b0 = b0; s.pre.N0 = n_in;
+    return s.N <= 64 ? launch_stream_n<true, EPI_DLRELU, 4, false, true>(s, (hipStream_t)stream) : launch_stream_n<true, EPI_DLRELU, 8, false, true>(s, (hipStream_t)stream);
+}
+
+int cl_wide_dense_wgrad_pre(const float* dZ, int lddz, const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, float leak, long long n,
+                            int n_out, int n_in, float* partials, int nsplit, const int* stop_flag, void* stream) {
+    if (int e = pre_check(X0, ldx0, n_in0, Wt0, b0, n_in)) return e;
+    if (dZ == nullptr || partials == nullptr || n < 1 || n > 0x7fffffffLL || n_out < 1 || nsplit < 1 || lddz < n_out) return -1;
+    GemmArgs g = {};
+    g.A = dZ; g.lda = lddz; g.B = X0; g.ldb = ldx0; g.C = partials;
+    g.M = n_out; g.N = n_in; g.K = (int)n; g.n_in = n_in;
+    g.ksplit = (int)((n + nsplit - 1) / nsplit);
+    g.ksplit = (g.ksplit + BK - 1) / BK * BK;
+    g.pstride = (long long)n_out * n_in + n_out;
+    g.leak = leak; g.stop_flag = stop_flag;
+    g.pre.X0 = X0; g.pre.ldx0 = ldx0; g.pre.K0 = n_in0; g.pre.W0 = Wt0; g.pre.b0 = b0; g.pre.N0 = n_in;
+    return launch_gemm<true, true, EPI_WGRAD>(g, nsplit, (hipStream_t)stream);
 }
 
 int cl_wide_wgrad_splits(long long n) {

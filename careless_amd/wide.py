@@ -92,18 +92,26 @@ class WidePath:
 
     WIDE_KEEP_BUDGET = 64 << 30     # bytes of activations of a whole observation set the forward pass may keep for the backward pass
 
+    def _wide_pre(self) -> bool:
+        """The first Dense layer is recomputed instead of stored (cl_wide_dense2_forward / _dgrad_pre / _wgrad_pre): at least two Dense
+        layers, at most 8 metadata columns, hidden width up to 128.  CARELESS_HIP_WIDE_PRE=0 keeps every layer's output (A/B runs)."""
+        import os
+        return (self.L >= 2 and bool(self.lib.cl_wide_pre_supported(self.d, self.w)) and os.environ.get("CARELESS_HIP_WIDE_PRE", "1") != "0")
+
     def _wide_keep_all(self, obs: ObsData):
         """Per-layer activation buffers over ALL rows of `obs` (list of tensors), or None when they do not fit: then the backward pass
         recomputes each chunk's forward into the chunk-sized buffers."""
         W = self._wide_setup()
-        need = 4 * W["nh"] * W["ldw"] * obs.N
+        need = 4 * (W["nh"] - (1 if self._wide_pre() else 0)) * W["ldw"] * obs.N
         have = getattr(obs, "wide_full", None)
         if have is not None:
             return have
         free = torch.cuda.mem_get_info(self.device)[0]
         if need > min(self.WIDE_KEEP_BUDGET, free // 4):
             return None
-        obs.wide_full = [torch.zeros(obs.N * W["ldw"], dtype=torch.float32, device=self.device) for _ in range(W["nh"])]
+        # (with the first layer recomputed its output has no buffer)
+        obs.wide_full = [None if (l == 0 and self._wide_pre()) else torch.zeros(obs.N * W["ldw"], dtype=torch.float32, device=self.device)
+                         for l in range(W["nh"])]
         return obs.wide_full
 
     def _wide_forward(self, obs: ObsData, chunk, keep: bool, st, full=None, head=None):
@@ -117,9 +125,21 @@ class WidePath:
         dst_of = (lambda l: full[l].data_ptr() + 4 * a * ldw) if full is not None else (lambda l: W["acts"][l if keep else l & 1].data_ptr())
         hs = [(obs.meta_rm.data_ptr() + 4 * a * obs.meta_ld, obs.meta_ld)]
         self._head_fused = False
+        pre = self._wide_pre()
         for l, (ow, ob, fan_in) in enumerate(layers):
+            if pre and l == 0:
+                hs.append((None, ldw))          # h_0 is never stored: layer 1's launch makes it from the metadata
+                continue
             dst = dst_of(l)
-            if head is not None and l == self.L - 1 and self.imgl is None and fan_in <= 128 and self.w <= 128:
+            if pre and l == 1:
+                (ow0, ob0, d0) = layers[0]
+                with_head = head is not None and self.L == 2 and self.imgl is None
+                off_head, loc_ptr, sig_ptr = head if with_head else (0, None, None)
+                check(lib.cl_wide_dense2_forward(hs[0][0], hs[0][1], d0, base + 4 * ow0, base + 4 * ob0, base + 4 * ow, base + 4 * ob, n, self.w, self.w,
+                                                 leak, dst, ldw, (base + 4 * off_head) if with_head else None, self.bij_kind, self.mlp.epsilon,
+                                                 loc_ptr, sig_ptr, sf, st), "cl_wide_dense2_forward")
+                self._head_fused = with_head
+            elif head is not None and l == self.L - 1 and self.imgl is None and fan_in <= 128 and self.w <= 128:
                 # the top layer carries the Dense(2) head in its epilogue: (loc, sigma) come out of the same pass
                 off_head, loc_ptr, sig_ptr = head
                 check(lib.cl_wide_dense_forward_head(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, dst, ldw,
@@ -186,8 +206,20 @@ class WidePath:
                       "cl_wide_image_dgrad")
                 dz, dzn = dzn, dz
             nsplit = min(W["nsplit"], int(lib.cl_wide_wgrad_splits(n)))
+            pre = self._wide_pre()
             for l in range(self.L - 1, -1, -1):
                 ow, ob, fan_in = layers[l]
+                if pre and l == 1:
+                    # the layer's input h_0 is recomputed from the metadata: as the weight gradient's operand and as the dgrad's mask
+                    ow0, ob0, d0 = layers[0]
+                    x0, ld0 = hs[0]
+                    check(lib.cl_wide_dense_wgrad_pre(ptr(dz), ldw, x0, ld0, d0, pbase + 4 * ow0, pbase + 4 * ob0, leak, n, w, fan_in, ptr(W["wpart"]),
+                                                      nsplit, sf, st), "cl_wide_dense_wgrad_pre")
+                    check(lib.cl_reduce_partials(ptr(W["wpart"]), nsplit, w * fan_in + w, gbase + 4 * ow, sf, st), "cl_reduce_partials")
+                    check(lib.cl_wide_dense_dgrad_pre(ptr(dz), ldw, pbase + 4 * ow, n, w, fan_in, x0, ld0, d0, pbase + 4 * ow0, pbase + 4 * ob0, leak,
+                                                      ptr(dzn), ldw, sf, st), "cl_wide_dense_dgrad_pre")
+                    dz, dzn = dzn, dz
+                    continue
                 check(lib.cl_wide_dense_wgrad(ptr(dz), ldw, hs[l][0], hs[l][1], n, w, fan_in, ptr(W["wpart"]), nsplit, sf, st), "cl_wide_dense_wgrad")
                 check(lib.cl_reduce_partials(ptr(W["wpart"]), nsplit, w * fan_in + w, gbase + 4 * ow, sf, st), "cl_reduce_partials")
                 if l > 0:

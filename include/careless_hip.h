@@ -247,6 +247,22 @@ int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const f
 /* dX[n][n_in] = (dZ[n][n_out] Wt) * LeakyReLU'(Hprev[n][n_in])   (Hprev = the layer's input = the previous layer's output; NULL: no mask) */
 int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* Hprev, int ldh, float leak,
                         float* dX, int ldo, const int* stop_flag, void* stream);
+/* The FIRST Dense layer recomputed instead of stored (round 4): with at most 8 metadata columns and a hidden width of at most 128
+ * (cl_wide_pre_supported) its output h_0 = LeakyReLU(X0 Wt0^T + b0) is an eighth of a 128 x 128 layer's work, so it is made again
+ * wherever it is needed -- 4 w bytes per row are never written, nor read three times:
+ *   cl_wide_dense2_forward   layers 0 and 1 in one launch (h_0 stays in registers, in the operand layout of layer 1); `head` non-NULL:
+ *                            the Dense(2) head in the epilogue as in cl_wide_dense_forward_head (a two-layer scaler);
+ *   cl_wide_dense_dgrad_pre  layer 1's dgrad, the mask LeakyReLU'(h_0) recomputed from the metadata (replaces Hprev);
+ *   cl_wide_dense_wgrad_pre  layer 1's weight gradient, its input operand h_0 recomputed while the tiles are staged (replaces H).
+ * X0 = metadata rows [n][ldx0] (ldx0 = cl_wide_ld(n_in0), 16-byte aligned, padding columns zero).                                   */
+int cl_wide_pre_supported(int n_in0, int w);
+int cl_wide_dense2_forward(const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, const float* Wt1, const float* b1, long long n,
+                           int w0, int w1, float leak, float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out,
+                           const int* stop_flag, void* stream);
+int cl_wide_dense_dgrad_pre(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* X0, int ldx0, int n_in0,
+                            const float* Wt0, const float* b0, float leak, float* dX, int ldo, const int* stop_flag, void* stream);
+int cl_wide_dense_wgrad_pre(const float* dZ, int lddz, const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, float leak, long long n,
+                            int n_out, int n_in, float* partials, int nsplit, const int* stop_flag, void* stream);
 /* partials[s][n_out * n_in + n_out] = (dWt | db) over the s-th of nsplit row ranges; H is the layer's input */
 int cl_wide_wgrad_splits(long long n);
 int cl_wide_dense_wgrad(const float* dZ, int lddz, const float* H, int ldh, long long n, int n_out, int n_in, float* partials, int nsplit,
