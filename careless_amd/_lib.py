@@ -71,7 +71,7 @@ class MlpArgs(C.Structure):
         ("imgl", _vp), ("d_imgl", _vp), ("n_imgl", C.c_int), ("n_images", C.c_int), ("tile_img", _vp), ("row_map", _vp),
         ("gmeta", _vp), ("tile_gmax", _vp), ("noise_row", _vp),
         ("act_out", _vp), ("dH_ext", _vp), ("dX_out", _vp),
-        ("dzf_obs", _vp), ("dimg_obs", _vp), ("nll_part", _vp),
+        ("dzf_obs", _vp), ("dimg_obs", _vp), ("nll_part", _vp), ("det_slot", _vp),
     ]
 
 

@@ -15,7 +15,7 @@ void cl_abi_sizes(size_t out[5]) {
 }
 
 int cl_det_reduce(const cl_det_args* a, void* stream) {
-    if (a == nullptr || a->dzf_obs == nullptr || a->perm_refl == nullptr || a->seg_refl == nullptr || a->dz_f == nullptr || a->R < 1 || a->S < 1 ||
+    if (a == nullptr || a->dzf_obs == nullptr || a->seg_refl == nullptr || a->dz_f == nullptr || a->R < 1 || a->S < 1 ||
         a->nll_part == nullptr || a->nparts < 1 || a->scalars == nullptr)
         return -1;
     if (a->d_img != nullptr && (a->dimg_obs == nullptr || a->perm_img == nullptr || a->seg_img == nullptr || a->n_images < 1)) return -1;

@@ -518,12 +518,22 @@ __global__ __launch_bounds__(256) void det_refl_kernel(const cl_det_args A) {
     const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool on = r < A.R;
     const int k0 = on ? A.seg_refl[r] : 0, k1 = on ? A.seg_refl[r + 1] : 0;
-    for (int s = 0; s < A.S; ++s) {
+    // the sixteen lanes of a reflection = (row slot, sample): the S' = 1, 2, 4, 8 or 16 samples of a row are consecutive lanes (a row's
+    // record is S consecutive floats: one request), 16 / S' rows are in flight per pass; more than 16 samples go in chunks of 16
+    const int Sp = A.S <= 1 ? 1 : (A.S <= 2 ? 2 : (A.S <= 4 ? 4 : (A.S <= 8 ? 8 : 16)));
+    const int ss = sub & (Sp - 1), slot = sub / Sp, nslot = 16 / Sp;
+    for (int s0 = 0; s0 < A.S; s0 += 16) {
+        const int s = s0 + ss;
         float acc = 0.0f;
-        for (int k = k0 + sub; k < k1; k += 16) acc += A.dzf_obs[(size_t)A.perm_refl[k] * A.S + s];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (on && sub == 0) A.dz_f[(size_t)r * A.S + s] += acc;
+        if (s < A.S) {
+            if (A.perm_refl != nullptr) {
+                for (int k = k0 + slot; k < k1; k += nslot) acc += A.dzf_obs[(size_t)A.perm_refl[k] * A.S + s];
+            } else {            // the records were stored in reflection order (cl_mlp_args.det_slot): a contiguous read
+                for (int k = k0 + slot; k < k1; k += nslot) acc += A.dzf_obs[(size_t)k * A.S + s];
+            }
+        }
+        for (int off = 8; off >= Sp; off >>= 1) acc += __shfl_xor(acc, off);      // over the row slots, fixed order
+        if (on && slot == 0 && s < A.S) A.dz_f[(size_t)r * A.S + s] += acc;
     }
 }
 

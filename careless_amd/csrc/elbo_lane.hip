@@ -42,15 +42,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CL_LANE_SCHED
 #define CL_LANE_SCHED 1
 #endif
-#ifndef CL_LANE_PKDZ
-#define CL_LANE_PKDZ 0          /* LeakyReLU derivative on packed fp32: step(h) as a clamped multiply, slope = leak + (1 - leak) step, dZ = dH slope (three packed instructions per feature pair instead of a multiply, two compares and two selects) */
-#endif
-#ifndef CL_LANE_NO_DZF
-#define CL_LANE_NO_DZF 0        /* diagnostic builds only (WRONG gradients): 1 drops the amplitude-gradient atomics -- what is left of WRITE_SIZE is everything else the kernel writes */
-#endif
-#ifndef CL_LANE_PAIRS
-#define CL_LANE_PAIRS 0         /* 1: the sampling epilogue takes two MC samples at a time on packed fp32 (monochromatic data, S >= 2, production instance) */
-#endif
 #ifndef CL_LANE_FAST_DIV
 #define CL_LANE_FAST_DIV 1      /* Student-T: 1/nu hoisted, the per-sample division as reciprocal + Newton step (a lone wave pays ~8 cycles per instruction of the two IEEE divisions) */
 #endif
@@ -87,9 +78,6 @@ __device__ __forceinline__ f32x4 mfma_bk(float a, float b, f32x4 c) { return __b
 // wait states between them; the only other reader is the flush, a barrier later.)
 #ifndef CL_LANE_ASM_ACC
 #define CL_LANE_ASM_ACC 1
-#endif
-#ifndef CL_LANE_ACC2
-#define CL_LANE_ACC2 1          /* 1: two accumulators per layer (consecutive weight-gradient MFMAs never depend on each other); 0: one */
 #endif
 __device__ __forceinline__ void mfma16_acc(f32x4& acc, float a, float b) {
 #if CL_LANE_ASM_ACC
@@ -302,9 +290,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     constexpr int PAR = (TPAR - 1) * 16 * PIT;         // second copy of sZ / sH (layers alternate between the two; LX: one copy)
 
     // ---- accumulators that live across all tiles of this wave ----------------------------------------------------------
-    f32x4 wacc[NL], wacd[CL_LANE_ACC2 ? NL : 1];           // dW_l = wacc + wacd: lane (j, q), element t = dW_l[out 4 q + t][in j]  (in 15: the bias)
+    f32x4 wacc[NL], wacd[NL];           // dW_l = wacc + wacd: lane (j, q), element t = dW_l[out 4 q + t][in j]  (in 15: the bias)
 #pragma unroll
-    for (int l = 0; l < NL; ++l) { wacc[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; if (CL_LANE_ACC2) wacd[CL_LANE_ACC2 ? l : 0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    for (int l = 0; l < NL; ++l) { wacc[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; wacd[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
     f32x4 wacc0b = {0.0f, 0.0f, 0.0f, 0.0f}, wacd0b = {0.0f, 0.0f, 0.0f, 0.0f};      // LX: layer 0's second input block (columns 15 .. 30)
     f32x2 hacc[W + 1];                  // head: per-lane sums of (dloc, draw) x top activation k; [W]: the bias
 #pragma unroll
@@ -373,11 +361,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     if (wt_begin < n_wt) prefetch(wt_begin, 0);
 
     const float ones = 1.0f;
-#if CL_LANE_PKDZ
-    const f32x2 inf2 = {__builtin_inff(), __builtin_inff()}, oml2 = {1.0f - leak, 1.0f - leak};
-    f32x2 leak2 = {leak, leak};
-    asm volatile("" : "+v"(leak2));          // (a register pair: a packed instruction reads one scalar-register operand)
-#endif
     const int rr16 = lane & 15, kq = lane >> 4;
     const float* const rdZ = sZ + rr16 * PIT + 4 * kq;       // wgrad operands: row (lane & 15), observations 16 c + 4 kq .. + 3
     const float* const rdH = sH + rr16 * PIT + 4 * kq;
@@ -437,6 +420,10 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 nkey = (long long)ld_uo(A.noise_row, 4u * (unsigned)(wt * WT + lane));
             }
         }
+        // deterministic mode with caller-assigned record slots (det_slot: reflection order): this lane's slot -- a plain-layout lane's
+        // row is its position, a packed one's comes from row_map (rme), both known here for in-range rows only
+        int dslot_raw = 0;
+        if (det && A.det_slot != nullptr && !PACKED) dslot_raw = ld_uo(A.det_slot, 4u * (unsigned)min(wt * WT + lane, A.n_obs - 1));
         LSTAMP(0);
         // ================= forward ==========================================================================================
         // (activations and dZ in aligned register pairs: the packed fp32 instructions of the backward pass take them as they stand)
@@ -535,6 +522,8 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         const float aim = (A.use_img && img > 0 && rid >= 0) ? aim_raw : 1.0f;
         const long long gobs = PACKED ? (long long)rme : (long long)wt * WT + lane;      // this lane's observation in the caller's order
         const unsigned zoff = 4u * (unsigned)(rid < 0 ? 0 : rid) * (unsigned)S;
+        // record of this lane's observation in dzf_obs (deterministic mode)
+        const unsigned drec = (det && A.det_slot != nullptr) ? (unsigned)(PACKED ? (rid >= 0 ? A.det_slot[gobs] : 0) : dslot_raw) : (unsigned)gobs;
         float dsig_draw;
         const float sigma = cl_scale_bij(o1, A.bij_kind, A.eps, &dsig_draw);
         float pdl = 0.0f, pds = 0.0f, pda = 0.0f;
@@ -592,55 +581,16 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
                 const float dzs = gi * zf * zf;
                 if (coal) sS[(s & (SPRE - 1)) * 64 + lane] = gi * zs * 2.0f * zf;      // (the sample's slot: its amplitude was read at the start of this sample)
-                else if (det) *reinterpret_cast<float*>(reinterpret_cast<char*>(A.dzf_obs) + 4u * ((unsigned)gobs * (unsigned)S + (unsigned)s)) = gi * zs * 2.0f * zf;
-                else if (!CL_LANE_NO_DZF) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
+                else if (det) *reinterpret_cast<float*>(reinterpret_cast<char*>(A.dzf_obs) + 4u * (drec * (unsigned)S + (unsigned)s)) = gi * zs * 2.0f * zf;
+                else atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dzf_p) + zoff + 4u * s), gi * zs * 2.0f * zf);
                 const float dt = dzs * aim;
                 pdl += dt;
                 pds += dt * eta;
                 pda += dzs * tq;
             }
         };
-#if CL_LANE_PAIRS
-        // Two MC samples of this lane's observation at once, as the halves of packed fp32 registers (v_pk_fma / mul / add_f32): a lone
-        // wave pays ~8 cycles per instruction whatever it does, so the ~75 instructions of a sample are halved in number, the hardware
-        // reciprocal / logarithm alone stay per sample.  Production instance only (monochromatic data, in-kernel noise, no Evans-2011
-        // terms, no prediction output), gradients through LDS (coal); arithmetic of cl_lik_log_prob3.
-        f32x2 nll2 = {0.0f, 0.0f}, pdl2 = {0.0f, 0.0f}, pds2 = {0.0f, 0.0f}, pda2 = {0.0f, 0.0f};
-        const bool pairs = !FULL && !PACKED && coal;        // wave-uniform
-        auto sample2 = [&](int s, f32x2 eta, f32x2 zf) {
-            const f32x2 tq = (sigma * eta + o0) + shift;
-            const f32x2 zs = aim * tq;
-            const f32x2 zz = zf * zf;
-            const f32x2 ipred = zs * zz;
-            const f32x2 y = (ipred - io) * inv_sg;
-            f32x2 dll, ll;
-            if (lik_kind == CL_LIK_NORMAL) {
-                dll = -y * inv_sg;
-                ll = (-0.5f * y) * y - (0.5f * CL_LOG_2PI_F + log_sg);
-            } else {
-                const f32x2 y2 = y * y;
-                const f32x2 den = y2 + dof;
-                f32x2 r = {cl_fast_rcp(den[0]), cl_fast_rcp(den[1])};
-                r = r * (2.0f - den * r);
-                dll = ((-(dof + 1.0f) * inv_sg) * y) * r;
-                const f32x2 xx = y2 * inv_dof, u = xx + 1.0f;
-                const f32x2 lg = {cl_fast_log(u[0]), cl_fast_log(u[1])}, ru = {cl_fast_rcp(u[0]), cl_fast_rcp(u[1])};
-                ll = (-0.5f * (dof + 1.0f)) * (lg + (xx - (u - 1.0f)) * ru) + (lik_const - log_sg);
-            }
-            nll2 -= ll * w_ll;
-            const f32x2 gi = -dll * w_ll;
-            const f32x2 dzs = gi * zz;
-            const f32x2 ga = (gi * zs) * (2.0f * zf);
-            sS[(s & (SPRE - 1)) * 64 + lane] = ga[0];
-            sS[((s + 1) & (SPRE - 1)) * 64 + lane] = ga[1];
-            const f32x2 dt = dzs * aim;
-            pdl2 += dt;
-            pds2 += dt * eta;
-            pda2 += dzs * tq;
-        };
-#endif
         // (deterministic mode: the observation's own record in dzf_obs instead of its reflection's row of dz_f)
-        if (coal) sQ[lane] = (rid >= 0) ? (det ? 4u * (unsigned)gobs * (unsigned)S : zoff) : 0xFFFFFFFFu;
+        if (coal) sQ[lane] = (rid >= 0) ? (det ? 4u * drec * (unsigned)S : zoff) : 0xFFFFFFFFu;
         int sb = 0;                                      // first sample of the batch
         do {
             const int se = (sb + SPRE < S) ? sb + SPRE : S;
@@ -678,17 +628,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                         sample(s, act ? eta_p[s] : 0.0f, act ? zf : 0.0f);
                     }
                 } else {
-                    int s = sb;
-#if CL_LANE_PAIRS
-                    if (pairs) {                                 // (not Laue: this lane's row is a real observation here)
-                        for (; s + 2 <= se; s += 2) {
-                            const f32x2 zf = {(s > 0) ? sS[(s & (SPRE - 1)) * 64 + lane] : zf0, sS[((s + 1) & (SPRE - 1)) * 64 + lane]};
-                            const f32x2 et = {sE[(s & (SPRE - 1)) * 64 + lane], sE[((s + 1) & (SPRE - 1)) * 64 + lane]};
-                            sample2(s, et, zf);
-                        }
-                    }
-#endif
-                    for (; s < se; ++s) {
+                    for (int s = sb; s < se; ++s) {
                         const float zf = (s > 0) ? sS[(s & (SPRE - 1)) * 64 + lane] : zf0;
                         sample(s, sE[(s & (SPRE - 1)) * 64 + lane], act ? zf : 0.0f);
                     }
@@ -702,18 +642,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     const float g = sS[ss * 64 + 8 * j + oj];
                     if (sb + ss < S && zq != 0xFFFFFFFFu) {
                         if (det) *reinterpret_cast<float*>(reinterpret_cast<char*>(A.dzf_obs) + zq + 4u * (unsigned)(sb + ss)) = g;
-                        else if (!CL_LANE_NO_DZF) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(A.dz_f) + zq + 4u * (unsigned)(sb + ss)), g);
+                        else atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(A.dz_f) + zq + 4u * (unsigned)(sb + ss)), g);
                     }
                 }
             }
             sb += SPRE;
         } while (sb < S);
-#if CL_LANE_PAIRS
-        nll_acc += nll2[0] + nll2[1];
-        pdl += pdl2[0] + pdl2[1];
-        pds += pds2[0] + pds2[1];
-        pda += pda2[0] + pda2[1];
-#endif
         if (A.use_img && det) {
             if (rid >= 0) A.dimg_obs[gobs] = pda;                        // summed per image, in row order, by cl_det_reduce
         } else if (A.use_img) {
@@ -755,18 +689,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             // into VCC, wait states, select, per element) a lone wave pays ~9 cycles per instruction; compares into scalar
             // register pairs first and the selects after them issue back to back (scripts/probe/pkfma_probe.hip: 5.4 cycles).
             auto dz_of = [&](f32x2 (&dzp)[W / 2], const f32x2 (&hp)[W / 2], const f32x4 (&dh)[NC]) {
-#if CL_LANE_PKDZ
-                // step(h) = clamp(h * inf) (h > 0 -> 1; h < 0 -> 0; h = 0 -> NaN -> 0 under the code object's clamp mode), slope = leak +
-                // (1 - leak) step (exactly 1 or leak for the reference's 0.01), dZ = dH * slope: packed, two features per instruction
-#pragma unroll
-                for (int p = 0; p < W / 2; ++p) {
-                    f32x2 st, sl;
-                    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(st) : "v"(hp[p]), "s"(inf2));
-                    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(sl) : "v"(st), "s"(oml2), "v"(leak2));
-                    const f32x2 d2 = {dh[p >> 1][2 * (p & 1)], dh[p >> 1][2 * (p & 1) + 1]};
-                    dzp[p] = d2 * sl;
-                }
-#else
                 f32x4 lk[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) lk[c] = dh[c] * leak;
@@ -783,7 +705,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                             asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(dzp[f >> 1][f & 1]) : "v"(lk[f >> 2][f & 3]), "v"(dh[f >> 2][f & 3]), "s"(m[i]));
                     }
                 }
-#endif
             };
             // LDS operation number i of layer ll: staging writes (dZ, the layer's input: feature pairs) into the tiles of the
             // layer's parity, then the transposed reads of its weight-gradient operands; past those, the dgrad weights of the
@@ -834,7 +755,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 static_for<0, 16>([&](auto ic_) {
                     constexpr int i = decltype(ic_)::value, c = (i >> 3) * 2, t = (i >> 1) & 3;
                     if constexpr ((i & 1) == 0) mfma16_acc(wacc[l], pa[q][c][t], pb[q][c][t]);
-                    else mfma16_acc(CL_LANE_ACC2 ? wacd[CL_LANE_ACC2 ? l : 0] : wacc[l], pa[q][c + 1][t], pb[q][c + 1][t]);
+                    else mfma16_acc(wacd[l], pa[q][c + 1][t], pb[q][c + 1][t]);
                     if constexpr (l > 0) {
                         lds_op(std::integral_constant<int, (l > 0 ? l - 1 : 0)>{}, std::integral_constant<int, 2 * i>{});
                         lds_op(std::integral_constant<int, (l > 0 ? l - 1 : 0)>{}, std::integral_constant<int, 2 * i + 1>{});
@@ -850,7 +771,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     static_for<0, 16>([&](auto ic_) {
                         constexpr int i = decltype(ic_)::value, c = (i >> 3) * 2, t = (i >> 1) & 3;
                         if constexpr ((i & 1) == 0) mfma16_acc(wacc0b, pa[0][c][t], pb[1][c][t]);
-                        else mfma16_acc(CL_LANE_ACC2 ? wacd0b : wacc0b, pa[0][c + 1][t], pb[1][c + 1][t]);
+                        else mfma16_acc(wacd0b, pa[0][c + 1][t], pb[1][c + 1][t]);
                         LFENCE();
                     });
                 }
@@ -867,11 +788,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     // fixed binary tree over the waves (deterministic): at stride s the waves with (wv & (2s - 1)) == s park their sums in the
     // region of wave wv - s, which adds them to its own
     constexpr int REG = SM::REG;
-#if CL_LANE_ACC2
 #pragma unroll
     for (int l = 0; l < NL; ++l) wacc[l] += wacd[l];
     wacc0b += wacd0b;
-#endif
     float* const sHead = smem + (NWV / 2) * REG;            // [wave][2 * 16]: the head's sums of every wave
     {
         // head: wave sums of the per-lane sums

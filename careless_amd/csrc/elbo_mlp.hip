@@ -460,7 +460,20 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     // ---- per-image layers: gradient flush and weight reload on an image change ---------------------------------
     int cur_img = -1;
     const size_t imgl_blk = ILAY ? (size_t)A.n_images * (size_t)(w * w + w) : 0;      // floats per image layer
+    // An image whose tiles all lie inside this workgroup's (contiguous) range has ONE writer: its gradient is stored, not added with
+    // atomics (round 4).  Only the image a range starts in the middle of, and the one it ends in the middle of, are shared with the
+    // neighbouring workgroup -- 2 of the ~37 images of a range at 1 000 rows per image; before, every swap sent w * w + w float atomics
+    // per image layer to the memory side (39 M per step on the bench workload, twice the amplitude-gradient atomics of the whole launch).
+    int img_first = -1, img_last = -1;
+    bool first_shared = false, last_shared = false;
+    if (ILAY && A.n_imgl > 0 && tile_begin < tile_end) {
+        img_first = __builtin_amdgcn_readfirstlane(A.tile_img[tile_begin]);
+        img_last = __builtin_amdgcn_readfirstlane(A.tile_img[tile_end - 1]);
+        first_shared = tile_begin > 0 && __builtin_amdgcn_readfirstlane(A.tile_img[tile_begin - 1]) == img_first;
+        last_shared = tile_end < ntiles && __builtin_amdgcn_readfirstlane(A.tile_img[tile_end]) == img_last;
+    }
     auto imgl_flush = [&](int im) {
+        const bool shared_img = (im == img_first && first_shared) || (im == img_last && last_shared);      // workgroup-uniform
 #pragma unroll
         for (int l = 1; l < LMAX; ++l) {
             if (l >= Ld && l < L) {
@@ -469,6 +482,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 float* __restrict__ gB = A.d_imgl + (size_t)(l - Ld) * imgl_blk + (size_t)A.n_images * (size_t)(w * w) + (size_t)im * w;
                 const int grp = wv % WG::GROUPS;
                 const int ob = (grp * WG::BPW) / FB, ib0 = (grp * WG::BPW) - ob * FB;
+                // (a block that several waves accumulate over different observations -- fewer blocks than waves -- has several writers)
+                const bool shared = shared_img || WG::GROUPS < CL_NW;
 #pragma unroll
                 for (int b = 0; b < WB; ++b) {
                     if (b < WG::BPW) {
@@ -478,8 +493,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         for (int t = 0; t < 4; ++t) {
                             const int o = 16 * ob + 4 * q + t;
                             const float g = in_lds ? acc_slot(l)[t] : wacc[l < LREG ? l : 0][b][t];
-                            if (sl(o) < w && sl(i) < w) atomicAdd(gW + sl(o) * w + sl(i), g);
-                            if (BONE && sl(o) < w && i == 15) atomicAdd(gB + sl(o), g);
+                            if (sl(o) < w && sl(i) < w) { if (shared) atomicAdd(gW + sl(o) * w + sl(i), g); else gW[sl(o) * w + sl(i)] = g; }
+                            if (BONE && sl(o) < w && i == 15) { if (shared) atomicAdd(gB + sl(o), g); else gB[sl(o)] = g; }
                             if (!in_lds) wacc[l < LREG ? l : 0][b][t] = 0.0f;
                         }
                         if (in_lds) acc_slot(l) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -545,6 +560,12 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             nkey = (E0->noise_row != nullptr) ? (long long)E0->noise_row[gobs_e] : E0->obs_offset + rme;
         }
         const unsigned eoff = IMGL ? 4u * (unsigned)rme * (unsigned)S : eoff_t;
+#if CL_DET
+        // deterministic mode: byte offset of this observation's record in dzf_obs -- its own row, or the slot the caller assigns it
+        // (det_slot: reflection order, so that cl_det_reduce reads contiguously)
+        unsigned dzo = 4u * (unsigned)gobs_e * (unsigned)S;
+        if (MODE == 0 && rid >= 0 && E0->det_slot != nullptr) dzo = 4u * (unsigned)E0->det_slot[gobs_e] * (unsigned)S;
+#endif
         const float* __restrict__ eta_t = E0->eta ? (IMGL ? E0->eta : E0->eta + (size_t)tile_u * CL_TILE * S) : nullptr;
         float* __restrict__ ipred_t = E0->ipred_out ? (IMGL ? E0->ipred_out : E0->ipred_out + (size_t)tile_u * CL_TILE * S) : nullptr;
         if (MODE == 0 && rid >= 0) {
@@ -778,7 +799,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     const float gi = -dll * E->w_ll;                 // dNLL / d ipred
                     const float dzs = gi * zf * zf;
 #if CL_DET
-                    *ptr_uo(E->dzf_obs + (size_t)tile_u * CL_TILE * S, eoff_t + 4u * s) = gi * zs * 2.0f * zf;      // summed per reflection, in row order, by cl_det_reduce
+                    *ptr_uo(E->dzf_obs, dzo + 4u * s) = gi * zs * 2.0f * zf;      // summed per reflection, in row order, by cl_det_reduce
 #else
                     atomicAdd(ptr_uo(E->dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
 #endif

@@ -395,7 +395,8 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
         const long long gobs = PACKED ? (long long)rme : (long long)wt * WT + (lane & (WT - 1));      // this lane's observation in the caller's order
         const unsigned zoff = 4u * (unsigned)(rid < 0 ? 0 : rid) * (unsigned)S;
         const bool det = E->dzf_obs != nullptr;                            // wave-uniform: deterministic mode (stores instead of float atomics)
-        const unsigned dob = 4u * (unsigned)gobs * (unsigned)S;            // this observation's record in dzf_obs (< 4 GiB: cl_launch_narrow)
+        // this observation's record in dzf_obs (< 4 GiB: cl_launch_narrow): its own row, or the slot the caller assigns it (det_slot)
+        const unsigned dob = 4u * (unsigned)((det && E->det_slot != nullptr && rid >= 0) ? E->det_slot[gobs] : (int)gobs) * (unsigned)S;
         float o0 = acc_h[0], o1 = acc_h[1];
         if (S > 1) {                                     // wave-uniform
             o0 = __shfl(o0, lane & 31);

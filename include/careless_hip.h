@@ -191,6 +191,9 @@ typedef struct cl_mlp_args {
     float* dzf_obs;             /* [n_obs][S]                                                                          */
     float* dimg_obs;            /* [n_obs]                                                                             */
     double* nll_part;           /* [grid]                                                                              */
+    const int* det_slot;        /* optional [n_obs] (round 4): observation i's record goes to dzf_obs[det_slot[i]][S] instead of dzf_obs[i][S] --
+                                   the caller's reflection-sorted position, so that cl_det_reduce (perm_refl NULL) reads every reflection's
+                                   records contiguously instead of gathering them; the scattered STORES cost the kernel nothing it waits for */
 } cl_mlp_args;
 
 enum { CL_LIK_NORMAL_ = 0, CL_LIK_STUDENTT_ = 1 };
@@ -217,7 +220,7 @@ int cl_reduce_partials(const float* partials, int nparts, int P, float* grad_mlp
  * perm_img / seg_img the same by image.  dz_f[r][s] += sum in that order; d_img[m-1] += ... (image 0 is pinned); scalars[NLL] += sum
  * of nll_part in index order.                                                                                              */
 typedef struct cl_det_args {
-    const float* dzf_obs; const int* perm_refl; const int* seg_refl; int R, S; float* dz_f;
+    const float* dzf_obs; const int* perm_refl; const int* seg_refl; int R, S; float* dz_f;      /* perm_refl NULL: records already in reflection order (det_slot) */
     const float* dimg_obs; const int* perm_img; const int* seg_img; int n_images; float* d_img;      /* d_img NULL: no image scales */
     const double* nll_part; int nparts; double* scalars;
     const int* stop_flag;
