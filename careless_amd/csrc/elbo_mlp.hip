@@ -26,8 +26,8 @@
 //     by all of them: LDS operands are double-buffered by hand one MFMA group ahead (CL_SCHED_FENCE) and the post-barrier
 //     latency windows are filled with independent work (bias-gradient reads, the next layer's dZ, staging writes between the
 //     dgrad MFMAs) -- DESIGN.md section 4.1.
-// The file is compiled five times (build.py): plain; the same with the epilogue's atomics turned into stores (-DCL_DET=1, the
-// deterministic mode of include/careless_hip.h: dzf_obs / dimg_obs / nll_part); packed layout + per-image layers (-DCL_IMGL=1, NeuralImageScaler); packed
+// The file is compiled seven times (build.py): plain; the same with the epilogue's atomics turned into stores (-DCL_DET=1, the
+// deterministic mode of include/careless_hip.h: dzf_obs / dimg_obs / nll_part; once more for the packed layout, -DCL_IMGL=2 -DCL_DET=1); packed layout + per-image layers (-DCL_IMGL=1, NeuralImageScaler); packed
 // layout only (-DCL_IMGL=2, single-pass Laue: harmonic group sums as lane reductions in the epilogue); layer-block chains
 // (-DCL_CHAIN=1, scalers deeper than one launch holds).
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
@@ -460,20 +460,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     // ---- per-image layers: gradient flush and weight reload on an image change ---------------------------------
     int cur_img = -1;
     const size_t imgl_blk = ILAY ? (size_t)A.n_images * (size_t)(w * w + w) : 0;      // floats per image layer
-    // An image whose tiles all lie inside this workgroup's (contiguous) range has ONE writer: its gradient is stored, not added with
-    // atomics (round 4).  Only the image a range starts in the middle of, and the one it ends in the middle of, are shared with the
-    // neighbouring workgroup -- 2 of the ~37 images of a range at 1 000 rows per image; before, every swap sent w * w + w float atomics
-    // per image layer to the memory side (39 M per step on the bench workload, twice the amplitude-gradient atomics of the whole launch).
-    int img_first = -1, img_last = -1;
-    bool first_shared = false, last_shared = false;
-    if (ILAY && A.n_imgl > 0 && tile_begin < tile_end) {
-        img_first = __builtin_amdgcn_readfirstlane(A.tile_img[tile_begin]);
-        img_last = __builtin_amdgcn_readfirstlane(A.tile_img[tile_end - 1]);
-        first_shared = tile_begin > 0 && __builtin_amdgcn_readfirstlane(A.tile_img[tile_begin - 1]) == img_first;
-        last_shared = tile_end < ntiles && __builtin_amdgcn_readfirstlane(A.tile_img[tile_end]) == img_last;
-    }
     auto imgl_flush = [&](int im) {
-        const bool shared_img = (im == img_first && first_shared) || (im == img_last && last_shared);      // workgroup-uniform
 #pragma unroll
         for (int l = 1; l < LMAX; ++l) {
             if (l >= Ld && l < L) {
@@ -482,8 +469,6 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 float* __restrict__ gB = A.d_imgl + (size_t)(l - Ld) * imgl_blk + (size_t)A.n_images * (size_t)(w * w) + (size_t)im * w;
                 const int grp = wv % WG::GROUPS;
                 const int ob = (grp * WG::BPW) / FB, ib0 = (grp * WG::BPW) - ob * FB;
-                // (a block that several waves accumulate over different observations -- fewer blocks than waves -- has several writers)
-                const bool shared = shared_img || WG::GROUPS < CL_NW;
 #pragma unroll
                 for (int b = 0; b < WB; ++b) {
                     if (b < WG::BPW) {
@@ -493,8 +478,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         for (int t = 0; t < 4; ++t) {
                             const int o = 16 * ob + 4 * q + t;
                             const float g = in_lds ? acc_slot(l)[t] : wacc[l < LREG ? l : 0][b][t];
-                            if (sl(o) < w && sl(i) < w) { if (shared) atomicAdd(gW + sl(o) * w + sl(i), g); else gW[sl(o) * w + sl(i)] = g; }
-                            if (BONE && sl(o) < w && i == 15) { if (shared) atomicAdd(gB + sl(o), g); else gB[sl(o)] = g; }
+                            if (sl(o) < w && sl(i) < w) atomicAdd(gW + sl(o) * w + sl(i), g);
+                            if (BONE && sl(o) < w && i == 15) atomicAdd(gB + sl(o), g);
                             if (!in_lds) wacc[l < LREG ? l : 0][b][t] = 0.0f;
                         }
                         if (in_lds) acc_slot(l) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -563,8 +548,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #if CL_DET
         // deterministic mode: byte offset of this observation's record in dzf_obs -- its own row, or the slot the caller assigns it
         // (det_slot: reflection order, so that cl_det_reduce reads contiguously)
-        unsigned dzo = 4u * (unsigned)gobs_e * (unsigned)S;
-        if (MODE == 0 && rid >= 0 && E0->det_slot != nullptr) dzo = 4u * (unsigned)E0->det_slot[gobs_e] * (unsigned)S;
+        const int drow = IMGL ? rme : gobs_e;                      // (packed layouts: the caller's row, as for eta / ipred_out)
+        unsigned dzo = 4u * (unsigned)drow * (unsigned)S;
+        if (MODE == 0 && rid >= 0 && E0->det_slot != nullptr) dzo = 4u * (unsigned)E0->det_slot[drow] * (unsigned)S;
 #endif
         const float* __restrict__ eta_t = E0->eta ? (IMGL ? E0->eta : E0->eta + (size_t)tile_u * CL_TILE * S) : nullptr;
         float* __restrict__ ipred_t = E0->ipred_out ? (IMGL ? E0->ipred_out : E0->ipred_out + (size_t)tile_u * CL_TILE * S) : nullptr;
@@ -758,7 +744,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         if (mem == 0) nll_acc -= ll * E->w_ll;
                         const float gi = -dll * E->w_ll;                 // dNLL / d iconv = dNLL / d ipred of every member
                         const float dzs = gi * zf * zf;
+#if CL_DET
+                        *ptr_uo(E->dzf_obs, dzo + 4u * s) = gi * zs * 2.0f * zf;      // summed per reflection, in a fixed order, by cl_det_reduce
+#else
                         atomicAdd(ptr_uo(E->dz_f, zoff + 4u * s), gi * zs * 2.0f * zf);
+#endif
                         const float dt = dzs * aim;
                         pdl += dt;
                         pds += dt * eta;
@@ -818,7 +808,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             STAMP(12);
 #if CL_DET
             if (E->use_img) {
-                if (qe == 0 && rid >= 0) E->dimg_obs[gobs_e] = pda;      // summed per image, in row order, by cl_det_reduce
+                if (qe == 0 && rid >= 0) E->dimg_obs[IMGL ? rme : gobs_e] = pda;      // summed per image, in row order, by cl_det_reduce
             }
 #else
             if (E->use_img) {
@@ -1408,7 +1398,14 @@ static bool narrow_enabled() {          // CARELESS_HIP_NARROW=0 keeps narrow sc
 }
 #endif
 
-#if CL_DET
+#if CL_DET && CL_IMGL == 2
+// packed layout (single-pass Laue) without float atomics: the seventh compilation of this file (build.py: elbo_mlp_packed_det)
+int cl_launch_mlp_packed_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (mode != 0 || a.row_map == nullptr || a.n_obs != a.n_pad || a.n_imgl != 0 || a.ev11 != nullptr) return -2;
+    if (a.gmeta != nullptr && a.tile_gmax == nullptr) return -1;
+    if (a.dzf_obs == nullptr || a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
+    if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+#elif CL_DET
 int cl_launch_mlp_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     // plain layout, full step, no Evans-2011 terms (their gradients are wave atomics), every store target present
     if (mode != 0 || a.row_map != nullptr || a.n_imgl > 0 || a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr || a.ev11 != nullptr) return -2;
@@ -1442,6 +1439,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
             if (cl_lane_supports(a) && lane_enabled()) return cl_launch_lane(a, g, st);
             if (cl_narrow_supports(a) && narrow_enabled()) return cl_launch_narrow(a, g, st);
         }
+        if (a.row_map != nullptr && a.n_imgl == 0) return cl_launch_mlp_packed_det(a, mode, grid, st);      // single-pass Laue, wider than 15
         return cl_launch_mlp_det(a, mode, grid, st);
     }
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
@@ -1479,7 +1477,7 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     if (a.dzf_obs != nullptr) {
         if (mode == 0 && a.ev11 == nullptr && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
         if (mode == 0 && a.ev11 == nullptr && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
-        unit = ", deterministic";
+        unit = (a.row_map != nullptr && a.n_imgl == 0) ? ", packed deterministic" : ", deterministic";
     } else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
     else if (a.n_imgl > 0) unit = ", image layers";
     else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }

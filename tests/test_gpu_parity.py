@@ -1064,11 +1064,15 @@ def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
                                 # single-pass Laue on the default scaler's kernels (packed layout: stores by the caller's row)
                                 dict(N=900, R=50, L=20, w=10, S=3, laue=True, perturb=0.02),
                                 dict(N=700, R=40, L=4, w=12, S=2, laue=True, perturb=0.03, likelihood="studentt", dof=8.0),
+                                # ... and on the 64- / 32-wide fused kernel (the packed deterministic compilation of elbo_mlp.hip)
+                                dict(N=900, R=50, L=5, w=64, S=3, laue=True),
+                                dict(N=700, R=40, L=3, w=32, S=9, laue=True, likelihood="studentt", dof=8.0, extra_meta=14),
                                 # the double-Wilson prior (fixed r): parents pull their children's terms in list order
                                 dict(N=800, R=60, d0=5, L=5, w=64, S=3, double_wilson=True),
                                 dict(N=900, R=50, d0=5, L=20, w=10, S=2, double_wilson=True, perturb=0.02, likelihood="studentt", dof=8.0)],
                          ids=["mono_5x64", "cli_default_20x10", "rows_in_arbitrary_order_S8", "no_image_scales_klweight",
-                              "lane_posenc_d21_S8", "lane_20x8_S11", "narrow_6x10_S5", "narrow_9x13_d12", "laue_lane_20x10_S3", "laue_narrow_4x12", "double_wilson_5x64", "double_wilson_lane_20x10"])
+                              "lane_posenc_d21_S8", "lane_20x8_S11", "narrow_6x10_S5", "narrow_9x13_d12", "laue_lane_20x10_S3", "laue_narrow_4x12", "laue_5x64_S3", "laue_3x32_d20_S9",
+                              "double_wilson_5x64", "double_wilson_lane_20x10"])
 def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypatch):
     """`model.deterministic = True` (or CARELESS_HIP_DETERMINISTIC=1): the fused kernel stores per-observation contributions instead of
     issuing float atomics and `cl_det_reduce` sums them in row order (include/careless_hip.h).  Same parity bar against the oracle,
