@@ -26,10 +26,16 @@
 // (forward, recomputed forward, dgrad, wgrad).
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdlib>
 #include "cl_math.h"
 #include "cl_kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef CL_WIDE_DIAG
+#define CL_WIDE_DIAG 0      /* diagnostic builds only (WRONG results): 1 = the stream kernels read no row operand from global memory, 2 = they store no
+                               output, 4 = the tiled kernel reads no operand tiles; what is left of a kernel's time is its MFMA + LDS floor */
+#endif
 
 namespace {
 
@@ -85,6 +91,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
         if (!KMAJOR) { row = row0 + idx / (BK / 4); k = k0 + 4 * (idx % (BK / 4)); }          // 8 threads per row: 128 contiguous bytes
         else { k = k0 + idx / (ROWS / 4); row = row0 + 4 * (idx % (ROWS / 4)); }              // ROWS / 4 threads per contraction index
         f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (CL_WIDE_DIAG & 4) { r[v] = f32x4{1.0f, 0.5f, -0.25f, 0.125f}; continue; }
         if (!KMAJOR) {
             if (row < rows_lim) {
                 const float* p = P + (size_t)row * ld + k;
@@ -119,12 +126,45 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&
     }
 }
 
+// Transposing forms for an operand stored contraction-major (the weight gradient's dZ[k][m], H[k][n]; round 4): item (m, kq) = 4
+// CONSECUTIVE contraction indices of one row -- four dword loads a lane (consecutive lanes = consecutive rows: 256-byte pieces of the
+// source rows), ONE ds_write_b128 into the [row][BK + 4] layout of the contraction-contiguous operands -- so that the MFMA loop reads
+// every operand quad with one ds_read_b128 instead of four ds_read_b32 on a [BK][rows + 4] tile.  The diagnostic build without operand
+// loads (scripts/r4_wide_diag.sh) showed the weight-gradient kernel at 63 % of its MFMA time with or without its global loads: 40
+// LDS read instructions (two-way bank conflicts between the k-groups) per 64 MFMAs were what held it.
+template <int ROWS>
+__device__ __forceinline__ void load_tile_tr(const float* __restrict__ P, int ld, int row0, int k0, int rows_lim, int k_lim, f32x4 (&r)[ROWS * BK / 1024], int tid) {
+    constexpr int NV = ROWS * BK / 1024;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int id = v * 256 + tid;
+        const int row = row0 + id % ROWS, k = k0 + 4 * (id / ROWS);
+        f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (row < rows_lim) {
+            const float* p = P + (size_t)k * ld + row;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (k + e < k_lim) x[e] = p[(size_t)e * ld];
+        }
+        r[v] = x;
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_tile_tr(float* __restrict__ s, const f32x4 (&r)[ROWS * BK / 1024], int tid) {
+    constexpr int NV = ROWS * BK / 1024;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int id = v * 256 + tid;
+        *reinterpret_cast<f32x4*>(s + (id % ROWS) * PK + 4 * (id / ROWS)) = r[v];
+    }
+}
+
 // BN: 64 or 128 output columns per workgroup (128: the row operand of a layer of width <= 128 is read once)
 template <bool AK, bool BK_, int EPI, int BN>
 __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     if (G.stop_flag != nullptr && *G.stop_flag != 0) return;      // a previous step hit a non-finite gradient norm
     constexpr int PMB = BN + 4, NB = BN / 16;
     constexpr int SB = (BN * PK > BK * PMB) ? BN * PK : BK * PMB;
+    constexpr bool TR = (EPI == EPI_WGRAD) && AK && BK_;      // contraction-major operands staged transposed (load_tile_tr): b128 operand reads
     __shared__ __attribute__((aligned(16))) float sA[2][SA];
     __shared__ __attribute__((aligned(16))) float sB[2][SB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -152,51 +192,62 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     // EPI_WGRAD with the recomputed first layer as B operand: the thread's four columns of the tile are fixed (BN / 4 threads per
     // contraction index, 256 a multiple of it), so their weight rows and biases sit in registers for the whole launch
     const bool pre = EPI == EPI_WGRAD && BK_ && G.pre.X0 != nullptr;
-    float w0r[4][K0WG], b0r[4];
-    const int pcol = n0 + 4 * (tid % (BN / 4));
+    // (TR: item (n, kq) of a thread has the column n = n0 + tid % BN, the same for all its items: ONE row of W0 and one bias in registers)
+    float w0r[K0WG], b0r = 0.0f;
+    const int pcol = n0 + tid % BN;
     if (pre) {
+        b0r = (pcol < G.pre.N0) ? G.pre.b0[pcol] : 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            b0r[e] = (pcol + e < G.pre.N0) ? G.pre.b0[pcol + e] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < K0WG; ++i) w0r[e][i] = (pcol + e < G.pre.N0 && i < G.pre.K0) ? G.pre.W0[(size_t)(pcol + e) * G.pre.K0 + i] : 0.0f;
-        }
+        for (int i = 0; i < K0WG; ++i) w0r[i] = (pcol < G.pre.N0 && i < G.pre.K0) ? G.pre.W0[(size_t)pcol * G.pre.K0 + i] : 0.0f;
     }
+    auto load_a = [&](int kk0, f32x4 (&r)[BM * BK / 1024]) {
+        if (TR) load_tile_tr<BM>(G.A, G.lda, m0, kk0, G.M, kend, r, tid);
+        else load_tile<BM, AK>(G.A, G.lda, m0, kk0, G.M, kend, vecA, r, tid);
+    };
     auto load_b = [&](int kk0, f32x4 (&r)[BN * BK / 1024]) {
-        if (!pre) { load_tile<BN, BK_>(G.B, G.ldb, n0, kk0, G.N, kend, vecB, r, tid); return; }
+        if (!pre) {
+            if (TR) load_tile_tr<BN>(G.B, G.ldb, n0, kk0, G.N, kend, r, tid);
+            else load_tile<BN, BK_>(G.B, G.ldb, n0, kk0, G.N, kend, vecB, r, tid);
+            return;
+        }
+        // (pre implies TR) the layer's input = the recomputed first layer: h_0 of four consecutive observations in this thread's column
 #pragma unroll
         for (int v = 0; v < BN * BK / 1024; ++v) {
-            const int k = kk0 + (v * 256 + tid) / (BN / 4);          // observation (contraction index)
-            f32x4 xa = {0.0f, 0.0f, 0.0f, 0.0f}, xb = {0.0f, 0.0f, 0.0f, 0.0f}, out = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (k < kend) {
-                const float* x = G.pre.X0 + (size_t)k * G.pre.ldx0;      // (ldx0 is a multiple of four, the padding columns are zero)
-                xa = *reinterpret_cast<const f32x4*>(x);
-                if (G.pre.ldx0 > 4) xb = *reinterpret_cast<const f32x4*>(x + 4);
+            const int k = kk0 + 4 * ((v * 256 + tid) / BN);
+            f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e) {
+                if (k + e < kend) {
+                    const float* x = G.pre.X0 + (size_t)(k + e) * G.pre.ldx0;      // (ldx0 is a multiple of four, the padding columns are zero; the same address in all lanes of a k-quad)
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(x);
+                    f32x4 xb = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (G.pre.ldx0 > 4) xb = *reinterpret_cast<const f32x4*>(x + 4);
                     // the contraction order of the forward kernels' MFMAs (step t takes k = t, 4 + t), the bias after it: the same bits
                     float z = 0.0f;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) { z = fmaf(w0r[e][t], xa[t], z); z = fmaf(w0r[e][4 + t], xb[t], z); }
-                    z += b0r[e];
+                    for (int t = 0; t < 4; ++t) { z = fmaf(w0r[t], xa[t], z); z = fmaf(w0r[4 + t], xb[t], z); }
+                    z += b0r;
                     out[e] = fmaxf(z, G.leak * z);
                 }
             }
             r[v] = out;
         }
     };
+    auto stage = [&](float* sa, float* sb) {
+        if (TR) { store_tile_tr<BM>(sa, ra, tid); store_tile_tr<BN>(sb, rb, tid); }
+        else { store_tile<BM, AK>(sa, ra, tid); store_tile<BN, BK_>(sb, rb, tid); }
+    };
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
-        load_tile<BM, AK>(G.A, G.lda, m0, kbeg, G.M, kend, vecA, ra, tid);
+        load_a(kbeg, ra);
         load_b(kbeg, rb);
-        store_tile<BM, AK>(sA[0], ra, tid);
-        store_tile<BN, BK_>(sB[0], rb, tid);
+        stage(sA[0], sB[0]);
     }
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
         const int cur = it & 1;
         if (it + 1 < nk) {           // the next chunk's global loads fly under this chunk's MFMAs
-            load_tile<BM, AK>(G.A, G.lda, m0, kbeg + (it + 1) * BK, G.M, kend, vecA, ra, tid);
+            load_a(kbeg + (it + 1) * BK, ra);
             load_b(kbeg + (it + 1) * BK, rb);
         }
         const float* a_s = sA[cur];
@@ -208,7 +259,7 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int row = 32 * wv + 16 * a + j;
-                if (!AK) af[a] = *reinterpret_cast<const f32x4*>(a_s + row * PK + 16 * kc + 4 * q);
+                if (!AK || TR) af[a] = *reinterpret_cast<const f32x4*>(a_s + row * PK + 16 * kc + 4 * q);
                 else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) af[a][t] = a_s[(16 * kc + 4 * q + t) * PMA + row];
@@ -217,7 +268,7 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int col = 16 * b + j;
-                if (!BK_) bf[b] = *reinterpret_cast<const f32x4*>(b_s + col * PK + 16 * kc + 4 * q);
+                if (!BK_ || TR) bf[b] = *reinterpret_cast<const f32x4*>(b_s + col * PK + 16 * kc + 4 * q);
                 else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) bf[b][t] = b_s[(16 * kc + 4 * q + t) * PMB + col];
@@ -231,14 +282,19 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
                     for (int b = 0; b < NB; ++b) acc[a][b] = mfma4(af[a][t], bf[b][t], acc[a][b]);
         }
         if (EPI == EPI_WGRAD && AK && blockIdx.y == 0 && tid < BM) {
-            // (the A tile is staged contraction-major: thread m sums its column over the chunk's 32 rows)
+            // (thread m sums its output unit's dZ over the chunk's 32 observations: a row of the transposed tile, a column of the other)
+            if (TR) {
 #pragma unroll
-            for (int k = 0; k < BK; ++k) bsum += a_s[k * PMA + tid];
+                for (int k4 = 0; k4 < BK / 4; ++k4) {
+                    const f32x4 z4 = *reinterpret_cast<const f32x4*>(a_s + tid * PK + 4 * k4);
+                    bsum += (z4[0] + z4[1]) + (z4[2] + z4[3]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < BK; ++k) bsum += a_s[k * PMA + tid];
+            }
         }
-        if (it + 1 < nk) {
-            store_tile<BM, AK>(sA[cur ^ 1], ra, tid);
-            store_tile<BN, BK_>(sB[cur ^ 1], rb, tid);
-        }
+        if (it + 1 < nk) stage(sA[cur ^ 1], sB[cur ^ 1]);
         __syncthreads();
     }
 
@@ -468,6 +524,7 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
     auto load_x = [&](long long b, int kc) -> f32x4 {
         const long long row = row0 + b * 16 + j;
         f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (CL_WIDE_DIAG & 1) return f32x4{1.0f, 0.5f, -0.25f, 0.125f};
         if (row < rend) {
             const int k = 16 * kc + 4 * q;
             const float* p = S.X + (size_t)row * S.ldx + k;
@@ -568,6 +625,7 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
                         for (int t = 0; t < 4; ++t) v[t] = (hm[a][t] > 0.0f) ? v[t] : S.leak * v[t];
                     }
                     float* y = S.Y + (size_t)row * S.ldy + c;
+                    if ((CL_WIDE_DIAG & 2) && v[0] != 12345.0f) continue;
                     if (c + 3 < N && vecy) *reinterpret_cast<f32x4*>(y) = v;
                     else {
 #pragma unroll
@@ -742,6 +800,201 @@ int launch_stream2(const Stream2Args& s, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// square layers (hidden -> hidden: N and K span the same number NA of 16-column blocks), round 4
+// ---------------------------------------------------------------------------------------------------------------------------
+// The diagnostic builds of round 4 (scripts/r4_wide_diag.sh, profiles/r4_wide_diag.txt) put numbers on wide_stream_kernel at 128 x 128 and
+// 1 M rows: 0.355 ms as shipped, 0.31 ms without its global loads, 0.33 without its stores, 0.28 with neither -- against 0.209 ms of MFMA
+// issue.  So a quarter of the time is the memory side NOT overlapping (the next chunk's operand is requested one chunk = 0.4 us of
+// MFMAs ahead, less than a loaded HBM round trip) and another quarter is vector / scalar work around the MFMAs (run-time block counts,
+// bounds tests, 64-bit address arithmetic per chunk and per store).  This kernel takes both out for the common case:
+//   * the block count is a template argument, the block body straight-line code; ld's are multiples of four by contract
+//     (cl_wide_ld), padding columns zero: every access is a float4, the only test per access is "inside the row buffer";
+//   * the rows' operand of a WHOLE 16-row block sits in NA register quads; a quad is refilled with the NEXT block's chunk right
+//     after the MFMAs that read it have been issued (an MFMA reads its operands at issue; the load lands a microsecond later): the
+//     prefetch distance is a full block (3.4 us of MFMAs at NA = 8) with no second buffer;
+//   * the dgrad mask (the layer's input activations, or the recomputed first layer) is requested at the start of the block.
+// Same arithmetic, same order of the contraction as wide_stream_kernel (chunk by chunk, step t inside a chunk): the same bits.
+template <bool WKM, int EPI, int NA, bool PRE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void wide_sq_kernel(const StreamArgs S) {
+    if (S.stop_flag != nullptr && *S.stop_flag != 0) return;
+    extern __shared__ __attribute__((aligned(16))) float sWq[];      // [16 NA][SKP], zero outside N x K
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int N = S.N, K = S.K;
+    constexpr int tot = 16 * NA * SKP;
+    float* const sBias = sWq + tot;                                  // [16 NA]
+    float* const sHead = sBias + 16 * NA;                            // [2][16 NA]
+    float* const sW0 = sHead + 32 * NA;                              // PRE: [16 NA][S0P], [16 NA]
+    float* const sB0 = sW0 + 16 * NA * S0P;
+    for (int base = 0; base < tot; base += 8 * 512) {
+        float v[8];
+        int at[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * 512 + tid;
+            int o, k;
+            if (!WKM) { o = idx / SKP; k = idx - o * SKP; }
+            else { k = idx / (16 * NA); o = idx - k * (16 * NA); }
+            at[u] = (idx < tot && k < SKP) ? o * SKP + k : -1;
+            v[u] = 0.0f;
+            if (idx < tot && o < N && k < K) v[u] = WKM ? S.W[(size_t)k * S.ldw + o] : S.W[(size_t)o * S.ldw + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (at[u] >= 0) sWq[at[u]] = v[u];
+    }
+    if (EPI == EPI_BIAS_LRELU && tid < 16 * NA) sBias[tid] = (tid < N) ? S.bias[tid] : 0.0f;
+    if (EPI == EPI_BIAS_LRELU && S.head_W != nullptr && tid < 32 * NA) {
+        const int r = tid / (16 * NA), c = tid - r * 16 * NA;
+        sHead[tid] = (c < N) ? S.head_W[r * N + c] : 0.0f;
+    }
+    if (PRE) {
+        for (int idx = tid; idx < 16 * NA * S0P; idx += 512) {
+            const int o = idx / S0P, k = idx - o * S0P;
+            sW0[idx] = (o < N && k < S.pre.K0) ? S.pre.W0[(size_t)o * S.pre.K0 + k] : 0.0f;
+        }
+        if (tid < 16 * NA) sB0[tid] = (tid < N) ? S.pre.b0[tid] : 0.0f;
+    }
+    __syncthreads();
+    const long long nblk = (S.n + 15) >> 4;
+    const float* const wrow = sWq + j * SKP + 4 * q;
+    // per-lane element offsets inside a row: chunk kc of the operand at 16 kc + 4 q, block a of the output / mask at 16 a + 4 q
+    const int cq = 4 * q;
+    auto x_ptr = [&](long long b) -> const float* {                  // this lane's row of block b (rows past the end: the last row, never stored)
+        long long row = b * 16 + j;
+        if (row >= S.n) row = S.n - 1;
+        return S.X + (size_t)row * S.ldx + cq;
+    };
+    long long blk = (long long)blockIdx.x * 8 + wv;
+    const long long bstep = (long long)gridDim.x * 8;
+    f32x4 xb[NA];
+    if (blk < nblk) {
+        const float* xp = x_ptr(blk);
+#pragma unroll
+        for (int kc = 0; kc < NA; ++kc) xb[kc] = (16 * kc + cq < S.ldx) ? *reinterpret_cast<const f32x4*>(xp + 16 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+    for (; blk < nblk; blk += bstep) {
+        const long long row = blk * 16 + j;
+        const long long rowc = row < S.n ? row : S.n - 1;
+        // the mask of the dgrad epilogue, requested now (the layer's input activations), consumed after the MFMAs
+        f32x4 hm[NA];
+        if (EPI == EPI_DLRELU && !PRE && S.H != nullptr) {
+            const float* hp = S.H + (size_t)rowc * S.ldh + cq;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) hm[a] = (16 * a + cq < S.ldh) ? *reinterpret_cast<const f32x4*>(hp + 16 * a) : f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        }
+        f32x4 x0 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (PRE && cq < S.pre.ldx0) x0 = *reinterpret_cast<const f32x4*>(S.pre.X0 + (size_t)rowc * S.pre.ldx0 + cq);
+        const bool more = blk + bstep < nblk;
+        const float* xnext = x_ptr(more ? blk + bstep : blk);
+        f32x4 acc[NA];
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kc = 0; kc < NA; ++kc) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + 16 * a * SKP + 16 * kc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[a] = mfma4(wf[t], xb[kc][t], acc[a]);
+            }
+            // this quad's MFMAs are issued: refill it with the next block's chunk (a whole block of MFMAs ahead of its use)
+            if (more && 16 * kc + cq < S.ldx) xb[kc] = *reinterpret_cast<const f32x4*>(xnext + 16 * kc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (PRE) {
+            // the recomputed first layer's pre-activations of this lane's row and columns (every lane takes part: an MFMA reads the
+            // weights of feature 16 a + j from all lanes)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(sW0 + (16 * a + j) * S0P + cq);
+                f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) z = mfma4(wf[t], x0[t], z);
+                hm[a] = z + *reinterpret_cast<const f32x4*>(sB0 + 16 * a + cq);
+            }
+        }
+        if (row < S.n) {
+            float* yp = S.Y + (size_t)row * S.ldy + cq;
+            float ho0 = 0.0f, ho1 = 0.0f;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                f32x4 v = acc[a];
+                if (EPI == EPI_BIAS_LRELU) {
+                    v += *reinterpret_cast<const f32x4*>(sBias + 16 * a + cq);
+                    if (S.act) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], S.leak * v[t]);
+                    }
+                    if (S.head_W != nullptr) {
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(sHead + 16 * a + cq), g1 = *reinterpret_cast<const f32x4*>(sHead + 16 * NA + 16 * a + cq);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { ho0 = fmaf(v[t], g0[t], ho0); ho1 = fmaf(v[t], g1[t], ho1); }
+                    }
+                } else if (PRE || S.H != nullptr) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = (hm[a][t] > 0.0f) ? v[t] : S.leak * v[t];
+                }
+                if (16 * a + cq < S.ldy) *reinterpret_cast<f32x4*>(yp + 16 * a) = v;      // (columns N .. ld - 1 get the zeros the padded weights produce)
+            }
+            if (EPI == EPI_BIAS_LRELU && S.head_W != nullptr) {
+                ho0 += __shfl_xor(ho0, 16); ho1 += __shfl_xor(ho1, 16);
+                ho0 += __shfl_xor(ho0, 32); ho1 += __shfl_xor(ho1, 32);
+                if (q == 0) {
+                    float dd;
+                    S.loc_out[row] = ho0 + S.head_W[2 * N];
+                    S.sig_out[row] = cl_scale_bij(ho1 + S.head_W[2 * N + 1], S.bij_kind, S.eps, &dd);
+                }
+            }
+        }
+    }
+}
+
+// 1: the square-layer kernel takes this call (same block count on both sides, row buffers laid out as cl_wide_ld says, 16-byte aligned)
+static bool sq_ok(const StreamArgs& s) {
+    if (s.seg != nullptr) return false;
+    const int NA = (s.N + 15) >> 4, KA = (s.K + 15) >> 4;
+    if (NA != KA || NA < 5) return false;                      // (up to 64 the generic instance is as good; 65 .. 128 is what this path is for)
+    if (s.ldx % 4 != 0 || s.ldy % 4 != 0 || s.ldx < s.K || s.ldy < s.N || s.ldx > 16 * NA || s.ldy > 16 * NA) return false;
+    if ((reinterpret_cast<uintptr_t>(s.X) & 15) != 0 || (reinterpret_cast<uintptr_t>(s.Y) & 15) != 0) return false;
+    if (s.H != nullptr && (s.ldh % 4 != 0 || s.ldh > 16 * NA || (reinterpret_cast<uintptr_t>(s.H) & 15) != 0)) return false;
+    static const bool off = [] { const char* e = getenv("CARELESS_HIP_WIDE_SQ"); return e != nullptr && e[0] == '0'; }();      // A/B runs
+    return !off;
+}
+
+template <bool WKM, int EPI, int NA, bool PRE>
+int launch_sq_n(const StreamArgs& s, hipStream_t st) {
+    const size_t sm = (size_t)(16 * NA * SKP + 3 * 16 * NA + (PRE ? 16 * NA * (S0P + 1) : 0)) * sizeof(float);
+    auto kern = wide_sq_kernel<WKM, EPI, NA, PRE>;
+    static std::atomic<size_t> configured{0};
+    size_t have = configured.load(std::memory_order_acquire);
+    if (have < sm) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) return (int)e;
+        while (have < sm && !configured.compare_exchange_weak(have, sm, std::memory_order_release, std::memory_order_acquire)) {}
+    }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long nblk = (s.n + 15) >> 4;
+    long long grid = (nblk + 7) / 8;
+    if (grid > 2LL * cus) grid = 2LL * cus;
+    if (grid < 1) grid = 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sm, st, s);
+    return (int)hipGetLastError();
+}
+
+template <bool WKM, int EPI, bool PRE>
+int launch_sq(const StreamArgs& s, hipStream_t st) {
+    switch ((s.N + 15) >> 4) {
+        case 5: return launch_sq_n<WKM, EPI, 5, PRE>(s, st);
+        case 6: return launch_sq_n<WKM, EPI, 6, PRE>(s, st);
+        case 7: return launch_sq_n<WKM, EPI, 7, PRE>(s, st);
+        default: return launch_sq_n<WKM, EPI, 8, PRE>(s, st);
+    }
+}
+
 template <bool WKM, int EPI, int NAT, bool GRP, bool PRE = false>
 int launch_stream_n(const StreamArgs& s, hipStream_t st) {
     const int NA = (s.N + 15) >> 4;
@@ -795,6 +1048,7 @@ int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float*
         StreamArgs s = {};
         s.X = X; s.ldx = ldx; s.W = Wt; s.ldw = n_in; s.Y = Y; s.ldy = ldy; s.n = n; s.N = n_out; s.K = n_in;
         s.bias = b; s.leak = leak; s.act = act; s.stop_flag = stop_flag;
+        if (sq_ok(s)) return launch_sq<false, EPI_BIAS_LRELU, false>(s, (hipStream_t)stream);
         return launch_stream<false, EPI_BIAS_LRELU>(s, (hipStream_t)stream);
     }
     GemmArgs g = {};
@@ -817,6 +1071,7 @@ int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const f
     s.X = X; s.ldx = ldx; s.W = Wt; s.ldw = n_in; s.Y = Y; s.ldy = ldy; s.n = n; s.N = n_out; s.K = n_in;
     s.bias = b; s.leak = leak; s.act = 1; s.stop_flag = stop_flag;
     s.head_W = head; s.bij_kind = bij_kind; s.eps = eps; s.loc_out = loc_out; s.sig_out = sig_out;
+    if (sq_ok(s)) return launch_sq<false, EPI_BIAS_LRELU, false>(s, (hipStream_t)stream);
     return launch_stream<false, EPI_BIAS_LRELU>(s, (hipStream_t)stream);
 }
 
@@ -827,6 +1082,7 @@ int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n,
         StreamArgs s = {};
         s.X = dZ; s.ldx = lddz; s.W = Wt; s.ldw = n_in; s.Y = dX; s.ldy = ldo; s.n = n; s.N = n_in; s.K = n_out;
         s.H = Hprev; s.ldh = ldh; s.leak = leak; s.stop_flag = stop_flag;
+        if (sq_ok(s)) return launch_sq<true, EPI_DLRELU, false>(s, (hipStream_t)stream);
         return launch_stream<true, EPI_DLRELU>(s, (hipStream_t)stream);
     }
     GemmArgs g = {};
@@ -879,6 +1135,7 @@ int cl_wide_dense_dgrad_pre(const float* dZ, int lddz, const float* Wt, long lon
     s.X = dZ; s.ldx = lddz; s.W = Wt; s.ldw = n_in; s.Y = dX; s.ldy = ldo; s.n = n; s.N = n_in; s.K = n_out;
     s.leak = leak; s.stop_flag = stop_flag;
     s.pre.X0 = X0; s.pre.ldx0 = ldx0; s.pre.K0 = n_in0; s.pre.W0 = Wt0; s.pre.b0 = b0; s.pre.N0 = n_in;
+    if (sq_ok(s)) return launch_sq<true, EPI_DLRELU, true>(s, (hipStream_t)stream);
     return s.N <= 64 ? launch_stream_n<true, EPI_DLRELU, 4, false, true>(s, (hipStream_t)stream) : launch_stream_n<true, EPI_DLRELU, 8, false, true>(s, (hipStream_t)stream);
 }
 
