@@ -126,36 +126,41 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, const f32x4 (&
     }
 }
 
-// Transposing forms for an operand stored contraction-major (the weight gradient's dZ[k][m], H[k][n]; round 4): item (m, kq) = 4
-// CONSECUTIVE contraction indices of one row -- four dword loads a lane (consecutive lanes = consecutive rows: 256-byte pieces of the
-// source rows), ONE ds_write_b128 into the [row][BK + 4] layout of the contraction-contiguous operands -- so that the MFMA loop reads
-// every operand quad with one ds_read_b128 instead of four ds_read_b32 on a [BK][rows + 4] tile.  The diagnostic build without operand
-// loads (scripts/r4_wide_diag.sh) showed the weight-gradient kernel at 63 % of its MFMA time with or without its global loads: 40
-// LDS read instructions (two-way bank conflicts between the k-groups) per 64 MFMAs were what held it.
+// Transposing forms for an operand stored contraction-major (the weight gradient's dZ[k][m], H[k][n]; round 4).  The MFMA loop reads an
+// operand quad -- four consecutive contraction indices of one row -- with ONE ds_read_b128 when the tile is staged [row][BK + 4]; from a
+// [BK][rows + 4] tile it takes four ds_read_b32 with two-way bank conflicts between the k-groups: 40 LDS instructions per 64 MFMAs, which
+// is what held the weight-gradient kernel at 63 % of its MFMA time with or without its global loads (scripts/r4_wide_diag.sh).  A thread
+// takes ONE item = 4 rows x 4 contraction indices: four float4 loads along the rows (the coalesced pattern of the plain form: 512-byte
+// pieces of four consecutive source rows), transposed in registers (free), four ds_write_b128.  Consecutive lanes write rows 16 bytes x 9
+// apart: the quad column is XOR-swizzled with bits 3..5 of the row -- constant over the 8 rows a ds_read_b128 group of the MFMA loop
+// touches (so the reads stay conflict-free as in the [row][BK + 4] form) and spreading 8 consecutive writers over all 32 banks.
+// (First attempt, measured and dropped: four dword loads per item down the contraction axis -- 32 instead of 8 vector-memory
+// instructions per thread and chunk with their address arithmetic: the kernel went from 0.355 to 0.447 ms per 1 M rows.)
+__device__ __forceinline__ int tr_quad(int row, int c4) { return 4 * (c4 ^ ((row >> 3) & 7)); }
 template <int ROWS>
-__device__ __forceinline__ void load_tile_tr(const float* __restrict__ P, int ld, int row0, int k0, int rows_lim, int k_lim, f32x4 (&r)[ROWS * BK / 1024], int tid) {
-    constexpr int NV = ROWS * BK / 1024;
+__device__ __forceinline__ void load_tile_tr(const float* __restrict__ P, int ld, int row0, int k0, int rows_lim, int k_lim, bool vec_ok, f32x4 (&r)[4], int tid) {
+    static_assert(ROWS * BK == 16 * 256, "one item per thread");
+    const int row = row0 + 4 * (tid % (ROWS / 4)), k = k0 + 4 * (tid / (ROWS / 4));
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int id = v * 256 + tid;
-        const int row = row0 + id % ROWS, k = k0 + 4 * (id / ROWS);
+    for (int e = 0; e < 4; ++e) {
         f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (row < rows_lim) {
-            const float* p = P + (size_t)k * ld + row;
+        if (k + e < k_lim) {
+            const float* p = P + (size_t)(k + e) * ld + row;
+            if (vec_ok && row + 3 < rows_lim) x = *reinterpret_cast<const f32x4*>(p);
+            else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (k + e < k_lim) x[e] = p[(size_t)e * ld];
+                for (int c = 0; c < 4; ++c) if (row + c < rows_lim) x[c] = p[c];
+            }
         }
-        r[v] = x;
+        r[e] = x;                      // r[e][c] = source[k + e][row + c]
     }
 }
 template <int ROWS>
-__device__ __forceinline__ void store_tile_tr(float* __restrict__ s, const f32x4 (&r)[ROWS * BK / 1024], int tid) {
-    constexpr int NV = ROWS * BK / 1024;
+__device__ __forceinline__ void store_tile_tr(float* __restrict__ s, const f32x4 (&r)[4], int tid) {
+    const int row = 4 * (tid % (ROWS / 4)), c4 = tid / (ROWS / 4);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int id = v * 256 + tid;
-        *reinterpret_cast<f32x4*>(s + (id % ROWS) * PK + 4 * (id / ROWS)) = r[v];
-    }
+    for (int c = 0; c < 4; ++c)
+        *reinterpret_cast<f32x4*>(s + (row + c) * PK + tr_quad(row + c, c4)) = f32x4{r[0][c], r[1][c], r[2][c], r[3][c]};
 }
 
 // BN: 64 or 128 output columns per workgroup (128: the row operand of a layer of width <= 128 is read once)
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     constexpr int PMB = BN + 4, NB = BN / 16;
     constexpr int SB = (BN * PK > BK * PMB) ? BN * PK : BK * PMB;
     constexpr bool TR = (EPI == EPI_WGRAD) && AK && BK_;      // contraction-major operands staged transposed (load_tile_tr): b128 operand reads
+    constexpr bool TRB = TR && BN == 128;                     // (a 64-column B tile is half an item per thread: it keeps the [BK][rows + 4] form)
     __shared__ __attribute__((aligned(16))) float sA[2][SA];
     __shared__ __attribute__((aligned(16))) float sB[2][SB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -192,50 +198,60 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     // EPI_WGRAD with the recomputed first layer as B operand: the thread's four columns of the tile are fixed (BN / 4 threads per
     // contraction index, 256 a multiple of it), so their weight rows and biases sit in registers for the whole launch
     const bool pre = EPI == EPI_WGRAD && BK_ && G.pre.X0 != nullptr;
-    // (TR: item (n, kq) of a thread has the column n = n0 + tid % BN, the same for all its items: ONE row of W0 and one bias in registers)
-    float w0r[K0WG], b0r = 0.0f;
-    const int pcol = n0 + tid % BN;
+    // the recomputed first layer as B operand: the thread's four columns of the tile are fixed (both forms map tid % (BN / 4) to the
+    // column quad), so their weight rows and biases sit in registers for the whole launch
+    float w0r[4][K0WG], b0r[4];
+    const int pcol = n0 + 4 * (tid % (BN / 4));
     if (pre) {
-        b0r = (pcol < G.pre.N0) ? G.pre.b0[pcol] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < K0WG; ++i) w0r[i] = (pcol < G.pre.N0 && i < G.pre.K0) ? G.pre.W0[(size_t)pcol * G.pre.K0 + i] : 0.0f;
+        for (int e = 0; e < 4; ++e) {
+            b0r[e] = (pcol + e < G.pre.N0) ? G.pre.b0[pcol + e] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < K0WG; ++i) w0r[e][i] = (pcol + e < G.pre.N0 && i < G.pre.K0) ? G.pre.W0[(size_t)(pcol + e) * G.pre.K0 + i] : 0.0f;
+        }
     }
+    // h_0 of observation k in the thread's four columns (the contraction order of the forward kernels' MFMAs -- step t takes k = t, 4 + t --,
+    // the bias after it: the same bits)
+    auto pre_row = [&](int k) -> f32x4 {
+        f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (k < kend) {
+            const float* x = G.pre.X0 + (size_t)k * G.pre.ldx0;      // (ldx0 is a multiple of four, the padding columns are zero)
+            const f32x4 xa = *reinterpret_cast<const f32x4*>(x);
+            f32x4 xb = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (G.pre.ldx0 > 4) xb = *reinterpret_cast<const f32x4*>(x + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float z = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { z = fmaf(w0r[e][t], xa[t], z); z = fmaf(w0r[e][4 + t], xb[t], z); }
+                z += b0r[e];
+                out[e] = fmaxf(z, G.leak * z);
+            }
+        }
+        return out;
+    };
     auto load_a = [&](int kk0, f32x4 (&r)[BM * BK / 1024]) {
-        if (TR) load_tile_tr<BM>(G.A, G.lda, m0, kk0, G.M, kend, r, tid);
+        if constexpr (TR) load_tile_tr<BM>(G.A, G.lda, m0, kk0, G.M, kend, vecA, r, tid);
         else load_tile<BM, AK>(G.A, G.lda, m0, kk0, G.M, kend, vecA, r, tid);
     };
     auto load_b = [&](int kk0, f32x4 (&r)[BN * BK / 1024]) {
         if (!pre) {
-            if (TR) load_tile_tr<BN>(G.B, G.ldb, n0, kk0, G.N, kend, r, tid);
+            if constexpr (TRB) load_tile_tr<BN>(G.B, G.ldb, n0, kk0, G.N, kend, vecB, r, tid);
             else load_tile<BN, BK_>(G.B, G.ldb, n0, kk0, G.N, kend, vecB, r, tid);
             return;
         }
-        // (pre implies TR) the layer's input = the recomputed first layer: h_0 of four consecutive observations in this thread's column
+        if constexpr (TRB) {
+            const int k = kk0 + 4 * (tid / (BN / 4));                 // the item's four observations
 #pragma unroll
-        for (int v = 0; v < BN * BK / 1024; ++v) {
-            const int k = kk0 + 4 * ((v * 256 + tid) / BN);
-            f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int e = 0; e < 4; ++e) r[e] = pre_row(k + e);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (k + e < kend) {
-                    const float* x = G.pre.X0 + (size_t)(k + e) * G.pre.ldx0;      // (ldx0 is a multiple of four, the padding columns are zero; the same address in all lanes of a k-quad)
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(x);
-                    f32x4 xb = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (G.pre.ldx0 > 4) xb = *reinterpret_cast<const f32x4*>(x + 4);
-                    // the contraction order of the forward kernels' MFMAs (step t takes k = t, 4 + t), the bias after it: the same bits
-                    float z = 0.0f;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) { z = fmaf(w0r[t], xa[t], z); z = fmaf(w0r[4 + t], xb[t], z); }
-                    z += b0r;
-                    out[e] = fmaxf(z, G.leak * z);
-                }
-            }
-            r[v] = out;
+            for (int v = 0; v < BN * BK / 1024; ++v) r[v] = pre_row(kk0 + (v * 256 + tid) / (BN / 4));
         }
     };
     auto stage = [&](float* sa, float* sb) {
-        if (TR) { store_tile_tr<BM>(sa, ra, tid); store_tile_tr<BN>(sb, rb, tid); }
-        else { store_tile<BM, AK>(sa, ra, tid); store_tile<BN, BK_>(sb, rb, tid); }
+        if constexpr (TR) store_tile_tr<BM>(sa, ra, tid); else store_tile<BM, AK>(sa, ra, tid);
+        if constexpr (TRB) store_tile_tr<BN>(sb, rb, tid); else store_tile<BN, BK_>(sb, rb, tid);
     };
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
@@ -252,35 +268,42 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
         }
         const float* a_s = sA[cur];
         const float* b_s = sB[cur];
+        // MFMA step t of 16-deep sub-chunk kc contracts k = 16 kc + 4 q + t (q = lane >> 4), the same map for both operands.  The operand
+        // quads of BOTH sub-chunks are requested before the first MFMA (round 4: the kernel holds two waves per SIMD -- LDS-limited --
+        // and 256 registers a wave: the second sub-chunk's LDS round trip hides under the first one's 64 MFMAs instead of standing
+        // between them)
+        f32x4 af[BK / 16][2], bf[BK / 16][NB];
 #pragma unroll
         for (int kc = 0; kc < BK / 16; ++kc) {
-            // MFMA step t of this 16-deep sub-chunk contracts k = 16 kc + 4 q + t (q = lane >> 4), the same map for both operands
-            f32x4 af[2], bf[NB];
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const int row = 32 * wv + 16 * a + j;
-                if (!AK || TR) af[a] = *reinterpret_cast<const f32x4*>(a_s + row * PK + 16 * kc + 4 * q);
+                if (TR) af[kc][a] = *reinterpret_cast<const f32x4*>(a_s + row * PK + tr_quad(row, 4 * kc + q));
+                else if (!AK) af[kc][a] = *reinterpret_cast<const f32x4*>(a_s + row * PK + 16 * kc + 4 * q);
                 else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) af[a][t] = a_s[(16 * kc + 4 * q + t) * PMA + row];
+                    for (int t = 0; t < 4; ++t) af[kc][a][t] = a_s[(16 * kc + 4 * q + t) * PMA + row];
                 }
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int col = 16 * b + j;
-                if (!BK_ || TR) bf[b] = *reinterpret_cast<const f32x4*>(b_s + col * PK + 16 * kc + 4 * q);
+                if (TRB) bf[kc][b] = *reinterpret_cast<const f32x4*>(b_s + col * PK + tr_quad(col, 4 * kc + q));
+                else if (!BK_) bf[kc][b] = *reinterpret_cast<const f32x4*>(b_s + col * PK + 16 * kc + 4 * q);
                 else {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) bf[b][t] = b_s[(16 * kc + 4 * q + t) * PMB + col];
+                    for (int t = 0; t < 4; ++t) bf[kc][b][t] = b_s[(16 * kc + 4 * q + t) * PMB + col];
                 }
             }
+        }
+#pragma unroll
+        for (int kc = 0; kc < BK / 16; ++kc)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[a][b] = mfma4(af[a][t], bf[b][t], acc[a][b]);
-        }
+                    for (int b = 0; b < NB; ++b) acc[a][b] = mfma4(af[kc][a][t], bf[kc][b][t], acc[a][b]);
         if (EPI == EPI_WGRAD && AK && blockIdx.y == 0 && tid < BM) {
             // (thread m sums its output unit's dZ over the chunk's 32 observations: a row of the transposed tile, a column of the other)
             if (TR) {

@@ -18,7 +18,7 @@ for rep in 1 2; do
   CARELESS_HIP_LIB=$PWD/careless_amd/lib/exp_r4w_old.so timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_old.json 2> $O/w_old.err || tail -3 $O/w_old.err
   line "old wide_gemm.hip (round-4 commit fa08310)" $O/w_old.json
   CARELESS_HIP_WIDE_SQ=0 timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_tr.json 2> $O/w_tr.err || tail -3 $O/w_tr.err
-  line "transposed wgrad staging only (WIDE_SQ=0)" $O/w_tr.json
+  line "register-transposed swizzled wgrad staging only (WIDE_SQ=0)" $O/w_tr.json
   timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_new.json 2> $O/w_new.err || tail -3 $O/w_new.err
   line "+ square-layer streaming kernel (shipped)" $O/w_new.json
 done 2>&1 | tee $O/wide_ab.log
