@@ -68,26 +68,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CL_DPP_REDUCE
 #define CL_DPP_REDUCE 1
 #endif
-#ifndef CL_LEAK_VGPR
-#define CL_LEAK_VGPR 0
-#endif
-#ifndef CL_FAST_DIV
-#define CL_FAST_DIV 0     /* 1: reciprocal + Newton step for the Student-T derivative, 1/nu hoisted (measured: no gain) */
-#endif
-#ifndef CL_FAST_SG
-#define CL_FAST_SG 0     /* 1: hardware rcp / log for 1/sigma, log sigma in the epilogue (measured: no gain on the 64-wide instances) */
-#endif
-#ifndef CL_ASM_STAGE
-#define CL_ASM_STAGE 1     /* staging writes of the dgrad phase as single ds_write_b32 with immediate offsets (inline assembly): +0.4 % on the bench line */
-#endif
-#ifndef CL_VOL_STAGE
-#define CL_VOL_STAGE 0
-#endif
-#if CL_VOL_STAGE
-#define CL_STAGE_Q volatile
-#else
-#define CL_STAGE_Q
-#endif
 #ifndef CL_PF_NEXT
 #define CL_PF_NEXT 1
 #endif
@@ -290,12 +270,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     const int d = A.d, w = A.w;
     const int Ld = A.L;                              // Dense layers (parameters in A.mlp)
     const int L = ILAY ? A.L + A.n_imgl : A.L;       // all hidden layers (Dense + per-image)
-#if CL_LEAK_VGPR
-    float leak = A.leak;                 // (in a vector register: a vector instruction with a scalar-register operand issues at half rate beside a second wave)
-    asm volatile("" : "+v"(leak));
-#else
     const float leak = A.leak;
-#endif
     const bool no_head = CHAIN && ((MODE == 1 && A.act_out != nullptr) || (MODE == 2 && A.dH_ext != nullptr));
 
     // ---- stage the weights (global W^T layout, see cl_kernels.h) into padded LDS images, zero-filled ---------
@@ -704,9 +679,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 const int lfirst = 4 * (je - mem) + qe;
                 const int gmax = __builtin_amdgcn_readfirstlane(E->tile_gmax[tile]);
                 // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
-                const float inv_sg = CL_FAST_SG ? cl_fast_rcp(sg) : 1.0f / sg;
-                const float log_sg = CL_FAST_SG ? cl_fast_log(sg) : logf(sg);
-                const float inv_dof = (E->lik_kind == CL_LIK_STUDENTT) ? 1.0f / E->dof : 0.0f;       // wave-uniform
+                const float inv_sg = 1.0f / sg;
+                const float log_sg = logf(sg);
                 float eta_sin = 0.0f;
                 const int K = (S + 3) >> 2;
                 for (int k = 0; k < K; ++k) {                     // wave-uniform trip count: all lanes take part in the shuffles
@@ -739,7 +713,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                             ll = cl_lik_ev11(tot, io, sg, E->lik_kind, E->dof, E->lik_const, ev, &dll, &gf, &gb, &ga);
                             if (mem == 0) { ev_g0 -= gf * E->w_ll; ev_g1 -= ga * E->w_ll; ev_g2 -= gb * E->w_ll; }
                         } else {
-                            ll = CL_FAST_DIV ? cl_lik_log_prob3(tot, io, inv_sg, log_sg, E->lik_kind, E->dof, inv_dof, E->lik_const, &dll) : cl_lik_log_prob2(tot, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
+                            ll = cl_lik_log_prob2(tot, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
                         }
                         if (mem == 0) nll_acc -= ll * E->w_ll;
                         const float gi = -dll * E->w_ll;                 // dNLL / d iconv = dNLL / d ipred of every member
@@ -757,9 +731,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 }
             } else if (rid >= 0) {
                 // hardware reciprocal and logarithm (1 ulp): sigma is an input, its log enters the NLL additively
-                const float inv_sg = CL_FAST_SG ? cl_fast_rcp(sg) : 1.0f / sg;
-                const float log_sg = CL_FAST_SG ? cl_fast_log(sg) : logf(sg);
-                const float inv_dof = (E->lik_kind == CL_LIK_STUDENTT) ? 1.0f / E->dof : 0.0f;       // wave-uniform
+                const float inv_sg = 1.0f / sg;
+                const float log_sg = logf(sg);
                 int k = 0;
                 float eta_sin = 0.0f;
                 for (int s = qe; s < S; s += 4, ++k) {
@@ -783,7 +756,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                         ll = cl_lik_ev11(ipred, io, sg, E->lik_kind, E->dof, E->lik_const, ev, &dll, &gf, &gb, &ga);
                         ev_g0 -= gf * E->w_ll; ev_g1 -= ga * E->w_ll; ev_g2 -= gb * E->w_ll;     // order: Sdfac, Sdadd, SdB
                     } else {
-                        ll = CL_FAST_DIV ? cl_lik_log_prob3(ipred, io, inv_sg, log_sg, E->lik_kind, E->dof, inv_dof, E->lik_const, &dll) : cl_lik_log_prob2(ipred, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
+                        ll = cl_lik_log_prob2(ipred, io, inv_sg, log_sg, E->lik_kind, E->dof, E->lik_const, &dll);
                     }
                     nll_acc -= ll * E->w_ll;
                     const float gi = -dll * E->w_ll;                 // dNLL / d ipred
@@ -1047,17 +1020,11 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                                 const int gi = (mb / MBS) * FB + kb;
 #pragma unroll
                                 for (int e = IPG * gi; e < IPG * (gi + 1); ++e) {
-                                    // (CL_VOL_STAGE: volatile stores are not merged into ds_write2_b32, whose 8-bit offsets cost a
-                                    // v_add_u32 of the base per pair -- a vector instruction beside the MFMAs -- where single
-                                    // ds_write_b32 take the whole offset as an immediate)
-#if CL_ASM_STAGE
+                                    // (plain stores are merged into ds_write2_b32, whose 8-bit offsets cost a v_add_u32 of the base per pair -- a vector
+                                    //  instruction beside the MFMAs -- where single ds_write_b32 take the whole offset as an immediate: +0.4 % on the bench line)
                                     // single ds_write_b32 with the whole offset as an immediate (no ds_write2 merge, no re-basing add)
                                     if (e < 4 * FB) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"((unsigned)(size_t)stz), "v"(dH[(e / 4) % FB][e % 4]), "n"(4 * (16 * (e / 4) + (e % 4)) * PB) : "memory");
                                     else asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"((unsigned)(size_t)sth), "v"(hs[l > 0 ? l - 1 : 0][((e - 4 * FB) / 4) % FB][e % 4]), "n"(4 * (16 * ((e - 4 * FB) / 4) + (e % 4)) * PB) : "memory");
-#else
-                                    if (e < 4 * FB) *(CL_STAGE_Q float*)&stz[(16 * (e / 4) + (e % 4)) * PB] = dH[(e / 4) % FB][e % 4];
-                                    else *(CL_STAGE_Q float*)&sth[(16 * ((e - 4 * FB) / 4) + (e % 4)) * PB] = hs[l > 0 ? l - 1 : 0][((e - 4 * FB) / 4) % FB][e % 4];
-#endif
                                 }
 #pragma unroll
                                 for (int k = 0; k < IPG; ++k) {

@@ -32,6 +32,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CL_WIDE_NBUF
+#define CL_WIDE_NBUF 2      /* LDS copies of the tiled kernel's operand tiles: 2 = the next chunk is staged while this one is read (one barrier per chunk,
+                               73.7 KB: two 4-wave workgroups per CU); 1 = one copy, two barriers per chunk, 36.9 KB: three workgroups per CU (register-limited) */
+#endif
 #ifndef CL_WIDE_DIAG
 #define CL_WIDE_DIAG 0      /* diagnostic builds only (WRONG results): 1 = the stream kernels read no row operand from global memory, 2 = they store no
                                output, 4 = the tiled kernel reads no operand tiles; what is left of a kernel's time is its MFMA + LDS floor */
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     constexpr int SB = (BN * PK > BK * PMB) ? BN * PK : BK * PMB;
     constexpr bool TR = (EPI == EPI_WGRAD) && AK && BK_;      // contraction-major operands staged transposed (load_tile_tr): b128 operand reads
     constexpr bool TRB = TR && BN == 128;                     // (a 64-column B tile is half an item per thread: it keeps the [BK][rows + 4] form)
-    __shared__ __attribute__((aligned(16))) float sA[2][SA];
-    __shared__ __attribute__((aligned(16))) float sB[2][SB];
+    __shared__ __attribute__((aligned(16))) float sA[CL_WIDE_NBUF][SA];
+    __shared__ __attribute__((aligned(16))) float sB[CL_WIDE_NBUF][SB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     }
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
-        const int cur = it & 1;
+        const int cur = (CL_WIDE_NBUF == 2) ? (it & 1) : 0;
         if (it + 1 < nk) {           // the next chunk's global loads fly under this chunk's MFMAs
             load_a(kbeg + (it + 1) * BK, ra);
             load_b(kbeg + (it + 1) * BK, rb);
@@ -317,7 +321,8 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
                 for (int k = 0; k < BK; ++k) bsum += a_s[k * PMA + tid];
             }
         }
-        if (it + 1 < nk) stage(sA[cur ^ 1], sB[cur ^ 1]);
+        if (CL_WIDE_NBUF == 1) __syncthreads();          // (one copy: every wave is done reading this chunk before the next one lands)
+        if (it + 1 < nk) stage(sA[(CL_WIDE_NBUF == 2) ? (cur ^ 1) : 0], sB[(CL_WIDE_NBUF == 2) ? (cur ^ 1) : 0]);
         __syncthreads();
     }
 
