@@ -147,6 +147,8 @@ EXPORTS = {
     "cl_wide_dense_wgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "cl_wide_image_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_longlong, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
     "cl_wide_image_dgrad": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_longlong, C.c_int, _vp, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_image_forward_tiles": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_image_dgrad_tiles": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
     "cl_wide_image_wgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_longlong, C.c_int, _vp, _vp, _vp, _vp]),
     "cl_wide_head_forward": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
     "cl_wide_head_blocks": (C.c_int, [C.c_longlong]),

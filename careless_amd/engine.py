@@ -233,8 +233,6 @@ class ElboEngine(WidePath):
         if imgl is not None and not self.wide and self.L + imgl.n_image_layers > int(self.lib.cl_mlp_max_layers_imgl(self.w)):
             self.wide = True        # more hidden layers (Dense + per-image) than one fused launch holds: layer by layer as well
         max_plain = 1 if self.wide else int(self.lib.cl_mlp_max_layers(self.w))
-        if self.wide and imgl is not None and self.w > 128:
-            raise NotImplementedError(f"per-image layers of width {self.w}: the HIP engine supports them up to width 128")
         if not self.wide and imgl is None and self.L > max_plain:
             # deeper than one launch holds in registers: a chain of layer blocks, activations exchanged through HBM
             self.blocks = chain_plan(self.d, self.w, self.L, max_plain)
@@ -320,7 +318,10 @@ class ElboEngine(WidePath):
             self.obs.alloc_chain(self.lib, self.blocks, self.w, dev)
         RS = self.R * self.S
         o_dz = 0
-        o_g = (RS + 3) // 4 * 4
+        # the buffer a step all-reduces starts on a 16-byte boundary: the flat gradient (row split), or -- reflection-owner split -- what
+        # lies behind a and b in it (two floats of padding in front of the gradient when 2 R is not a multiple of four)
+        pad = (-2 * self.R) % 4 if self.owner else 0
+        o_g = (RS + 3) // 4 * 4 + pad
         o_sc = (o_g + lay.n + 8 + 3) // 4 * 4           # 4 floats of slack, then the 4 norm terms of the owner-mode message; 16-byte aligned
         o_seg = o_sc + 8                                # 4 doubles = 8 floats
         o_own = o_seg + 2 * self.nseg                   # owner mode: 4 double accumulators + the block ticket of cl_owner_qnorm
@@ -333,7 +334,8 @@ class ElboEngine(WidePath):
         self.own_scratch = self.ws[o_own:o_own + 10].view(torch.float64)
         self.msg_norm = self.ws[o_g + lay.n + 4:o_g + lay.n + 8]                # [raw, sanitised, sanitised a, sanitised b]
         self.msg = self.ws[o_g + 2 * self.R:o_g + lay.n + 8]                    # what an owner-mode step all-reduces
-        self.ws_step = self.ws[o_g:]                                            # owner mode zeroes this and its own slice of dz_f per step
+        self.ws_step = self.ws[o_g - pad:]                                      # owner mode zeroes this (16-byte aligned) and its own slice of dz_f per step
+        assert (self.msg if self.owner else self.grads).data_ptr() % 16 == 0 and self.ws_step.data_ptr() % 16 == 0
         self.norm_part = torch.zeros(2 * 1024, dtype=torch.float64, device=dev)                  # per-workgroup norm sums of cl_adam_step (<= 1024 workgroups)
         self.kl_part = torch.zeros((self.R + 255) // 256, dtype=torch.float64, device=dev)      # per-workgroup KL sums of cl_tn_forward
         self.kl_part_dw = torch.zeros_like(self.kl_part) if self.double_wilson else None        # ... and of cl_dw_prior_forward
@@ -1012,9 +1014,8 @@ def scaler_forward(mlp, metadata, imgl=None, image_id=None):
         # ElboEngine._data_term_wide), forward only; per-image layers run grouped on the rows sorted by image
         w, L, st = mlp.width, mlp.n_layers, _stream()
         order = seg = None
+        keep = []
         if imgl is not None:
-            if w > 128:
-                raise NotImplementedError(f"per-image layers of width {w}: the HIP engine supports them up to width 128")
             imgl.build(d)
             if imgl.flat.device != dev:
                 imgl.flat = imgl.flat.to(dev)
@@ -1056,8 +1057,15 @@ def scaler_forward(mlp, metadata, imgl=None, image_id=None):
                 dst = hb[nl & 1]
                 M = imgl.max_images
                 kb = imgl.flat.data_ptr() + 4 * k * M * (w * w + w)
-                check(lib.cl_wide_image_forward(src[0], src[1], kb + 4 * m0 * w * w, kb + 4 * (M * w * w + m0 * w), ptr(sg), sg.numel() - 1, b - a, w,
-                                                mlp.leakiness, ptr(dst), ldw, None, st), "cl_wide_image_forward")
+                if w > 128:                         # wider than the grouped streaming kernel holds: the tiled kernel over a list of row pieces
+                    from careless_amd.wide import image_tiles
+                    tl = image_tiles(sg.cpu().numpy(), dev)
+                    keep.append(tl)
+                    check(lib.cl_wide_image_forward_tiles(src[0], src[1], kb + 4 * m0 * w * w, kb + 4 * (M * w * w + m0 * w), ptr(sg), ptr(tl), tl.numel() // 2,
+                                                          w, mlp.leakiness, ptr(dst), ldw, None, st), "cl_wide_image_forward_tiles")
+                else:
+                    check(lib.cl_wide_image_forward(src[0], src[1], kb + 4 * m0 * w * w, kb + 4 * (M * w * w + m0 * w), ptr(sg), sg.numel() - 1, b - a, w,
+                                                    mlp.leakiness, ptr(dst), ldw, None, st), "cl_wide_image_forward")
                 src, nl = (dst.data_ptr(), ldw), nl + 1
             check(lib.cl_wide_head_forward(src[0], src[1], base + 4 * off, b - a, w, bij, mlp.epsilon, loc.data_ptr() + 4 * a,
                                            sig.data_ptr() + 4 * a, None, st), "cl_wide_head_forward")

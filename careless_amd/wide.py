@@ -14,6 +14,17 @@ from careless_amd._lib import check, ptr
 from careless_amd.obs import ObsData
 
 
+def image_tiles(rel_seg: np.ndarray, device) -> torch.Tensor:
+    """(group, first row) pairs covering every group's rows in 128-row pieces: the x-blocks of cl_wide_image_forward_tiles /
+    _dgrad_tiles (per-image layers wider than 128).  `rel_seg` = the groups' row starts relative to the call's first row."""
+    rel = np.asarray(rel_seg, dtype=np.int64)
+    n = np.maximum(0, -(-(rel[1:] - rel[:-1]) // 128))                      # pieces per group
+    g = np.repeat(np.arange(len(n)), n)
+    first = np.repeat(np.concatenate([[0], np.cumsum(n)[:-1]]), n)
+    row = rel[:-1][g] + 128 * (np.arange(int(n.sum())) - first)
+    return torch.as_tensor(np.stack([g, row], axis=1).astype(np.int32).reshape(-1), device=device)
+
+
 class WidePath:
     # -- scalers wider than 64 ---------------------------------------------------------------------------------------------
     WIDE_BUDGET = 4 << 30     # bytes of activation storage a row chunk may take ((L + 2) buffers of chunk x ld floats), and never more
@@ -69,6 +80,10 @@ class WidePath:
                 if seg[m1] > seg[m0]:
                     rel = torch.as_tensor((seg[m0:m1 + 1] - seg[m0]).astype(np.int32), device=self.device)
                     chunks.append((int(seg[m0]), int(seg[m1]), m0, rel))
+                    if self.w > 128:            # wider than the grouped streaming kernel holds: the tiled kernel's list of row pieces
+                        if getattr(obs, "wide_tiles", None) is None:
+                            obs.wide_tiles = {}
+                        obs.wide_tiles[int(seg[m0])] = image_tiles(seg[m0:m1 + 1] - seg[m0], self.device)
                 m0 = m1
             self._wide_buffers(max(b - a for a, b, _, _ in chunks))
         obs.wide_chunks = chunks
@@ -154,8 +169,13 @@ class WidePath:
             l = self.L + k
             dst = dst_of(l)
             wk, bk = self._imgl_ptrs(self.params, k, m0)
-            check(lib.cl_wide_image_forward(hs[-1][0], hs[-1][1], wk, bk, ptr(seg), seg.numel() - 1, n, self.w, leak, dst, ldw, sf, st),
-                  "cl_wide_image_forward")
+            if self.w > 128:
+                tl = obs.wide_tiles[a]
+                check(lib.cl_wide_image_forward_tiles(hs[-1][0], hs[-1][1], wk, bk, ptr(seg), ptr(tl), tl.numel() // 2, self.w, leak, dst, ldw, sf, st),
+                      "cl_wide_image_forward_tiles")
+            else:
+                check(lib.cl_wide_image_forward(hs[-1][0], hs[-1][1], wk, bk, ptr(seg), seg.numel() - 1, n, self.w, leak, dst, ldw, sf, st),
+                      "cl_wide_image_forward")
             hs.append((dst, ldw))
         return hs
 
@@ -202,8 +222,13 @@ class WidePath:
                 gw, gb = self._imgl_ptrs(self.grads, k, m0)
                 wk, _ = self._imgl_ptrs(self.params, k, m0)
                 check(lib.cl_wide_image_wgrad(ptr(dz), ldw, hs[l][0], hs[l][1], ptr(seg), seg.numel() - 1, n, w, gw, gb, sf, st), "cl_wide_image_wgrad")
-                check(lib.cl_wide_image_dgrad(ptr(dz), ldw, wk, ptr(seg), seg.numel() - 1, n, w, hs[l][0], hs[l][1], leak, ptr(dzn), ldw, sf, st),
-                      "cl_wide_image_dgrad")
+                if w > 128:
+                    tl = obs.wide_tiles[a]
+                    check(lib.cl_wide_image_dgrad_tiles(ptr(dz), ldw, wk, ptr(seg), ptr(tl), tl.numel() // 2, w, hs[l][0], hs[l][1], leak, ptr(dzn), ldw, sf, st),
+                          "cl_wide_image_dgrad_tiles")
+                else:
+                    check(lib.cl_wide_image_dgrad(ptr(dz), ldw, wk, ptr(seg), seg.numel() - 1, n, w, hs[l][0], hs[l][1], leak, ptr(dzn), ldw, sf, st),
+                          "cl_wide_image_dgrad")
                 dz, dzn = dzn, dz
             nsplit = min(W["nsplit"], int(lib.cl_wide_wgrad_splits(n)))
             pre = self._wide_pre()

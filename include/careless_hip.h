@@ -279,6 +279,13 @@ int cl_wide_image_dgrad(const float* dZ, int lddz, const float* W, const int* se
                         float* dX, int ldo, const int* stop_flag, void* stream);
 int cl_wide_image_wgrad(const float* dZ, int lddz, const float* H, int ldh, const int* seg, int n_groups, long long n, int w, float* dW, float* db,
                         const int* stop_flag, void* stream);
+/* ... wider than 128 (round 4: the reference has no limit, careless/models/scaling/image.py:66-125): forward and dgrad on the tiled kernel, one
+ * workgroup column per entry of `tiles` = n_tiles (group, first row) pairs covering every group's rows in 128-row pieces (the caller
+ * builds the list from its row counts); cl_wide_image_wgrad takes any width as it is */
+int cl_wide_image_forward_tiles(const float* X, int ldx, const float* W, const float* b, const int* seg, const int* tiles, int n_tiles, int w, float leak,
+                                float* Y, int ldy, const int* stop_flag, void* stream);
+int cl_wide_image_dgrad_tiles(const float* dZ, int lddz, const float* W, const int* seg, const int* tiles, int n_tiles, int w, const float* Hprev, int ldh,
+                              float leak, float* dX, int ldo, const int* stop_flag, void* stream);
 /* Dense(2) head: Wo = [Wo^T (2 x w) | bo (2)]; forward writes loc and sigma = bijector(raw) + eps per row; backward takes
  * dO[n][2] = dL/d(loc, sigma), writes dZ of the top layer and partials[nblocks][2 w + 2] of the head's gradient              */
 int cl_wide_head_forward(const float* H, int ldh, const float* Wo, long long n, int w, int bij_kind, float eps, float* loc_out, float* sig_out,

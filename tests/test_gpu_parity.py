@@ -116,6 +116,10 @@ CASES = {
     "wide_image_layers1_2x96_S3": dict(N=700, R=40, d0=5, L=2, w=96, S=3, n_images=5, image_layers=1),
     "wide_image_layers2_1x128_studentt_rows_in_arbitrary_order": dict(N=900, R=50, d0=5, L=1, w=128, S=2, n_images=7, image_layers=2, likelihood="studentt",
                                                                       dof=6.0, shuffle_rows=True),
+    # per-image layers wider than 128 (round 4: the tiled kernel over a list of (image, 128-row piece) blocks; the reference has no limit)
+    "wide_image_layers2_2x144_S2": dict(N=900, R=40, d0=5, L=2, w=144, S=2, n_images=6, image_layers=2, perturb=0.03),
+    "wide_laue_image_layers1_1x160_studentt": dict(N=500, R=40, L=1, w=160, S=2, laue=True, n_images=4, image_layers=1, likelihood="studentt", dof=8.0,
+                                                   perturb=0.03),
     "deep_image_layers2_5x64_S2": dict(N=800, R=40, d0=5, L=5, w=64, S=2, n_images=6, image_layers=2),
     "deep_image_layers3_9x32_softplus": dict(N=600, R=40, d0=5, L=9, w=32, S=2, n_images=4, image_layers=3, bijector="softplus", shift=0.5, perturb=0.03),
     "wide_laue_image_layers1_2x80": dict(N=600, R=50, L=2, w=80, S=2, laue=True, n_images=4, image_layers=1),
