@@ -144,15 +144,23 @@ template <int ROWS>
 __device__ __forceinline__ void load_tile_tr(const float* __restrict__ P, int ld, int row0, int k0, int rows_lim, int k_lim, bool vec_ok, f32x4 (&r)[4], int tid) {
     static_assert(ROWS * BK == 16 * 256, "one item per thread");
     const int row = row0 + 4 * (tid % (ROWS / 4)), k = k0 + 4 * (tid / (ROWS / 4));
+    const float* p = P + (size_t)k * ld + row;
+    if (vec_ok && row0 + ROWS <= rows_lim && k0 + BK <= k_lim) {
+        // the whole tile lies inside the operand (workgroup-uniform; every chunk but the last of a contraction range): four plain float4
+        // loads, no per-element tests -- those and their address selects were a fifth of the kernel's vector instructions
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = *reinterpret_cast<const f32x4*>(p + (size_t)e * ld);
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
         if (k + e < k_lim) {
-            const float* p = P + (size_t)(k + e) * ld + row;
-            if (vec_ok && row + 3 < rows_lim) x = *reinterpret_cast<const f32x4*>(p);
+            const float* pe = p + (size_t)e * ld;
+            if (vec_ok && row + 3 < rows_lim) x = *reinterpret_cast<const f32x4*>(pe);
             else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (row + c < rows_lim) x[c] = p[c];
+                for (int c = 0; c < 4; ++c) if (row + c < rows_lim) x[c] = pe[c];
             }
         }
         r[e] = x;                      // r[e][c] = source[k + e][row + c]
