@@ -227,3 +227,52 @@ def test_owner_bounds_balance_observations_and_fall_back_when_impossible():
     b = owner_bounds(rid, 40, 2)
     assert b.tolist() == [0, 1, 40] or (b[0] == 0 and b[-1] == 40)
     assert owner_bounds(np.array([0, 0, 0, 1]), 5, 3) is None and owner_shard(np.array([0, 0, 0, 1]), 5, 0, 3) is None   # -> row split
+
+
+def _format_worker(rank, world, port, q, fail):
+    """`careless._format_once_per_node` under two gloo ranks: only rank 0 formats; every rank ends up with the same arrays (read-only maps of
+    rank 0's files) and the same ASU object; a formatting error on rank 0 raises on EVERY rank (no rank is left in a barrier)."""
+    import careless_amd.careless as cc
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"n": 0}
+
+    def fake_format(parser):
+        calls["n"] += 1
+        if fail:
+            raise OSError("cannot read the reflection file")
+        rng = np.random.default_rng(3)
+        inputs = (rng.integers(0, 9, (50, 1)), rng.integers(0, 4, (50, 1)), np.zeros((50, 1), np.int64), rng.normal(size=(50, 3)).astype(np.float32),
+                  rng.normal(size=(50, 1)).astype(np.float32), np.ones((50, 1), np.float32))
+        return inputs, {"asu": "collection", "n": 9}
+    cc._format = fake_format
+    try:
+        inputs, rac = cc._format_once_per_node(None, rank, world)
+        ok = len(inputs) == 6 and rac == {"asu": "collection", "n": 9} and (rank == 0 or not inputs[3].flags.writeable)
+        q.put((rank, "ok" if ok else "bad", calls["n"], float(np.asarray(inputs[3], dtype=np.float64).sum())))
+    except OSError as e:
+        q.put((rank, "raised", calls["n"], str(e)))
+    except RuntimeError as e:
+        q.put((rank, "raised", calls["n"], str(e)))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_reflection_files_are_formatted_once_per_node_and_failures_reach_every_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    for fail in (False, True):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_format_worker, args=(r, world, port, q, fail)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = sorted(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert [g[2] for g in got] == [1, 0]                       # rank 0 formatted, rank 1 did not
+        if fail:
+            assert [g[1] for g in got] == ["raised", "raised"]     # both ranks leave with an error; nobody waits in a collective
+        else:
+            assert [g[1] for g in got] == ["ok", "ok"] and got[0][3] == got[1][3]
