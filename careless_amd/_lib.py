@@ -136,11 +136,16 @@ EXPORTS = {
     "cl_mlp_kernel_name": (C.c_int, [C.POINTER(MlpArgs), C.c_int, C.c_char_p, C.c_size_t]),
     "cl_wide_ld": (C.c_int, [C.c_int]),
     "cl_wide_dense_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int, _vp, _vp]),
-    "cl_wide_dense_forward_head": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp]),
+    "cl_wide_dense_forward_head": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "cl_wide_head_bwd_supported": (C.c_int, [C.c_int, C.c_int]),
+    "cl_wide_dense_wgrad_head": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_float, _vp, C.c_int, C.c_longlong, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_dense_dgrad_head": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
     "cl_wide_pre_supported": (C.c_int, [C.c_int, C.c_int]),
     "cl_wide_dense2_forward": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, C.c_int, C.c_float,
                                          _vp, _vp, _vp, _vp]),
     "cl_wide_dense_dgrad_pre": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_float, _vp, C.c_int, _vp, _vp]),
+    "cl_wide_dgrad_wgrad0_parts": (C.c_int, [C.c_longlong]),
+    "cl_wide_dense_dgrad_pre_wgrad0": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "cl_wide_dense_wgrad_pre": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, C.c_float, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "cl_wide_dense_dgrad": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),
     "cl_wide_wgrad_splits": (C.c_int, [C.c_longlong]),

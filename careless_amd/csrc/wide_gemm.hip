@@ -78,6 +78,11 @@ struct GemmArgs {
     // Grouped forward / dgrad (per-image layers wider than the streaming kernel holds, round 4): x-block i works on the BM rows from
     // tiles[2 i + 1] of group tiles[2 i] (rows seg[g] .. seg[g + 1]), whose B operand sits at B + g * bgs and bias at bias + g * biasgs
     const int* tiles; long long bgs, biasgs;
+    // EPI_WGRAD of the TOP layer with the head's backward pass fused (HEADW instances, round 4): A = the top layer's activations h_L[k][m] in
+    // place of dZ_L, which is made from them while the tile is staged: dZ_L[k][m] = (g0[k] Wo[0][m] + g1[k] Wo[1][m]) * LeakyReLU'(h_L[k][m]),
+    // g0 = dL/dloc, g1 = dL/dsigma * dsigma/draw of observation k; the head's own weight gradient (sums of h_L g over k) is taken on the way
+    const float* hd_dO; const float* hd_dsd; const float* hd_W;     // [K][2], [K], the head's flat layout [Wo (2 x M) | bo (2)]
+    float* hd_part;                                                 // [z][2 M + 2] partial sums of (dWo | dbo)
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -175,8 +180,9 @@ __device__ __forceinline__ void store_tile_tr(float* __restrict__ s, const f32x4
 }
 
 // BN: 64 or 128 output columns per workgroup (128: the row operand of a layer of width <= 128 is read once)
-template <bool AK, bool BK_, int EPI, int BN>
+template <bool AK, bool BK_, int EPI, int BN, bool HEADW = false>
 __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
+    static_assert(!HEADW || (EPI == EPI_WGRAD && AK && BK_), "the fused head backward feeds the weight gradient's transposing loader");
     if (G.stop_flag != nullptr && *G.stop_flag != 0) return;      // a previous step hit a non-finite gradient norm
     constexpr int PMB = BN + 4, NB = BN / 16;
     constexpr int SB = (BN * PK > BK * PMB) ? BN * PK : BK * PMB;
@@ -251,9 +257,56 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
         }
         return out;
     };
+    // HEADW: the thread's four output units are fixed (as `pcol` on the other operand): the head's two weights of each in registers, the
+    // head's weight-gradient sums of those columns over the thread's observations, dL/d(loc, sigma) and dsigma/draw of the item's four rows
+    float hw0[4], hw1[4], ha0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, ha1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, hsb0 = 0.0f, hsb1 = 0.0f;
+    f32x4 rg0 = {0.0f, 0.0f, 0.0f, 0.0f}, rg1 = rg0, rgd = rg0;
+    if (HEADW) {
+        const int hcol = m0 + 4 * (tid % (BM / 4));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            hw0[c] = (hcol + c < G.M) ? G.hd_W[hcol + c] : 0.0f;
+            hw1[c] = (hcol + c < G.M) ? G.hd_W[G.M + hcol + c] : 0.0f;
+        }
+    }
     auto load_a = [&](int kk0, f32x4 (&r)[BM * BK / 1024]) {
         if constexpr (TR) load_tile_tr<BM>(G.A, G.lda, m0, kk0, Mlim, kend, vecA, r, tid);
         else load_tile<BM, AK>(G.A, G.lda, m0, kk0, Mlim, kend, vecA, r, tid);
+        if constexpr (HEADW) {
+            const int k = kk0 + 4 * (tid / (BM / 4));                 // the item's four observations (k is a multiple of four: aligned quads)
+            if (k + 3 < kend) {
+                rg0 = *reinterpret_cast<const f32x4*>(G.hd_dO + 2 * (size_t)k);
+                rg1 = *reinterpret_cast<const f32x4*>(G.hd_dO + 2 * (size_t)k + 4);
+                rgd = *reinterpret_cast<const f32x4*>(G.hd_dsd + k);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool in = k + e < kend;
+                    const float a0 = in ? G.hd_dO[2 * (size_t)(k + e)] : 0.0f, a1 = in ? G.hd_dO[2 * (size_t)(k + e) + 1] : 0.0f;
+                    if (e < 2) { rg0[2 * e] = a0; rg0[2 * e + 1] = a1; } else { rg1[2 * e - 4] = a0; rg1[2 * e - 3] = a1; }
+                    rgd[e] = in ? G.hd_dsd[k + e] : 0.0f;
+                }
+            }
+        }
+    };
+    // HEADW: h_L in `ra` -> dZ_L, in place, just before the tile is staged (the loads were issued a chunk of MFMAs earlier)
+    auto head_xform = [&]() {
+        if constexpr (HEADW) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float g0 = (e < 2) ? rg0[2 * e] : rg1[2 * e - 4];
+                const float g1 = ((e < 2) ? rg0[2 * e + 1] : rg1[2 * e - 3]) * rgd[e];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float h = ra[e][c];
+                    ha0[c] = fmaf(h, g0, ha0[c]);
+                    ha1[c] = fmaf(h, g1, ha1[c]);
+                    const float dh = fmaf(g1, hw1[c], g0 * hw0[c]);
+                    ra[e][c] = (h > 0.0f) ? dh : G.leak * dh;
+                }
+                hsb0 += g0; hsb1 += g1;
+            }
+        }
     };
     auto load_b = [&](int kk0, f32x4 (&r)[BN * BK / 1024]) {
         if (!pre) {
@@ -278,6 +331,7 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     if (nk > 0) {
         load_a(kbeg, ra);
         load_b(kbeg, rb);
+        head_xform();
         stage(sA[0], sB[0]);
     }
     __syncthreads();
@@ -339,8 +393,32 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
             }
         }
         // (one LDS copy with two barriers per chunk -- 36.9 KB, three workgroups per CU instead of two -- measured equal: 5.19 vs 5.19 ms per step)
-        if (it + 1 < nk) stage(sA[cur ^ 1], sB[cur ^ 1]);
+        if (it + 1 < nk) { head_xform(); stage(sA[cur ^ 1], sB[cur ^ 1]); }
         __syncthreads();
+    }
+    if constexpr (HEADW) {
+        // the head's weight gradient of this workgroup's observations: eight k-groups of threads hold sums for the same columns; LDS is free
+        // after the loop's last barrier.  Layout of the partial: [dWo (2 x M) | dbo (2)]
+        float* sh = &sA[0][0];
+        const int kg = tid / (BM / 4), c0 = 4 * (tid % (BM / 4));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sh[kg * 2 * BM + c0 + c] = ha0[c]; sh[kg * 2 * BM + BM + c0 + c] = ha1[c]; }
+        if (tid % (BM / 4) == 0) { sh[16 * BM + 2 * kg] = hsb0; sh[16 * BM + 2 * kg + 1] = hsb1; }
+        __syncthreads();
+        float* part = G.hd_part + (size_t)blockIdx.z * (2 * (size_t)G.M + 2);
+        for (int i = tid; i < 2 * BM + 2; i += 256) {
+            float t = 0.0f;
+            if (i < 2 * BM) {
+                const int r = i / BM, c = i - r * BM;
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) t += sh[g8 * 2 * BM + i];
+                if (c < G.M) part[(size_t)r * G.M + c] = t;
+            } else {
+#pragma unroll
+                for (int g8 = 0; g8 < 8; ++g8) t += sh[16 * BM + 2 * g8 + (i - 2 * BM)];
+                part[2 * (size_t)G.M + (i - 2 * BM)] = t;
+            }
+        }
     }
 
     // epilogue: accumulator (a, b), element t of lane (j, q) = C[m0 + 32 wv + 16 a + 4 q + t][n0 + 16 b + j]
@@ -505,7 +583,11 @@ struct StreamArgs {
     const float* head_W;             // [2][N] then [2] biases (the head's flat layout) or NULL
     int bij_kind; float eps;
     float* loc_out; float* sig_out;  // [n]
+    float* dsd_out;                  // [n] or NULL: d sigma / d raw of the row (the bijector's derivative), for the head's backward pass fused into
+                                     // the top layer's dgrad / weight gradient (HEADB instances, cl_wide_dense_wgrad_head)
+    const float* dO; const float* dsd;   // HEADB: dL/d(loc, sigma) [n][2] and d sigma / d raw [n]; X = the TOP layer's activations h_L, head_W = the head
     PreArgs pre;                     // EPI_DLRELU: the activations whose sign selects the derivative are the recomputed first layer (H unused)
+    float* wg0_part;                 // WG0 instances: [gridDim.x][N K0 + N] partial sums of the FIRST layer's weight gradient (flat W^T layout)
 };
 
 // NAT: 16-column blocks of the output an instance holds (4: N <= 64, 8: N <= 128); GRP: the grouped form (its own instances: the
@@ -687,6 +769,7 @@ __global__ __launch_bounds__(512) void wide_stream_kernel(const StreamArgs S) {
                     float d;
                     S.loc_out[row] = ho0 + S.head_W[2 * N];
                     S.sig_out[row] = cl_scale_bij(ho1 + S.head_W[2 * N + 1], S.bij_kind, S.eps, &d);
+                    if (S.dsd_out != nullptr) S.dsd_out[row] = d;
                 }
             }
         }
@@ -860,9 +943,21 @@ int launch_stream2(const Stream2Args& s, hipStream_t st) {
 //     prefetch distance is a full block (3.4 us of MFMAs at NA = 8) with no second buffer;
 //   * the dgrad mask (the layer's input activations, or the recomputed first layer) is requested at the start of the block.
 // Same arithmetic, same order of the contraction as wide_stream_kernel (chunk by chunk, step t inside a chunk): the same bits.
-template <bool WKM, int EPI, int NA, bool PRE>
+// WG0 (round 4, with PRE on the dgrad of the SECOND layer): the kernel's output dZ_0 = (dZ_1 Wt_1) * LeakyReLU'(h_0) is the first layer's
+// pre-activation gradient, whose only use is that layer's weight gradient dWt_0 = dZ_0^T X_0 (the metadata are not trained).  With the
+// MFMA operands SWAPPED (A = the rows' operand, B = the weights: the same registers, the same products in the same order) the output
+// block comes out as lane (j, q), element t = dZ_0[row 4 q + t][column 16 a + j] -- the B-operand layout of a contraction over the
+// block's 16 rows.  Four more MFMAs per 16 columns against A = X_0^T (lane (i, q), step t = X_0[row 4 q + t][i], a row of ones behind
+// the metadata for the bias gradient) add the block into per-wave accumulators dWt_0[16 a + j][i = 4 q + t] that live for the whole
+// launch: dZ_0 is never stored (512 B per row at width 128) and the separate weight-gradient launch that read it back is gone.
+// HEADB (round 4, the dgrad of the TOP layer): its row operand dZ_L = (g Wo) * LeakyReLU'(h_L), g = dL/d(loc, raw sigma) of the row, is a rank-2
+// product behind a mask -- made from h_L (the same bytes per row as dZ_L) and the row's two numbers while the chunk is on its way to the
+// MFMAs, instead of being written by a launch of its own (cl_wide_head_backward) and read back twice.
+template <bool WKM, int EPI, int NA, bool PRE, bool WG0 = false, bool HEADB = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void wide_sq_kernel(const StreamArgs S) {
+    static_assert(!WG0 || (PRE && EPI == EPI_DLRELU), "the fused first-layer weight gradient rides on the dgrad with the recomputed mask");
+    static_assert(!HEADB || (!PRE && EPI == EPI_DLRELU), "the fused head backward feeds the dgrad of the top layer");
     if (S.stop_flag != nullptr && *S.stop_flag != 0) return;
     extern __shared__ __attribute__((aligned(16))) float sWq[];      // [16 NA][SKP], zero outside N x K
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -890,9 +985,10 @@ void wide_sq_kernel(const StreamArgs S) {
         for (int u = 0; u < 8; ++u) if (at[u] >= 0) sWq[at[u]] = v[u];
     }
     if (EPI == EPI_BIAS_LRELU && tid < 16 * NA) sBias[tid] = (tid < N) ? S.bias[tid] : 0.0f;
-    if (EPI == EPI_BIAS_LRELU && S.head_W != nullptr && tid < 32 * NA) {
+    if ((EPI == EPI_BIAS_LRELU || HEADB) && S.head_W != nullptr && tid < 32 * NA) {
         const int r = tid / (16 * NA), c = tid - r * 16 * NA;
-        sHead[tid] = (c < N) ? S.head_W[r * N + c] : 0.0f;
+        const int Nh = HEADB ? K : N;                                // (the head reads the layer's output: the forward's N, the dgrad's K)
+        sHead[tid] = (c < Nh) ? S.head_W[r * Nh + c] : 0.0f;
     }
     if (PRE) {
         for (int idx = tid; idx < 16 * NA * S0P; idx += 512) {
@@ -913,15 +1009,33 @@ void wide_sq_kernel(const StreamArgs S) {
     };
     long long blk = (long long)blockIdx.x * 8 + wv;
     const long long bstep = (long long)gridDim.x * 8;
+    f32x4 acc0[WG0 ? NA : 1];                    // WG0: dWt_0[16 a + j][4 q + t] of this wave's blocks (column K0 = the bias gradient)
+#pragma unroll
+    for (int a = 0; a < (WG0 ? NA : 1); ++a) acc0[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int K0 = S.pre.K0;
     f32x4 xb[NA];
+    float gc0 = 0.0f, gc1 = 0.0f;                 // HEADB: g of this lane's row of the current block
     if (blk < nblk) {
         const float* xp = x_ptr(blk);
 #pragma unroll
         for (int kc = 0; kc < NA; ++kc) xb[kc] = (16 * kc + cq < S.ldx) ? *reinterpret_cast<const f32x4*>(xp + 16 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (HEADB) {
+            long long r = blk * 16 + j;
+            if (r >= S.n) r = S.n - 1;
+            gc0 = S.dO[2 * (size_t)r];
+            gc1 = S.dO[2 * (size_t)r + 1] * S.dsd[r];
+        }
     }
     for (; blk < nblk; blk += bstep) {
         const long long row = blk * 16 + j;
         const long long rowc = row < S.n ? row : S.n - 1;
+        // HEADB: the next block's row numbers, requested a block ahead like its operand
+        float gn0 = 0.0f, gn1 = 0.0f, gnd = 0.0f;
+        if (HEADB && blk + bstep < nblk) {
+            long long r = (blk + bstep) * 16 + j;
+            if (r >= S.n) r = S.n - 1;
+            gn0 = S.dO[2 * (size_t)r]; gn1 = S.dO[2 * (size_t)r + 1]; gnd = S.dsd[r];
+        }
         // the mask of the dgrad epilogue, requested now (the layer's input activations), consumed after the MFMAs
         f32x4 hm[NA];
         if (EPI == EPI_DLRELU && !PRE && S.H != nullptr) {
@@ -931,6 +1045,18 @@ void wide_sq_kernel(const StreamArgs S) {
         }
         f32x4 x0 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (PRE && cq < S.pre.ldx0) x0 = *reinterpret_cast<const f32x4*>(S.pre.X0 + (size_t)rowc * S.pre.ldx0 + cq);
+        // WG0: X_0^T as A operand -- lane (i = j, q), step t = X_0[row 4 q + t][i]; lane K0 carries ones (bias gradient), lanes past it zeros.
+        // Requested now (lines the mask's x0 just touched), used after the MFMAs; rows past the end are zeroed at the use point.
+        f32x4 xg = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (WG0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                long long r = blk * 16 + cq + t;
+                if (r >= S.n) r = S.n - 1;
+                xg[t] = (j == K0) ? 1.0f : 0.0f;
+                if (j < K0) xg[t] = S.pre.X0[(size_t)r * S.pre.ldx0 + j];
+            }
+        }
         const bool more = blk + bstep < nblk;
         const float* xnext = x_ptr(more ? blk + bstep : blk);
         f32x4 acc[NA];
@@ -938,15 +1064,46 @@ void wide_sq_kernel(const StreamArgs S) {
         for (int a = 0; a < NA; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int kc = 0; kc < NA; ++kc) {
+            f32x4 xv = xb[kc];
+            if (HEADB) {
+                // dZ_L[row][16 kc + 4 q + t] from h_L (in xb) and the row's g: (g0 Wo[0][c] + g1 Wo[1][c]) * LeakyReLU'(h_L[row][c])
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(sHead + 16 * kc + cq), h1 = *reinterpret_cast<const f32x4*>(sHead + 16 * NA + 16 * kc + cq);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float dh = fmaf(gc1, h1[t], gc0 * h0[t]);
+                    xv[t] = (xb[kc][t] > 0.0f) ? dh : S.leak * dh;
+                }
+            }
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 const f32x4 wf = *reinterpret_cast<const f32x4*>(wrow + 16 * a * SKP + 16 * kc);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[a] = mfma4(wf[t], xb[kc][t], acc[a]);
+                for (int t = 0; t < 4; ++t) acc[a] = WG0 ? mfma4(xv[t], wf[t], acc[a]) : mfma4(wf[t], xv[t], acc[a]);
             }
             // this quad's MFMAs are issued: refill it with the next block's chunk (a whole block of MFMAs ahead of its use)
             if (more && 16 * kc + cq < S.ldx) xb[kc] = *reinterpret_cast<const f32x4*>(xnext + 16 * kc);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (HEADB) { gc0 = gn0; gc1 = gn1 * gnd; }
+        if constexpr (WG0) {
+            const long long nleft = S.n - (blk * 16 + cq);          // rows 4 q + t < nleft exist
+            f32x4 xa;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xa[t] = (t < nleft) ? xg[t] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(sW0 + (16 * a + j) * S0P + cq);
+                f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) z = mfma4(x0[t], wf[t], z);      // h_0's pre-activations [row 4 q + t][column 16 a + j], bias below
+                const float b0 = sB0[16 * a + j];
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = (z[t] + b0 > 0.0f) ? acc[a][t] : S.leak * acc[a][t];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc0[a] = mfma4(xa[t], v[t], acc0[a]);
+            }
+            continue;                                                // (nothing is stored per row)
         }
         if (PRE) {
             // the recomputed first layer's pre-activations of this lane's row and columns (every lane takes part: an MFMA reads the
@@ -990,7 +1147,26 @@ void wide_sq_kernel(const StreamArgs S) {
                     float dd;
                     S.loc_out[row] = ho0 + S.head_W[2 * N];
                     S.sig_out[row] = cl_scale_bij(ho1 + S.head_W[2 * N + 1], S.bij_kind, S.eps, &dd);
+                    if (S.dsd_out != nullptr) S.dsd_out[row] = dd;
                 }
+            }
+        }
+    }
+    if constexpr (WG0) {
+        // the eight waves' accumulators -> this workgroup's partial, in the first layer's flat layout [Wt_0 (N x K0) | b_0 (N)]; the weight
+        // image's LDS is free once every wave has left the loop (8 x 16 NA x 16 floats fit its 16 NA x 132)
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < NA; ++a) *reinterpret_cast<f32x4*>(sWq + ((wv * 16 * NA + 16 * a + j) * 16 + cq)) = acc0[a];
+        __syncthreads();
+        float* part = S.wg0_part + (size_t)blockIdx.x * ((size_t)N * K0 + N);
+        for (int idx = tid; idx < 16 * NA * 16; idx += 512) {
+            const int c = idx >> 4, i = idx & 15;
+            if (c < N && i <= K0) {
+                float t = 0.0f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) t += sWq[(w8 * 16 * NA + c) * 16 + i];
+                if (i < K0) part[(size_t)c * K0 + i] = t; else part[(size_t)N * K0 + c] = t;
             }
         }
     }
@@ -1008,10 +1184,19 @@ static bool sq_ok(const StreamArgs& s) {
     return !off;
 }
 
-template <bool WKM, int EPI, int NA, bool PRE>
+static long long sq_grid(long long n) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long nblk = (n + 15) >> 4;
+    long long grid = (nblk + 7) / 8;
+    if (grid > 2LL * cus) grid = 2LL * cus;
+    return grid < 1 ? 1 : grid;
+}
+
+template <bool WKM, int EPI, int NA, bool PRE, bool WG0 = false, bool HEADB = false>
 int launch_sq_n(const StreamArgs& s, hipStream_t st) {
     const size_t sm = (size_t)(16 * NA * SKP + 3 * 16 * NA + (PRE ? 16 * NA * (S0P + 1) : 0)) * sizeof(float);
-    auto kern = wide_sq_kernel<WKM, EPI, NA, PRE>;
+    auto kern = wide_sq_kernel<WKM, EPI, NA, PRE, WG0, HEADB>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -1019,24 +1204,19 @@ int launch_sq_n(const StreamArgs& s, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         while (have < sm && !configured.compare_exchange_weak(have, sm, std::memory_order_release, std::memory_order_acquire)) {}
     }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const long long nblk = (s.n + 15) >> 4;
-    long long grid = (nblk + 7) / 8;
-    if (grid > 2LL * cus) grid = 2LL * cus;
-    if (grid < 1) grid = 1;
+    const long long grid = sq_grid(s.n);
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), sm, st, s);
     return (int)hipGetLastError();
 }
 
-template <bool WKM, int EPI, bool PRE>
+template <bool WKM, int EPI, bool PRE, bool WG0 = false, bool HEADB = false>
 int launch_sq(const StreamArgs& s, hipStream_t st) {
     switch ((s.N + 15) >> 4) {
-        case 5: return launch_sq_n<WKM, EPI, 5, PRE>(s, st);
-        case 6: return launch_sq_n<WKM, EPI, 6, PRE>(s, st);
-        case 7: return launch_sq_n<WKM, EPI, 7, PRE>(s, st);
-        default: return launch_sq_n<WKM, EPI, 8, PRE>(s, st);
+        case 5: return launch_sq_n<WKM, EPI, 5, PRE, WG0, HEADB>(s, st);
+        case 6: return launch_sq_n<WKM, EPI, 6, PRE, WG0, HEADB>(s, st);
+        case 7: return launch_sq_n<WKM, EPI, 7, PRE, WG0, HEADB>(s, st);
+        default: return launch_sq_n<WKM, EPI, 8, PRE, WG0, HEADB>(s, st);
     }
 }
 
@@ -1114,7 +1294,7 @@ int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float*
  * loc = Y . Wo[0] + bo[0], sigma = bijector(Y . Wo[1] + bo[1]) + eps per row (`head` = the head's flat layout [Wo (2 x n_out) | bo (2)]).
  * Layers up to 128 x 128 (the streaming kernel); -2 otherwise: the caller then runs cl_wide_dense_forward + cl_wide_head_forward.      */
 int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak,
-                               float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out,
+                               float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out, float* dsig_draw_out,
                                const int* stop_flag, void* stream) {
     if (X == nullptr || Wt == nullptr || b == nullptr || Y == nullptr || head == nullptr || loc_out == nullptr || sig_out == nullptr || n < 1 ||
         n > 0x7fffffffLL || n_in < 1 || n_out < 1 || ldx < n_in || ldy < n_out)
@@ -1123,9 +1303,32 @@ int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const f
     StreamArgs s = {};
     s.X = X; s.ldx = ldx; s.W = Wt; s.ldw = n_in; s.Y = Y; s.ldy = ldy; s.n = n; s.N = n_out; s.K = n_in;
     s.bias = b; s.leak = leak; s.act = 1; s.stop_flag = stop_flag;
-    s.head_W = head; s.bij_kind = bij_kind; s.eps = eps; s.loc_out = loc_out; s.sig_out = sig_out;
+    s.head_W = head; s.bij_kind = bij_kind; s.eps = eps; s.loc_out = loc_out; s.sig_out = sig_out; s.dsd_out = dsig_draw_out;
     if (sq_ok(s)) return launch_sq<false, EPI_BIAS_LRELU, false>(s, (hipStream_t)stream);
     return launch_stream<false, EPI_BIAS_LRELU>(s, (hipStream_t)stream);
+}
+
+/* The Dense(2) head's backward pass inside the TOP layer's dgrad and weight gradient (round 4; replaces cl_wide_head_backward + its dZ_L buffer):
+ * Htop = the top layer's activations h_L [n][ldt] as cl_wide_dense_forward_head stored them, dO = dL/d(loc, sigma) per row [n][2],
+ * dsig_draw = that call's dsig_draw_out, head = the head's flat layout.  dZ_L = (g Wo) * LeakyReLU'(h_L), g = (dO[0], dO[1] dsig_draw), is
+ * made where the kernels read their dZ operand.  Width 65 .. 128 on both sides of the layer (cl_wide_head_bwd_supported), else -2.            */
+int cl_wide_head_bwd_supported(int n_out, int n_in) {
+    const int NA = (n_in + 15) >> 4, KA = (n_out + 15) >> 4;
+    return n_in >= 1 && n_out >= 1 && NA == KA && NA >= 5 && NA <= SMAX / 16;
+}
+
+int cl_wide_dense_dgrad_head(const float* Htop, int ldt, const float* head, const float* dO, const float* dsig_draw, const float* Wt, long long n,
+                             int n_out, int n_in, const float* Hprev, int ldh, float leak, float* dX, int ldo, const int* stop_flag, void* stream) {
+    if (Htop == nullptr || head == nullptr || dO == nullptr || dsig_draw == nullptr || Wt == nullptr || dX == nullptr || n < 1 || n > 0x7fffffffLL ||
+        n_in < 1 || n_out < 1 || ldt < n_out || ldo < n_in)
+        return -1;
+    if (!cl_wide_head_bwd_supported(n_out, n_in)) return -2;
+    StreamArgs s = {};
+    s.X = Htop; s.ldx = ldt; s.W = Wt; s.ldw = n_in; s.Y = dX; s.ldy = ldo; s.n = n; s.N = n_in; s.K = n_out;
+    s.H = Hprev; s.ldh = ldh; s.leak = leak; s.stop_flag = stop_flag;
+    s.head_W = head; s.dO = dO; s.dsd = dsig_draw;
+    if (!sq_ok(s)) return -2;
+    return launch_sq<true, EPI_DLRELU, false, false, true>(s, (hipStream_t)stream);
 }
 
 int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* Hprev, int ldh, float leak,
@@ -1192,6 +1395,27 @@ int cl_wide_dense_dgrad_pre(const float* dZ, int lddz, const float* Wt, long lon
     return s.N <= 64 ? launch_stream_n<true, EPI_DLRELU, 4, false, true>(s, (hipStream_t)stream) : launch_stream_n<true, EPI_DLRELU, 8, false, true>(s, (hipStream_t)stream);
 }
 
+/* The second layer's dgrad and the FIRST layer's weight gradient in one launch (round 4): dZ_0 = (dZ Wt) * LeakyReLU'(h_0) with h_0 recomputed
+ * from the metadata as in cl_wide_dense_dgrad_pre, contracted with the metadata rows on the spot -- dZ_0 is not stored.  Writes
+ * cl_wide_dgrad_wgrad0_parts(n) partial sums of [dWt_0 (n_in x n_in0) | db_0 (n_in)] into `partials` (add them with cl_reduce_partials).
+ * -2: shape not taken (the square-layer kernel's envelope: 65 .. 128 on both sides, same number of 16-column blocks): the caller then
+ * runs cl_wide_dense_dgrad_pre + cl_wide_dense_wgrad.                                                                               */
+int cl_wide_dgrad_wgrad0_parts(long long n) { return n < 1 ? 0 : (int)sq_grid(n); }
+
+int cl_wide_dense_dgrad_pre_wgrad0(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* X0, int ldx0, int n_in0,
+                                   const float* Wt0, const float* b0, float leak, float* partials, const int* stop_flag, void* stream) {
+    if (int e = pre_check(X0, ldx0, n_in0, Wt0, b0, n_in)) return e;
+    if (dZ == nullptr || Wt == nullptr || partials == nullptr || n < 1 || n > 0x7fffffffLL || n_out < 1 || lddz < n_out) return -1;
+    if (n_out > SMAX) return -2;
+    StreamArgs s = {};
+    s.X = dZ; s.ldx = lddz; s.W = Wt; s.ldw = n_in; s.Y = const_cast<float*>(dZ); s.ldy = lddz; s.n = n; s.N = n_in; s.K = n_out;   /* (Y: never written; set for sq_ok's layout tests) */
+    s.leak = leak; s.stop_flag = stop_flag;
+    s.pre.X0 = X0; s.pre.ldx0 = ldx0; s.pre.K0 = n_in0; s.pre.W0 = Wt0; s.pre.b0 = b0; s.pre.N0 = n_in;
+    s.wg0_part = partials;
+    if (!sq_ok(s)) return -2;
+    return launch_sq<true, EPI_DLRELU, true, true>(s, (hipStream_t)stream);
+}
+
 int cl_wide_dense_wgrad_pre(const float* dZ, int lddz, const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, float leak, long long n,
                             int n_out, int n_in, float* partials, int nsplit, const int* stop_flag, void* stream) {
     if (int e = pre_check(X0, ldx0, n_in0, Wt0, b0, n_in)) return e;
@@ -1225,6 +1449,28 @@ int cl_wide_dense_wgrad(const float* dZ, int lddz, const float* H, int ldh, long
     g.pstride = (long long)n_out * n_in + n_out;
     g.stop_flag = stop_flag;
     return launch_gemm<true, true, EPI_WGRAD>(g, nsplit, (hipStream_t)stream);
+}
+
+/* head_partials[s][2 n_out + 2] = (dWo | dbo) over the s-th row range, next to the layer's own partials as cl_wide_dense_wgrad writes them */
+int cl_wide_dense_wgrad_head(const float* Htop, int ldt, const float* head, const float* dO, const float* dsig_draw, float leak, const float* H, int ldh,
+                             long long n, int n_out, int n_in, float* partials, float* head_partials, int nsplit, const int* stop_flag, void* stream) {
+    if (Htop == nullptr || head == nullptr || dO == nullptr || dsig_draw == nullptr || H == nullptr || partials == nullptr || head_partials == nullptr ||
+        n < 1 || n > 0x7fffffffLL || n_in < 1 || n_out < 1 || nsplit < 1 || ldt < n_out || ldh < n_in)
+        return -1;
+    if (!cl_wide_head_bwd_supported(n_out, n_in)) return -2;
+    // (the loader reads dO and dsig_draw as aligned quads of four consecutive rows)
+    if ((reinterpret_cast<uintptr_t>(dO) & 15) != 0 || (reinterpret_cast<uintptr_t>(dsig_draw) & 15) != 0) return -1;
+    GemmArgs g = {};
+    g.A = Htop; g.lda = ldt; g.B = H; g.ldb = ldh; g.C = partials;
+    g.M = n_out; g.N = n_in; g.K = (int)n; g.n_in = n_in;
+    g.ksplit = (int)((n + nsplit - 1) / nsplit);
+    g.ksplit = (g.ksplit + BK - 1) / BK * BK;
+    g.pstride = (long long)n_out * n_in + n_out;
+    g.leak = leak; g.stop_flag = stop_flag;
+    g.hd_dO = dO; g.hd_dsd = dsig_draw; g.hd_W = head; g.hd_part = head_partials;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((wide_gemm_kernel<true, true, EPI_WGRAD, 128, true>), dim3(1, 1, nsplit), dim3(256), 0, (hipStream_t)stream, g);
+    return (int)hipGetLastError();
 }
 
 /* per-image layers (grouped): rows sorted by image, seg[g] .. seg[g+1] = rows of image g of this call (n_groups images);

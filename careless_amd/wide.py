@@ -6,6 +6,7 @@ fused launch takes): the layer-by-layer path of the engine on the GEMM kernels o
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -57,7 +58,9 @@ class WidePath:
         W["dz"] = [torch.zeros(rows * ldw, dtype=torch.float32, device=dev) for _ in range(2)]
         W["nsplit"], W["nblk"] = int(lib.cl_wide_wgrad_splits(rows)), int(lib.cl_wide_head_blocks(rows))
         pmax = max(self.w * self.d + self.w, self.w * self.w + self.w)
-        W["wpart"] = torch.empty(W["nsplit"] * pmax, dtype=torch.float32, device=dev)
+        # (the fused dgrad + first-layer weight gradient writes one partial per workgroup: more of them, each smaller)
+        W["wpart"] = torch.empty(max(W["nsplit"] * pmax, int(lib.cl_wide_dgrad_wgrad0_parts(rows)) * (self.w * self.d + self.w)),
+                                 dtype=torch.float32, device=dev)
         W["hpart"] = torch.empty(W["nblk"] * (2 * self.w + 2), dtype=torch.float32, device=dev)
         W["rows"] = rows
 
@@ -113,6 +116,13 @@ class WidePath:
         import os
         return (self.L >= 2 and bool(self.lib.cl_wide_pre_supported(self.d, self.w)) and os.environ.get("CARELESS_HIP_WIDE_PRE", "1") != "0")
 
+    def _wide_head_bwd(self) -> bool:
+        """The Dense(2) head's backward pass runs inside the top Dense layer's weight gradient and dgrad (cl_wide_dense_wgrad_head /
+        _dgrad_head) instead of a launch of its own that writes dZ_L: Dense-only scalers whose top layer is a square one of the streaming
+        kernel's widths and not the layer fed by the recomputed first one.  CARELESS_HIP_WIDE_HEADB=0: the separate launch (A/B runs)."""
+        return (self.imgl is None and self.L >= 2 and not (self._wide_pre() and self.L == 2) and
+                bool(self.lib.cl_wide_head_bwd_supported(self.w, self.w)) and os.environ.get("CARELESS_HIP_WIDE_HEADB", "1") != "0")
+
     def _wide_keep_all(self, obs: ObsData):
         """Per-layer activation buffers over ALL rows of `obs` (list of tensors), or None when they do not fit: then the backward pass
         recomputes each chunk's forward into the chunk-sized buffers."""
@@ -149,16 +159,17 @@ class WidePath:
             if pre and l == 1:
                 (ow0, ob0, d0) = layers[0]
                 with_head = head is not None and self.L == 2 and self.imgl is None
-                off_head, loc_ptr, sig_ptr = head if with_head else (0, None, None)
+                off_head, loc_ptr, sig_ptr = head[:3] if with_head else (0, None, None)
                 check(lib.cl_wide_dense2_forward(hs[0][0], hs[0][1], d0, base + 4 * ow0, base + 4 * ob0, base + 4 * ow, base + 4 * ob, n, self.w, self.w,
                                                  leak, dst, ldw, (base + 4 * off_head) if with_head else None, self.bij_kind, self.mlp.epsilon,
                                                  loc_ptr, sig_ptr, sf, st), "cl_wide_dense2_forward")
                 self._head_fused = with_head
             elif head is not None and l == self.L - 1 and self.imgl is None and fan_in <= 128 and self.w <= 128:
                 # the top layer carries the Dense(2) head in its epilogue: (loc, sigma) come out of the same pass
-                off_head, loc_ptr, sig_ptr = head
+                off_head, loc_ptr, sig_ptr = head[:3]
+                dsd_ptr = head[3] if len(head) > 3 else None       # d sigma / d raw per row, for the head backward fused into this layer's backward
                 check(lib.cl_wide_dense_forward_head(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, dst, ldw,
-                                                     base + 4 * off_head, self.bij_kind, self.mlp.epsilon, loc_ptr, sig_ptr, sf, st),
+                                                     base + 4 * off_head, self.bij_kind, self.mlp.epsilon, loc_ptr, sig_ptr, dsd_ptr, sf, st),
                       "cl_wide_dense_forward_head")
                 self._head_fused = True
             else:
@@ -199,9 +210,14 @@ class WidePath:
         # backward pass comes (8 P_mm).
         full = self._wide_keep_all(obs)
         kept = []
+        headb = self._wide_head_bwd()
+        if headb and getattr(obs, "wide_dsd", None) is None:
+            obs.wide_dsd = torch.empty(obs.N, dtype=torch.float32, device=self.device)
         for ch in chunks:
             a, b = ch[0], ch[1]
             head = (off_head, obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a)
+            if headb:
+                head = head + (obs.wide_dsd.data_ptr() + 4 * a,)
             hs = self._wide_forward(obs, ch, True, st, full=full, head=head) if full is not None else self._wide_forward(obs, ch, False, st, head=head)
             kept.append(hs)
             if not self._head_fused:
@@ -213,10 +229,23 @@ class WidePath:
             n = b - a
             hs = kept[ic] if full is not None else self._wide_forward(obs, ch, True, st)
             dz, dzn = W["dz"]
-            nblk = min(W["nblk"], int(lib.cl_wide_head_blocks(n)))
-            check(lib.cl_wide_head_backward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, obs.laue_dO.data_ptr() + 8 * a, n, w, self.bij_kind,
-                                            self.mlp.epsilon, leak, ptr(dz), ldw, ptr(W["hpart"]), nblk, sf, st), "cl_wide_head_backward")
-            check(lib.cl_reduce_partials(ptr(W["hpart"]), nblk, 2 * w + 2, gbase + 4 * off_head, sf, st), "cl_reduce_partials")
+            nsplit = min(W["nsplit"], int(lib.cl_wide_wgrad_splits(n)))
+            if headb:
+                # the head's backward pass rides on the top layer's two backward kernels: dZ_L is made from h_L where they read it
+                l = self.L - 1
+                ow, ob, fan_in = layers[l]
+                hd = (hs[-1][0], hs[-1][1], pbase + 4 * off_head, obs.laue_dO.data_ptr() + 8 * a, obs.wide_dsd.data_ptr() + 4 * a)
+                check(lib.cl_wide_dense_wgrad_head(*hd, leak, hs[l][0], hs[l][1], n, w, fan_in, ptr(W["wpart"]), ptr(W["hpart"]), nsplit, sf, st),
+                      "cl_wide_dense_wgrad_head")
+                check(lib.cl_reduce_partials(ptr(W["wpart"]), nsplit, w * fan_in + w, gbase + 4 * ow, sf, st), "cl_reduce_partials")
+                check(lib.cl_reduce_partials(ptr(W["hpart"]), nsplit, 2 * w + 2, gbase + 4 * off_head, sf, st), "cl_reduce_partials")
+                check(lib.cl_wide_dense_dgrad_head(*hd, pbase + 4 * ow, n, w, fan_in, hs[l][0], hs[l][1], leak, ptr(dz), ldw, sf, st),
+                      "cl_wide_dense_dgrad_head")
+            else:
+                nblk = min(W["nblk"], int(lib.cl_wide_head_blocks(n)))
+                check(lib.cl_wide_head_backward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, obs.laue_dO.data_ptr() + 8 * a, n, w, self.bij_kind,
+                                                self.mlp.epsilon, leak, ptr(dz), ldw, ptr(W["hpart"]), nblk, sf, st), "cl_wide_head_backward")
+                check(lib.cl_reduce_partials(ptr(W["hpart"]), nblk, 2 * w + 2, gbase + 4 * off_head, sf, st), "cl_reduce_partials")
             for k in range(K - 1, -1, -1):          # per-image layers: each image's gradient is written once (its rows sit in one chunk)
                 l = self.L + k
                 gw, gb = self._imgl_ptrs(self.grads, k, m0)
@@ -230,9 +259,8 @@ class WidePath:
                     check(lib.cl_wide_image_dgrad(ptr(dz), ldw, wk, ptr(seg), seg.numel() - 1, n, w, hs[l][0], hs[l][1], leak, ptr(dzn), ldw, sf, st),
                           "cl_wide_image_dgrad")
                 dz, dzn = dzn, dz
-            nsplit = min(W["nsplit"], int(lib.cl_wide_wgrad_splits(n)))
             pre = self._wide_pre()
-            for l in range(self.L - 1, -1, -1):
+            for l in range(self.L - (2 if headb else 1), -1, -1):
                 ow, ob, fan_in = layers[l]
                 if pre and l == 1:
                     # the layer's input h_0 is recomputed from the metadata: as the weight gradient's operand and as the dgrad's mask
@@ -241,6 +269,16 @@ class WidePath:
                     check(lib.cl_wide_dense_wgrad_pre(ptr(dz), ldw, x0, ld0, d0, pbase + 4 * ow0, pbase + 4 * ob0, leak, n, w, fan_in, ptr(W["wpart"]),
                                                       nsplit, sf, st), "cl_wide_dense_wgrad_pre")
                     check(lib.cl_reduce_partials(ptr(W["wpart"]), nsplit, w * fan_in + w, gbase + 4 * ow, sf, st), "cl_reduce_partials")
+                    # layer 1's dgrad with layer 0's weight gradient taken where dZ_0 is produced (it is never stored) ...
+                    rc = -2 if os.environ.get("CARELESS_HIP_WIDE_WG0", "1") == "0" else \
+                        lib.cl_wide_dense_dgrad_pre_wgrad0(ptr(dz), ldw, pbase + 4 * ow, n, w, fan_in, x0, ld0, d0, pbase + 4 * ow0, pbase + 4 * ob0, leak,
+                                                           ptr(W["wpart"]), sf, st)
+                    if rc != -2:
+                        check(rc, "cl_wide_dense_dgrad_pre_wgrad0")
+                        check(lib.cl_reduce_partials(ptr(W["wpart"]), int(lib.cl_wide_dgrad_wgrad0_parts(n)), w * d0 + w, gbase + 4 * ow0, sf, st),
+                              "cl_reduce_partials")
+                        break
+                    # ... or, outside that kernel's envelope, the two launches
                     check(lib.cl_wide_dense_dgrad_pre(ptr(dz), ldw, pbase + 4 * ow, n, w, fan_in, x0, ld0, d0, pbase + 4 * ow0, pbase + 4 * ob0, leak,
                                                       ptr(dzn), ldw, sf, st), "cl_wide_dense_dgrad_pre")
                     dz, dzn = dzn, dz

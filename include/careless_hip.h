@@ -243,10 +243,21 @@ int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float*
 /* The TOP Dense layer with the Dense(2) head in its epilogue (round 4; replaces cl_wide_dense_forward + cl_wide_head_forward for layers up
  * to 128 x 128, -2 beyond): Y as above -- the backward pass needs it -- and loc = Y . Wo[0] + bo[0], sigma = bijector(Y . Wo[1] + bo[1]) + eps
  * per row from the registers the activations are in (reference: NormalLayer, careless/models/scaling/nn.py:10-25, 84-87).
- * head = [Wo^T (2 x n_out) | bo (2)].                                                                                                */
+ * head = [Wo^T (2 x n_out) | bo (2)].  dsig_draw_out (or NULL): the bijector's derivative d sigma / d raw per row, which the fused head
+ * backward below takes instead of recomputing the head.                                                                               */
 int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak,
-                               float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out,
+                               float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out, float* dsig_draw_out,
                                const int* stop_flag, void* stream);
+/* The head's backward pass inside the TOP layer's weight gradient and dgrad (round 4; replaces cl_wide_head_backward and the dZ_L buffer it
+ * wrote: tape.gradient through NormalLayer, careless/models/scaling/nn.py:10-25, variational.py:197-202).  dZ_L = (g Wo) * LeakyReLU'(h_L) with
+ * g = (dO[row][0], dO[row][1] * dsig_draw[row]) is a rank-2 product behind a mask: both kernels make it from Htop = h_L (the same bytes per
+ * row) where they read their dZ operand.  cl_wide_dense_wgrad_head also writes the head's own partial sums head_partials[s][2 n_out + 2] =
+ * (dWo | dbo).  Layers of width 65 .. 128 with the same number of 16-column blocks on both sides (cl_wide_head_bwd_supported), -2 otherwise. */
+int cl_wide_head_bwd_supported(int n_out, int n_in);
+int cl_wide_dense_wgrad_head(const float* Htop, int ldt, const float* head, const float* dO, const float* dsig_draw, float leak, const float* H, int ldh,
+                             long long n, int n_out, int n_in, float* partials, float* head_partials, int nsplit, const int* stop_flag, void* stream);
+int cl_wide_dense_dgrad_head(const float* Htop, int ldt, const float* head, const float* dO, const float* dsig_draw, const float* Wt, long long n,
+                             int n_out, int n_in, const float* Hprev, int ldh, float leak, float* dX, int ldo, const int* stop_flag, void* stream);
 /* dX[n][n_in] = (dZ[n][n_out] Wt) * LeakyReLU'(Hprev[n][n_in])   (Hprev = the layer's input = the previous layer's output; NULL: no mask) */
 int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* Hprev, int ldh, float leak,
                         float* dX, int ldo, const int* stop_flag, void* stream);
@@ -256,7 +267,12 @@ int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n,
  *   cl_wide_dense2_forward   layers 0 and 1 in one launch (h_0 stays in registers, in the operand layout of layer 1); `head` non-NULL:
  *                            the Dense(2) head in the epilogue as in cl_wide_dense_forward_head (a two-layer scaler);
  *   cl_wide_dense_dgrad_pre  layer 1's dgrad, the mask LeakyReLU'(h_0) recomputed from the metadata (replaces Hprev);
- *   cl_wide_dense_wgrad_pre  layer 1's weight gradient, its input operand h_0 recomputed while the tiles are staged (replaces H).
+ *   cl_wide_dense_wgrad_pre  layer 1's weight gradient, its input operand h_0 recomputed while the tiles are staged (replaces H);
+ *   cl_wide_dense_dgrad_pre_wgrad0   layer 1's dgrad AND layer 0's weight gradient in one launch: the dgrad's output dZ_0 is contracted
+ *                            with the metadata rows where it is produced and never stored.  Writes cl_wide_dgrad_wgrad0_parts(n) partial sums
+ *                            of [dWt_0 (n_in x n_in0) | db_0 (n_in)] into `partials` (cl_reduce_partials adds them); -2 outside the
+ *                            square-layer kernel's envelope (widths 65 .. 128, same number of 16-column blocks on both sides): the caller
+ *                            then runs cl_wide_dense_dgrad_pre + cl_wide_dense_wgrad.
  * X0 = metadata rows [n][ldx0] (ldx0 = cl_wide_ld(n_in0), 16-byte aligned, padding columns zero).                                   */
 int cl_wide_pre_supported(int n_in0, int w);
 int cl_wide_dense2_forward(const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, const float* Wt1, const float* b1, long long n,
@@ -266,6 +282,9 @@ int cl_wide_dense_dgrad_pre(const float* dZ, int lddz, const float* Wt, long lon
                             const float* Wt0, const float* b0, float leak, float* dX, int ldo, const int* stop_flag, void* stream);
 int cl_wide_dense_wgrad_pre(const float* dZ, int lddz, const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, float leak, long long n,
                             int n_out, int n_in, float* partials, int nsplit, const int* stop_flag, void* stream);
+int cl_wide_dgrad_wgrad0_parts(long long n);
+int cl_wide_dense_dgrad_pre_wgrad0(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* X0, int ldx0, int n_in0,
+                                   const float* Wt0, const float* b0, float leak, float* partials, const int* stop_flag, void* stream);
 /* partials[s][n_out * n_in + n_out] = (dWt | db) over the s-th of nsplit row ranges; H is the layer's input */
 int cl_wide_wgrad_splits(long long n);
 int cl_wide_dense_wgrad(const float* dZ, int lddz, const float* H, int ldh, long long n, int n_out, int n_in, float* partials, int nsplit,

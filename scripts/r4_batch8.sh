@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 4, eighth GPU pass: wide path, the first layer's weight gradient taken inside the second layer's dgrad (CARELESS_HIP_WIDE_WG0=0: the two launches)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4b8; mkdir -p $O
+( timeout 1500 python -m pytest tests -m gpu -q --no-header -x -k "wide or random_engine or image_layers" 2>&1 | tail -6 ) 2>&1 | tee $O/pytest.log
+line() {
+python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r = d["roofline"]
+    print("%-60s ms/step %.4f kernel ms %.4f frac %.4f step frac %.4f" % (sys.argv[1], d["ms_per_step"], r["kernel_ms"], r["frac"], r["frac_on_step_time"]))
+except Exception as e:
+    print(sys.argv[1], "failed", e)
+PY
+}
+for rep in 1 2; do
+  CARELESS_HIP_WIDE_WG0=0 timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_prev.json 2> $O/w_prev.err || tail -3 $O/w_prev.err
+  line "dgrad + separate first-layer weight gradient (WIDE_WG0=0)" $O/w_prev.json
+  timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_new.json 2> $O/w_new.err || tail -3 $O/w_new.err
+  line "first-layer weight gradient inside the dgrad" $O/w_new.json
+done 2>&1 | tee $O/wide_ab.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_wide -o t -- python3 bench.py --workload mono_2M_studentt_3x128_S4 --steps 10 --warmup 3 --no-cpu-baseline > $O/wide_bench.json 2> $O/wide_bench.err
+f=$(find $O/prof_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/wide_kernel_stats.csv && head -12 $O/wide_kernel_stats.csv | cut -c1-150
+rm -rf $O/prof_wide
