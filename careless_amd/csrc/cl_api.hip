@@ -25,6 +25,7 @@ int cl_det_reduce(const cl_det_args* a, void* stream) {
 int cl_laue_predict(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_predict(*a, (hipStream_t)stream) : -1; }
 int cl_laue_likelihood(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_likelihood(*a, (hipStream_t)stream) : -1; }
 int cl_laue_backward(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_backward(*a, (hipStream_t)stream) : -1; }
+int cl_slot_rows(const cl_laue_args* a, void* stream) { return a ? cl_launch_slot_rows(*a, (hipStream_t)stream) : -1; }
 
 int cl_mlp_default_grid(void) {
     int dev = 0, cus = 0;

@@ -35,6 +35,7 @@ int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, 
 int cl_launch_laue_predict(const cl_laue_args& a, hipStream_t st);
 int cl_launch_laue_likelihood(const cl_laue_args& a, hipStream_t st);
 int cl_launch_laue_backward(const cl_laue_args& a, hipStream_t st);
+int cl_launch_slot_rows(const cl_laue_args& a, hipStream_t st);
 
 // The kernel arguments, re-read from the kernarg segment behind an opaque pointer.  hipcc loads every field of a by-value argument
 // struct at kernel entry and keeps it in SGPRs for the whole kernel (more than the ~100 there are: it then parks them in VGPR lanes
@@ -56,6 +57,14 @@ __device__ __forceinline__ cl_args_p kernargs_again() {
 __device__ __forceinline__ float cl_quad_sum(float v) {
     v = CL_DPP_ADD(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
     v = CL_DPP_ADD(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+    return v;
+}
+// sum over each aligned group of S consecutive lanes (S = 1, 2, 4, 8 or 16: inside a 16-lane row), left in all lanes of the group
+__device__ __forceinline__ float cl_group_sum(float v, int S) {
+    if (S >= 2) v = CL_DPP_ADD(v, 0xB1, 0xF);
+    if (S >= 4) v = CL_DPP_ADD(v, 0x4E, 0xF);
+    if (S >= 8) v = CL_DPP_ADD(v, 0x141, 0xF);    // row_half_mirror
+    if (S >= 16) v = CL_DPP_ADD(v, 0x140, 0xF);   // row_mirror
     return v;
 }
 // sum over the 64 lanes of a wave, returned as a wave-uniform value: a butterfly inside the 16-lane rows, then the rows through row_bcast
@@ -121,6 +130,7 @@ typedef const cl_mlp_args* cl_args_p;                                        // 
 __host__ __device__ inline cl_args_p kernargs_again() { return nullptr; }
 __host__ __device__ inline float cl_quad_sum(float v) { return v; }
 __host__ __device__ inline float cl_wave_sum(float v) { return v; }
+__host__ __device__ inline float cl_group_sum(float v, int) { return v; }
 __host__ __device__ inline void cl_image_grad_segments(float*, int, float, bool, int) {}
 __host__ __device__ inline void cl_reduce_partials_block(const float*, int, int, float*, int) {}
 #endif

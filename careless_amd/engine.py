@@ -813,6 +813,10 @@ class ElboEngine(WidePath):
         la.scalars, la.ipred_out, la.stop_flag = ptr(self.scalars), ptr(ipred_out), ptr(self.stop_flag)
         la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
         la.row_index = ptr(obs.row_index)
+        if obs.harmonic_id is None and os.environ.get("CARELESS_HIP_SLOT_ROWS", "1") != "0":
+            # every row its own slot (monochromatic data on the layer-by-layer path): one launch, no round trip through iconv
+            check(lib.cl_slot_rows(C.byref(la), st), "cl_slot_rows")
+            return
         check(lib.cl_laue_predict(C.byref(la), st), "cl_laue_predict")
         check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
         check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")

@@ -353,6 +353,10 @@ typedef struct cl_laue_args {
 int cl_laue_predict(const cl_laue_args* args, void* stream);
 int cl_laue_likelihood(const cl_laue_args* args, void* stream);
 int cl_laue_backward(const cl_laue_args* args, void* stream);
+/* The three calls above in ONE launch for rows that are their own slot (harmonic_id NULL: the monochromatic likelihood of
+ * careless/models/likelihoods/mono.py:10-73 on the layer-by-layer path of scalers wider than 64): predict, log-prob and its gradient back to
+ * dz_f / d_img / dO per (row, sample) with nothing in between; iconv is not touched.  -2 when harmonic_id is set.                    */
+int cl_slot_rows(const cl_laue_args* args, void* stream);
 
 /* --- gradient norm, sanitise, clip, Adam -------------------------------------------------------------------------
  * replaces: tf.linalg.global_norm, tf.where(is_finite), optimizer.apply_gradients (variational.py:202-209)

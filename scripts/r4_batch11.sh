@@ -1,0 +1,29 @@
+#!/bin/bash
+# round 4, eleventh GPU pass: wide path, quad pairs swapped in rows 4..11 of every 16 (conflict-free ds_read_b128 under the hardware's lane groups, offsets stay immediates)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4b11; mkdir -p $O
+( timeout 1500 python -m pytest tests -m gpu -q --no-header -x -k "wide or random_engine or image_layers" 2>&1 | tail -6 ) 2>&1 | tee $O/pytest.log
+line() {
+python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r = d["roofline"]
+    print("%-60s ms/step %.4f kernel ms %.4f frac %.4f step frac %.4f" % (sys.argv[1], d["ms_per_step"], r["kernel_ms"], r["frac"], r["frac_on_step_time"]))
+except Exception as e:
+    print(sys.argv[1], "failed", e)
+PY
+}
+for rep in 1 2 3; do
+  CARELESS_HIP_LIB=$PWD/careless_amd/lib/exp_r4w_swzb0.so timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_0.json 2> $O/w_0.err || tail -3 $O/w_0.err
+  line "round-3 LDS layouts (CL_WIDE_SWZB=0)" $O/w_0.json
+  timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_1.json 2> $O/w_1.err || tail -3 $O/w_1.err
+  line "quad pairs swapped in rows 4..11 of 16" $O/w_1.json
+done 2>&1 | tee $O/wide_ab.log
+for v in 0 1; do
+  L=$PWD/careless_amd/lib/exp_r4w_swzb0.so; [ $v = 1 ] && L=$PWD/careless_amd/lib/libcareless_hip.so
+  export CARELESS_HIP_LIB=$L
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$v -o t -- python3 bench.py --workload mono_2M_studentt_3x128_S4 --steps 10 --warmup 3 --no-cpu-baseline > $O/wide_bench_$v.json 2> $O/wide_bench_$v.err
+  f=$(find $O/prof_$v -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/wide_kernel_stats_swzb$v.csv && head -8 $O/wide_kernel_stats_swzb$v.csv | cut -c1-150
+  rm -rf $O/prof_$v
+done
+unset CARELESS_HIP_LIB

@@ -15,7 +15,7 @@ for d in "ABCD":
     for f in glob.glob(f"gpurun_out/pmc{d}_{T}/*/*counter_collection.csv"):
         acc=collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if any(k in r['Kernel_Name'] for k in ('elbo_mlp', 'elbo_narrow', 'elbo_lane', 'wide_stream', 'wide_gemm', 'wide_head')):
+            if any(k in r['Kernel_Name'] for k in ('elbo_mlp', 'elbo_narrow', 'elbo_lane', 'wide_stream', 'wide_sq', 'wide_gemm', 'wide_head')):
                 acc[r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in acc.items(): print(d,k,len(v)//steps,sum(v)/steps)
 print('# per STEP: counter summed over the launches of the dominant kernel(s) in one step (column 3 = launches per step).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request: double it (calibrated on the fused kernel\'s own access pattern with scripts/calib_fetch.sh: forward-only launch, 960 MB of metadata -> FETCH_SIZE 469117 KiB; WRITE_SIZE exact, an atomic request is tallied as a 32-B write)')
