@@ -33,15 +33,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CL_NARROW_SCHED
 #define CL_NARROW_SCHED 1
 #endif
-#ifndef CL_NARROW_STAGGER
-#define CL_NARROW_STAGGER 0     /* x 127 x 64 cycles of start delay for the second wave of every SIMD (measured: no effect) */
-#endif
-#ifndef CL_NARROW_PRIO
-#define CL_NARROW_PRIO 0
-#endif
-#ifndef CL_NARROW_BFI
-#define CL_NARROW_BFI 0     /* 1: multiply + sign mask + bit select instead of compare + conditional move (measured slower: hipcc emits 5 ops) */
-#endif
 
 
 namespace {
@@ -61,16 +52,11 @@ __device__ __forceinline__ float lrelu(float x, float leak) {
 }
 
 // dZ = dH * lrelu'(h): dH where h > 0, leak dH otherwise (h == 0 takes the leak branch, like `h > 0 ? ... : ...`; -0.0 cannot
-// occur: h = max(x, leak x)).  Written as multiply + sign mask + bit select: beside fp32 MFMAs a compare / conditional-move pair
-// costs ~50 % more issue time than a shift / bit-field-insert pair (scripts/probe/coissue_probe.hip).
+// occur: h = max(x, leak x)).  A compare / conditional-move pair; the multiply + sign mask + bit select form the issue-time probe
+// (scripts/probe/coissue_probe.hip) suggested was measured slower -- hipcc makes five instructions of it
+// (scripts/patches/r2_narrow_closed_switches.diff, with the start stagger and the static priority of the second wave: no effect).
 __device__ __forceinline__ float lrelu_bwd(float h, float dh, float leak) {
-#if CL_NARROW_BFI
-    const float p = leak * dh;
-    const int pos = __builtin_bit_cast(int, -h) >> 31;             // all ones where h > 0 (h is never -0.0 / NaN-free path aside)
-    return __builtin_bit_cast(float, (__builtin_bit_cast(int, dh) & pos) | (__builtin_bit_cast(int, p) & ~pos));
-#else
     return (h > 0.0f) ? dh : leak * dh;
-#endif
 }
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -274,20 +260,6 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
     };
     const int wt_begin = (int)blockIdx.x * NWAVES + wv;
     if (wt_begin < n_wt) prefetch(wt_begin, kernargs_again());
-#if CL_NARROW_STAGGER
-    // Two waves per SIMD run the same program with no barrier between them: started together they would stay in lockstep and
-    // reach their latency-bound phases (epilogue, tile prologue) at the same time, leaving the matrix pipe idle.  The second wave
-    // of every SIMD starts about half a tile late; nothing in the loop re-synchronises them.
-    if (NWAVES > 4 && wv >= 4) {
-#pragma unroll
-        for (int i = 0; i < CL_NARROW_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-
-#if CL_NARROW_PRIO
-    // static priority for the younger half (the second wave of every SIMD loses the arbitration otherwise)
-    if (NWAVES > 4 && wv >= NWAVES / 2) __builtin_amdgcn_s_setprio(CL_NARROW_PRIO);
-#endif
     const float* const wrow = sW + j * NPW + 4 * q;        // forward A operands: image row j, slots 4q .. 4q+3 (one ds_read_b128)
     const float* const wcol = sW + (4 * q) * NPW + j;      // dgrad A operands: image rows 4q + t, column j
     float* const stw = sZ + (4 * q) * PBW + j;             // staging writes: rows 4q + t, this lane's observation column (+ 16 g)
