@@ -580,6 +580,36 @@ def test_wide_fused_backward_equals_the_separate_launches(monkeypatch, S):
         assert util.rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-5
 
 
+@pytest.mark.parametrize("keep", [True, False], ids=["activations_kept", "forward_recomputed_per_chunk"])
+def test_wide_path_in_several_row_chunks_equals_one_chunk(monkeypatch, keep):
+    """The layer-by-layer path walks the observations in row chunks sized from a memory budget, and keeps all activations only when they
+    fit (otherwise every chunk's forward pass is run again when its turn in the backward pass comes).  With the budgets lowered to five
+    chunks of 512 rows (and no kept activations): the gradient sums over the chunks, the head's dsigma/draw of the first pass feeds the
+    fused backward kernels of the second -- the same step as with one chunk, to summation order."""
+    from careless_amd.engine import ElboEngine
+    from careless_amd.wide import WidePath
+    kw = dict(N=2117, R=90, d0=8, L=3, w=128, S=2, perturb=0.02, likelihood="studentt", dof=10.0, n_images=5)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    inputs = util.reference_inputs(data)
+    eng = ElboEngine(util.build_model(data, cfg, params, 3, 128), inputs, seed=5)
+    eng.forward_backward(2)
+    torch.cuda.synchronize()
+    assert len(eng._wide_chunks(eng.obs)) == 1
+    ta, ga = eng.loss_terms(), eng.grads.clone()
+    monkeypatch.setattr(WidePath, "WIDE_BUDGET", 4 * (3 + 2) * 128 * 600)          # 600 rows of the five row buffers: chunks of 512
+    if not keep:
+        monkeypatch.setattr(WidePath, "WIDE_KEEP_BUDGET", 0)
+    eng2 = ElboEngine(util.build_model(data, cfg, params, 3, 128), inputs, seed=5)
+    eng2.forward_backward(2)
+    torch.cuda.synchronize()
+    assert len(eng2._wide_chunks(eng2.obs)) == 5
+    assert (getattr(eng2.obs, "wide_full", None) is not None) == keep
+    tb, gb = eng2.loss_terms(), eng2.grads
+    assert abs(ta["nll"] - tb["nll"]) <= 1e-6 * abs(ta["nll"]) and ta["kl"] == tb["kl"]
+    for a, b in zip(eng._split(ga), eng2._split(gb)):
+        assert util.rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-5
+
+
 def test_image_layers_philox_noise_is_keyed_by_the_callers_rows():
     """--image-layers packs the observations by image inside the engine; the in-kernel noise must still be keyed by the caller's
     row index (rows arrive in arbitrary image order here), so the dumped stream replayed through the oracle gives the same loss."""
