@@ -99,6 +99,7 @@ class LaueArgs(C.Structure):
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("iconv", _vp), ("dz_f", _vp), ("d_img", _vp), ("dO", _vp), ("scalars", _vp), ("ipred_out", _vp), ("stop_flag", _vp),
         ("ev11", _vp), ("d_ev11", _vp), ("row_index", _vp), ("nll_part", _vp),
+        ("dzf_obs", _vp), ("dimg_obs", _vp), ("det_slot", _vp),
     ]
 
 

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void slot_rows_kernel(const cl_laue_args A, in
             nll -= (double)ll * (double)A.w_ll;
             const float gi = -dll * A.w_ll;             // dNLL / d ipred
             const float dzs = gi * zf * zf;
-            atomicAdd(A.dz_f + (size_t)P.rid * A.S + s, gi * aim * tq * 2.0f * zf);
+            const float dzf = gi * aim * tq * 2.0f * zf;
+            if (A.dzf_obs != nullptr) A.dzf_obs[(size_t)(A.det_slot != nullptr ? A.det_slot[i] : i) * A.S + s] = dzf;      // (summed per reflection by cl_det_reduce)
+            else atomicAdd(A.dz_f + (size_t)P.rid * A.S + s, dzf);
             const float dt = dzs * aim;
             dloc = dt;
             dsig = dt * eta;
@@ -230,7 +232,9 @@ __global__ __launch_bounds__(256) void slot_rows_kernel(const cl_laue_args A, in
             if (dO_store) { A.dO[2 * (size_t)i] = dloc; A.dO[2 * (size_t)i + 1] = dsig; }
             else { atomicAdd(A.dO + 2 * (size_t)i, dloc); atomicAdd(A.dO + 2 * (size_t)i + 1, dsig); }      // (a row that straddles two waves has two heads)
         }
-        if (A.use_img) {
+        if (A.use_img && A.dimg_obs != nullptr) {
+            if (head) A.dimg_obs[i] = im > 0 ? da : 0.0f;      // deterministic mode: summed per image, in row order, by cl_det_reduce
+        } else if (A.use_img) {
             // rows are (nearly) ordered by image, so a wave usually holds one image: one wave sum, one atomic
             const bool take = head && im > 0;            // (image 0 is pinned to 1, image.py:23-25)
             const unsigned long long m = __ballot(take);
@@ -296,6 +300,10 @@ int cl_launch_slot_rows(const cl_laue_args& a, hipStream_t st) {
     if (int e = laue_check(a)) return e;
     if (a.harmonic_id != nullptr) return -2;           // rows that share slots need the three passes (group sums between them)
     if (a.iobs == nullptr || a.sig == nullptr || a.scalars == nullptr || a.dz_f == nullptr || a.dO == nullptr || (a.use_img && a.d_img == nullptr)) return -1;
+    if (a.dzf_obs != nullptr) {          // deterministic mode: stores per (row, sample) / row / workgroup; a row's samples must sit inside one wave
+        if (64 % a.S != 0) return -2;
+        if (a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr) || a.ev11 != nullptr) return -1;
+    }
     (void)hipGetLastError();
     const int store = (64 % a.S == 0) ? 1 : 0;
     if (!store) {

@@ -246,11 +246,15 @@ class ElboEngine(WidePath):
         # per-observation stores + fixed-order sums (cl_det_reduce) -- so two runs give bit-identical gradients and parameters
         self.deterministic = bool(getattr(model, "deterministic", False)) or os.environ.get("CARELESS_HIP_DETERMINISTIC", "0") == "1"
         two_pass = self.laue and bool(getattr(model, "laue_two_pass", False))
-        if self.deterministic and (two_pass or self.wide or imgl is not None or self.ev11 or self.blocks is not None or
+        # (wide scalers: monochromatic rows only -- they are their own slots and one kernel holds every float atomic of the path --, with a
+        #  sample count that divides 64, so that a row's samples sit inside one wave)
+        wide_det_ok = self.wide and not self.laue and 64 % int(model.mc_sample_size) == 0
+        if self.deterministic and (two_pass or (self.wide and not wide_det_ok) or imgl is not None or self.ev11 or self.blocks is not None or
                                    (self.double_wilson and prior.r_raw is not None)):
             raise NotImplementedError("deterministic mode covers monochromatic and single-pass Laue data, the Wilson and the double-Wilson prior "
-                                      "(fixed r), Normal / Student-T likelihoods and scalers of one launch (width <= 64); the two-pass Laue path, "
-                                      "a trainable double-Wilson r, Evans-2011, per-image layers, chained and wide scalers keep their float atomics")
+                                      "(fixed r), Normal / Student-T likelihoods, scalers of one launch (width <= 64) and, for monochromatic data "
+                                      "with a sample count that divides 64, scalers wider than 64; the two-pass Laue path, a trainable "
+                                      "double-Wilson r, Evans-2011, per-image layers and chained scalers keep their float atomics")
         if self.deterministic and self.double_wilson:
             # parents pull their children's terms in list order instead of children scattering with atomics (cl_dw_prior_forward)
             par = np.asarray(prior.reflids).astype(np.int64)
@@ -409,7 +413,8 @@ class ElboEngine(WidePath):
             slot = torch.empty(n, dtype=torch.int32, device=dev)
             slot[perm_r.long()] = torch.arange(n, dtype=torch.int32, device=dev)
         obs.det = dict(slot=slot, dzf=torch.zeros(n * self.S, dtype=torch.float32, device=dev), dimg=torch.zeros(n, dtype=torch.float32, device=dev),
-                       nll=torch.zeros(len(pieces) * pieces[0].grid + (_lib.CL_LAUE_LIK_MAX_BLOCKS if self.laue else 0), dtype=torch.float64, device=dev),
+                       nll=torch.zeros(len(pieces) * pieces[0].grid + (_lib.CL_LAUE_LIK_MAX_BLOCKS if (self.laue or self.wide) else 0), dtype=torch.float64,
+                                       device=dev),
                        refl=(perm_r, seg_r), img=order(img, M), M=M, pieces=len(pieces), grid=pieces[0].grid)
         for k, p in enumerate(pieces):
             p.det_parent, p.det_index = obs, k
@@ -547,7 +552,7 @@ class ElboEngine(WidePath):
         """Name of the kernel instance the scaler launches of this engine run (`cl_mlp_kernel_name`: the library's own routing):
         what a rocprofv3 kernel trace lists for the dominant kernel."""
         if self.wide:
-            return "wide_gemm_kernel"
+            return "wide_gemm_kernel" + (" (slot likelihood: deterministic stores)" if self.deterministic else "")
         obs = self.obs.children[0] if isinstance(self.obs, ObsChunks) else self.obs
         ma = self._mlp_args(0, None, None, obs)
         if self.blocks is not None:
@@ -673,7 +678,10 @@ class ElboEngine(WidePath):
                 self._det_reduce(obs, st)
             return
         if self.wide:
-            return self._data_term_wide(obs, step, eta, ipred_out, st)
+            self._data_term_wide(obs, step, eta, ipred_out, st)
+            if self.deterministic and not _piece:
+                self._det_reduce(obs, st)
+            return
         ma = self._mlp_args(step, eta, ipred_out, obs)
         if self.blocks is not None:
             return self._data_term_chain(ma, obs, step, eta, ipred_out, st)
@@ -813,6 +821,14 @@ class ElboEngine(WidePath):
         la.scalars, la.ipred_out, la.stop_flag = ptr(self.scalars), ptr(ipred_out), ptr(self.stop_flag)
         la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
         la.row_index = ptr(obs.row_index)
+        if self.deterministic and obs.harmonic_id is None:
+            # no float atomics: the amplitude gradient of every (row, sample) and the image-scale term of every row are stored (records in
+            # reflection order: det_slot), every workgroup stores its NLL; cl_det_reduce sums them in a fixed order after the backward pass
+            det = obs.det_parent.det
+            la.dzf_obs, la.dimg_obs, la.det_slot = ptr(det["dzf"]), ptr(det["dimg"]), ptr(det["slot"])
+            la.nll_part = det["nll"].data_ptr() + 8 * det["pieces"] * det["grid"]
+            check(lib.cl_slot_rows(C.byref(la), st), "cl_slot_rows")
+            return
         if obs.harmonic_id is None and os.environ.get("CARELESS_HIP_SLOT_ROWS", "1") != "0":
             # every row its own slot (monochromatic data on the layer-by-layer path): one launch, no round trip through iconv
             check(lib.cl_slot_rows(C.byref(la), st), "cl_slot_rows")

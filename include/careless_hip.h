@@ -345,8 +345,12 @@ typedef struct cl_laue_args {
     float* d_ev11;              /* [3] +=                                     */
     const long long* row_index; /* optional [n_obs]: global row number of every local row (noise key) when the shard is not a
                                    contiguous range (data-parallel Laue keeps harmonic groups on one rank); NULL = obs_offset + i */
-    double* nll_part;           /* optional [CL_LAUE_LIK_MAX_BLOCKS] (deterministic mode): cl_laue_likelihood STORES every workgroup's NLL
-                                   here -- slots past its grid are left alone -- instead of adding it to scalars with an atomic       */
+    double* nll_part;           /* optional [CL_LAUE_LIK_MAX_BLOCKS] (deterministic mode): cl_laue_likelihood / cl_slot_rows STORE every
+                                   workgroup's NLL here -- slots past the grid are left alone -- instead of adding it to scalars with an atomic */
+    /* deterministic mode of cl_slot_rows (all three or none; S must divide 64: a row's samples inside one wave): the amplitude gradient
+     * of (row i, sample s) is STORED at dzf_obs[(det_slot ? det_slot[i] : i) * S + s] and the row's image-scale term at dimg_obs[i];
+     * cl_det_reduce sums them per reflection / image in a fixed order (as cl_mlp_args.dzf_obs / dimg_obs / det_slot)               */
+    float* dzf_obs; float* dimg_obs; const int* det_slot;
 } cl_laue_args;
 #define CL_LAUE_LIK_MAX_BLOCKS 2048
 

@@ -1134,10 +1134,14 @@ def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
                                 dict(N=700, R=40, L=3, w=32, S=9, laue=True, likelihood="studentt", dof=8.0, extra_meta=14),
                                 # the double-Wilson prior (fixed r): parents pull their children's terms in list order
                                 dict(N=800, R=60, d0=5, L=5, w=64, S=3, double_wilson=True),
-                                dict(N=900, R=50, d0=5, L=20, w=10, S=2, double_wilson=True, perturb=0.02, likelihood="studentt", dof=8.0)],
+                                dict(N=900, R=50, d0=5, L=20, w=10, S=2, double_wilson=True, perturb=0.02, likelihood="studentt", dof=8.0),
+                                # scalers wider than 64 (round 4): the layer-by-layer path's one kernel with float atomics -- the slot
+                                # likelihood of monochromatic rows -- stores per (row, sample) instead; everything else sums partials in order
+                                dict(N=1500, R=60, d0=5, L=3, w=128, S=4, likelihood="studentt", dof=8.0, n_images=7),
+                                dict(N=900, R=50, d0=5, L=2, w=96, S=2, use_image_scales=False)],
                          ids=["mono_5x64", "cli_default_20x10", "rows_in_arbitrary_order_S8", "no_image_scales_klweight",
                               "lane_posenc_d21_S8", "lane_20x8_S11", "narrow_6x10_S5", "narrow_9x13_d12", "laue_lane_20x10_S3", "laue_narrow_4x12", "laue_5x64_S3", "laue_3x32_d20_S9",
-                              "double_wilson_5x64", "double_wilson_lane_20x10"])
+                              "double_wilson_5x64", "double_wilson_lane_20x10", "wide_3x128_S4", "wide_2x96_noimg"])
 def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypatch):
     """`model.deterministic = True` (or CARELESS_HIP_DETERMINISTIC=1): the fused kernel stores per-observation contributions instead of
     issuing float atomics and `cl_det_reduce` sums them in row order (include/careless_hip.h).  Same parity bar against the oracle,
@@ -1172,8 +1176,8 @@ def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypat
     _assert_grads([g.cpu().numpy() for g in eng.grad_tensors()], grads, (data, cfg, params, u_f, eta), "deterministic")
     runs = []
     for cut in (False, False, True):
-        if cut and kw.get("laue"):
-            break                                   # (packed layouts are not cut into launches)
+        if cut and (kw.get("laue") or w > 64):
+            break                                   # (packed layouts and the layer-by-layer path are not cut into launches)
         if cut:
             d = np.asarray(data["metadata"]).shape[1]
             monkeypatch.setenv("CARELESS_HIP_MAX_LAUNCH_BYTES", str(4 * ((d + 3) // 4 * 4) * 400))
