@@ -310,3 +310,28 @@ def test_kernel_name_follows_the_librarys_routing():
     assert name(d=21, w=64, L=5, S=8, mode=1) == "elbo_mlp_kernel<64, 32, 5, 1, KS=4>"
     assert name(d=5, w=10, L=20, S=1, act_out=1, mode=1).startswith("elbo_mlp_kernel<16, 8, 20, 1, chain")
     assert lib.cl_mlp_kernel_name(None, 0, C.create_string_buffer(8), 8) < 0
+
+
+def test_wide_path_envelope_queries():
+    """Host functions of the layer-by-layer path (no GPU needed): which shapes take the recomputed first layer, the head's backward pass
+    fused into the top layer's kernels and the square-layer kernel's envelope, how many partials the fused dgrad + first-layer weight
+    gradient writes, the row pitch of the activation buffers."""
+    lib = _lib.get_lib()
+    assert [lib.cl_wide_ld(w) for w in (1, 4, 70, 128, 129)] == [4, 4, 72, 128, 132] and lib.cl_wide_ld(0) == 0
+    # first layer recomputed: at most 8 metadata columns, hidden width at most 128
+    assert lib.cl_wide_pre_supported(5, 128) == 1 and lib.cl_wide_pre_supported(8, 65) == 1
+    assert lib.cl_wide_pre_supported(9, 128) == 0 and lib.cl_wide_pre_supported(5, 129) == 0 and lib.cl_wide_pre_supported(0, 64) == 0
+    # fused head backward: square layers of 5 .. 8 sixteen-column blocks on both sides (widths 65 .. 128, same block count)
+    assert lib.cl_wide_head_bwd_supported(128, 128) == 1 and lib.cl_wide_head_bwd_supported(65, 80) == 1 and lib.cl_wide_head_bwd_supported(96, 90) == 1
+    assert lib.cl_wide_head_bwd_supported(64, 64) == 0 and lib.cl_wide_head_bwd_supported(129, 129) == 0 and lib.cl_wide_head_bwd_supported(96, 128) == 0
+    # one partial per workgroup of the streaming kernel: eight 16-row blocks per workgroup, two workgroups per CU at most
+    assert lib.cl_wide_dgrad_wgrad0_parts(0) == 0 and lib.cl_wide_dgrad_wgrad0_parts(1) == 1 and lib.cl_wide_dgrad_wgrad0_parts(16 * 8 * 3 + 1) == 4
+    big = lib.cl_wide_dgrad_wgrad0_parts(10_000_000)
+    assert big % 2 == 0 and 2 <= big <= 4096 and lib.cl_wide_dgrad_wgrad0_parts(100_000_000) == big
+    # weight-gradient splits: at least 512 observations each, at most 512 of them
+    assert lib.cl_wide_wgrad_splits(1) == 1 and lib.cl_wide_wgrad_splits(513) == 2 and lib.cl_wide_wgrad_splits(10_000_000) == 512
+    # the new entry points refuse missing buffers before touching a device
+    assert lib.cl_slot_rows(None, None) == -1
+    assert lib.cl_wide_dense_dgrad_head(None, 128, None, None, None, None, 100, 128, 128, None, 128, 0.01, None, 128, None, None) == -1
+    assert lib.cl_wide_dense_wgrad_head(None, 128, None, None, None, 0.01, None, 128, 100, 128, 128, None, None, 1, None, None) == -1
+    assert lib.cl_wide_dense_dgrad_pre_wgrad0(None, 128, None, 100, 128, 128, None, 8, 5, None, None, 0.01, None, None, None) == -1
