@@ -39,12 +39,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CL_LANE_COALESCE
 #define CL_LANE_COALESCE 2      /* smallest number of MC samples whose amplitude gradients leave through LDS (0: never) */
 #endif
-#ifndef CL_LANE_SCHED
-#define CL_LANE_SCHED 1
-#endif
-#ifndef CL_LANE_FAST_DIV
-#define CL_LANE_FAST_DIV 1      /* Student-T: 1/nu hoisted, the per-sample division as reciprocal + Newton step (a lone wave pays ~8 cycles per instruction of the two IEEE divisions) */
-#endif
 
 namespace {
 
@@ -76,15 +70,8 @@ __device__ __forceinline__ f32x4 mfma_bk(float a, float b, f32x4 c) { return __b
 // (two per layer, so that consecutive MFMAs never depend on each other): written as inline assembly, because with the compiler's
 // own choice every layer of every tile pays copies between the two register files.  (Same-destination MFMAs need no software
 // wait states between them; the only other reader is the flush, a barrier later.)
-#ifndef CL_LANE_ASM_ACC
-#define CL_LANE_ASM_ACC 1
-#endif
 __device__ __forceinline__ void mfma16_acc(f32x4& acc, float a, float b) {
-#if CL_LANE_ASM_ACC
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-#else
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-#endif
 }
 
 __device__ __forceinline__ float lrelu2(float x, float lx) {          // max(x, leak x), leak x given
@@ -99,11 +86,7 @@ __device__ __forceinline__ T ld_uo(const T* base, unsigned byte_off) {       // 
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-#if CL_LANE_SCHED
 #define LFENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define LFENCE()
-#endif
 
 #ifdef CL_STAMPS
 #define LSTAMP(k)                                                                                  \
@@ -574,8 +557,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     ll = cl_lik_ev11(lin, io, sg, lik_kind, dof, lik_const, ev, &dll, &gf, &gb, &ga);
                     if (counts) { ev_g0 -= gf * w_ll; ev_g1 -= ga * w_ll; ev_g2 -= gb * w_ll; }     // order: Sdfac, Sdadd, SdB
                 } else {
-                    ll = CL_LANE_FAST_DIV ? cl_lik_log_prob3(lin, io, inv_sg, log_sg, lik_kind, dof, inv_dof, lik_const, &dll)
-                                          : cl_lik_log_prob2(lin, io, inv_sg, log_sg, lik_kind, dof, lik_const, &dll);
+                    // (Student-T: 1/nu hoisted, the per-sample division as reciprocal + Newton step -- a lone wave pays ~8 cycles per
+                    //  instruction of the two IEEE divisions)
+                    ll = cl_lik_log_prob3(lin, io, inv_sg, log_sg, lik_kind, dof, inv_dof, lik_const, &dll);
                 }
                 if (counts) nll_acc -= ll * w_ll;
                 const float gi = -dll * w_ll;                 // dNLL / d ipred (of every member of the group)
@@ -779,9 +763,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         LSTAMP(5);
     }
     // ================= flush: sum the waves' accumulators, scatter into the flat W^T layout of this workgroup's partial ====
-#if CL_LANE_ASM_ACC
     asm volatile("s_nop 15\n\ts_nop 15");     // (the compiler does not know that the inline-assembly MFMAs' results take eight passes to land)
-#endif
     __syncthreads();
     const int offWo = w * d + w + (L - 1) * (w * w + w);
     const int Ptot = offWo + 2 * w + 2;

@@ -44,32 +44,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CL_META_RANGE
 #define CL_META_RANGE 2   /* largest KS1 (metadata k-steps) that takes the branch-free metadata prefetch */
 #endif
-#ifndef CL_META_OPAQUE
-#define CL_META_OPAQUE 1
-#endif
-#ifndef CL_ASM_MAX
-#define CL_ASM_MAX 1
-#endif
-#ifndef CL_OPAQUE_L
-#define CL_OPAQUE_L 1
-#endif
-#ifndef CL_KPERM
-#define CL_KPERM 1
-#endif
-#ifndef CL_WPIPE
-#define CL_WPIPE 1
-#endif
 #ifndef CL_ACC_WP
 #define CL_ACC_WP 16   /* widest instance with LDS-resident accumulators (32: measured -0.8 % on a 10 x 32 scaler) */
-#endif
-#ifndef CL_BIAS_ONE
-#define CL_BIAS_ONE 1
-#endif
-#ifndef CL_DPP_REDUCE
-#define CL_DPP_REDUCE 1
-#endif
-#ifndef CL_PF_NEXT
-#define CL_PF_NEXT 1
 #endif
 #ifndef CL_DET
 #define CL_DET 0             // 1: the deterministic compilation (build.py: elbo_mlp_det) -- the epilogue's float atomics (dz_f, image scales) and
@@ -140,14 +116,10 @@ __device__ __forceinline__ int opaque_uniform(int v) {
 
 // LeakyReLU as max(x, leak x) with a bare v_max_f32: fmaxf() makes hipcc canonicalise x first (a second v_max per element)
 __device__ __forceinline__ float lrelu(float x, float leak) {
-#if CL_ASM_MAX
     const float m = leak * x;
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
     return r;
-#else
-    return fmaxf(x, leak * x);
-#endif
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -248,12 +220,12 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     // LeakyReLU(1) = 1), and nothing reads it: the next layer's weight column 15 is zero padding.  Column 15 of a layer's dW^T
     // accumulator is then sum_obs dZ[o][obs] * 1 = the BIAS gradient, for free inside the wgrad MFMAs: no LMAX bias registers, no
     // re-read of the dZ tile (a third of this kernel's LDS traffic), no row sums.  Layer 0 (metadata input) keeps its own sum.
-    constexpr bool BONE = WLOC && (CL_BIAS_ONE != 0);
+    constexpr bool BONE = WLOC;
     // Narrow kernel: hidden feature f lives in accumulator row ("slot") 4 (f & 3) + (f >> 2) instead of row f (an involution; every
     // LDS image and the gradient flush use it consistently).  MFMA step t of a layer then contracts the features 4t .. 4t+3 rather
     // than {t, 4+t, 8+t, 12+t}, so for a width-w layer only ceil(w / 4) of the four forward and dgrad steps have anything to
     // multiply: the CLI default (w = 10) runs 3 + 3 + 4 MFMAs per layer instead of 12.  Slot 15 stays feature 15 (the bias ones).
-    constexpr bool KPERM = WLOC && (CL_KPERM != 0);
+    constexpr bool KPERM = WLOC;
     auto sl = [](int f) { return (KPERM && f < 16) ? (((f & 3) << 2) | (f >> 2)) : f; };
     using AP = AccPlan<WP, DP, LMAX, MODE, ILAY>;
     constexpr int LREG = AP::LREG;       // layers >= LREG accumulate their weight gradient in LDS (narrow kernel only)
@@ -391,7 +363,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     const int row4_b = 16 * A.n_pad;                            // bytes between feature groups (4 rows)
     auto load_meta = [&](int tile, float (&dst)[KS1]) {
         const int soff = tile * (CL_TILE * 4);
-        const int d4m = CL_META_OPAQUE ? opaque_uniform(d4) : d4;
+        const int d4m = opaque_uniform(d4);
 #pragma unroll
         for (int t = 0; t < KS1; ++t) {
             // the feature-group offset goes into the per-lane offset, which the hardware range-checks against the 4 d4 n_pad bytes of
@@ -479,14 +451,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     };
 
     for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
-#if CL_OPAQUE_L
         // the layer count, made opaque once per tile: otherwise hipcc hoists every `l == L - 1` / `l < L` test of the unrolled layer
         // loops out of the tile loop, runs out of SGPRs, parks the masks in VGPR lanes and pays v_readlane / v_writelane round trips
         // (plus bool -> VGPR -> bool conversions) inside every layer
         const int Lt = opaque_uniform(L);
-#else
-        const int Lt = L;
-#endif
         const int gobs = tile * CL_TILE + CL_WOBS * wv + j;      // this lane's observation (all four k-groups)
         if (ILAY && A.n_imgl > 0) {
             const int im = __builtin_amdgcn_readfirstlane(A.tile_img[tile]);
@@ -547,8 +515,8 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         f32x4 hs[LMAX][FB];                // post-activation H_l^T: block fb, reg t = feature 16fb + 4q + t, obs j
         float o0 = 0.0f, o1 = 0.0f;
         // Width <= 15: a layer is ONE chain of four dependent MFMAs, so there is no k-block loop to prefetch inside; the weight
-        // operand and the bias of the NEXT layer are requested before this layer's MFMAs instead (CL_PF_NEXT)
-        constexpr bool PFN = (FB == 1) && (CL_PF_NEXT != 0);
+        // operand and the bias of the NEXT layer are requested before this layer's MFMAs instead
+        constexpr bool PFN = (FB == 1);
         f32x4 pfw = {0.0f, 0.0f, 0.0f, 0.0f}, pfb = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
@@ -772,12 +740,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     pda += dzs * tq;
                 }
             }
-#if CL_DPP_REDUCE
             pdl = cl_quad_sum(pdl); pds = cl_quad_sum(pds); pda = cl_quad_sum(pda);      // the four sample slots of an observation
-#else
-            pdl += __shfl_xor(pdl, 1); pds += __shfl_xor(pds, 1); pda += __shfl_xor(pda, 1);
-            pdl += __shfl_xor(pdl, 2); pds += __shfl_xor(pds, 2); pda += __shfl_xor(pda, 2);
-#endif
             STAMP(12);
 #if CL_DET
             if (E->use_img) {
@@ -790,12 +753,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 const int img0 = __builtin_amdgcn_readfirstlane(img);
                 if (__all(img == img0 || rid < 0)) {
                     float v = (qe == 0 && rid >= 0) ? pda : 0.0f;
-#if CL_DPP_REDUCE
                     v = cl_wave_sum(v);
-#else
-#pragma unroll
-                    for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off);
-#endif
                     if (lane == 0 && img0 > 0) atomicAdd(ptr_uo(E->d_img, 4u * (unsigned)(img0 - 1)), v);
                 } else {
                     cl_image_grad_segments(E->d_img, img, pda, qe == 0 && rid >= 0 && img > 0, lane);
@@ -839,7 +797,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         // and its MFMAs run interleaved with the dgrad MFMAs of layer l-1, when the operands have long arrived.  The weight
         // operands of the dgrad are requested one iteration ahead as well.  With no wgrad pending (top layer) the operands are
         // zero and the MFMAs add exactly 0 to an accumulator, so the pipeline needs no branches.
-        constexpr bool WPIPE = WLOC && (CL_WPIPE != 0);
+        constexpr bool WPIPE = WLOC;
         f32x4 pa4 = {0.0f, 0.0f, 0.0f, 0.0f}, pb4 = {0.0f, 0.0f, 0.0f, 0.0f}, pacc = {0.0f, 0.0f, 0.0f, 0.0f};
         float r0w[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
 #pragma unroll
@@ -1346,8 +1304,8 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.w <= 15) {
         // the narrow instance comes in three step counts (hidden width <= 8, <= 12, <= 15); the forward-only launch keeps all four
         constexpr int L16 = (CL_IMGL == 1 ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16);
-        if (MODE != 1 && CL_KPERM && a.w <= 8) return launch_dp<16, L16, MODE, 2>(a, grid, st);
-        if (MODE != 1 && CL_KPERM && a.w <= 12) return launch_dp<16, L16, MODE, 3>(a, grid, st);
+        if (MODE != 1 && a.w <= 8) return launch_dp<16, L16, MODE, 2>(a, grid, st);
+        if (MODE != 1 && a.w <= 12) return launch_dp<16, L16, MODE, 3>(a, grid, st);
         return launch_dp<16, L16, MODE, 4>(a, grid, st);
     }
     if (a.w <= 32) return (a.L + (CL_IMGL == 1 ? a.n_imgl : 0) <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
@@ -1457,7 +1415,7 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     const int WP = a.w <= 15 ? 16 : (a.w <= 32 ? 32 : 64);
     const int DP = a.d <= 8 ? 8 : (a.d <= 32 ? 32 : 64);
     const int LM = a.w <= 15 ? (imgl ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16) : (a.w <= 32 ? (a.L + imgl <= 5 ? 5 : CL_MLP_LMAX_W32) : CL_MLP_LMAX_W64);
-    const int KS = (a.w <= 15 && mode != 1 && CL_KPERM) ? (a.w <= 8 ? 2 : (a.w <= 12 ? 3 : 4)) : 4;
+    const int KS = (a.w <= 15 && mode != 1) ? (a.w <= 8 ? 2 : (a.w <= 12 ? 3 : 4)) : 4;
     return snprintf(out, n, "elbo_mlp_kernel<%d, %d, %d, %d%s, KS=%d>", WP, DP, LM, mode, unit, KS);
 }
 

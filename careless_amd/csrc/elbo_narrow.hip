@@ -30,9 +30,6 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef CL_NARROW_SCHED
-#define CL_NARROW_SCHED 1
-#endif
 
 
 namespace {
@@ -79,11 +76,7 @@ __device__ __forceinline__ T ld_uo(const T* base, unsigned byte_off) {       // 
 }
 
 // pins the order of the hand-interleaved instruction stream: the scheduler may not move anything across it
-#if CL_NARROW_SCHED
 #define NFENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define NFENCE()
-#endif
 
 // Diagnostic build only (-DCL_STAMPS): per-wave cycle shares of the phases of a wave tile; the shipped library executes no stamp
 #ifdef CL_STAMPS
