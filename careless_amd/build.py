@@ -20,6 +20,7 @@ UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=
          ("elbo_mlp.hip", "elbo_mlp_chain", ["-DCL_CHAIN=1"]),
          ("elbo_mlp.hip", "elbo_mlp_det", ["-DCL_DET=1"]),               # deterministic mode: the epilogue's atomics as stores
          ("elbo_mlp.hip", "elbo_mlp_packed_det", ["-DCL_IMGL=2", "-DCL_DET=1"]),    # ... in the packed layout (single-pass Laue)
+         ("elbo_mlp.hip", "elbo_mlp_chain_det", ["-DCL_CHAIN=1", "-DCL_DET=1"]),    # ... for the last block of a layer-block chain
          ("elbo_narrow.hip", "elbo_narrow", ["-fno-slp-vectorize"]),     # (packed fp32 math costs more than it saves beside MFMAs)
          # (4x4x1 results feed vector code: no accumulator-register detour); four parts = four groups of instances, compiled in parallel
          ("elbo_lane.hip", "elbo_lane0", ["-DCL_LANE_PART=0", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),

@@ -11,6 +11,7 @@ int cl_launch_mlp_packed(const cl_mlp_args& a, int mode, int grid, hipStream_t s
 int cl_launch_mlp_chain(const cl_mlp_args& a, int mode, int grid, hipStream_t st);  // elbo_mlp.hip compiled with -DCL_CHAIN=1
 int cl_launch_mlp_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st);    // elbo_mlp.hip compiled with -DCL_DET=1 (no atomics)
 int cl_launch_mlp_packed_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st);   // ... with -DCL_IMGL=2 -DCL_DET=1 (single-pass Laue, no atomics)
+int cl_launch_mlp_chain_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st);    // ... with -DCL_CHAIN=1 -DCL_DET=1 (a chain's last block, no atomics)
 int cl_launch_det_reduce(const cl_det_args& a, hipStream_t st);                     // elbo_elem.hip: fixed-order sums of the deterministic mode
 int cl_narrow_supports(const cl_mlp_args& a);                                       // elbo_narrow.hip: width <= 15, metadata <= 15, plain layout
 int cl_launch_narrow(const cl_mlp_args& a, int grid, hipStream_t st);               // ... the full ELBO step on that kernel

@@ -26,10 +26,10 @@
 //     by all of them: LDS operands are double-buffered by hand one MFMA group ahead (CL_SCHED_FENCE) and the post-barrier
 //     latency windows are filled with independent work (bias-gradient reads, the next layer's dZ, staging writes between the
 //     dgrad MFMAs) -- DESIGN.md section 4.1.
-// The file is compiled seven times (build.py): plain; the same with the epilogue's atomics turned into stores (-DCL_DET=1, the
-// deterministic mode of include/careless_hip.h: dzf_obs / dimg_obs / nll_part; once more for the packed layout, -DCL_IMGL=2 -DCL_DET=1); packed layout + per-image layers (-DCL_IMGL=1, NeuralImageScaler); packed
-// layout only (-DCL_IMGL=2, single-pass Laue: harmonic group sums as lane reductions in the epilogue); layer-block chains
-// (-DCL_CHAIN=1, scalers deeper than one launch holds).
+// The file is compiled eight times (build.py): plain; packed layout + per-image layers (-DCL_IMGL=1, NeuralImageScaler); packed layout only
+// (-DCL_IMGL=2, single-pass Laue: harmonic group sums as lane reductions in the epilogue); layer-block chains (-DCL_CHAIN=1, scalers deeper
+// than one launch holds); and the plain, packed and chain forms once more with the epilogue's atomics turned into stores (-DCL_DET=1, the
+// deterministic mode of include/careless_hip.h: dzf_obs / dimg_obs / nll_part).
 // Roofline: fp32 MFMA (157.3 TFLOP/s); algorithmic flops per observation 6 (d w + (L-1) w^2 + 2 w).
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -1330,6 +1330,13 @@ int cl_launch_mlp_packed_det(const cl_mlp_args& a, int mode, int grid, hipStream
     if (a.gmeta != nullptr && a.tile_gmax == nullptr) return -1;
     if (a.dzf_obs == nullptr || a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
     if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+#elif CL_DET && CL_CHAIN
+// the LAST block of a layer-block chain (the one launch of a chained scaler with an epilogue) without float atomics: the eighth compilation
+// of this file (build.py: elbo_mlp_chain_det).  The chain's forward-only and backward-only launches have no atomics and keep the chain unit.
+int cl_launch_mlp_chain_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (mode != 0 || a.row_map != nullptr || a.n_imgl > 0 || a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out == nullptr || a.ev11 != nullptr) return -2;
+    if (a.dzf_obs == nullptr || a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
+    if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #elif CL_DET
 int cl_launch_mlp_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     // plain layout, full step, no Evans-2011 terms (their gradients are wave atomics), every store target present
@@ -1356,9 +1363,11 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
-    if (a.dzf_obs != nullptr) {
+    if (a.dzf_obs != nullptr && (mode == 0 || (a.act_out == nullptr && a.dH_ext == nullptr))) {
         // deterministic mode: the default scaler's shapes keep their own kernels (round 4: elbo_lane.hip / elbo_narrow.hip store per
-        // observation when dzf_obs is given), every other width <= 64 runs the deterministic compilation of this file
+        // observation when dzf_obs is given), every other width <= 64 runs the deterministic compilation of this file.  (The forward-only
+        // and backward-only launches of a layer-block chain have no float atomics: they take the chain unit below.)
+        if (mode == 0 && a.dX_out != nullptr) return cl_launch_mlp_chain_det(a, mode, grid, st);       // the chain's last block: the one with the epilogue
         if (mode == 0 && a.ev11 == nullptr && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1) {
             const int g = grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid;
             if (cl_lane_supports(a) && lane_enabled()) return cl_launch_lane(a, g, st);
@@ -1399,10 +1408,10 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
 int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     const char* unit = "";
     bool packed = false;
-    if (a.dzf_obs != nullptr) {
+    if (a.dzf_obs != nullptr && (mode == 0 || (a.act_out == nullptr && a.dH_ext == nullptr))) {
         if (mode == 0 && a.ev11 == nullptr && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
         if (mode == 0 && a.ev11 == nullptr && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
-        unit = (a.row_map != nullptr && a.n_imgl == 0) ? ", packed deterministic" : ", deterministic";
+        unit = (mode == 0 && a.dX_out != nullptr) ? ", chain deterministic" : ((a.row_map != nullptr && a.n_imgl == 0) ? ", packed deterministic" : ", deterministic");
     } else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
     else if (a.n_imgl > 0) unit = ", image layers";
     else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }

@@ -249,12 +249,12 @@ class ElboEngine(WidePath):
         # (wide scalers: monochromatic rows only -- they are their own slots and one kernel holds every float atomic of the path --, with a
         #  sample count that divides 64, so that a row's samples sit inside one wave)
         wide_det_ok = self.wide and not self.laue and 64 % int(model.mc_sample_size) == 0
-        if self.deterministic and (two_pass or (self.wide and not wide_det_ok) or imgl is not None or self.ev11 or self.blocks is not None or
-                                   (self.double_wilson and prior.r_raw is not None)):
+        if self.deterministic and (two_pass or (self.wide and not wide_det_ok) or imgl is not None or self.ev11 or
+                                   (self.blocks is not None and self.laue) or (self.double_wilson and prior.r_raw is not None)):
             raise NotImplementedError("deterministic mode covers monochromatic and single-pass Laue data, the Wilson and the double-Wilson prior "
-                                      "(fixed r), Normal / Student-T likelihoods, scalers of one launch (width <= 64) and, for monochromatic data "
-                                      "with a sample count that divides 64, scalers wider than 64; the two-pass Laue path, a trainable "
-                                      "double-Wilson r, Evans-2011, per-image layers and chained scalers keep their float atomics")
+                                      "(fixed r), Normal / Student-T likelihoods, scalers of any depth up to width 64 and, for monochromatic data "
+                                      "with a sample count that divides 64, scalers wider than 64; the two-pass Laue path (also under a chained "
+                                      "scaler), a trainable double-Wilson r, Evans-2011 and per-image layers keep their float atomics")
         if self.deterministic and self.double_wilson:
             # parents pull their children's terms in list order instead of children scattering with atomics (cl_dw_prior_forward)
             par = np.asarray(prior.reflids).astype(np.int64)
@@ -684,7 +684,10 @@ class ElboEngine(WidePath):
             return
         ma = self._mlp_args(step, eta, ipred_out, obs)
         if self.blocks is not None:
-            return self._data_term_chain(ma, obs, step, eta, ipred_out, st)
+            self._data_term_chain(ma, obs, step, eta, ipred_out, st)
+            if self.deterministic and not _piece:
+                self._det_reduce(obs, st)
+            return
         if self.laue and obs.fused_laue:
             # single pass: the harmonic group sums happen inside the fused kernel; the padded slots (no rows, iconv = 0,
             # reference formatter.py:637-640 / laue.py:24) only add their constant -- and, with Ev11, its gradient
