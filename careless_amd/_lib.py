@@ -19,6 +19,7 @@ CL_LIK_NORMAL, CL_LIK_STUDENTT = 0, 1
 CL_BIJ_EXP, CL_BIJ_SOFTPLUS = 0, 1
 CL_PRIOR_WILSON, CL_PRIOR_DOUBLE_WILSON = 0, 1
 CL_LAUE_LIK_MAX_BLOCKS = 2048
+CL_EV11_WAVES = 8               # wave slots per workgroup in ev11_part (include/careless_hip.h)
 
 _vp = C.c_void_p
 
@@ -71,7 +72,7 @@ class MlpArgs(C.Structure):
         ("imgl", _vp), ("d_imgl", _vp), ("n_imgl", C.c_int), ("n_images", C.c_int), ("tile_img", _vp), ("row_map", _vp),
         ("gmeta", _vp), ("tile_gmax", _vp), ("noise_row", _vp),
         ("act_out", _vp), ("dH_ext", _vp), ("dX_out", _vp),
-        ("dzf_obs", _vp), ("dimg_obs", _vp), ("nll_part", _vp), ("det_slot", _vp),
+        ("dzf_obs", _vp), ("dimg_obs", _vp), ("nll_part", _vp), ("det_slot", _vp), ("ev11_part", _vp),
     ]
 
 
@@ -82,6 +83,7 @@ class DetArgs(C.Structure):
         ("dimg_obs", _vp), ("perm_img", _vp), ("seg_img", _vp), ("n_images", C.c_int), ("d_img", _vp),
         ("nll_part", _vp), ("nparts", C.c_int), ("scalars", _vp),
         ("stop_flag", _vp),
+        ("ev11_part", _vp), ("n_ev11", C.c_int), ("d_ev11", _vp),
     ]
 
 
@@ -99,7 +101,7 @@ class LaueArgs(C.Structure):
         ("seed", C.c_ulonglong), ("step", C.c_uint),
         ("iconv", _vp), ("dz_f", _vp), ("d_img", _vp), ("dO", _vp), ("scalars", _vp), ("ipred_out", _vp), ("stop_flag", _vp),
         ("ev11", _vp), ("d_ev11", _vp), ("row_index", _vp), ("nll_part", _vp),
-        ("dzf_obs", _vp), ("dimg_obs", _vp), ("det_slot", _vp),
+        ("dzf_obs", _vp), ("dimg_obs", _vp), ("det_slot", _vp), ("ev11_part", _vp),
     ]
 
 

@@ -19,6 +19,7 @@ int cl_det_reduce(const cl_det_args* a, void* stream) {
         a->nll_part == nullptr || a->nparts < 1 || a->scalars == nullptr)
         return -1;
     if (a->d_img != nullptr && (a->dimg_obs == nullptr || a->perm_img == nullptr || a->seg_img == nullptr || a->n_images < 1)) return -1;
+    if (a->ev11_part != nullptr && (a->d_ev11 == nullptr || a->n_ev11 < 1)) return -1;
     return cl_launch_det_reduce(*a, (hipStream_t)stream);
 }
 

@@ -560,8 +560,19 @@ __global__ __launch_bounds__(64) void det_nll_kernel(const cl_det_args A) {
     if (threadIdx.x == 0) A.scalars[CL_SC_NLL] += acc;
 }
 
+// d_ev11[c] += the waves' shares of dL/d raw (Evans-2011 error model) in slot order: one wave, lane l sums slots l, l + 64, ..., then the fixed butterfly
+__global__ __launch_bounds__(64) void det_ev11_kernel(const cl_det_args A) {
+    if (A.stop_flag != nullptr && *A.stop_flag != 0) return;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    for (int k = threadIdx.x; k < A.n_ev11; k += 64) { a0 += A.ev11_part[3 * k]; a1 += A.ev11_part[3 * k + 1]; a2 += A.ev11_part[3 * k + 2]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); }
+    if (threadIdx.x == 0) { A.d_ev11[0] += a0; A.d_ev11[1] += a1; A.d_ev11[2] += a2; }
+}
+
 int cl_launch_det_reduce(const cl_det_args& a, hipStream_t st) {
     (void)hipGetLastError();
+    if (a.ev11_part != nullptr) hipLaunchKernelGGL(det_ev11_kernel, dim3(1), dim3(64), 0, st, a);
     hipLaunchKernelGGL(det_refl_kernel, dim3((unsigned)((a.R + 15) / 16)), dim3(256), 0, st, a);
     if (a.d_img != nullptr && a.n_images > 1) hipLaunchKernelGGL(det_img_kernel, dim3((a.n_images - 1 + 3) / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(det_nll_kernel, dim3(1), dim3(64), 0, st, a);

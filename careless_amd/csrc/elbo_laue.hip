@@ -84,7 +84,12 @@ __global__ __launch_bounds__(256) void laue_likelihood_kernel(const cl_laue_args
     if (A.ev11 != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { g0 += __shfl_xor(g0, off); g1 += __shfl_xor(g1, off); g2 += __shfl_xor(g2, off); }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(A.d_ev11 + 0, g0); atomicAdd(A.d_ev11 + 1, g1); atomicAdd(A.d_ev11 + 2, g2); }
+        if ((threadIdx.x & 63) == 0) {
+            if (A.ev11_part != nullptr) {            // deterministic mode: this wave's slot, summed in index order by cl_det_reduce
+                float* slot = A.ev11_part + 3 * (4 * (size_t)blockIdx.x + (threadIdx.x >> 6));
+                slot[0] = g0; slot[1] = g1; slot[2] = g2;
+            } else { atomicAdd(A.d_ev11 + 0, g0); atomicAdd(A.d_ev11 + 1, g1); atomicAdd(A.d_ev11 + 2, g2); }
+        }
     }
 }
 
@@ -267,7 +272,12 @@ __global__ __launch_bounds__(256) void slot_rows_kernel(const cl_laue_args A, in
     if (A.ev11 != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { g0 += __shfl_xor(g0, off); g1 += __shfl_xor(g1, off); g2 += __shfl_xor(g2, off); }
-        if (lane == 0) { atomicAdd(A.d_ev11 + 0, g0); atomicAdd(A.d_ev11 + 1, g1); atomicAdd(A.d_ev11 + 2, g2); }
+        if (lane == 0) {
+            if (A.ev11_part != nullptr) {
+                float* slot = A.ev11_part + 3 * (4 * (size_t)blockIdx.x + (threadIdx.x >> 6));
+                slot[0] = g0; slot[1] = g1; slot[2] = g2;
+            } else { atomicAdd(A.d_ev11 + 0, g0); atomicAdd(A.d_ev11 + 1, g1); atomicAdd(A.d_ev11 + 2, g2); }
+        }
     }
 }
 
@@ -302,7 +312,7 @@ int cl_launch_slot_rows(const cl_laue_args& a, hipStream_t st) {
     if (a.iobs == nullptr || a.sig == nullptr || a.scalars == nullptr || a.dz_f == nullptr || a.dO == nullptr || (a.use_img && a.d_img == nullptr)) return -1;
     if (a.dzf_obs != nullptr) {          // deterministic mode: stores per (row, sample) / row / workgroup; a row's samples must sit inside one wave
         if (64 % a.S != 0) return -2;
-        if (a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr) || a.ev11 != nullptr) return -1;
+        if (a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr) || (a.ev11 != nullptr && a.ev11_part == nullptr)) return -1;
     }
     (void)hipGetLastError();
     const int store = (64 % a.S == 0) ? 1 : 0;

@@ -1230,9 +1230,13 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 ev_g0 += __shfl_xor(ev_g0, off); ev_g1 += __shfl_xor(ev_g1, off); ev_g2 += __shfl_xor(ev_g2, off);
             }
             if (lane == 0) {                         // d softplus(raw)/d raw = sigmoid(raw)
-                atomicAdd(A.d_ev11 + 0, ev_g0 * cl_sigmoid(A.ev11[0]));
-                atomicAdd(A.d_ev11 + 1, ev_g1 * cl_sigmoid(A.ev11[1]));
-                atomicAdd(A.d_ev11 + 2, ev_g2 * cl_sigmoid(A.ev11[2]));
+                const float e0 = ev_g0 * cl_sigmoid(A.ev11[0]), e1 = ev_g1 * cl_sigmoid(A.ev11[1]), e2 = ev_g2 * cl_sigmoid(A.ev11[2]);
+                if (A.ev11_part != nullptr) {        // deterministic mode: this wave's slot, summed in index order by cl_det_reduce
+                    float* slot = A.ev11_part + 3 * (CL_EV11_WAVES * (size_t)blockIdx.x + wv);
+                    slot[0] = e0; slot[1] = e1; slot[2] = e2;
+                } else {
+                    atomicAdd(A.d_ev11 + 0, e0); atomicAdd(A.d_ev11 + 1, e1); atomicAdd(A.d_ev11 + 2, e2);
+                }
             }
         }
     }
@@ -1326,7 +1330,7 @@ static bool narrow_enabled() {          // CARELESS_HIP_NARROW=0 keeps narrow sc
 #if CL_DET && CL_IMGL == 2
 // packed layout (single-pass Laue) without float atomics: the seventh compilation of this file (build.py: elbo_mlp_packed_det)
 int cl_launch_mlp_packed_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
-    if (mode != 0 || a.row_map == nullptr || a.n_obs != a.n_pad || a.n_imgl != 0 || a.ev11 != nullptr) return -2;
+    if (mode != 0 || a.row_map == nullptr || a.n_obs != a.n_pad || a.n_imgl != 0 || (a.ev11 != nullptr && a.ev11_part == nullptr)) return -2;
     if (a.gmeta != nullptr && a.tile_gmax == nullptr) return -1;
     if (a.dzf_obs == nullptr || a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
     if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
@@ -1334,13 +1338,13 @@ int cl_launch_mlp_packed_det(const cl_mlp_args& a, int mode, int grid, hipStream
 // the LAST block of a layer-block chain (the one launch of a chained scaler with an epilogue) without float atomics: the eighth compilation
 // of this file (build.py: elbo_mlp_chain_det).  The chain's forward-only and backward-only launches have no atomics and keep the chain unit.
 int cl_launch_mlp_chain_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
-    if (mode != 0 || a.row_map != nullptr || a.n_imgl > 0 || a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out == nullptr || a.ev11 != nullptr) return -2;
+    if (mode != 0 || a.row_map != nullptr || a.n_imgl > 0 || a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out == nullptr || (a.ev11 != nullptr && a.ev11_part == nullptr)) return -2;
     if (a.dzf_obs == nullptr || a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
     if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #elif CL_DET
 int cl_launch_mlp_det(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
-    // plain layout, full step, no Evans-2011 terms (their gradients are wave atomics), every store target present
-    if (mode != 0 || a.row_map != nullptr || a.n_imgl > 0 || a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr || a.ev11 != nullptr) return -2;
+    // plain layout, full step, every store target present (with the Evans-2011 terms: their per-wave slots)
+    if (mode != 0 || a.row_map != nullptr || a.n_imgl > 0 || a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr || (a.ev11 != nullptr && a.ev11_part == nullptr)) return -2;
     if (a.dzf_obs == nullptr || a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
     if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #elif CL_CHAIN
@@ -1368,7 +1372,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
         // observation when dzf_obs is given), every other width <= 64 runs the deterministic compilation of this file.  (The forward-only
         // and backward-only launches of a layer-block chain have no float atomics: they take the chain unit below.)
         if (mode == 0 && a.dX_out != nullptr) return cl_launch_mlp_chain_det(a, mode, grid, st);       // the chain's last block: the one with the epilogue
-        if (mode == 0 && a.ev11 == nullptr && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1) {
+        if (mode == 0 && (a.ev11 == nullptr || a.ev11_part != nullptr) && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1) {
             const int g = grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid;
             if (cl_lane_supports(a) && lane_enabled()) return cl_launch_lane(a, g, st);
             if (cl_narrow_supports(a) && narrow_enabled()) return cl_launch_narrow(a, g, st);
@@ -1409,8 +1413,8 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     const char* unit = "";
     bool packed = false;
     if (a.dzf_obs != nullptr && (mode == 0 || (a.act_out == nullptr && a.dH_ext == nullptr))) {
-        if (mode == 0 && a.ev11 == nullptr && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
-        if (mode == 0 && a.ev11 == nullptr && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
+        if (mode == 0 && (a.ev11 == nullptr || a.ev11_part != nullptr) && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
+        if (mode == 0 && (a.ev11 == nullptr || a.ev11_part != nullptr) && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
         unit = (mode == 0 && a.dX_out != nullptr) ? ", chain deterministic" : ((a.row_map != nullptr && a.n_imgl == 0) ? ", packed deterministic" : ", deterministic");
     } else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
     else if (a.n_imgl > 0) unit = ", image layers";

@@ -663,9 +663,13 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                 ev_g0 += __shfl_xor(ev_g0, off); ev_g1 += __shfl_xor(ev_g1, off); ev_g2 += __shfl_xor(ev_g2, off);
             }
             if (lane == 0) {                         // d softplus(raw)/d raw = sigmoid(raw)
-                atomicAdd(A.d_ev11 + 0, ev_g0 * cl_sigmoid(A.ev11[0]));
-                atomicAdd(A.d_ev11 + 1, ev_g1 * cl_sigmoid(A.ev11[1]));
-                atomicAdd(A.d_ev11 + 2, ev_g2 * cl_sigmoid(A.ev11[2]));
+                const float e0 = ev_g0 * cl_sigmoid(A.ev11[0]), e1 = ev_g1 * cl_sigmoid(A.ev11[1]), e2 = ev_g2 * cl_sigmoid(A.ev11[2]);
+                if (A.ev11_part != nullptr) {        // deterministic mode: this wave's slot, summed in index order by cl_det_reduce
+                    float* slot = A.ev11_part + 3 * (CL_EV11_WAVES * (size_t)blockIdx.x + wv);
+                    slot[0] = e0; slot[1] = e1; slot[2] = e2;
+                } else {
+                    atomicAdd(A.d_ev11 + 0, e0); atomicAdd(A.d_ev11 + 1, e1); atomicAdd(A.d_ev11 + 2, e2);
+                }
             }
         }
     }
@@ -721,8 +725,8 @@ int cl_launch_narrow(const cl_mlp_args& a, int grid, hipStream_t st) {
         4ull * (unsigned long long)a.R * (unsigned long long)a.S >= (1ull << 32))
         return -4;
     if (grid < 1) return -1;
-    if (a.dzf_obs != nullptr) {          // deterministic mode: stores per (observation, sample) / observation / workgroup, no Evans-2011 terms
-        if (a.ev11 != nullptr) return -2;
+    if (a.dzf_obs != nullptr) {          // deterministic mode: stores per (observation, sample) / observation / workgroup / wave (Evans-2011 terms)
+        if (a.ev11 != nullptr && a.ev11_part == nullptr) return -2;      // (the Evans-2011 gradients need their per-wave slots)
         if (a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
         if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
     }

@@ -249,12 +249,12 @@ class ElboEngine(WidePath):
         # (wide scalers: monochromatic rows only -- they are their own slots and one kernel holds every float atomic of the path --, with a
         #  sample count that divides 64, so that a row's samples sit inside one wave)
         wide_det_ok = self.wide and not self.laue and 64 % int(model.mc_sample_size) == 0
-        if self.deterministic and (two_pass or (self.wide and not wide_det_ok) or imgl is not None or self.ev11 or
+        if self.deterministic and (two_pass or (self.wide and not wide_det_ok) or imgl is not None or
                                    (self.blocks is not None and self.laue) or (self.double_wilson and prior.r_raw is not None)):
             raise NotImplementedError("deterministic mode covers monochromatic and single-pass Laue data, the Wilson and the double-Wilson prior "
-                                      "(fixed r), Normal / Student-T likelihoods, scalers of any depth up to width 64 and, for monochromatic data "
-                                      "with a sample count that divides 64, scalers wider than 64; the two-pass Laue path (also under a chained "
-                                      "scaler), a trainable double-Wilson r, Evans-2011 and per-image layers keep their float atomics")
+                                      "(fixed r), Normal / Student-T likelihoods with or without the Evans-2011 error model, scalers of any depth up to "
+                                      "width 64 and, for monochromatic data with a sample count that divides 64, scalers wider than 64; the two-pass "
+                                      "Laue path (also under a chained scaler), a trainable double-Wilson r and per-image layers keep their float atomics")
         if self.deterministic and self.double_wilson:
             # parents pull their children's terms in list order instead of children scattering with atomics (cl_dw_prior_forward)
             par = np.asarray(prior.reflids).astype(np.int64)
@@ -416,6 +416,10 @@ class ElboEngine(WidePath):
                        nll=torch.zeros(len(pieces) * pieces[0].grid + (_lib.CL_LAUE_LIK_MAX_BLOCKS if (self.laue or self.wide) else 0), dtype=torch.float64,
                                        device=dev),
                        refl=(perm_r, seg_r), img=order(img, M), M=M, pieces=len(pieces), grid=pieces[0].grid)
+        if self.ev11:
+            # Evans-2011 gradients: one slot of three floats per wave of every launch (the fused launches' CL_EV11_WAVES per workgroup, then
+            # four per workgroup of the slot / padded-slot likelihood launch), summed in slot order by cl_det_reduce
+            obs.det["ev11"] = torch.zeros(3 * (_lib.CL_EV11_WAVES * len(pieces) * pieces[0].grid + 4 * _lib.CL_LAUE_LIK_MAX_BLOCKS), dtype=torch.float32, device=dev)
         for k, p in enumerate(pieces):
             p.det_parent, p.det_index = obs, k
 
@@ -546,6 +550,8 @@ class ElboEngine(WidePath):
                 a.dzf_obs = det["dzf"].data_ptr() + 4 * self.S * row0
             a.dimg_obs = det["dimg"].data_ptr() + 4 * row0
             a.nll_part = det["nll"].data_ptr() + 8 * det["grid"] * obs.det_index
+            if self.ev11:
+                a.ev11_part = det["ev11"].data_ptr() + 4 * 3 * _lib.CL_EV11_WAVES * det["grid"] * obs.det_index
         return a
 
     def kernel_name(self, mode: int = 0) -> str:
@@ -662,6 +668,8 @@ class ElboEngine(WidePath):
             a.n_images, a.d_img = det["M"], self.grads.data_ptr() + 4 * lay.off_img
         a.nll_part, a.nparts, a.scalars = ptr(det["nll"]), int(det["nll"].numel()), ptr(self.scalars)
         a.stop_flag = ptr(self.stop_flag)
+        if self.ev11:
+            a.ev11_part, a.n_ev11, a.d_ev11 = ptr(det["ev11"]), int(det["ev11"].numel()) // 3, self.grads.data_ptr() + 4 * lay.off_ev11
         check(self.lib.cl_det_reduce(C.byref(a), st), "cl_det_reduce")
 
     def _data_term(self, obs: ObsData, step: int, eta, ipred_out, st, _piece: bool = False, defer_reduce: bool = False):
@@ -705,6 +713,8 @@ class ElboEngine(WidePath):
                 if self.deterministic:      # the padded slots' workgroups store their NLL behind the fused launch's parts
                     det = obs.det_parent.det
                     la.nll_part = det["nll"].data_ptr() + 8 * det["pieces"] * det["grid"]
+                    if self.ev11:
+                        la.ev11_part = det["ev11"].data_ptr() + 4 * 3 * _lib.CL_EV11_WAVES * det["pieces"] * det["grid"]
                 check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
         elif self.laue:
             self._laue_passes(ma, obs, step, eta, ipred_out, st)
@@ -830,6 +840,8 @@ class ElboEngine(WidePath):
             det = obs.det_parent.det
             la.dzf_obs, la.dimg_obs, la.det_slot = ptr(det["dzf"]), ptr(det["dimg"]), ptr(det["slot"])
             la.nll_part = det["nll"].data_ptr() + 8 * det["pieces"] * det["grid"]
+            if self.ev11:
+                la.ev11_part = det["ev11"].data_ptr() + 4 * 3 * _lib.CL_EV11_WAVES * det["pieces"] * det["grid"]
             check(lib.cl_slot_rows(C.byref(la), st), "cl_slot_rows")
             return
         if obs.harmonic_id is None and os.environ.get("CARELESS_HIP_SLOT_ROWS", "1") != "0":

@@ -194,8 +194,12 @@ typedef struct cl_mlp_args {
     const int* det_slot;        /* optional [n_obs] (round 4): observation i's record goes to dzf_obs[det_slot[i]][S] instead of dzf_obs[i][S] --
                                    the caller's reflection-sorted position, so that cl_det_reduce (perm_refl NULL) reads every reflection's
                                    records contiguously instead of gathering them; the scattered STORES cost the kernel nothing it waits for */
+    float* ev11_part;           /* deterministic mode with the Evans-2011 error model (round 4): every wave of the launch STORES its share of dL/d raw
+                                   (Sdfac, Sdadd, SdB) at ev11_part[3 * (CL_EV11_WAVES * workgroup + wave)] instead of three float atomics on d_ev11;
+                                   [3 * CL_EV11_WAVES * grid] floats, cl_det_reduce adds them in index order                                          */
 } cl_mlp_args;
 
+#define CL_EV11_WAVES 8          /* wave slots per workgroup in ev11_part (the kernels run four or eight waves) */
 enum { CL_LIK_NORMAL_ = 0, CL_LIK_STUDENTT_ = 1 };
 enum { CL_BIJ_EXP_ = 0, CL_BIJ_SOFTPLUS_ = 1 };
 
@@ -224,6 +228,7 @@ typedef struct cl_det_args {
     const float* dimg_obs; const int* perm_img; const int* seg_img; int n_images; float* d_img;      /* d_img NULL: no image scales */
     const double* nll_part; int nparts; double* scalars;
     const int* stop_flag;
+    const float* ev11_part; int n_ev11; float* d_ev11;      /* optional: n_ev11 wave slots of three floats (cl_mlp_args / cl_laue_args.ev11_part), d_ev11[3] += their sums */
 } cl_det_args;
 int cl_det_reduce(const cl_det_args* args, void* stream);
 
@@ -351,6 +356,8 @@ typedef struct cl_laue_args {
      * of (row i, sample s) is STORED at dzf_obs[(det_slot ? det_slot[i] : i) * S + s] and the row's image-scale term at dimg_obs[i];
      * cl_det_reduce sums them per reflection / image in a fixed order (as cl_mlp_args.dzf_obs / dimg_obs / det_slot)               */
     float* dzf_obs; float* dimg_obs; const int* det_slot;
+    float* ev11_part;           /* deterministic mode with Evans-2011: cl_laue_likelihood / cl_slot_rows store every wave's share of dL/d raw at
+                                   ev11_part[3 * (4 * workgroup + wave)] (256-thread workgroups) instead of adding it to d_ev11 with atomics   */
 } cl_laue_args;
 #define CL_LAUE_LIK_MAX_BLOCKS 2048
 

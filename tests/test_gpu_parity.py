@@ -1141,10 +1141,17 @@ def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
                                 dict(N=900, R=50, d0=5, L=2, w=96, S=2, use_image_scales=False),
                                 # scalers deeper than one launch: the chain's last block is the launch with the epilogue
                                 dict(N=900, R=50, d0=5, L=12, w=64, S=3, likelihood="studentt", dof=8.0, n_images=6),
-                                dict(N=700, R=40, d0=5, L=25, w=10, S=2, perturb=0.02)],
+                                dict(N=700, R=40, d0=5, L=25, w=10, S=2, perturb=0.02),
+                                # the Evans-2011 error model: its three gradients leave as per-wave stores (cl_mlp_args / cl_laue_args.ev11_part)
+                                dict(N=900, R=50, d0=5, L=5, w=64, S=3, ev11=True),
+                                dict(N=900, R=50, d0=5, L=20, w=10, S=2, ev11=True, perturb=0.02),
+                                dict(N=800, R=40, d0=5, L=6, w=10, S=5, ev11=True, perturb=0.03, likelihood="studentt", dof=8.0),
+                                dict(N=700, R=40, L=3, w=32, S=2, laue=True, ev11=True),
+                                dict(N=900, R=50, d0=5, L=2, w=80, S=4, ev11=True)],
                          ids=["mono_5x64", "cli_default_20x10", "rows_in_arbitrary_order_S8", "no_image_scales_klweight",
                               "lane_posenc_d21_S8", "lane_20x8_S11", "narrow_6x10_S5", "narrow_9x13_d12", "laue_lane_20x10_S3", "laue_narrow_4x12", "laue_5x64_S3", "laue_3x32_d20_S9",
-                              "double_wilson_5x64", "double_wilson_lane_20x10", "wide_3x128_S4", "wide_2x96_noimg", "deep_12x64_S3", "deep_25x10"])
+                              "double_wilson_5x64", "double_wilson_lane_20x10", "wide_3x128_S4", "wide_2x96_noimg", "deep_12x64_S3", "deep_25x10",
+                              "ev11_5x64", "ev11_lane_20x10", "ev11_narrow_6x10_S5", "ev11_laue_3x32", "ev11_wide_2x80_S4"])
 def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypatch):
     """`model.deterministic = True` (or CARELESS_HIP_DETERMINISTIC=1): the fused kernel stores per-observation contributions instead of
     issuing float atomics and `cl_det_reduce` sums them in row order (include/careless_hip.h).  Same parity bar against the oracle,
