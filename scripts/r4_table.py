@@ -10,4 +10,4 @@ for w in ALL:
     per_step = sum(float(x["TotalDurationNs"]) for x in dom) / 13 / 1e6
     t = tr.get(w, {})
     print(f"| `{w}` | {d['value']:.3g} | {d['ms_per_step']:.3f} | {r['kernel_ms']:.3f} ({per_step:.3f}) | {r['frac']:.3f} ({r['frac_on_step_time']:.3f}) | "
-          f"{t.get('hbm_bytes_per_launch', 0) / 1e9:.2f} / {r.get('algorithmic_bytes', r.get('alg_bytes', 0)) / 1e9 if isinstance(r.get('algorithmic_bytes', r.get('alg_bytes', 0)), (int, float)) else 0:.2f} GB | {r.get('kernel', '')[:70]}")
+          f"{t.get('hbm_bytes_per_launch', 0) / 1e9:.2f} GB of HBM traffic per step | {r.get('kernel', '')[:70]}")
