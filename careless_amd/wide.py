@@ -192,10 +192,12 @@ class WidePath:
 
     def _data_term_wide(self, obs: ObsData, step: int, eta, ipred_out, st):
         """Hidden / metadata width > 64 (or more hidden layers with per-image layers than one fused launch holds): unfused scaler on
-        the GEMM kernels of csrc/wide_gemm.hip.  Forward (row chunks) -> (loc, sigma) per row -> the HIP slot likelihood kernels (mono
-        rows are their own groups) -> dL/d(loc, sigma) -> per chunk: forward again unless the one chunk's activations were kept, head
-        backward, then weight gradient and dgrad layer by layer, top down.  6 (one chunk) or 8 P_mm flops per observation; every
-        product in exact fp32."""
+        the GEMM kernels of csrc/wide_gemm.hip.  Forward (row chunks; the top layer carries the Dense(2) head) -> (loc, sigma) per row ->
+        the slot likelihood (one launch when every row is its own slot, the three Laue launches otherwise) -> dL/d(loc, sigma) -> per
+        chunk: forward again unless the activations were kept; the head's backward pass inside the top layer's weight gradient and
+        dgrad (or its own launch outside their envelope), then weight gradient and dgrad layer by layer, top down, the first layer's
+        weight gradient inside the second layer's dgrad when the first layer is recomputed.  6 (activations kept) or 8 P_mm flops per
+        observation; every product in exact fp32."""
         lib, lay, W = self.lib, self.layout, self._wide_setup()
         chunks = self._wide_chunks(obs)
         ma = self._mlp_args(step, eta, ipred_out, obs)
