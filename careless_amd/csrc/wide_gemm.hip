@@ -60,8 +60,9 @@ enum { EPI_BIAS_LRELU = 0, EPI_DLRELU = 1, EPI_WGRAD = 2 };
 // wherever its output is needed instead of being stored (round 4): it is a (rows x <= 16) x (<= 16 x w) product -- an eighth of a
 // 128 x 128 layer's work -- against 4 w bytes per row written once and read three times (the second layer's forward, its weight
 // gradient, the mask of its dgrad).  X0 == NULL: not in use.
-constexpr int K0MAX = 16;            // metadata columns the fused forms take in the forward / dgrad kernels (one 16-deep chunk) ...
-constexpr int K0WG = 8;              // ... and in the weight-gradient kernel (the thread's four weight rows live in registers)
+constexpr int K0MAX = 16;            // metadata columns of one 16-deep chunk: the fused forms' first-layer image [N0][K0MAX] ...
+constexpr int K0WG = 15;             // ... of which the recomputed first layer takes up to 15 (column K0 of the chunk carries the ones of the bias
+                                     // gradient in cl_wide_dense_dgrad_pre_wgrad0)
 constexpr int S0P = K0MAX + 4;       // pitch of the first layer's weight image [N0][K0MAX]
 struct PreArgs {
     const float* X0; int ldx0; int K0;      // metadata rows [n][ldx0], K0 columns in use
@@ -191,9 +192,14 @@ __device__ __forceinline__ void store_tile_tr(float* __restrict__ s, const f32x4
 }
 
 // BN: 64 or 128 output columns per workgroup (128: the row operand of a layer of width <= 128 is read once)
-template <bool AK, bool BK_, int EPI, int BN, bool HEADW = false>
+// PREM (round 4, EPI_WGRAD with the recomputed first layer as B operand, BN = 128): the B tile h_0[32 observations][128 columns] of a chunk is
+// made by MFMAs -- D[m = observation][n = column] = X_0 Wt_0^T, four steps per 16 x 16 block, sixteen blocks a chunk, four of them per wave --
+// whose result layout, lane (column j, q), element t = h_0[observation 4 q + t][column j], IS a quad of the staged tile [column][k]: one
+// ds_write_b128 per block and no per-thread dot products (the vector form cost 2.4 vector instructions per MFMA of the kernel).
+template <bool AK, bool BK_, int EPI, int BN, bool HEADW = false, bool PREM = false>
 __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     static_assert(!HEADW || (EPI == EPI_WGRAD && AK && BK_), "the fused head backward feeds the weight gradient's transposing loader");
+    static_assert(!PREM || (EPI == EPI_WGRAD && AK && BK_ && BN == 128 && !HEADW), "the MFMA-made first layer is the B tile of the 128-column weight gradient");
     if (G.stop_flag != nullptr && *G.stop_flag != 0) return;      // a previous step hit a non-finite gradient norm
     constexpr int PMB = BN + 4, NB = BN / 16;
     constexpr int SB = (BN * PK > BK * PMB) ? BN * PK : BK * PMB;
@@ -233,40 +239,28 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
     float bsum = 0.0f;              // EPI_WGRAD: bias gradient of output unit m0 + tid = column sum of the A operand (dZ)
 
     f32x4 ra[BM * BK / 1024], rb[BN * BK / 1024];
-    // EPI_WGRAD with the recomputed first layer as B operand: the thread's four columns of the tile are fixed (BN / 4 threads per
-    // contraction index, 256 a multiple of it), so their weight rows and biases sit in registers for the whole launch
-    const bool pre = EPI == EPI_WGRAD && BK_ && G.pre.X0 != nullptr;
-    // the recomputed first layer as B operand: the thread's four columns of the tile are fixed (both forms map tid % (BN / 4) to the
-    // column quad), so their weight rows and biases sit in registers for the whole launch
-    float w0r[4][K0WG], b0r[4];
-    const int pcol = n0 + 4 * (tid % (BN / 4));
-    if (pre) {
+    // PREM: this wave's four blocks of the B tile are columns 16 (2 wv + nb) .. + 15, nb = 0, 1, for both 16-observation halves of the chunk;
+    // Wt_0 of those columns as B operand (lane (column j, q), step t = Wt_0[column][4 q + t]) and their biases stay in registers
+    f32x4 w0b[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}}, xk[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+    float b0n[2] = {0.0f, 0.0f};
+    if (PREM) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            b0r[e] = (pcol + e < G.pre.N0) ? G.pre.b0[pcol + e] : 0.0f;
+        for (int nb = 0; nb < 2; ++nb) {
+            const int n = n0 + 16 * (2 * wv + nb) + j;
+            b0n[nb] = (n < G.pre.N0) ? G.pre.b0[n] : 0.0f;
 #pragma unroll
-            for (int i = 0; i < K0WG; ++i) w0r[e][i] = (pcol + e < G.pre.N0 && i < G.pre.K0) ? G.pre.W0[(size_t)(pcol + e) * G.pre.K0 + i] : 0.0f;
+            for (int t = 0; t < 4; ++t) w0b[nb][t] = (n < G.pre.N0 && 4 * q + t < G.pre.K0) ? G.pre.W0[(size_t)n * G.pre.K0 + 4 * q + t] : 0.0f;
         }
     }
-    // h_0 of observation k in the thread's four columns (the contraction order of the forward kernels' MFMAs -- step t takes k = t, 4 + t --,
-    // the bias after it: the same bits)
-    auto pre_row = [&](int k) -> f32x4 {
-        f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (k < kend) {
-            const float* x = G.pre.X0 + (size_t)k * G.pre.ldx0;      // (ldx0 is a multiple of four, the padding columns are zero)
-            const f32x4 xa = *reinterpret_cast<const f32x4*>(x);
-            f32x4 xb = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (G.pre.ldx0 > 4) xb = *reinterpret_cast<const f32x4*>(x + 4);
+    // the chunk's metadata rows as A operand: lane (observation j of half kb, q) holds X_0[k][4 q .. 4 q + 3] (rows past the range: zeros --
+    // their dZ rows are zero in the A tile, so what the bias makes of them here multiplies nothing)
+    auto load_x0 = [&](int kk0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float z = 0.0f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { z = fmaf(w0r[e][t], xa[t], z); z = fmaf(w0r[e][4 + t], xb[t], z); }
-                z += b0r[e];
-                out[e] = fmaxf(z, G.leak * z);
-            }
+        for (int kb = 0; kb < 2; ++kb) {
+            const int k = kk0 + 16 * kb + j;
+            xk[kb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (k < kend && 4 * q < G.pre.ldx0) xk[kb] = *reinterpret_cast<const f32x4*>(G.pre.X0 + (size_t)k * G.pre.ldx0 + 4 * q);
         }
-        return out;
     };
     // HEADW: the thread's four output units are fixed (as `pcol` on the other operand): the head's two weights of each in registers, the
     // head's weight-gradient sums of those columns over the thread's observations, dL/d(loc, sigma) and dsigma/draw of the item's four rows
@@ -320,23 +314,27 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(const GemmArgs G) {
         }
     };
     auto load_b = [&](int kk0, f32x4 (&r)[BN * BK / 1024]) {
-        if (!pre) {
-            if constexpr (TRB) load_tile_tr<BN>(Bp, G.ldb, n0, kk0, G.N, kend, vecB, r, tid);
-            else load_tile<BN, BK_>(Bp, G.ldb, n0, kk0, G.N, kend, vecB, r, tid);
-            return;
-        }
-        if constexpr (TRB) {
-            const int k = kk0 + 4 * (tid / (BN / 4));                 // the item's four observations
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = pre_row(k + e);
-        } else {
-#pragma unroll
-            for (int v = 0; v < BN * BK / 1024; ++v) r[v] = pre_row(kk0 + (v * 256 + tid) / (BN / 4));
-        }
+        if constexpr (PREM) { load_x0(kk0); return; }
+        if constexpr (TRB) load_tile_tr<BN>(Bp, G.ldb, n0, kk0, G.N, kend, vecB, r, tid);
+        else load_tile<BN, BK_>(Bp, G.ldb, n0, kk0, G.N, kend, vecB, r, tid);
     };
     auto stage = [&](float* sa, float* sb) {
         if constexpr (TR) store_tile_tr<BM>(sa, ra, tid); else store_tile<BM, AK>(sa, ra, tid);
-        if constexpr (TRB) store_tile_tr<BN>(sb, rb, tid); else store_tile<BN, BK_>(sb, rb, tid);
+        if constexpr (PREM) {
+            // h_0 = LeakyReLU(X_0 Wt_0^T + b_0) of this wave's four blocks, in the forward kernels' contraction order (the bias after the steps)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) z = mfma4(xk[kb][t], w0b[nb][t], z);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { const float v = z[t] + b0n[nb]; z[t] = fmaxf(v, G.leak * v); }
+                    const int col = 16 * (2 * wv + nb) + j;
+                    *reinterpret_cast<f32x4*>(sb + col * PK + tr_quad(col, 4 * kb + q)) = z;
+                }
+        } else if constexpr (TRB) store_tile_tr<BN>(sb, rb, tid); else store_tile<BN, BK_>(sb, rb, tid);
     };
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk > 0) {
@@ -1377,13 +1375,13 @@ int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n,
 }
 
 /* 1: the first Dense layer of a (n_in0 -> w -> w ...) stack can be recomputed instead of stored (cl_wide_dense2_forward,
- * cl_wide_dense_dgrad_pre, cl_wide_dense_wgrad_pre): metadata of at most 8 columns, hidden width at most 128 */
+ * cl_wide_dense_dgrad_pre, cl_wide_dense_wgrad_pre): metadata of at most 15 columns, hidden width at most 128 */
 int cl_wide_pre_supported(int n_in0, int w) { return n_in0 >= 1 && n_in0 <= K0WG && w >= 1 && w <= SMAX; }
 
 static int pre_check(const float* X0, int ldx0, int n_in0, const float* Wt0, const float* b0, int w) {
     if (X0 == nullptr || Wt0 == nullptr || b0 == nullptr) return -1;
     if (!cl_wide_pre_supported(n_in0, w)) return -2;
-    if (ldx0 < n_in0 || ldx0 % 4 != 0 || ldx0 > K0WG || (reinterpret_cast<uintptr_t>(X0) & 15) != 0) return -1;
+    if (ldx0 < n_in0 || ldx0 % 4 != 0 || ldx0 > K0MAX || (reinterpret_cast<uintptr_t>(X0) & 15) != 0) return -1;
     return 0;
 }
 
@@ -1457,7 +1455,12 @@ int cl_wide_dense_wgrad_pre(const float* dZ, int lddz, const float* X0, int ldx0
     g.pstride = (long long)n_out * n_in + n_out;
     g.leak = leak; g.stop_flag = stop_flag;
     g.pre.X0 = X0; g.pre.ldx0 = ldx0; g.pre.K0 = n_in0; g.pre.W0 = Wt0; g.pre.b0 = b0; g.pre.N0 = n_in;
-    return launch_gemm<true, true, EPI_WGRAD>(g, nsplit, (hipStream_t)stream);
+    // the layer's input tile is made by MFMAs where the kernel stages it: one 128-column tile of a 128-row output (cl_wide_pre_supported
+    // bounds both widths by 128; a width <= 64 never comes here -- the fused kernels take it)
+    if (n_in > 128 || n_out > 128) return -2;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((wide_gemm_kernel<true, true, EPI_WGRAD, 128, false, true>), dim3(1, 1, nsplit), dim3(256), 0, (hipStream_t)stream, g);
+    return (int)hipGetLastError();
 }
 
 int cl_wide_wgrad_splits(long long n) {

@@ -112,7 +112,7 @@ class WidePath:
 
     def _wide_pre(self) -> bool:
         """The first Dense layer is recomputed instead of stored (cl_wide_dense2_forward / _dgrad_pre / _wgrad_pre): at least two Dense
-        layers, at most 8 metadata columns, hidden width up to 128.  CARELESS_HIP_WIDE_PRE=0 keeps every layer's output (A/B runs)."""
+        layers, at most 15 metadata columns, hidden width up to 128.  CARELESS_HIP_WIDE_PRE=0 keeps every layer's output (A/B runs)."""
         import os
         return (self.L >= 2 and bool(self.lib.cl_wide_pre_supported(self.d, self.w)) and os.environ.get("CARELESS_HIP_WIDE_PRE", "1") != "0")
 

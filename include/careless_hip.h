@@ -266,7 +266,7 @@ int cl_wide_dense_dgrad_head(const float* Htop, int ldt, const float* head, cons
 /* dX[n][n_in] = (dZ[n][n_out] Wt) * LeakyReLU'(Hprev[n][n_in])   (Hprev = the layer's input = the previous layer's output; NULL: no mask) */
 int cl_wide_dense_dgrad(const float* dZ, int lddz, const float* Wt, long long n, int n_out, int n_in, const float* Hprev, int ldh, float leak,
                         float* dX, int ldo, const int* stop_flag, void* stream);
-/* The FIRST Dense layer recomputed instead of stored (round 4): with at most 8 metadata columns and a hidden width of at most 128
+/* The FIRST Dense layer recomputed instead of stored (round 4): with at most 15 metadata columns and a hidden width of at most 128
  * (cl_wide_pre_supported) its output h_0 = LeakyReLU(X0 Wt0^T + b0) is an eighth of a 128 x 128 layer's work, so it is made again
  * wherever it is needed -- 4 w bytes per row are never written, nor read three times:
  *   cl_wide_dense2_forward   layers 0 and 1 in one launch (h_0 stays in registers, in the operand layout of layer 1); `head` non-NULL:

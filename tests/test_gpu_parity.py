@@ -114,6 +114,8 @@ CASES = {
     # (8 columns: its weight gradient rides on the second layer's dgrad, round 4), the narrowest width of that kernel (5 blocks of 16)
     "wide_3x128_d8_rows2117_S2": dict(N=2117, R=90, d0=8, L=3, w=128, S=2, likelihood="studentt", dof=10.0),
     "wide_4x72_rows1301_noimg": dict(N=1301, R=70, d0=5, L=4, w=72, S=2, use_image_scales=False),
+    "wide_3x96_d15_rows1203": dict(N=1203, R=60, d0=15, L=3, w=96, S=2, likelihood="studentt", dof=8.0),      # (the widest recomputed first layer)
+    "wide_2x128_d12": dict(N=900, R=50, d0=12, L=2, w=128, S=3),
     "wide_mono_2x80_ev11_S4": dict(N=600, R=50, d0=5, L=2, w=80, S=4, ev11=True),      # (the Evans-2011 terms of the one-launch slot kernel)
     "wide_laue_2x80_ev11": dict(N=500, R=40, L=2, w=80, S=2, laue=True, ev11=True),
     # per-image layers beyond one fused launch: wider than 64, or more hidden layers (Dense + per-image) than a launch holds at the

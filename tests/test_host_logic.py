@@ -318,9 +318,9 @@ def test_wide_path_envelope_queries():
     gradient writes, the row pitch of the activation buffers."""
     lib = _lib.get_lib()
     assert [lib.cl_wide_ld(w) for w in (1, 4, 70, 128, 129)] == [4, 4, 72, 128, 132] and lib.cl_wide_ld(0) == 0
-    # first layer recomputed: at most 8 metadata columns, hidden width at most 128
-    assert lib.cl_wide_pre_supported(5, 128) == 1 and lib.cl_wide_pre_supported(8, 65) == 1
-    assert lib.cl_wide_pre_supported(9, 128) == 0 and lib.cl_wide_pre_supported(5, 129) == 0 and lib.cl_wide_pre_supported(0, 64) == 0
+    # first layer recomputed: at most 15 metadata columns, hidden width at most 128
+    assert lib.cl_wide_pre_supported(5, 128) == 1 and lib.cl_wide_pre_supported(15, 65) == 1
+    assert lib.cl_wide_pre_supported(16, 128) == 0 and lib.cl_wide_pre_supported(5, 129) == 0 and lib.cl_wide_pre_supported(0, 64) == 0
     # fused head backward: square layers of 5 .. 8 sixteen-column blocks on both sides (widths 65 .. 128, same block count)
     assert lib.cl_wide_head_bwd_supported(128, 128) == 1 and lib.cl_wide_head_bwd_supported(65, 80) == 1 and lib.cl_wide_head_bwd_supported(96, 90) == 1
     assert lib.cl_wide_head_bwd_supported(64, 64) == 0 and lib.cl_wide_head_bwd_supported(129, 129) == 0 and lib.cl_wide_head_bwd_supported(96, 128) == 0
