@@ -1020,63 +1020,73 @@ void wide_sq_kernel(const StreamArgs S) {
     const int cq0 = 4 * (q ^ swzb(j));                                // this lane's quad of a first-layer image row
     // per-lane element offsets inside a row: chunk kc of the operand at 16 kc + 4 q, block a of the output / mask at 16 a + 4 q
     const int cq = 4 * q;
-    auto x_ptr = [&](long long b) -> const float* {                  // this lane's row of block b (rows past the end: the last row, never stored)
-        long long row = b * 16 + j;
-        if (row >= S.n) row = S.n - 1;
-        return S.X + (size_t)row * S.ldx + cq;
+    // Addresses = a wave-uniform base (the block's first row: scalar registers, scalar arithmetic) + a 32-bit per-lane element offset (this
+    // lane's row inside the block, clamped to the last existing row -- such rows are never stored --, times the pitch, plus its quad): one
+    // vector register per operand instead of a 64-bit pointer each, which is what the fused instances spilled (round 4)
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    auto lane_row = [&](long long b) -> int {                        // row j of block b, or the block's last existing row
+        const long long left = S.n - b * 16;                         // (uniform)
+        return left >= 16 ? j : (j < (int)left ? j : (int)left - 1);
     };
-    long long blk = (long long)blockIdx.x * 8 + wv;
+    auto x_base = [&](long long b) -> const float* { return S.X + (size_t)b * 16 * (size_t)S.ldx; };
+    long long blk = (long long)blockIdx.x * 8 + wvu;
     const long long bstep = (long long)gridDim.x * 8;
     f32x4 acc0[WG0 ? NA : 1];                    // WG0: dWt_0[16 a + j][4 q + t] of this wave's blocks (column K0 = the bias gradient)
 #pragma unroll
     for (int a = 0; a < (WG0 ? NA : 1); ++a) acc0[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int K0 = S.pre.K0;
+    // The rows' operand quads are requested HALF a block ahead of their use: quad t = kc + H is refilled behind chunk kc's
+    // MFMAs -- with this block's chunk t, or, past the end, with chunk t - NA of the wave's next block -- so a quad is dead between its own
+    // chunk and the chunk H later, and only about half of the NA quads are live at any time (a full block of lead kept all of them live: the
+    // instances that carry a fusion spilled 18 - 25 registers, and a spill reload waits for every load in flight).  H chunks of MFMAs of four
+    // waves are several microseconds: still more than a loaded HBM round trip.
+    constexpr int H = (NA + 1) / 2;
     f32x4 xb[NA];
     float gc0 = 0.0f, gc1 = 0.0f;                 // HEADB: g of this lane's row of the current block
     if (blk < nblk) {
-        const float* xp = x_ptr(blk);
+        const float* xp = x_base(blk);
+        const unsigned xo = (unsigned)lane_row(blk) * (unsigned)S.ldx + cq;
 #pragma unroll
-        for (int kc = 0; kc < NA; ++kc) xb[kc] = (16 * kc + cq < S.ldx) ? *reinterpret_cast<const f32x4*>(xp + 16 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int kc = 0; kc < NA; ++kc) xb[kc] = (kc < H && 16 * kc + cq < S.ldx) ? *reinterpret_cast<const f32x4*>(xp + xo + 16 * kc) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         if (HEADB) {
-            long long r = blk * 16 + j;
-            if (r >= S.n) r = S.n - 1;
-            gc0 = S.dO[2 * (size_t)r];
-            gc1 = S.dO[2 * (size_t)r + 1] * S.dsd[r];
+            const unsigned r = (unsigned)lane_row(blk);
+            const float* gp = S.dO + 2 * (size_t)blk * 16;
+            gc0 = gp[2 * r];
+            gc1 = gp[2 * r + 1] * (S.dsd + (size_t)blk * 16)[r];
         }
     }
     for (; blk < nblk; blk += bstep) {
         const long long row = blk * 16 + j;
-        const long long rowc = row < S.n ? row : S.n - 1;
-        // HEADB: the next block's row numbers, requested a block ahead like its operand
+        const unsigned jc = (unsigned)lane_row(blk);                 // this lane's (clamped) row inside the block
+        // HEADB: the next block's row numbers are requested two chunks before the end of this block (below)
         float gn0 = 0.0f, gn1 = 0.0f, gnd = 0.0f;
-        if (HEADB && blk + bstep < nblk) {
-            long long r = (blk + bstep) * 16 + j;
-            if (r >= S.n) r = S.n - 1;
-            gn0 = S.dO[2 * (size_t)r]; gn1 = S.dO[2 * (size_t)r + 1]; gnd = S.dsd[r];
-        }
         // the mask of the dgrad epilogue, requested now (the layer's input activations), consumed after the MFMAs
         f32x4 hm[NA];
         if (EPI == EPI_DLRELU && !PRE && S.H != nullptr) {
-            const float* hp = S.H + (size_t)rowc * S.ldh + cq;
+            const float* hp = S.H + (size_t)blk * 16 * (size_t)S.ldh;
+            const unsigned ho = jc * (unsigned)S.ldh + cq;
 #pragma unroll
-            for (int a = 0; a < NA; ++a) hm[a] = (16 * a + cq < S.ldh) ? *reinterpret_cast<const f32x4*>(hp + 16 * a) : f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+            for (int a = 0; a < NA; ++a) hm[a] = (16 * a + cq < S.ldh) ? *reinterpret_cast<const f32x4*>(hp + ho + 16 * a) : f32x4{1.0f, 1.0f, 1.0f, 1.0f};
         }
         f32x4 x0 = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (PRE && cq < S.pre.ldx0) x0 = *reinterpret_cast<const f32x4*>(S.pre.X0 + (size_t)rowc * S.pre.ldx0 + cq);
+        const float* x0p = PRE ? S.pre.X0 + (size_t)blk * 16 * (size_t)S.pre.ldx0 : nullptr;
+        if (PRE && cq < S.pre.ldx0) x0 = *reinterpret_cast<const f32x4*>(x0p + jc * (unsigned)S.pre.ldx0 + cq);
         // WG0: X_0^T as A operand -- lane (i = j, q), step t = X_0[row 4 q + t][i]; lane K0 carries ones (bias gradient), lanes past it zeros.
         // Requested now (lines the mask's x0 just touched), used after the MFMAs; rows past the end are zeroed at the use point.
         f32x4 xg = {0.0f, 0.0f, 0.0f, 0.0f};
         if (WG0) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                long long r = blk * 16 + cq + t;
-                if (r >= S.n) r = S.n - 1;
+                const long long left = S.n - blk * 16;               // (uniform)
+                const unsigned r = (cq + t < left) ? (unsigned)(cq + t) : (unsigned)(left - 1);
                 xg[t] = (j == K0) ? 1.0f : 0.0f;
-                if (j < K0) xg[t] = S.pre.X0[(size_t)r * S.pre.ldx0 + j];
+                if (j < K0) xg[t] = x0p[r * (unsigned)S.pre.ldx0 + j];
             }
         }
         const bool more = blk + bstep < nblk;
-        const float* xnext = x_ptr(more ? blk + bstep : blk);
+        const long long bnext = more ? blk + bstep : blk;
+        const float* xnext = x_base(bnext) + ((unsigned)lane_row(bnext) * (unsigned)S.ldx + cq);
+        const float* xcur = x_base(blk) + (jc * (unsigned)S.ldx + cq);
         f32x4 acc[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1107,8 +1117,17 @@ void wide_sq_kernel(const StreamArgs S) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read (the next quad) ...
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // ... then this quad's four MFMAs
             }
-            // this quad's MFMAs are issued: refill it with the next block's chunk (a whole block of MFMAs ahead of its use)
-            if (more && 16 * kc + cq < S.ldx) xb[kc] = *reinterpret_cast<const f32x4*>(xnext + 16 * kc);
+            // this chunk's MFMAs are issued: request the quad that is used H chunks from now
+            {
+                const int t = kc + H;
+                if (t < NA) { if (16 * t + cq < S.ldx) xb[t] = *reinterpret_cast<const f32x4*>(xcur + 16 * t); }
+                else if (more && 16 * (t - NA) + cq < S.ldx) xb[t - NA] = *reinterpret_cast<const f32x4*>(xnext + 16 * (t - NA));
+            }
+            if (HEADB && kc == (NA >= 2 ? NA - 2 : 0) && more) {
+                const unsigned r = (unsigned)lane_row(bnext);
+                const float* gp = S.dO + 2 * (size_t)bnext * 16;
+                gn0 = gp[2 * r]; gn1 = gp[2 * r + 1]; gnd = (S.dsd + (size_t)bnext * 16)[r];
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (HEADB) { gc0 = gn0; gc1 = gn1 * gnd; }
@@ -1145,7 +1164,7 @@ void wide_sq_kernel(const StreamArgs S) {
             }
         }
         if (row < S.n) {
-            float* yp = S.Y + (size_t)row * S.ldy + cq;
+            float* yp = S.Y + (size_t)blk * 16 * (size_t)S.ldy + ((unsigned)j * (unsigned)S.ldy + cq);
             float ho0 = 0.0f, ho1 = 0.0f;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
