@@ -21,9 +21,16 @@
 // the layer's weights stay in LDS for the whole launch, every wave walks 16-row blocks on its own -- its rows' operand straight from
 // global memory into the MFMA B-operand layout (one float4 per lane and 16-deep chunk, the next block's in flight), the transposed
 // output tile in accumulators, one float4 store per lane and 16 output columns -- with no workgroup barrier in the loop.
+// Round 4 -- what a step of a Dense-only scaler of width 65 .. 128 launches: wide_stream2_kernel (layers 0 + 1, the first
+// layer's output never stored), wide_sq_kernel forward with the Dense(2) head in the top layer's epilogue, slot_rows_kernel (elbo_laue.hip),
+// then top down: weight gradient and dgrad of the top layer with the head's backward pass made where they read dZ (HEADW / HEADB instances),
+// plain weight gradients and dgrads in between, the second layer's weight gradient with the recomputed first layer made by MFMAs in the
+// staged layout (PREM), its dgrad with the FIRST layer's weight gradient taken from the output block in registers (WG0).  Every
+// weight-gradient partial is summed in index order by cl_reduce_partials: the path has no float atomic of its own.
 // Roofline: the layers are unfused, so a layer moves 4 (in + out) bytes per observation for 2 in out flops -- at width 128 that is
-// 32 flop / B against a ridge of 19.7: HBM and the fp32 matrix rate bind about equally; 8 P_mm flops per observation in all
-// (forward, recomputed forward, dgrad, wgrad).
+// 32 flop / B against a ridge of 19.7; measured (per-kernel counters, profiles/r4_pmc_by_kernel_*.txt) the kernels are bound by MFMA issue
+// with the matrix pipe 62 - 78 % busy, not by HBM (3 TB/s).  6 P_mm flops per observation when the forward pass keeps the activations
+// (the default), 8 when a data set is too large for that and every chunk's forward pass runs again in the backward pass.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdlib>
