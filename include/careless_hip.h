@@ -238,9 +238,13 @@ int cl_det_reduce(const cl_det_args* args, void* stream);
  *           hold (64): one fp32-MFMA GEMM per layer and direction, activations in HBM, in row chunks chosen by the caller.
  * Activation buffers are row-major [rows][ld], ld = cl_wide_ld(width) = the width rounded up to 4.
  * Weights in the W^T layout of the flat parameter vector (Wt[out][in], then b[out]).
- * Call order per row chunk: cl_wide_dense_forward x L -> cl_wide_head_forward -> [likelihood: cl_laue_predict / _likelihood /
- * _backward with every row its own slot] -> cl_wide_dense_forward x L (recompute, kept) -> cl_wide_head_backward ->
- * per layer, top down: cl_wide_dense_wgrad (+ cl_reduce_partials into the layer's gradient slice), cl_wide_dense_dgrad.          */
+ * Call order per row chunk, generic form (any width): cl_wide_dense_forward x L -> cl_wide_head_forward -> [likelihood: cl_slot_rows when
+ * every row is its own slot, cl_laue_predict / _likelihood / _backward otherwise] -> cl_wide_dense_forward x L again unless the activations
+ * were kept -> cl_wide_head_backward -> per layer, top down: cl_wide_dense_wgrad (+ cl_reduce_partials into the layer's gradient slice),
+ * cl_wide_dense_dgrad.  Widths 65 .. 128 take the fused forms declared below instead (round 4): cl_wide_dense2_forward (layers 0 + 1),
+ * cl_wide_dense_forward_head (top layer + head), cl_wide_dense_wgrad_head / _dgrad_head (top layer's backward with the head's inside),
+ * cl_wide_dense_wgrad_pre and cl_wide_dense_dgrad_pre_wgrad0 (second layer's backward with the first layer recomputed and its weight
+ * gradient taken on the way).                                                                                                       */
 int cl_wide_ld(int width);
 /* Y[n][n_out] = act(X[n][n_in] Wt^T + b), act = LeakyReLU(leak) or identity */
 int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak, int act,
