@@ -241,3 +241,15 @@ def test_deterministic_command_line_runs_write_identical_files(tmp_path, monkeyp
     ha = np.genfromtxt(outs[0] + "_history.csv", delimiter=",", names=True)
     hb = np.genfromtxt(outs[1] + "_history.csv", delimiter=",", names=True)
     assert np.array_equal(ha["NLL"], hb["NLL"])
+    # ... and `--refine-uncertainties` on the default scaler's depth and on a scaler wider than 64 (round 4: the Evans-2011 gradients
+    # leave the kernels as per-wave stores; the layer-by-layer path's slot kernel stores per (row, sample))
+    for tag, extra in (("ev11", "--refine-uncertainties --mlp-layers 20 --mc-samples 2"), ("wide", "--mlp-layers 2 --mlp-width 72 --mc-samples 4")):
+        flags = f"mono --iterations={niter} --disable-progress-bar {extra} dHKL,image_id"
+        outs = []
+        for k in range(2):
+            out = str(tmp_path / f"{tag}{k}")
+            _run(flags, [PYP], out, False)
+            outs.append(out)
+        a, b = read_mtz(outs[0] + "_0.mtz"), read_mtz(outs[1] + "_0.mtz")
+        for col in ("F", "SigF", "I", "SigI"):
+            assert np.array_equal(a.columns[col], b.columns[col]), (tag, col)
