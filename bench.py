@@ -299,7 +299,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     # harmonic sums (two-pass Laue fallback)
     timed_names = ("cl_elbo_mono_fwd_bwd", "cl_mlp_forward", "cl_mlp_backward_ext")
     if eng.wide:                    # width > 64: the layer-by-layer GEMM launches of csrc/wide_gemm.hip are the dominant kernels
-        timed_names = ("cl_wide_dense_forward", "cl_wide_dense_forward_head", "cl_wide_dense2_forward", "cl_wide_dense_dgrad", "cl_wide_dense_dgrad_pre",
+        timed_names = ("cl_wide_dense_forward", "cl_wide_dense_forward_head", "cl_wide_dense_forward_head_lik", "cl_wide_dense2_forward", "cl_wide_dense_dgrad", "cl_wide_dense_dgrad_pre",
                        "cl_wide_dense_dgrad_pre_wgrad0", "cl_wide_dense_dgrad_head", "cl_wide_dense_wgrad", "cl_wide_dense_wgrad_pre", "cl_wide_dense_wgrad_head",
                        "cl_wide_head_forward", "cl_wide_head_backward")
     ev = []

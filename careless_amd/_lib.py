@@ -140,6 +140,8 @@ EXPORTS = {
     "cl_wide_ld": (C.c_int, [C.c_int]),
     "cl_wide_dense_forward": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_int, _vp, C.c_int, _vp, _vp]),
     "cl_wide_dense_forward_head": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "cl_wide_dense_forward_head_lik": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_longlong, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp, _vp,
+                                                 C.POINTER(LaueArgs), _vp, _vp]),
     "cl_wide_head_bwd_supported": (C.c_int, [C.c_int, C.c_int]),
     "cl_wide_dense_wgrad_head": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_float, _vp, C.c_int, C.c_longlong, C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
     "cl_wide_dense_dgrad_head": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int, C.c_float, _vp, C.c_int, _vp, _vp]),

@@ -603,6 +603,17 @@ struct StreamArgs {
                                      // the top layer's dgrad / weight gradient (HEADB instances, cl_wide_dense_wgrad_head)
     const float* dO; const float* dsd;   // HEADB: dL/d(loc, sigma) [n][2] and d sigma / d raw [n]; X = the TOP layer's activations h_L, head_W = the head
     PreArgs pre;                     // EPI_DLRELU: the activations whose sign selects the derivative are the recomputed first layer (H unused)
+    // LIK instances (forward with the fused head, rows that are their own slot): the slot likelihood of the call's rows in the same epilogue --
+    // sample, predict, log-prob, its gradient back to dz_f / the image scales / dO -- as cl_slot_rows does it (elbo_laue.hip), for the rows'
+    // (loc, sigma) sit in registers here and the amplitude-gradient atomics are fire-and-forget under the MFMAs of the next block
+    struct Lik {
+        const int* refl_id; const int* image_id; const float* iobs; const float* sig;      // per row of the call
+        const long long* row_index; long long obs_offset;                                   // noise key of row i: row_index[i] or obs_offset + i
+        const float* img; int use_img; const float* z_f; int S;
+        int lik_kind; float dof, lik_const, shift, w_ll;
+        unsigned long long seed; unsigned step;
+        float* dz_f; float* d_img; float* dO; double* scalars;
+    } lik;
     float* wg0_part;                 // WG0 instances: [gridDim.x][N K0 + N] partial sums of the FIRST layer's weight gradient (flat W^T layout)
 };
 
@@ -977,9 +988,10 @@ int launch_stream2(const Stream2Args& s, hipStream_t st) {
 // HEADB (round 4, the dgrad of the TOP layer): its row operand dZ_L = (g Wo) * LeakyReLU'(h_L), g = dL/d(loc, raw sigma) of the row, is a rank-2
 // product behind a mask -- made from h_L (the same bytes per row as dZ_L) and the row's two numbers while the chunk is on its way to the
 // MFMAs, instead of being written by a launch of its own (cl_wide_head_backward) and read back twice.
-template <bool WKM, int EPI, int NA, bool PRE, bool WG0 = false, bool HEADB = false>
+template <bool WKM, int EPI, int NA, bool PRE, bool WG0 = false, bool HEADB = false, bool LIK = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void wide_sq_kernel(const StreamArgs S) {
+    static_assert(!LIK || (EPI == EPI_BIAS_LRELU && !PRE && !WG0 && !HEADB), "the slot likelihood rides on the forward pass of the top layer");
     static_assert(!WG0 || (PRE && EPI == EPI_DLRELU), "the fused first-layer weight gradient rides on the dgrad with the recomputed mask");
     static_assert(!HEADB || (!PRE && EPI == EPI_DLRELU), "the fused head backward feeds the dgrad of the top layer");
     if (S.stop_flag != nullptr && *S.stop_flag != 0) return;
@@ -1062,9 +1074,12 @@ void wide_sq_kernel(const StreamArgs S) {
             gc1 = gp[2 * r + 1] * (S.dsd + (size_t)blk * 16)[r];
         }
     }
+    float l_nll = 0.0f;                           // LIK: this lane's share of the NLL over all its blocks
     for (; blk < nblk; blk += bstep) {
         const long long row = blk * 16 + j;
         const unsigned jc = (unsigned)lane_row(blk);                 // this lane's (clamped) row inside the block
+        float l_da = 0.0f;                        // LIK: image-scale term of the row (summed over its lanes in the epilogue)
+        bool l_take = false;
         // HEADB: the next block's row numbers are requested two chunks before the end of this block (below)
         float gn0 = 0.0f, gn1 = 0.0f, gnd = 0.0f;
         // the mask of the dgrad epilogue, requested now (the layer's input activations), consumed after the MFMAs
@@ -1089,6 +1104,16 @@ void wide_sq_kernel(const StreamArgs S) {
                 xg[t] = (j == K0) ? 1.0f : 0.0f;
                 if (j < K0) xg[t] = x0p[r * (unsigned)S.pre.ldx0 + j];
             }
+        }
+        // LIK: what the epilogue needs of this lane's row (the four lanes of a row read the same addresses), requested now; the amplitudes of
+        // the lane's first two samples follow half a block later, when the reflection id has landed
+        int l_rid = 0, l_img = 0;
+        float l_io = 0.0f, l_sg = 1.0f, l_aim = 1.0f, l_zf0 = 0.0f, l_zf1 = 0.0f;
+        if (LIK) {
+            const size_t r0 = (size_t)blk * 16;
+            l_rid = (S.lik.refl_id + r0)[jc];
+            if (S.lik.use_img) l_img = (S.lik.image_id + r0)[jc];
+            l_io = (S.lik.iobs + r0)[jc]; l_sg = (S.lik.sig + r0)[jc];
         }
         const bool more = blk + bstep < nblk;
         const long long bnext = more ? blk + bstep : blk;
@@ -1129,6 +1154,11 @@ void wide_sq_kernel(const StreamArgs S) {
                 const int t = kc + H;
                 if (t < NA) { if (16 * t + cq < S.ldx) xb[t] = *reinterpret_cast<const f32x4*>(xcur + 16 * t); }
                 else if (more && 16 * (t - NA) + cq < S.ldx) xb[t - NA] = *reinterpret_cast<const f32x4*>(xnext + 16 * (t - NA));
+            }
+            if (LIK && kc == NA / 2) {
+                if (q < S.lik.S) l_zf0 = S.lik.z_f[(size_t)l_rid * S.lik.S + q];
+                if (q + 4 < S.lik.S) l_zf1 = S.lik.z_f[(size_t)l_rid * S.lik.S + q + 4];
+                if (S.lik.use_img && l_img > 0) l_aim = S.lik.img[l_img - 1];
             }
             if (HEADB && kc == (NA >= 2 ? NA - 2 : 0) && more) {
                 const unsigned r = (unsigned)lane_row(bnext);
@@ -1196,13 +1226,63 @@ void wide_sq_kernel(const StreamArgs S) {
             if (EPI == EPI_BIAS_LRELU && S.head_W != nullptr) {
                 ho0 += __shfl_xor(ho0, 16); ho1 += __shfl_xor(ho1, 16);
                 ho0 += __shfl_xor(ho0, 32); ho1 += __shfl_xor(ho1, 32);
+                float dd;
+                const float loc = ho0 + S.head_W[2 * N];
+                const float sigma = cl_scale_bij(ho1 + S.head_W[2 * N + 1], S.bij_kind, S.eps, &dd);
                 if (q == 0) {
-                    float dd;
-                    S.loc_out[row] = ho0 + S.head_W[2 * N];
-                    S.sig_out[row] = cl_scale_bij(ho1 + S.head_W[2 * N + 1], S.bij_kind, S.eps, &dd);
+                    S.loc_out[row] = loc;
+                    S.sig_out[row] = sigma;
                     if (S.dsd_out != nullptr) S.dsd_out[row] = dd;
                 }
+                if (LIK) {
+                    // the row's samples over its four lanes: lane q takes s = q, q + 4, ... (reference: mono.py:10-37 on variational.py:167's prediction)
+                    const unsigned long long gidx = S.lik.row_index != nullptr ? (unsigned long long)(S.lik.row_index + (size_t)blk * 16)[jc]
+                                                                               : (unsigned long long)(S.lik.obs_offset + row);
+                    float dl = 0.0f, ds = 0.0f;
+                    for (int sm = q; sm < S.lik.S; sm += 4) {
+                        const float zf = sm == q ? l_zf0 : (sm == q + 4 ? l_zf1 : S.lik.z_f[(size_t)l_rid * S.lik.S + sm]);
+                        const float eta = cl_noise_normal(S.lik.seed, S.lik.step, (uint32_t)sm, gidx);
+                        const float tq = loc + sigma * eta + S.lik.shift;
+                        float dll;
+                        const float ll = cl_lik_log_prob(l_aim * tq * zf * zf, l_io, l_sg, S.lik.lik_kind, S.lik.dof, S.lik.lik_const, &dll);
+                        l_nll -= ll * S.lik.w_ll;
+                        const float gi = -dll * S.lik.w_ll;             // dNLL / d ipred
+                        const float dzs = gi * zf * zf;
+                        atomicAdd(S.lik.dz_f + (size_t)l_rid * S.lik.S + sm, gi * l_aim * tq * 2.0f * zf);
+                        const float dt = dzs * l_aim;
+                        dl += dt; ds += dt * eta; l_da += dzs * tq;
+                    }
+                    dl += __shfl_xor(dl, 16); ds += __shfl_xor(ds, 16); l_da += __shfl_xor(l_da, 16);
+                    dl += __shfl_xor(dl, 32); ds += __shfl_xor(ds, 32); l_da += __shfl_xor(l_da, 32);
+                    if (q == 0) { (S.lik.dO + 2 * (size_t)blk * 16)[2 * j] = dl; (S.lik.dO + 2 * (size_t)blk * 16)[2 * j + 1] = ds; }
+                    l_take = q == 0 && l_img > 0;
+                }
             }
+        }
+        if (LIK && S.lik.use_img) {
+            // image-scale gradients of the wave's sixteen rows (every lane calls: the reduction is wave-wide; image 0 is pinned, image.py:23-25)
+            const unsigned long long m = __ballot(l_take);
+            if (m != 0ull) {
+                const int im0 = __builtin_amdgcn_readlane(l_img, __builtin_ctzll(m));
+                if (__all(!l_take || l_img == im0)) {
+                    const float v = cl_wave_sum(l_take ? l_da : 0.0f);
+                    if (lane == 0) atomicAdd(S.lik.d_img + (im0 - 1), v);
+                } else {
+                    cl_image_grad_segments(S.lik.d_img, l_img, l_da, l_take, lane);
+                }
+            }
+        }
+    }
+    if constexpr (LIK) {
+        // the NLL of this workgroup's rows: one fp64 atomic (same-address atomics serialise: not one per wave)
+        const float v = cl_wave_sum(l_nll);
+        __syncthreads();
+        if (lane == 0) sBias[wv] = v;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int k = 0; k < 8; ++k) t += (double)sBias[k];
+            atomicAdd(S.lik.scalars + CL_SC_NLL, t);
         }
     }
     if constexpr (WG0) {
@@ -1246,10 +1326,10 @@ static long long sq_grid(long long n) {
     return grid < 1 ? 1 : grid;
 }
 
-template <bool WKM, int EPI, int NA, bool PRE, bool WG0 = false, bool HEADB = false>
+template <bool WKM, int EPI, int NA, bool PRE, bool WG0 = false, bool HEADB = false, bool LIK = false>
 int launch_sq_n(const StreamArgs& s, hipStream_t st) {
     const size_t sm = (size_t)(16 * NA * SKP + 3 * 16 * NA + (PRE ? 16 * NA * (S0P + 1) : 0)) * sizeof(float);
-    auto kern = wide_sq_kernel<WKM, EPI, NA, PRE, WG0, HEADB>;
+    auto kern = wide_sq_kernel<WKM, EPI, NA, PRE, WG0, HEADB, LIK>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -1263,13 +1343,13 @@ int launch_sq_n(const StreamArgs& s, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-template <bool WKM, int EPI, bool PRE, bool WG0 = false, bool HEADB = false>
+template <bool WKM, int EPI, bool PRE, bool WG0 = false, bool HEADB = false, bool LIK = false>
 int launch_sq(const StreamArgs& s, hipStream_t st) {
     switch ((s.N + 15) >> 4) {
-        case 5: return launch_sq_n<WKM, EPI, 5, PRE, WG0, HEADB>(s, st);
-        case 6: return launch_sq_n<WKM, EPI, 6, PRE, WG0, HEADB>(s, st);
-        case 7: return launch_sq_n<WKM, EPI, 7, PRE, WG0, HEADB>(s, st);
-        default: return launch_sq_n<WKM, EPI, 8, PRE, WG0, HEADB>(s, st);
+        case 5: return launch_sq_n<WKM, EPI, 5, PRE, WG0, HEADB, LIK>(s, st);
+        case 6: return launch_sq_n<WKM, EPI, 6, PRE, WG0, HEADB, LIK>(s, st);
+        case 7: return launch_sq_n<WKM, EPI, 7, PRE, WG0, HEADB, LIK>(s, st);
+        default: return launch_sq_n<WKM, EPI, 8, PRE, WG0, HEADB, LIK>(s, st);
     }
 }
 
@@ -1359,6 +1439,37 @@ int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const f
     s.head_W = head; s.bij_kind = bij_kind; s.eps = eps; s.loc_out = loc_out; s.sig_out = sig_out; s.dsd_out = dsig_draw_out;
     if (sq_ok(s)) return launch_sq<false, EPI_BIAS_LRELU, false>(s, (hipStream_t)stream);
     return launch_stream<false, EPI_BIAS_LRELU>(s, (hipStream_t)stream);
+}
+
+/* cl_wide_dense_forward_head with the slot likelihood of the call's rows in the same epilogue (round 4): what cl_slot_rows computes from
+ * (loc, sigma) per row -- sample, predict, log-prob, gradient -- where those two numbers are made; `lik` as for cl_slot_rows with its row
+ * arrays at the call's first row (loc / sigma / iconv unused).  Rows that are their own slot, in-kernel noise, no ipred_out, no
+ * Evans-2011 terms, no deterministic stores, the square-layer kernel's envelope: -2 otherwise (the caller then runs
+ * cl_wide_dense_forward_head and cl_slot_rows).                                                                                          */
+int cl_wide_dense_forward_head_lik(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak,
+                                   float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out, float* dsig_draw_out,
+                                   const cl_laue_args* lik, const int* stop_flag, void* stream) {
+    if (X == nullptr || Wt == nullptr || b == nullptr || Y == nullptr || head == nullptr || loc_out == nullptr || sig_out == nullptr || lik == nullptr ||
+        n < 1 || n > 0x7fffffffLL || n_in < 1 || n_out < 1 || ldx < n_in || ldy < n_out)
+        return -1;
+    if (n_in > SMAX || n_out > SMAX) return -2;
+    const cl_laue_args& a = *lik;
+    if (a.harmonic_id != nullptr || a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr || a.dzf_obs != nullptr || a.nll_part != nullptr) return -2;
+    if (a.refl_id == nullptr || a.iobs == nullptr || a.sig == nullptr || a.z_f == nullptr || a.dz_f == nullptr || a.dO == nullptr || a.scalars == nullptr ||
+        a.S < 1 || a.n_obs != (int)n || (a.use_img && (a.image_id == nullptr || a.img == nullptr || a.d_img == nullptr)))
+        return -1;
+    StreamArgs s = {};
+    s.X = X; s.ldx = ldx; s.W = Wt; s.ldw = n_in; s.Y = Y; s.ldy = ldy; s.n = n; s.N = n_out; s.K = n_in;
+    s.bias = b; s.leak = leak; s.act = 1; s.stop_flag = stop_flag;
+    s.head_W = head; s.bij_kind = bij_kind; s.eps = eps; s.loc_out = loc_out; s.sig_out = sig_out; s.dsd_out = dsig_draw_out;
+    if (!sq_ok(s)) return -2;
+    s.lik.refl_id = a.refl_id; s.lik.image_id = a.image_id; s.lik.iobs = a.iobs; s.lik.sig = a.sig;
+    s.lik.row_index = a.row_index; s.lik.obs_offset = a.obs_offset;
+    s.lik.img = a.img; s.lik.use_img = a.use_img; s.lik.z_f = a.z_f; s.lik.S = a.S;
+    s.lik.lik_kind = a.lik_kind; s.lik.dof = a.dof; s.lik.lik_const = a.lik_const; s.lik.shift = a.shift; s.lik.w_ll = a.w_ll;
+    s.lik.seed = a.seed; s.lik.step = a.step;
+    s.lik.dz_f = a.dz_f; s.lik.d_img = a.d_img; s.lik.dO = a.dO; s.lik.scalars = a.scalars;
+    return launch_sq<false, EPI_BIAS_LRELU, false, false, false, true>(s, (hipStream_t)stream);
 }
 
 /* The Dense(2) head's backward pass inside the TOP layer's dgrad and weight gradient (round 4; replaces cl_wide_head_backward + its dZ_L buffer):

@@ -814,26 +814,33 @@ class ElboEngine(WidePath):
         ma.dO_ext = ptr(obs.laue_dO)
         check(lib.cl_mlp_backward_ext(C.byref(ma), obs.grid, st), "cl_mlp_backward_ext")
 
-    def _slot_likelihood(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
-        """From (loc, sigma) per row in obs.laue_loc / laue_sig: sample, predict, group sums, slot likelihood (NLL into the
-        scalars), its gradient back on the rows -> dz_f, d(image scales), obs.laue_dO = dL/d(loc, sigma) per row."""
-        lib = self.lib
+    def _slot_args(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, a: int = 0, n: Optional[int] = None) -> LaueArgs:
+        """Arguments of the slot likelihood kernels for the rows [a, a + n) of `obs` (default: all of them)."""
         la = LaueArgs()
-        if obs.harmonic_id is not None:
-            obs.laue_iconv.zero_()          # (group sums accumulate by atomics; rows that are their own slot -- harmonic_id None -- store)
-        la.refl_id, la.image_id, la.harmonic_id = ptr(obs.refl_id), ptr(obs.image_id), ptr(obs.harmonic_id)
-        la.loc, la.sigma, la.iobs, la.sig = ptr(obs.laue_loc), ptr(obs.laue_sig), ptr(obs.iobs), ptr(obs.sig)
-        la.n_obs, la.obs_offset = obs.N, obs.start
+        n = obs.N - a if n is None else n
+        off = lambda t, size: None if t is None else t.data_ptr() + size * a
+        la.refl_id, la.image_id, la.harmonic_id = off(obs.refl_id, 4), off(obs.image_id, 4), off(obs.harmonic_id, 4)
+        la.loc, la.sigma, la.iobs, la.sig = off(obs.laue_loc, 4), off(obs.laue_sig, 4), off(obs.iobs, 4), off(obs.sig, 4)
+        la.n_obs, la.obs_offset = n, obs.start + a
         la.img, la.use_img = ma.img, ma.use_img
         la.z_f, la.R, la.S = ptr(self.z_f), self.R, self.S
         la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
         la.shift, la.w_ll = ma.shift, ma.w_ll
-        la.eta = ptr(eta)
+        la.eta = off(eta, 4 * self.S)
         la.seed, la.step = self.seed, step & 0xFFFFFFFF
-        la.iconv, la.dz_f, la.d_img, la.dO = ptr(obs.laue_iconv), ptr(self.dz_f), ma.d_img, ptr(obs.laue_dO)
-        la.scalars, la.ipred_out, la.stop_flag = ptr(self.scalars), ptr(ipred_out), ptr(self.stop_flag)
+        la.iconv, la.dz_f, la.d_img, la.dO = off(obs.laue_iconv, 4 * self.S), ptr(self.dz_f), ma.d_img, off(obs.laue_dO, 8)
+        la.scalars, la.ipred_out, la.stop_flag = ptr(self.scalars), off(ipred_out, 4 * self.S), ptr(self.stop_flag)
         la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
-        la.row_index = ptr(obs.row_index)
+        la.row_index = off(obs.row_index, 8)
+        return la
+
+    def _slot_likelihood(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
+        """From (loc, sigma) per row in obs.laue_loc / laue_sig: sample, predict, group sums, slot likelihood (NLL into the
+        scalars), its gradient back on the rows -> dz_f, d(image scales), obs.laue_dO = dL/d(loc, sigma) per row."""
+        lib = self.lib
+        if obs.harmonic_id is not None:
+            obs.laue_iconv.zero_()          # (group sums accumulate by atomics; rows that are their own slot -- harmonic_id None -- store)
+        la = self._slot_args(ma, obs, step, eta, ipred_out)
         if self.deterministic and obs.harmonic_id is None:
             # no float atomics: the amplitude gradient of every (row, sample) and the image-scale term of every row are stored (records in
             # reflection order: det_slot), every workgroup stores its NLL; cl_det_reduce sums them in a fixed order after the backward pass

@@ -139,7 +139,7 @@ class WidePath:
                          for l in range(W["nh"])]
         return obs.wide_full
 
-    def _wide_forward(self, obs: ObsData, chunk, keep: bool, st, full=None, head=None):
+    def _wide_forward(self, obs: ObsData, chunk, keep: bool, st, full=None, head=None, lik=None):
         """Hidden layers on one row chunk of `obs`: layer l's output lands in acts[l] when `keep` (else two buffers alternate), or
         in the chunk's rows of the whole-set buffers `full`; returns the (buffer, ld) pairs of h_0 .. h_(L + K)."""
         a, b, m0, seg = chunk
@@ -149,7 +149,7 @@ class WidePath:
         sf, leak = ptr(self.stop_flag), self.mlp.leakiness
         dst_of = (lambda l: full[l].data_ptr() + 4 * a * ldw) if full is not None else (lambda l: W["acts"][l if keep else l & 1].data_ptr())
         hs = [(obs.meta_rm.data_ptr() + 4 * a * obs.meta_ld, obs.meta_ld)]
-        self._head_fused = False
+        self._head_fused = self._lik_fused = False
         pre = self._wide_pre()
         for l, (ow, ob, fan_in) in enumerate(layers):
             if pre and l == 0:
@@ -168,9 +168,19 @@ class WidePath:
                 # the top layer carries the Dense(2) head in its epilogue: (loc, sigma) come out of the same pass
                 off_head, loc_ptr, sig_ptr = head[:3]
                 dsd_ptr = head[3] if len(head) > 3 else None       # d sigma / d raw per row, for the head backward fused into this layer's backward
-                check(lib.cl_wide_dense_forward_head(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, dst, ldw,
-                                                     base + 4 * off_head, self.bij_kind, self.mlp.epsilon, loc_ptr, sig_ptr, dsd_ptr, sf, st),
-                      "cl_wide_dense_forward_head")
+                rc = -2
+                if lik is not None:
+                    # ... and the slot likelihood of the chunk's rows too: (loc, sigma) never wait in memory for a launch of their own
+                    rc = lib.cl_wide_dense_forward_head_lik(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, dst, ldw,
+                                                            base + 4 * off_head, self.bij_kind, self.mlp.epsilon, loc_ptr, sig_ptr, dsd_ptr,
+                                                            C.byref(lik), sf, st)
+                    if rc != -2:
+                        check(rc, "cl_wide_dense_forward_head_lik")
+                        self._lik_fused = True
+                if rc == -2:
+                    check(lib.cl_wide_dense_forward_head(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, dst, ldw,
+                                                         base + 4 * off_head, self.bij_kind, self.mlp.epsilon, loc_ptr, sig_ptr, dsd_ptr, sf, st),
+                          "cl_wide_dense_forward_head")
                 self._head_fused = True
             else:
                 check(lib.cl_wide_dense_forward(hs[-1][0], hs[-1][1], base + 4 * ow, base + 4 * ob, n, fan_in, self.w, leak, 1,
@@ -215,17 +225,28 @@ class WidePath:
         headb = self._wide_head_bwd()
         if headb and getattr(obs, "wide_dsd", None) is None:
             obs.wide_dsd = torch.empty(obs.N, dtype=torch.float32, device=self.device)
+        # The slot likelihood rides in the top layer's forward epilogue when a production step asks for nothing else of it (rows that are
+        # their own slot, in-kernel noise, no predictions out, no Evans-2011 terms, not the deterministic mode; CARELESS_HIP_WIDE_LIK=0: the
+        # launch of its own -- A/B runs); the library decides by shape (-2), the same for every chunk
+        want_lik = (obs.harmonic_id is None and eta is None and ipred_out is None and not self.ev11 and not self.deterministic and
+                    os.environ.get("CARELESS_HIP_WIDE_LIK", "1") != "0")
+        lik_fused = []
         for ch in chunks:
             a, b = ch[0], ch[1]
             head = (off_head, obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a)
             if headb:
                 head = head + (obs.wide_dsd.data_ptr() + 4 * a,)
-            hs = self._wide_forward(obs, ch, True, st, full=full, head=head) if full is not None else self._wide_forward(obs, ch, False, st, head=head)
+            lik = self._slot_args(ma, obs, step, None, None, a, b - a) if want_lik else None
+            hs = (self._wide_forward(obs, ch, True, st, full=full, head=head, lik=lik) if full is not None
+                  else self._wide_forward(obs, ch, False, st, head=head, lik=lik))
             kept.append(hs)
+            lik_fused.append(self._lik_fused)
             if not self._head_fused:
                 check(lib.cl_wide_head_forward(hs[-1][0], hs[-1][1], pbase + 4 * off_head, b - a, w, self.bij_kind, self.mlp.epsilon,
                                                obs.laue_loc.data_ptr() + 4 * a, obs.laue_sig.data_ptr() + 4 * a, sf, st), "cl_wide_head_forward")
-        self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
+        if not all(lik_fused):
+            assert not any(lik_fused)
+            self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
         for ic, ch in enumerate(chunks):
             a, b, m0, seg = ch
             n = b - a

@@ -257,6 +257,16 @@ int cl_wide_dense_forward(const float* X, int ldx, const float* Wt, const float*
 int cl_wide_dense_forward_head(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak,
                                float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out, float* dsig_draw_out,
                                const int* stop_flag, void* stream);
+/* ... and with the slot likelihood of the call's rows in the same epilogue (round 4): what cl_slot_rows computes from (loc, sigma) per row
+ * -- sample, predict, log-prob (careless/models/likelihoods/mono.py:10-37 on variational.py:167's prediction), gradient -- where the two
+ * numbers are made.  `lik` as for cl_slot_rows, its per-row arrays (refl_id, image_id, iobs, sig, dO, row_index) at the call's first row,
+ * obs_offset = that row's global number, n_obs = n (loc / sigma / iconv unused).  Rows that are their own slot, in-kernel noise, no
+ * ipred_out, no Evans-2011 terms, no deterministic stores, widths 65 .. 128 with the same block count on both sides: -2 otherwise (the
+ * caller then runs cl_wide_dense_forward_head and cl_slot_rows).                                                                    */
+struct cl_laue_args;
+int cl_wide_dense_forward_head_lik(const float* X, int ldx, const float* Wt, const float* b, long long n, int n_in, int n_out, float leak,
+                                   float* Y, int ldy, const float* head, int bij_kind, float eps, float* loc_out, float* sig_out, float* dsig_draw_out,
+                                   const struct cl_laue_args* lik, const int* stop_flag, void* stream);
 /* The head's backward pass inside the TOP layer's weight gradient and dgrad (round 4; replaces cl_wide_head_backward and the dZ_L buffer it
  * wrote: tape.gradient through NormalLayer, careless/models/scaling/nn.py:10-25, variational.py:197-202).  dZ_L = (g Wo) * LeakyReLU'(h_L) with
  * g = (dO[row][0], dO[row][1] * dsig_draw[row]) is a rank-2 product behind a mask: both kernels make it from Htop = h_L (the same bytes per

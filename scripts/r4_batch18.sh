@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 4, eighteenth GPU pass: wide path, the slot likelihood in the top layer's forward epilogue (CARELESS_HIP_WIDE_LIK=0: the launch of its own)
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4b18; mkdir -p $O
+( timeout 1500 python -m pytest tests -m gpu -q --no-header -x -k "wide or random_engine or several_row_chunks or fused_backward" 2>&1 | tail -6 ) 2>&1 | tee $O/pytest.log
+line() {
+python3 - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r = d["roofline"]
+    print("%-60s ms/step %.4f kernel ms %.4f frac %.4f step frac %.4f" % (sys.argv[1], d["ms_per_step"], r["kernel_ms"], r["frac"], r["frac_on_step_time"]))
+except Exception as e:
+    print(sys.argv[1], "failed", e)
+PY
+}
+for rep in 1 2 3; do
+  CARELESS_HIP_WIDE_LIK=0 timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_0.json 2> $O/w_0.err || tail -3 $O/w_0.err
+  line "slot likelihood as a launch of its own (WIDE_LIK=0)" $O/w_0.json
+  timeout 600 python bench.py --workload mono_2M_studentt_3x128_S4 --steps 20 --warmup 3 --no-cpu-baseline > $O/w_1.json 2> $O/w_1.err || tail -3 $O/w_1.err
+  line "slot likelihood in the top layer's forward epilogue" $O/w_1.json
+done 2>&1 | tee $O/wide_ab.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python3 bench.py --workload mono_2M_studentt_3x128_S4 --steps 10 --warmup 3 --no-cpu-baseline > $O/wide_bench.json 2> $O/wide_bench.err
+f=$(find $O/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/wide_kernel_stats.csv && head -9 $O/wide_kernel_stats.csv | cut -c1-160
+rm -rf $O/prof
