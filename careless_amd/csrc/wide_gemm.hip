@@ -617,6 +617,16 @@ struct StreamArgs {
     float* wg0_part;                 // WG0 instances: [gridDim.x][N K0 + N] partial sums of the FIRST layer's weight gradient (flat W^T layout)
 };
 
+// The kernel's argument block again, behind an opaque pointer (as kernargs_again of cl_kernels.h): the likelihood's two dozen scalars are
+// read where the epilogue uses them -- kept in scalar registers for the whole launch they spill into vector-register lanes (47 of them) and
+// every use in the block loop pays a v_readlane.  Valid in kernels whose single parameter is a StreamArgs by value.
+typedef const __attribute__((address_space(4))) StreamArgs* sargs_p;
+__device__ __forceinline__ sargs_p sargs_again() {
+    sargs_p p = (sargs_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // NAT: 16-column blocks of the output an instance holds (4: N <= 64, 8: N <= 128); GRP: the grouped form (its own instances: the
 // group loop costs the plain ones registers)
 template <bool WKM, int EPI, int NAT, bool GRP, bool PRE = false>
@@ -1110,10 +1120,11 @@ void wide_sq_kernel(const StreamArgs S) {
         int l_rid = 0, l_img = 0;
         float l_io = 0.0f, l_sg = 1.0f, l_aim = 1.0f, l_zf0 = 0.0f, l_zf1 = 0.0f;
         if (LIK) {
+            const sargs_p L = sargs_again();
             const size_t r0 = (size_t)blk * 16;
-            l_rid = (S.lik.refl_id + r0)[jc];
-            if (S.lik.use_img) l_img = (S.lik.image_id + r0)[jc];
-            l_io = (S.lik.iobs + r0)[jc]; l_sg = (S.lik.sig + r0)[jc];
+            l_rid = (L->lik.refl_id + r0)[jc];
+            if (L->lik.use_img) l_img = (L->lik.image_id + r0)[jc];
+            l_io = (L->lik.iobs + r0)[jc]; l_sg = (L->lik.sig + r0)[jc];
         }
         const bool more = blk + bstep < nblk;
         const long long bnext = more ? blk + bstep : blk;
@@ -1156,9 +1167,11 @@ void wide_sq_kernel(const StreamArgs S) {
                 else if (more && 16 * (t - NA) + cq < S.ldx) xb[t - NA] = *reinterpret_cast<const f32x4*>(xnext + 16 * (t - NA));
             }
             if (LIK && kc == NA / 2) {
-                if (q < S.lik.S) l_zf0 = S.lik.z_f[(size_t)l_rid * S.lik.S + q];
-                if (q + 4 < S.lik.S) l_zf1 = S.lik.z_f[(size_t)l_rid * S.lik.S + q + 4];
-                if (S.lik.use_img && l_img > 0) l_aim = S.lik.img[l_img - 1];
+                const sargs_p L = sargs_again();
+                const int Ss = L->lik.S;
+                if (q < Ss) l_zf0 = L->lik.z_f[(size_t)l_rid * Ss + q];
+                if (q + 4 < Ss) l_zf1 = L->lik.z_f[(size_t)l_rid * Ss + q + 4];
+                if (L->lik.use_img && l_img > 0) l_aim = L->lik.img[l_img - 1];
             }
             if (HEADB && kc == (NA >= 2 ? NA - 2 : 0) && more) {
                 const unsigned r = (unsigned)lane_row(bnext);
@@ -1235,40 +1248,42 @@ void wide_sq_kernel(const StreamArgs S) {
                     if (S.dsd_out != nullptr) S.dsd_out[row] = dd;
                 }
                 if (LIK) {
+                    const sargs_p L = sargs_again();
                     // the row's samples over its four lanes: lane q takes s = q, q + 4, ... (reference: mono.py:10-37 on variational.py:167's prediction)
-                    const unsigned long long gidx = S.lik.row_index != nullptr ? (unsigned long long)(S.lik.row_index + (size_t)blk * 16)[jc]
-                                                                               : (unsigned long long)(S.lik.obs_offset + row);
+                    const unsigned long long gidx = L->lik.row_index != nullptr ? (unsigned long long)(L->lik.row_index + (size_t)blk * 16)[jc]
+                                                                               : (unsigned long long)(L->lik.obs_offset + row);
                     float dl = 0.0f, ds = 0.0f;
-                    for (int sm = q; sm < S.lik.S; sm += 4) {
-                        const float zf = sm == q ? l_zf0 : (sm == q + 4 ? l_zf1 : S.lik.z_f[(size_t)l_rid * S.lik.S + sm]);
-                        const float eta = cl_noise_normal(S.lik.seed, S.lik.step, (uint32_t)sm, gidx);
-                        const float tq = loc + sigma * eta + S.lik.shift;
+                    for (int sm = q; sm < L->lik.S; sm += 4) {
+                        const float zf = sm == q ? l_zf0 : (sm == q + 4 ? l_zf1 : L->lik.z_f[(size_t)l_rid * L->lik.S + sm]);
+                        const float eta = cl_noise_normal(L->lik.seed, L->lik.step, (uint32_t)sm, gidx);
+                        const float tq = loc + sigma * eta + L->lik.shift;
                         float dll;
-                        const float ll = cl_lik_log_prob(l_aim * tq * zf * zf, l_io, l_sg, S.lik.lik_kind, S.lik.dof, S.lik.lik_const, &dll);
-                        l_nll -= ll * S.lik.w_ll;
-                        const float gi = -dll * S.lik.w_ll;             // dNLL / d ipred
+                        const float ll = cl_lik_log_prob(l_aim * tq * zf * zf, l_io, l_sg, L->lik.lik_kind, L->lik.dof, L->lik.lik_const, &dll);
+                        l_nll -= ll * L->lik.w_ll;
+                        const float gi = -dll * L->lik.w_ll;             // dNLL / d ipred
                         const float dzs = gi * zf * zf;
-                        atomicAdd(S.lik.dz_f + (size_t)l_rid * S.lik.S + sm, gi * l_aim * tq * 2.0f * zf);
+                        atomicAdd(L->lik.dz_f + (size_t)l_rid * L->lik.S + sm, gi * l_aim * tq * 2.0f * zf);
                         const float dt = dzs * l_aim;
                         dl += dt; ds += dt * eta; l_da += dzs * tq;
                     }
                     dl += __shfl_xor(dl, 16); ds += __shfl_xor(ds, 16); l_da += __shfl_xor(l_da, 16);
                     dl += __shfl_xor(dl, 32); ds += __shfl_xor(ds, 32); l_da += __shfl_xor(l_da, 32);
-                    if (q == 0) { (S.lik.dO + 2 * (size_t)blk * 16)[2 * j] = dl; (S.lik.dO + 2 * (size_t)blk * 16)[2 * j + 1] = ds; }
+                    if (q == 0) { (L->lik.dO + 2 * (size_t)blk * 16)[2 * j] = dl; (L->lik.dO + 2 * (size_t)blk * 16)[2 * j + 1] = ds; }
                     l_take = q == 0 && l_img > 0;
                 }
             }
         }
-        if (LIK && S.lik.use_img) {
+        if (LIK && sargs_again()->lik.use_img) {
+            const sargs_p L = sargs_again();
             // image-scale gradients of the wave's sixteen rows (every lane calls: the reduction is wave-wide; image 0 is pinned, image.py:23-25)
             const unsigned long long m = __ballot(l_take);
             if (m != 0ull) {
                 const int im0 = __builtin_amdgcn_readlane(l_img, __builtin_ctzll(m));
                 if (__all(!l_take || l_img == im0)) {
                     const float v = cl_wave_sum(l_take ? l_da : 0.0f);
-                    if (lane == 0) atomicAdd(S.lik.d_img + (im0 - 1), v);
+                    if (lane == 0) atomicAdd(L->lik.d_img + (im0 - 1), v);
                 } else {
-                    cl_image_grad_segments(S.lik.d_img, l_img, l_da, l_take, lane);
+                    cl_image_grad_segments(L->lik.d_img, l_img, l_da, l_take, lane);
                 }
             }
         }
@@ -1282,7 +1297,7 @@ void wide_sq_kernel(const StreamArgs S) {
         if (tid == 0) {
             double t = 0.0;
             for (int k = 0; k < 8; ++k) t += (double)sBias[k];
-            atomicAdd(S.lik.scalars + CL_SC_NLL, t);
+            atomicAdd(sargs_again()->lik.scalars + CL_SC_NLL, t);
         }
     }
     if constexpr (WG0) {
