@@ -556,14 +556,15 @@ def test_lane_kernel_production_instance_equals_the_full_one(w, d0, posenc, S):
     assert bool(torch.isfinite(ip).all()) and float(ip.abs().max()) > 0
 
 
-@pytest.mark.parametrize("S", [3, 4], ids=["S3_rows_straddle_waves", "S4_rows_inside_waves"])
-def test_wide_fused_backward_equals_the_separate_launches(monkeypatch, S):
+@pytest.mark.parametrize("S,img", [(3, True), (4, True), (4, False), (9, True)],
+                         ids=["S3_rows_straddle_waves", "S4_rows_inside_waves", "S4_no_image_scales", "S9_three_samples_a_lane"])
+def test_wide_fused_backward_equals_the_separate_launches(monkeypatch, S, img):
     """Round 4 folded three launches of the layer-by-layer path into their neighbours: the first layer's weight gradient into the second
     layer's dgrad, the Dense(2) head's backward pass into the top layer's weight gradient and dgrad, predict / log-prob / gradient of
     rows that are their own slot into one kernel (S = 3: a row's samples straddle waves -- dO by atomics; S = 4: stored) and that
     kernel into the top layer's forward epilogue.  The switches bring the separate launches back; same in-kernel noise: every loss term and gradient must agree to summation order."""
     from careless_amd.engine import ElboEngine
-    kw = dict(N=2117, R=90, d0=8, L=3, w=128, S=S, perturb=0.02, likelihood="studentt", dof=10.0, n_images=5)
+    kw = dict(N=2117, R=90, d0=8, L=3, w=128, S=S, perturb=0.02, likelihood="studentt", dof=10.0, n_images=5, use_image_scales=img)
     data, cfg, params, x, u_f, eta = util.make_problem(**kw)
     inputs = util.reference_inputs(data)
     res = []
