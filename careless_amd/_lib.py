@@ -174,6 +174,7 @@ EXPORTS = {
     "cl_owner_qnorm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "cl_step_finalize": (C.c_int, [_vp, C.c_float, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "cl_adam_grid": (C.c_int, [C.POINTER(AdamArgs)]),
+    "cl_tn_moments": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_float, _vp, _vp, _vp, _vp]),
     "cl_debug_noise": (C.c_int, [C.c_ulonglong, C.c_uint, C.c_int, C.c_longlong, C.c_longlong, C.c_int, _vp, _vp]),
 }
 
@@ -220,6 +221,9 @@ def check(code: int, what: str) -> None:
     """Turn a C-ABI return code into an exception."""
     if code == 0:
         return
+    if code == -2 and what.startswith("cl_wide"):
+        raise NotImplementedError(f"{what}: this layer shape / buffer layout is outside the kernel's envelope (row pitch = cl_wide_ld(width), "
+                                  "16-byte aligned buffers; the fused forms take hidden widths 65 .. 128)")
     if code == -2:
         raise NotImplementedError(
             f"{what}: scaler geometry not supported by the fused gfx950 kernel "

@@ -19,23 +19,35 @@ def _format(parser):
 
 
 def _format_once_per_node(parser, rank: int, world: int):
-    """Data-parallel launch: rank 0 alone reads and formats the reflection files (MTZ parsing, ASU mapping, metadata standardisation:
-    host work of the order of the file size) and leaves the formatted arrays as `.npy` files in /dev/shm; after a flag all-reduce
-    (so that a formatting error ends every rank instead of leaving them in a barrier) the ranks map the files read-only -- the node
-    holds ONE copy of the inputs, the engine of a rank copies only its shard's rows (engine.ObsData) -- and rank 0 removes them (the
-    maps keep the pages alive).  The ASU collection (small) travels as a pickle.  One node is what the launch supports (bench.py uses
-    the same scheme for its synthetic problems)."""
+    """Data-parallel launch: ONE rank per node -- local rank 0 -- reads and formats the reflection files (MTZ parsing, ASU mapping,
+    metadata standardisation: host work of the order of the file size) and leaves the formatted arrays as `.npy` files in its node's
+    /dev/shm; after a flag all-reduce (so that a formatting error ends every rank instead of leaving them in a barrier) the ranks
+    map the files read-only -- a node holds ONE copy of the inputs, the engine of a rank copies only its shard's rows
+    (engine.ObsData) -- and, after a second flag all-reduce over the loads (a rank whose pickle / map fails must not leave the
+    others in a barrier), the formatting rank removes them (the maps keep the pages alive).  The ASU collection (small) travels as a
+    pickle.  The node is told apart by LOCAL_RANK / LOCAL_WORLD_SIZE as `torch.distributed.run` sets them (absent: one node);
+    formatting is deterministic, so every node's copy is the same.  The directory also goes away if the formatting rank dies
+    in between (atexit) -- short of a SIGKILL."""
     if world <= 1:
         return _format(parser)
+    import atexit
     import os
     import pickle
     import shutil
-    import torch.distributed as dist
-    path = f"/dev/shm/careless_amd_{os.environ.get('MASTER_ADDR', 'local')}_{os.environ.get('MASTER_PORT', '0')}"
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if not (0 <= local_rank < local_world <= world) or world % local_world != 0:
+        raise RuntimeError(f"careless_amd: inconsistent launch environment (RANK {rank}, WORLD_SIZE {world}, LOCAL_RANK {local_rank}, "
+                           f"LOCAL_WORLD_SIZE {local_world})")
+    formats = local_rank == 0
+    node = rank // local_world                                  # (in the name only so that a one-machine rehearsal of two "nodes" works)
+    path = f"/dev/shm/careless_amd_{os.environ.get('MASTER_ADDR', 'local')}_{os.environ.get('MASTER_PORT', '0')}_n{node}"
+    cleanup = lambda: shutil.rmtree(path, ignore_errors=True)
     err = None
-    if rank == 0:
+    if formats:
+        atexit.register(cleanup)
         try:
-            shutil.rmtree(path, ignore_errors=True)
+            cleanup()
             os.makedirs(path)
             inputs, rac = _format(parser)
             for i, a in enumerate(inputs):
@@ -44,16 +56,22 @@ def _format_once_per_node(parser, rank: int, world: int):
                 pickle.dump((len(inputs), rac), f)
         except Exception as e:                                  # noqa: BLE001  (every rank raises below)
             err = e
-    if not _all_ranks_ok(err is None, world):
-        if rank == 0:
-            shutil.rmtree(path, ignore_errors=True)
-        raise err if err is not None else RuntimeError("careless_amd: rank 0 could not format the reflection files (see its traceback)")
-    with open(os.path.join(path, "rac.pickle"), "rb") as f:
-        n, rac = pickle.load(f)
-    inputs = tuple(np.load(os.path.join(path, f"input_{i:02d}.npy"), mmap_mode="r") for i in range(n))
-    dist.barrier()
-    if rank == 0:
-        shutil.rmtree(path, ignore_errors=True)
+    try:
+        if not _all_ranks_ok(err is None, world):
+            raise err if err is not None else RuntimeError("careless_amd: a rank could not format the reflection files (see its traceback)")
+        inputs = rac = None
+        try:
+            with open(os.path.join(path, "rac.pickle"), "rb") as f:
+                n, rac = pickle.load(f)
+            inputs = tuple(np.load(os.path.join(path, f"input_{i:02d}.npy"), mmap_mode="r") for i in range(n))
+        except Exception as e:                                  # noqa: BLE001
+            err = e
+        if not _all_ranks_ok(err is None, world):               # (also the barrier before the files go away)
+            raise err if err is not None else RuntimeError("careless_amd: a rank could not map the formatted inputs (see its traceback)")
+    finally:
+        if formats:
+            cleanup()
+            atexit.unregister(cleanup)
     return inputs, rac
 
 

@@ -160,6 +160,13 @@ int cl_step_finalize(double* scalars, float kl_weight_or_one, double* history, i
 
 int cl_adam_grid(const cl_adam_args* a) { return a == nullptr ? -1 : cl_adam_grid_of(*a); }
 
+int cl_tn_moments(const float* q_loc_raw, const float* q_scale_raw, const float* low, int R, double high_moments, double high_m4, float eps,
+                  float* mean, float* std, double* m4, void* stream) {
+    if (q_loc_raw == nullptr || q_scale_raw == nullptr || low == nullptr || R < 1) return -1;
+    if (mean == nullptr && std == nullptr && m4 == nullptr) return -1;
+    return cl_launch_tn_moments(q_loc_raw, q_scale_raw, low, R, high_moments, high_m4, eps, mean, std, m4, (hipStream_t)stream);
+}
+
 int cl_debug_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
                    void* stream) {
     if (out == nullptr || S < 1 || n < 1) return -1;

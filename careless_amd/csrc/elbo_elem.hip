@@ -392,6 +392,46 @@ __global__ void finalize_kernel(double* scalars, float kl_weight_or_one, double*
     if (stop_flag != nullptr && !isfinite(gn)) *stop_flag = 1;     // variational.py:271-274
 }
 
+// Output step (include/careless_hip.h: cl_tn_moments): mean, standard deviation and fourth raw moment of q(F_h) = Normal(loc, scale)
+// truncated to [low, high], from the raw vectors; reference surrogate_posteriors.py:55-73 (_tf_moment_4: the closed form of Orjebin's
+// note) and the TFP truncated-normal moments behind .mean() / .stddev().  fp64: once per run over R values, and the caller subtracts
+// <F^2>^2 from <F^4>.  With alpha = (low - loc) / scale <= ~0 (loc = exp(a) > 0 >= low) the normaliser Phi(beta) - Phi(alpha) is
+// taken as (erfc(alpha / sqrt 2) - erfc(beta / sqrt 2)) / 2: no cancellation on the side that matters.
+__global__ __launch_bounds__(256) void tn_moments_kernel(const float* __restrict__ qa, const float* __restrict__ qb, const float* __restrict__ low, int R,
+                                                         double high, double high4, float eps, float* __restrict__ mean, float* __restrict__ sd,
+                                                         double* __restrict__ m4) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    const double mu = (double)expf(qa[r]), sg = (double)(expf(qb[r]) + eps), a = (double)low[r];
+    constexpr double RSQRT2 = 0.70710678118654752440, RSQRT2PI = 0.39894228040143267794;
+    const double za = (a - mu) / sg;
+    const double pa = RSQRT2PI * exp(-0.5 * za * za);
+    if (mean != nullptr || sd != nullptr) {
+        const bool open = !(high < 1e30);
+        const double zb = open ? 0.0 : (high - mu) / sg;
+        const double pb = open ? 0.0 : RSQRT2PI * exp(-0.5 * zb * zb);
+        const double zn = 0.5 * (erfc(za * RSQRT2) - (open ? 0.0 : erfc(zb * RSQRT2)));
+        const double ratio = (pa - pb) / zn;
+        if (mean != nullptr) mean[r] = (float)(mu + sg * ratio);
+        if (sd != nullptr) {
+            const double bpb = pb > 0.0 ? zb * pb : 0.0;
+            sd[r] = (float)sqrt(sg * sg * (1.0 + (za * pa - bpb) / zn - ratio * ratio));
+        }
+    }
+    if (m4 != nullptr) {
+        const bool open = !(high4 < 1e30);
+        double bterm = 0.0, cb = 0.0;
+        if (!open) {
+            const double b = high4, zb = (b - mu) / sg;
+            bterm = (b * b * b + b * b * mu + b * mu * mu + sg * sg * (3.0 * b + 5.0 * mu) + mu * mu * mu) * RSQRT2PI * exp(-0.5 * zb * zb);
+            cb = erfc(zb * RSQRT2);
+        }
+        const double aterm = (a * a * a + a * a * mu + a * mu * mu + sg * sg * (3.0 * a + 5.0 * mu) + mu * mu * mu) * pa;
+        const double den = 0.5 * (erfc(za * RSQRT2) - cb);
+        m4[r] = mu * mu * mu * mu + 6.0 * mu * mu * sg * sg + 3.0 * sg * sg * sg * sg - sg * (bterm - aterm) / den;
+    }
+}
+
 // debug / test aid: the noise the kernels would draw for (seed, step)
 __global__ void noise_kernel(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind,
                              float* out) {
@@ -495,6 +535,12 @@ int cl_launch_finalize(double* scalars, float klw, double* history, int step_ind
                        const double* norm_part, int n_norm_part, hipStream_t st) {
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, st, scalars, klw, history, step_index, hist_stride, stop_flag, norm_part, n_norm_part);
+    return (int)hipGetLastError();
+}
+int cl_launch_tn_moments(const float* a, const float* b, const float* low, int R, double high, double high4, float eps, float* mean, float* sd,
+                         double* m4, hipStream_t st) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tn_moments_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, a, b, low, R, high, high4, eps, mean, sd, m4);
     return (int)hipGetLastError();
 }
 int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,

@@ -962,9 +962,8 @@ int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {
         if (a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
         if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
     }
-    // (CARELESS_HIP_LANE_ROWS_FROM=k: metadata as LDS rows from k columns on instead of 16 -- A/B runs)
-    static const int rows_from = [] { const char* e = getenv("CARELESS_HIP_LANE_ROWS_FROM"); const int v = e ? atoi(e) : DMAX_ALL + 1; return v < 1 ? 1 : (v > DMAX_ALL + 1 ? DMAX_ALL + 1 : v); }();
-    const bool rows = a.d >= rows_from;
+    // metadata as LDS rows from DMAX_ALL + 1 columns on (from 9 on it measured slower than the register instances, round 3)
+    const bool rows = a.d > DMAX_ALL;
     if (a.row_map != nullptr) {
         if (a.n_obs != a.n_pad || (a.gmeta != nullptr && a.tile_gmax == nullptr)) return -1;
         if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;

@@ -711,10 +711,8 @@ static int launch_narrow_ks(const cl_mlp_args& a, int grid, hipStream_t st) {
     const int m = a.w > a.d ? a.w : a.d;               // the metadata layer takes the same number of k-steps as the hidden ones
     if (m <= 8) return launch_narrow_one<2, 2, 8, PACKED>(a, grid, st);
     if (m <= 12) return launch_narrow_one<2, 3, 8, PACKED>(a, grid, st);
-    // widths 13 .. 15: four k-steps.  Two waves per SIMD spill ~90 registers at that size; one wave per SIMD holds everything
-    // (CARELESS_HIP_NARROW_W4=1 selects it: A/B runs)
-    static const bool w4 = [] { const char* e = getenv("CARELESS_HIP_NARROW_W4"); return e != nullptr && e[0] == '1'; }();
-    if (w4) return launch_narrow_one<2, 4, 4, PACKED>(a, grid, st);
+    // widths 13 .. 15: four k-steps.  Two waves per SIMD spill ~90 registers at that size; a one-wave-per-SIMD instance (<2, 4, 4>: no spill)
+    // measured no faster in round 3 (DESIGN / NOTEBOOK: 20 x 13 1.60 vs 1.56 ms) and is not instantiated any more
     return launch_narrow_one<2, 4, 8, PACKED>(a, grid, st);
 }
 

@@ -1084,7 +1084,7 @@ void wide_sq_kernel(const StreamArgs S) {
             gc1 = gp[2 * r + 1] * (S.dsd + (size_t)blk * 16)[r];
         }
     }
-    float l_nll = 0.0f;                           // LIK: this lane's share of the NLL over all its blocks
+    double l_nll = 0.0;                           // LIK: this lane's share of the NLL over all its blocks (fp64 across rows, like slot_rows_kernel)
     for (; blk < nblk; blk += bstep) {
         const long long row = blk * 16 + j;
         const unsigned jc = (unsigned)lane_row(blk);                 // this lane's (clamped) row inside the block
@@ -1252,20 +1252,21 @@ void wide_sq_kernel(const StreamArgs S) {
                     // the row's samples over its four lanes: lane q takes s = q, q + 4, ... (reference: mono.py:10-37 on variational.py:167's prediction)
                     const unsigned long long gidx = L->lik.row_index != nullptr ? (unsigned long long)(L->lik.row_index + (size_t)blk * 16)[jc]
                                                                                : (unsigned long long)(L->lik.obs_offset + row);
-                    float dl = 0.0f, ds = 0.0f;
+                    float dl = 0.0f, ds = 0.0f, row_nll = 0.0f;
                     for (int sm = q; sm < L->lik.S; sm += 4) {
                         const float zf = sm == q ? l_zf0 : (sm == q + 4 ? l_zf1 : L->lik.z_f[(size_t)l_rid * L->lik.S + sm]);
                         const float eta = cl_noise_normal(L->lik.seed, L->lik.step, (uint32_t)sm, gidx);
                         const float tq = loc + sigma * eta + L->lik.shift;
                         float dll;
                         const float ll = cl_lik_log_prob(l_aim * tq * zf * zf, l_io, l_sg, L->lik.lik_kind, L->lik.dof, L->lik.lik_const, &dll);
-                        l_nll -= ll * L->lik.w_ll;
+                        row_nll -= ll * L->lik.w_ll;
                         const float gi = -dll * L->lik.w_ll;             // dNLL / d ipred
                         const float dzs = gi * zf * zf;
                         atomicAdd(L->lik.dz_f + (size_t)l_rid * L->lik.S + sm, gi * l_aim * tq * 2.0f * zf);
                         const float dt = dzs * l_aim;
                         dl += dt; ds += dt * eta; l_da += dzs * tq;
                     }
+                    l_nll += (double)row_nll;
                     dl += __shfl_xor(dl, 16); ds += __shfl_xor(ds, 16); l_da += __shfl_xor(l_da, 16);
                     dl += __shfl_xor(dl, 32); ds += __shfl_xor(ds, 32); l_da += __shfl_xor(l_da, 32);
                     if (q == 0) { (L->lik.dO + 2 * (size_t)blk * 16)[2 * j] = dl; (L->lik.dO + 2 * (size_t)blk * 16)[2 * j + 1] = ds; }
@@ -1290,13 +1291,16 @@ void wide_sq_kernel(const StreamArgs S) {
     }
     if constexpr (LIK) {
         // the NLL of this workgroup's rows: one fp64 atomic (same-address atomics serialise: not one per wave)
-        const float v = cl_wave_sum(l_nll);
+        double v = l_nll;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
         __syncthreads();
-        if (lane == 0) sBias[wv] = v;
+        double* const sNll = reinterpret_cast<double*>(sBias);      // (16 NA floats >= 8 doubles; sBias sits on a 16-byte boundary)
+        if (lane == 0) sNll[wv] = v;
         __syncthreads();
         if (tid == 0) {
             double t = 0.0;
-            for (int k = 0; k < 8; ++k) t += (double)sBias[k];
+            for (int k = 0; k < 8; ++k) t += sNll[k];
             atomicAdd(sargs_again()->lik.scalars + CL_SC_NLL, t);
         }
     }
@@ -1328,8 +1332,7 @@ static bool sq_ok(const StreamArgs& s) {
     if (s.ldx % 4 != 0 || s.ldy % 4 != 0 || s.ldx < s.K || s.ldy < s.N || s.ldx > 16 * NA || s.ldy > 16 * NA) return false;
     if ((reinterpret_cast<uintptr_t>(s.X) & 15) != 0 || (reinterpret_cast<uintptr_t>(s.Y) & 15) != 0) return false;
     if (s.H != nullptr && (s.ldh % 4 != 0 || s.ldh > 16 * NA || (reinterpret_cast<uintptr_t>(s.H) & 15) != 0)) return false;
-    static const bool off = [] { const char* e = getenv("CARELESS_HIP_WIDE_SQ"); return e != nullptr && e[0] == '0'; }();      // A/B runs
-    return !off;
+    return true;
 }
 
 static long long sq_grid(long long n) {

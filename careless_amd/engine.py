@@ -152,6 +152,7 @@ def chain_plan(d: int, w: int, L: int, max_layers: int) -> List[LayerBlock]:
 # the engine
 # ------------------------------------------------------------------------------------------------------------
 class ElboEngine(WidePath):
+    SLOT_ROWS_ONE_LAUNCH = True      # rows that are their own slot: predict + log-prob + gradient in one `cl_slot_rows` launch (tests flip it)
     def __init__(self, model, inputs, seed: int = 1234, shard: Optional[Shard] = None, process_group=None,
                  grid: Optional[int] = None):
         self.device = require_gpu("ElboEngine")
@@ -302,15 +303,15 @@ class ElboEngine(WidePath):
         # its Adam update are then local to the owner (1 / world of the replicated work of the row split), and the step's all-reduce
         # carries the scaler's gradient and four norm terms instead of 2 R floats.  Laue data (a harmonic group mixes reflections),
         # the double-Wilson prior (a child's parent may live on another rank), per-image layers, wide scalers and the deterministic
-        # mode keep the row split.  By default from four ranks on: an owner shard holds 1 / world of every image's rows, so more waves
-        # span two images -- on one device that costs the lane kernel 2.7 % at two ranks, more than the smaller message
-        # can win back there, 0.4 % at four, nothing at eight.  `model.owner_shard = True / False` or CARELESS_HIP_OWNER_SHARD=1 / 0
-        # force the choice (tests, A/B runs).
+        # mode keep the row split.  OPT-IN (`model.owner_shard = True` or CARELESS_HIP_OWNER_SHARD=1) since round 5: the split has been
+        # verified on one device and over gloo (parity suite, shard-sum tests) but has never met RCCL on a multi-GPU node, and on one
+        # device its compute side is worth <= 1 % at eight ranks; the row split stays the default until
+        # `scripts/scale_curve.sh` has measured both on a node.
         self.owner = False
         want = getattr(model, "owner_shard", None)
         if want is None:
             env = os.environ.get("CARELESS_HIP_OWNER_SHARD", "")
-            want = (env == "1") if env in ("0", "1") else self.shard.world >= 4
+            want = env == "1"
         if (want and self.shard.world > 1 and not self.laue and not self.double_wilson and not self.wide and imgl is None
                 and not self.deterministic and not self.shard.owner):
             osh = owner_shard(_np(BaseModel.get_refl_id(inputs)).reshape(-1), self.R, self.shard.rank, self.shard.world)
@@ -851,7 +852,7 @@ class ElboEngine(WidePath):
                 la.ev11_part = det["ev11"].data_ptr() + 4 * 3 * _lib.CL_EV11_WAVES * det["pieces"] * det["grid"]
             check(lib.cl_slot_rows(C.byref(la), st), "cl_slot_rows")
             return
-        if obs.harmonic_id is None and os.environ.get("CARELESS_HIP_SLOT_ROWS", "1") != "0":
+        if obs.harmonic_id is None and self.SLOT_ROWS_ONE_LAUNCH:
             # every row its own slot (monochromatic data on the layer-by-layer path): one launch, no round trip through iconv
             check(lib.cl_slot_rows(C.byref(la), st), "cl_slot_rows")
             return
@@ -1037,6 +1038,29 @@ def tn_sample(q, n: int, seed=None, u_f=None) -> torch.Tensor:
     a.z_f, a.scalars = ptr(z), ptr(sc)
     check(lib.cl_tn_forward(C.byref(a), _stream()), "cl_tn_forward")
     return z.view(R, n).t()
+
+
+def tn_moments(q, high_m4=np.inf, want=("mean", "std", "m4")):
+    """Moments of the truncated-normal posterior for the output step via `cl_tn_moments` (reference surrogate_posteriors.py:23-27,
+    55-102; consumed at io/manager.py:188-197): dict with `mean`, `std` (fp32 torch tensors on the device) and `m4` (fp64).
+    `high_m4` is the upper bound of the fourth moment (the reference's `moment_4(high=np.inf)` default); mean / std use q.high."""
+    dev = require_gpu("TruncatedNormal moments")
+    lib = _lib.get_lib()
+    R = q.loc_raw.numel()
+    loc_raw = q.loc_raw.to(dev, torch.float32).contiguous()
+    scale_raw = q.scale_raw.to(dev, torch.float32).contiguous()
+    low = q.low.to(dev, torch.float32).contiguous()
+    out = {}
+    if "mean" in want:
+        out["mean"] = torch.empty(R, dtype=torch.float32, device=dev)
+    if "std" in want:
+        out["std"] = torch.empty(R, dtype=torch.float32, device=dev)
+    if "m4" in want:
+        out["m4"] = torch.empty(R, dtype=torch.float64, device=dev)
+    hi4 = float("inf") if high_m4 is None else float(high_m4)
+    check(lib.cl_tn_moments(ptr(loc_raw), ptr(scale_raw), ptr(low), R, float(q.high), hi4, float(q.scale_shift),
+                            ptr(out.get("mean")), ptr(out.get("std")), ptr(out.get("m4")), _stream()), "cl_tn_moments")
+    return out
 
 
 def scaler_forward(mlp, metadata, imgl=None, image_id=None):

@@ -3,7 +3,8 @@
 Mirror of `careless/models/merging/surrogate_posteriors.py:11-131` (reference): `TruncatedNormal` with
 `from_loc_and_scale` (loc = Exp(raw), scale = Shift(eps)(Exp(raw))), `sample` clamped at `low`, `log_prob`, `mean`,
 `stddev`, `moment_4`.  Sampling, log-prob and their gradients on the training path run in the HIP kernels
-`cl_tn_forward` / `cl_tn_backward`; the moment accessors used by the output step are closed forms in torch.
+`cl_tn_forward` / `cl_tn_backward`; the moment accessors used by the output step (`mean`, `stddev`, `moment_4(method='tf')`) run
+in `cl_tn_moments`.  `moment_4(method='scipy')` is scipy on the host, as in the reference.
 """
 from __future__ import annotations
 
@@ -99,29 +100,22 @@ class TruncatedNormal(SurrogatePosterior):
         return torch.where((z < self.low) | (z > self.high), torch.full_like(lp, -math.inf), lp)
 
     def mean(self):
-        loc, scale = self.loc.double(), self.scale.double()
-        a, b = (self.low.double() - loc) / scale, (self.high - loc) / scale
-        zn = _ndtr(-a) - _ndtr(-b)
-        pa = torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
-        pb = torch.exp(-0.5 * b * b) / math.sqrt(2 * math.pi)
-        return (loc + scale * (pa - pb) / zn).float()
-
-    def variance(self):
-        loc, scale = self.loc.double(), self.scale.double()
-        a, b = (self.low.double() - loc) / scale, (self.high - loc) / scale
-        zn = _ndtr(-a) - _ndtr(-b)
-        pa = torch.exp(-0.5 * a * a) / math.sqrt(2 * math.pi)
-        pb = torch.exp(-0.5 * b * b) / math.sqrt(2 * math.pi)
-        bpb = torch.where(pb > 0, b * pb, torch.zeros_like(pb))
-        r = (pa - pb) / zn
-        return (scale * scale * (1.0 + (a * pa - bpb) / zn - r * r)).float()
+        """E[z] of the truncated normal (tfd.TruncatedNormal.mean behind surrogate_posteriors.py:23-24); `cl_tn_moments` on the GPU."""
+        from careless_amd.engine import tn_moments
+        return tn_moments(self, want=("mean",))["mean"]
 
     def stddev(self):
-        return torch.sqrt(self.variance())
+        """sqrt(Var[z]) (surrogate_posteriors.py:26-27); `cl_tn_moments` on the GPU."""
+        from careless_amd.engine import tn_moments
+        return tn_moments(self, want=("std",))["std"]
+
+    def variance(self):
+        sd = self.stddev()
+        return sd * sd
 
     def moment_4(self, high=np.inf, method="scipy"):
         """Fourth raw moment (surrogate_posteriors.py:55-102).  'scipy' = scipy.stats.truncnorm.moment,
-        'tf' = the closed form of `_tf_moment_4` (evaluated here in torch, fp64)."""
+        'tf' = the closed form of `_tf_moment_4`, evaluated by `cl_tn_moments` on the GPU (fp64)."""
         if method == "scipy":
             from scipy.stats import truncnorm
             loc = self.loc.detach().cpu().numpy().astype(np.float64)
@@ -131,22 +125,7 @@ class TruncatedNormal(SurrogatePosterior):
             a, b = (low - loc) / scale, (hi - loc) / scale
             return truncnorm.moment(4, a, b, loc, scale)
         if method == "tf":
-            mu, sigma = self.loc.double(), self.scale.double()
-            a = self.low.double()
-            if high is None:
-                high = self.high
-            z_a = (a - mu) / sigma
-            pdf = lambda z: torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
-            aterm = (a ** 3 + a * a * mu + a * mu * mu + sigma * sigma * (3 * a + 5 * mu) + mu ** 3) * pdf(z_a)
-            if high == np.inf:
-                bterm = 0.0
-                nb = torch.ones_like(mu)
-            else:
-                b = torch.as_tensor(float(high), dtype=torch.float64, device=mu.device)
-                z_b = (b - mu) / sigma
-                bterm = (b ** 3 + b * b * mu + b * mu * mu + sigma * sigma * (3 * b + 5 * mu) + mu ** 3) * pdf(z_b)
-                nb = _ndtr(z_b)
-            num = bterm - aterm
-            den = nb - _ndtr(z_a)
-            return (mu ** 4 + 6 * mu * mu * sigma * sigma + 3 * sigma ** 4 - sigma * num / den).cpu().numpy()
+            from careless_amd.engine import tn_moments
+            hi = self.high if high is None else high
+            return tn_moments(self, high_m4=hi, want=("m4",))["m4"].cpu().numpy()
         raise ValueError(f"Unknown method {method} for computing moment_4")

@@ -161,9 +161,15 @@ class VariationalMergingModel(BaseModel):
         q = self.surrogate_posterior
         dist = self.scaling_model(inputs)
         smean, sstd = dist.mean().double().cpu(), dist.stddev().double().cpu()
-        f2 = (q.mean().double() ** 2 + q.stddev().double() ** 2).cpu()
+        if hasattr(q, "loc_raw"):                           # truncated normal: mean, stddev and <F^4> from one `cl_tn_moments` launch
+            from careless_amd.engine import tn_moments
+            mom = tn_moments(q)
+            f2 = (mom["mean"].double() ** 2 + mom["std"].double() ** 2).cpu()
+            f4 = mom["m4"].cpu()
+        else:
+            f2 = (q.mean().double() ** 2 + q.stddev().double() ** 2).cpu()
+            f4 = torch.as_tensor(np.asarray(q.moment_4(method="scipy"), dtype=np.float64))
         iexp = smean * f2[refl_id]
-        f4 = torch.as_tensor(np.asarray(q.moment_4(method="scipy"), dtype=np.float64))
         s2 = smean ** 2 + sstd ** 2
         ivar = f4[refl_id] * s2 - iexp * iexp              # var(I) = <F^4><Sigma^2> - <I>^2
         iexp, ivar = iexp.numpy(), ivar.numpy()

@@ -23,10 +23,15 @@ def get_results(surrogate_posterior, inputs, output_parameters: bool = True, max
     """Reference manager.py:188-236 as a dict of per-reflection arrays:
     F, SigF, I, SigI, N, observed (N > 0) and, with `output_parameters`, the q parameters high / loc / low / scale."""
     q = surrogate_posterior
-    F = _np(q.mean()).astype(np.float32)
-    SigF = _np(q.stddev()).astype(np.float32)
+    if hasattr(q, "loc_raw"):                                # the truncated normal: one `cl_tn_moments` launch for all three
+        from careless_amd.engine import tn_moments
+        mom = tn_moments(q)                                  # (the reference takes <F^4> from scipy on the host, manager.py:192)
+        F, SigF, f4 = _np(mom["mean"]), _np(mom["std"]), _np(mom["m4"])
+    else:
+        F = _np(q.mean()).astype(np.float32)
+        SigF = _np(q.stddev()).astype(np.float32)
+        f4 = np.asarray(q.moment_4(method="scipy"))          # <I^2> = <F^4>
     I = SigF * SigF + F * F
-    f4 = np.asarray(q.moment_4(method="scipy"))              # <I^2> = <F^4>
     ivar = np.square(I * max_intensity_snr)
     ivar = np.maximum(ivar, f4 - I * I)                      # var(I) = <F^4> - <I>^2, floored (manager.py:195-197)
     SigI = np.sqrt(ivar).astype(np.float32)

@@ -67,6 +67,7 @@ def make_synthetic(N: int, R: Optional[int] = None, d0: int = 5, posenc: bool = 
         refl_id=refl_id, image_id=image_id, file_id=np.zeros(N, dtype=np.int64),
         metadata=meta.astype(np.float32), iobs=iobs.astype(np.float32), sigiobs=sigi.astype(np.float32),
         centric=centric, multiplicity=mult.astype(np.float32), n_images=M, n_refl=R,
+        f_true=f_true.astype(np.float32),        # the amplitudes the intensities were generated from (recovery tests; no kernel sees them)
     )
 
 

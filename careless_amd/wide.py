@@ -6,7 +6,6 @@ fused launch takes): the layer-by-layer path of the engine on the GEMM kernels o
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -109,19 +108,25 @@ class WidePath:
         return base + 4 * m0 * w * w, base + 4 * (M * w * w + m0 * w)
 
     WIDE_KEEP_BUDGET = 64 << 30     # bytes of activations of a whole observation set the forward pass may keep for the backward pass
+    # The fusions of round 4, each with the separate launches it replaced still behind it (the fallback of shapes outside the fused
+    # kernels' envelopes).  Class attributes, not environment switches: the A/Bs are closed (NOTEBOOK.md), one parity test flips them
+    # to hold the fused step against the separate launches (tests/test_gpu_parity.py).
+    FUSE_PRE = True          # first Dense layer recomputed instead of stored (cl_wide_dense2_forward / _dgrad_pre / _wgrad_pre)
+    FUSE_WG0 = True          # first layer's weight gradient inside the second layer's dgrad (cl_wide_dense_dgrad_pre_wgrad0)
+    FUSE_HEADB = True        # the Dense(2) head's backward pass inside the top layer's weight gradient and dgrad
+    FUSE_LIK = True          # the slot likelihood in the top layer's forward epilogue (cl_wide_dense_forward_head_lik)
 
     def _wide_pre(self) -> bool:
         """The first Dense layer is recomputed instead of stored (cl_wide_dense2_forward / _dgrad_pre / _wgrad_pre): at least two Dense
-        layers, at most 15 metadata columns, hidden width up to 128.  CARELESS_HIP_WIDE_PRE=0 keeps every layer's output (A/B runs)."""
-        import os
-        return (self.L >= 2 and bool(self.lib.cl_wide_pre_supported(self.d, self.w)) and os.environ.get("CARELESS_HIP_WIDE_PRE", "1") != "0")
+        layers, at most 15 metadata columns, hidden width up to 128."""
+        return self.FUSE_PRE and self.L >= 2 and bool(self.lib.cl_wide_pre_supported(self.d, self.w))
 
     def _wide_head_bwd(self) -> bool:
         """The Dense(2) head's backward pass runs inside the top Dense layer's weight gradient and dgrad (cl_wide_dense_wgrad_head /
         _dgrad_head) instead of a launch of its own that writes dZ_L: Dense-only scalers whose top layer is a square one of the streaming
-        kernel's widths and not the layer fed by the recomputed first one.  CARELESS_HIP_WIDE_HEADB=0: the separate launch (A/B runs)."""
-        return (self.imgl is None and self.L >= 2 and not (self._wide_pre() and self.L == 2) and
-                bool(self.lib.cl_wide_head_bwd_supported(self.w, self.w)) and os.environ.get("CARELESS_HIP_WIDE_HEADB", "1") != "0")
+        kernel's widths and not the layer fed by the recomputed first one."""
+        return (self.FUSE_HEADB and self.imgl is None and self.L >= 2 and not (self._wide_pre() and self.L == 2) and
+                bool(self.lib.cl_wide_head_bwd_supported(self.w, self.w)))
 
     def _wide_keep_all(self, obs: ObsData):
         """Per-layer activation buffers over ALL rows of `obs` (list of tensors), or None when they do not fit: then the backward pass
@@ -226,10 +231,9 @@ class WidePath:
         if headb and getattr(obs, "wide_dsd", None) is None:
             obs.wide_dsd = torch.empty(obs.N, dtype=torch.float32, device=self.device)
         # The slot likelihood rides in the top layer's forward epilogue when a production step asks for nothing else of it (rows that are
-        # their own slot, in-kernel noise, no predictions out, no Evans-2011 terms, not the deterministic mode; CARELESS_HIP_WIDE_LIK=0: the
-        # launch of its own -- A/B runs); the library decides by shape (-2), the same for every chunk
-        want_lik = (obs.harmonic_id is None and eta is None and ipred_out is None and not self.ev11 and not self.deterministic and
-                    os.environ.get("CARELESS_HIP_WIDE_LIK", "1") != "0")
+        # their own slot, in-kernel noise, no predictions out, no Evans-2011 terms, not the deterministic mode); the library decides by
+        # shape (-2), the same for every chunk
+        want_lik = (self.FUSE_LIK and obs.harmonic_id is None and eta is None and ipred_out is None and not self.ev11 and not self.deterministic)
         lik_fused = []
         for ch in chunks:
             a, b = ch[0], ch[1]
@@ -293,7 +297,7 @@ class WidePath:
                                                       nsplit, sf, st), "cl_wide_dense_wgrad_pre")
                     check(lib.cl_reduce_partials(ptr(W["wpart"]), nsplit, w * fan_in + w, gbase + 4 * ow, sf, st), "cl_reduce_partials")
                     # layer 1's dgrad with layer 0's weight gradient taken where dZ_0 is produced (it is never stored) ...
-                    rc = -2 if os.environ.get("CARELESS_HIP_WIDE_WG0", "1") == "0" else \
+                    rc = -2 if not self.FUSE_WG0 else \
                         lib.cl_wide_dense_dgrad_pre_wgrad0(ptr(dz), ldw, pbase + 4 * ow, n, w, fan_in, x0, ld0, d0, pbase + 4 * ow0, pbase + 4 * ob0, leak,
                                                            ptr(W["wpart"]), sf, st)
                     if rc != -2:

@@ -428,6 +428,19 @@ int cl_step_finalize(double* scalars, float kl_weight_or_one, double* history, i
 /* workgroups cl_adam_step launches for these arguments (the length / 2 of norm_part) */
 int cl_adam_grid(const cl_adam_args* args);
 
+/* --- output step: merged amplitudes ---------------------------------------------------------------------------------
+ * replaces: TruncatedNormal.mean / .stddev (tfd.TruncatedNormal moments behind SurrogatePosterior.mean / .stddev,
+ *           careless/models/merging/surrogate_posteriors.py:23-27, 45-48) and TruncatedNormal._tf_moment_4 / moment_4
+ *           (careless/models/merging/surrogate_posteriors.py:55-102), as DataManager.get_results consumes them
+ *           (careless/io/manager.py:188-197: F = mean, SigF = stddev, var(I) = <F^4> - <F^2>^2).
+ * From the raw trainable vectors a = log(loc), b = log(scale - eps) and the lower truncation point, per reflection:
+ *   mean[r]  = E[z],  std[r] = sqrt(Var[z]),  m4[r] = E[z^4]   for z ~ Normal(loc, scale) truncated to [low, high].
+ * high >= 1e30 (or inf) is "no upper truncation", the reference's moment_4 default (high = np.inf).  The arithmetic is fp64 on the
+ * device (R values once per run; the subtraction <F^4> - <F^2>^2 downstream cancels): mean / std are stored as fp32 like the
+ * reference's fp32 TFP moments, m4 as fp64 like scipy.stats.truncnorm.moment.  Any output pointer may be NULL.                     */
+int cl_tn_moments(const float* q_loc_raw, const float* q_scale_raw, const float* low, int R, double high_moments, double high_m4, float eps,
+                  float* mean, float* std, double* m4, void* stream);
+
 /* --- diagnostics -------------------------------------------------------------------------------------------------- */
 const char* cl_version(void);
 /* sizeof(cl_tn_args), sizeof(cl_mlp_args), sizeof(cl_adam_args), sizeof(cl_laue_args), sizeof(cl_det_args): lets a binding verify its mirrors */

@@ -234,12 +234,20 @@ def _format_worker(rank, world, port, q, fail):
     rank 0's files) and the same ASU object; a formatting error on rank 0 raises on EVERY rank (no rank is left in a barrier)."""
     import careless_amd.careless as cc
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for k in ("LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        os.environ.pop(k, None)
+    if fail == "two_nodes":                      # one rank per "node": each formats its own copy (advisor, round 4: a second node used to hang)
+        os.environ.update(LOCAL_RANK="0", LOCAL_WORLD_SIZE="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     calls = {"n": 0}
+    if fail == "load" and rank == 1:             # a rank-local failure AFTER the formatting flag: the others must not be left in a barrier
+        def broken_load(*a, **k):
+            raise OSError("/dev/shm is full")
+        cc.np.load = broken_load
 
     def fake_format(parser):
         calls["n"] += 1
-        if fail:
+        if fail is True:
             raise OSError("cannot read the reflection file")
         rng = np.random.default_rng(3)
         inputs = (rng.integers(0, 9, (50, 1)), rng.integers(0, 4, (50, 1)), np.zeros((50, 1), np.int64), rng.normal(size=(50, 3)).astype(np.float32),
@@ -261,7 +269,7 @@ def _format_worker(rank, world, port, q, fail):
 def test_reflection_files_are_formatted_once_per_node_and_failures_reach_every_rank():
     world = 2
     ctx = mp.get_context("spawn")
-    for fail in (False, True):
+    for fail in (False, True, "load", "two_nodes"):
         q = ctx.Queue()
         port = _free_port()
         procs = [ctx.Process(target=_format_worker, args=(r, world, port, q, fail)) for r in range(world)]
@@ -271,8 +279,9 @@ def test_reflection_files_are_formatted_once_per_node_and_failures_reach_every_r
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
-        assert [g[2] for g in got] == [1, 0]                       # rank 0 formatted, rank 1 did not
-        if fail:
+        assert [g[2] for g in got] == ([1, 1] if fail == "two_nodes" else [1, 0])     # one formatting rank per node
+        if fail in (True, "load"):
             assert [g[1] for g in got] == ["raised", "raised"]     # both ranks leave with an error; nobody waits in a collective
         else:
             assert [g[1] for g in got] == ["ok", "ok"] and got[0][3] == got[1][3]
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith(f"careless_amd_127.0.0.1_{port}")]    # nothing left behind

@@ -562,15 +562,15 @@ def test_wide_fused_backward_equals_the_separate_launches(monkeypatch, S, img):
     """Round 4 folded three launches of the layer-by-layer path into their neighbours: the first layer's weight gradient into the second
     layer's dgrad, the Dense(2) head's backward pass into the top layer's weight gradient and dgrad, predict / log-prob / gradient of
     rows that are their own slot into one kernel (S = 3: a row's samples straddle waves -- dO by atomics; S = 4: stored) and that
-    kernel into the top layer's forward epilogue.  The switches bring the separate launches back; same in-kernel noise: every loss term and gradient must agree to summation order."""
+    kernel into the top layer's forward epilogue.  The class switches bring the separate launches back; same in-kernel noise: every loss term and gradient must agree to summation order."""
     from careless_amd.engine import ElboEngine
     kw = dict(N=2117, R=90, d0=8, L=3, w=128, S=S, perturb=0.02, likelihood="studentt", dof=10.0, n_images=5, use_image_scales=img)
     data, cfg, params, x, u_f, eta = util.make_problem(**kw)
     inputs = util.reference_inputs(data)
     res = []
     for fused in (True, False):
-        for k in ("CARELESS_HIP_WIDE_WG0", "CARELESS_HIP_WIDE_HEADB", "CARELESS_HIP_SLOT_ROWS", "CARELESS_HIP_WIDE_LIK"):
-            monkeypatch.setenv(k, "1" if fused else "0")
+        for k in ("FUSE_WG0", "FUSE_HEADB", "FUSE_LIK", "SLOT_ROWS_ONE_LAUNCH"):
+            monkeypatch.setattr(ElboEngine, k, fused)
         eng = ElboEngine(util.build_model(data, cfg, params, 3, 128), inputs, seed=5)
         assert eng.wide
         eng.forward_backward(2)

@@ -145,3 +145,55 @@ def test_poly_cli_prediction_file_holds_the_per_group_sums(tmp_path):
     assert np.array_equal(tab.columns["Iobs"], np.asarray(BaseModel.get_intensities(inputs)).reshape(-1)[:G])
     multi = np.bincount(hid, minlength=G) > 1
     assert multi.any() and not np.allclose(tab.columns["Ipred"][multi], iexp[np.unique(hid, return_index=True)[1]][multi], rtol=1e-3)
+
+
+@pytest.mark.parametrize("low", [0.0, 1e-32])
+def test_cl_tn_moments_matches_scipy_and_the_oracle(low):
+    """`cl_tn_moments` (the C-ABI entry behind F / SigF / <F^4> of the output step) against scipy.stats.truncnorm at the reference's own
+    tolerance (tests/models/merging/test_truncated_normal.py:29-42: loc, scale ~ U(0, 1) + 1e-3, rtol 1e-5), on a wider range
+    (loc / scale from 1e-3 to 1e3: converged posteriors sit at loc >> scale), and against the oracle's closed forms."""
+    from scipy.stats import truncnorm
+    from careless_amd.engine import tn_moments
+    from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal
+    rng = np.random.default_rng(11)
+    loc = np.concatenate([rng.random(100), 10 ** rng.uniform(-2, 2, 400)]).astype(np.float32)
+    scale = np.concatenate([rng.random(100) + 1e-3, loc[100:] * 10 ** rng.uniform(-3, 1, 400)]).astype(np.float32)
+    q = TruncatedNormal.from_loc_and_scale(loc, scale, low=np.full(len(loc), low, dtype=np.float32))
+    mom = tn_moments(q)
+    mu, sg = q.loc.double().cpu().numpy(), q.scale.double().cpu().numpy()            # the fp32 parameters the kernel sees
+    a = (low - mu) / sg
+    assert np.allclose(mom["m4"].cpu().numpy(), truncnorm.moment(4, a, np.inf, mu, sg), rtol=1e-5)
+    assert np.allclose(q.moment_4(method="tf"), truncnorm.moment(4, a, np.inf, mu, sg), rtol=1e-5)
+    assert np.allclose(q.moment_4(method="tf", high=None), truncnorm.moment(4, a, (1e10 - mu) / sg, mu, sg), rtol=1e-5)
+    assert np.allclose(mom["mean"].cpu().numpy(), truncnorm.mean(a, (1e10 - mu) / sg, mu, sg), rtol=1e-5)
+    assert np.allclose(mom["std"].cpu().numpy(), truncnorm.std(a, (1e10 - mu) / sg, mu, sg), rtol=1e-4)
+    T = lambda v: torch.as_tensor(v, dtype=torch.float64)
+    lo = T(np.full(len(loc), low))
+    assert _close(mom["mean"].cpu().numpy(), O.tn_mean(T(mu), T(sg), lo, 1e10).numpy(), 1e-5)
+    assert _close(mom["std"].cpu().numpy(), torch.sqrt(O.tn_variance(T(mu), T(sg), lo, 1e10)).numpy(), 1e-4)
+    assert _close(mom["m4"].cpu().numpy(), O.tn_moment_4(T(mu), T(sg), lo).numpy(), 1e-5)
+    assert torch.equal(q.mean(), mom["mean"]) and torch.equal(q.stddev(), mom["std"])
+
+
+def test_get_results_matches_scipy_moments():
+    """reference io/manager.py:188-236: F, SigF, I, SigI (with the I/SigI cap), N, q parameters"""
+    from scipy import stats
+    from careless_amd.results import get_results
+    data, cfg, params, x, u_f, eta = util.make_problem(N=120, R=30, S=1)
+    model = util.build_model(data, cfg, params, 2, 32)
+    inputs = util.reference_inputs(data)
+    inputs = (inputs[0].copy(),) + inputs[1:]
+    inputs[0][inputs[0] == 29] = 0                       # make reflection 29 unobserved
+    res = get_results(model.surrogate_posterior, inputs)
+    q = model.surrogate_posterior
+    loc, scale = q.loc.cpu().numpy().astype(float), q.scale.cpu().numpy().astype(float)
+    a = (q.low.cpu().numpy() - loc) / scale
+    assert np.allclose(res["F"], stats.truncnorm.mean(a, np.inf, loc, scale), rtol=1e-5)
+    assert np.allclose(res["SigF"], stats.truncnorm.std(a, np.inf, loc, scale), rtol=1e-4)
+    assert np.allclose(res["I"], res["F"] ** 2 + res["SigF"] ** 2, rtol=1e-6)
+    f4 = stats.truncnorm.moment(4, a, np.inf, loc, scale)
+    expect = np.sqrt(np.maximum((res["I"] * 1e-5) ** 2, f4 - res["I"].astype(float) ** 2))
+    assert np.allclose(res["SigI"], expect, rtol=1e-3)
+    assert res["N"].sum() == 120 and res["N"][29] == 0 and not res["observed"][29] and res["observed"][:29].all()
+    assert set(["high", "loc", "low", "scale"]) <= set(res) and np.allclose(res["loc"], loc, rtol=1e-6)
+    assert np.all(res["high"] == np.float32(1e10))
