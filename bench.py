@@ -179,11 +179,7 @@ def cpu_baseline(workload: str, n_sample: int, steps: int, full: bool = False):
         steps = max(5, steps)
         # autograd keeps ~(2 L w + 14 S) fp32 values per observation alive; stay inside the host's free memory
         per_obs = 4 * (3 * spec["L"] * spec["w"] + 24 * S)
-        try:
-            free = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024
-            n_sample = int(min(n_sample, 0.6 * free / per_obs))
-        except Exception:
-            pass
+        n_sample = int(min(n_sample, 0.6 * _host_free_bytes() / per_obs))
     step = problem(n_sample)
     step()                                            # warm-up (allocator, thread pool)
     times = [step() for _ in range(steps)]
@@ -194,6 +190,44 @@ def cpu_baseline(workload: str, n_sample: int, steps: int, full: bool = False):
             "sample": f"{n_sample} observations of the same workload ({size}), median of "
                       f"{steps} steps after one warm-up step, {cores} torch threads (picked on a separate 100k problem), "
                       f"fp32 PyTorch-CPU restatement of the reference graph (not TensorFlow), torch {torch.__version__}"}
+
+
+def _host_free_bytes() -> float:
+    """Memory this process may still take: MemAvailable, cut to what the cgroup (container / lease) leaves -- /proc/meminfo does not see
+    that limit, and a baseline sized past it is killed without a word."""
+    free = float("inf")
+    try:
+        free = int([l for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0].split()[1]) * 1024.0
+    except Exception:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            v = open(lim).read().strip()
+            if v != "max" and int(v) < (1 << 60):
+                free = min(free, float(int(v) - int(open(cur).read().strip())))
+        except Exception:
+            pass
+    return free
+
+
+def cpu_baseline_child(workload: str, n_sample: int, steps: int, full: bool):
+    """The CPU baseline in a FRESH child process (no GPU in it): if the host kills it -- memory -- or it fails, the bench line keeps its
+    GPU result and says what happened, and a bounded 2 M-observation sample is tried instead."""
+    import subprocess
+    here = os.path.abspath(__file__)
+    for n, st, fl in ((n_sample, steps, full), (min(n_sample, 2_000_000), 3, False)):
+        try:
+            r = subprocess.run([sys.executable, here, "--cpu-child", json.dumps([workload, n, st, fl])], capture_output=True, text=True, timeout=3600)
+            if r.returncode == 0:
+                return json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+            err = f"exit code {r.returncode}: {r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ''}"
+        except Exception as e:       # noqa: BLE001
+            err = repr(e)
+        print(f"bench.py: CPU baseline on {n} observations failed ({err})", file=sys.stderr, flush=True)
+        if n <= 2_000_000:
+            break
+    return {"value": None, "unit": "reflections/s", "cores": None, "kind": "port", "sample": f"not measured: {err}"}
 
 
 def _traffic_from(workload: str, world: int):
@@ -340,7 +374,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     eng.lib = _LibProxy(real_lib, timed)
     # Python's cyclic garbage collector stays out of the timed region: a generation-2 collection of this process (torch + the
     # problem's host arrays) takes 35 - 55 ms -- more than the 20 timed steps of an 8-rank run together -- and landed inside the timed
-    # region of some short runs (scripts/diag_rowsplit.sh: 40 steps of a simulated 8-rank shard, 0.35 -> 1.26 ms per step)
+    # region of some short runs (scripts/archive/diag_rowsplit.sh: 40 steps of a simulated 8-rank shard, 0.35 -> 1.26 ms per step)
     import gc
     gc.collect()
     gc_was = gc.isenabled()
@@ -389,6 +423,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
                    "image_layers": spec.get("image_layers", 0), "noise": "in-kernel philox",
                    "parallelism": (("reflection-owner shard" if eng.owner else "obs-shard") + f" x{eng.shard.world}") if eng.shard.world > 1 else "single",
                    "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
+        "loss_history": [float(v) for v in hist["loss"]],
         "roofline": {"bound": "mfma", "kernel": (kernel_name + " (" + ("cl_wide_* GEMM launches" if eng.wide else ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd")) + ")"),
                      "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
                      "traffic": traffic_bytes(name, world)[0], "traffic_from": _traffic_from(name, world), "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
@@ -473,8 +508,11 @@ def worker(args) -> int:
         out = {"metric": "reflections/sec per ELBO step", "value": res["value"], "unit": "reflections/s",
                "n_gpus": world, "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None),
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+               "timing": f"mean of {args.steps} steps in one region bracketed by barrier + synchronize (the driver's contract; SURVEY 8d's median of "
+                         "single steps would need a host sync per step -- step-to-step jitter is 0.2 %)",
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "build": _build_id(), "config": res["config"], "roofline": res["roofline"], "obs_per_rank": res["obs_per_rank"],
+               "build": _build_id(), "config": res["config"], "roofline": res["roofline"], "loss_history": res["loss_history"],
+               "obs_per_rank": res["obs_per_rank"],
                "host_peak_rss_gib_per_rank": res["host_peak_rss_gib_per_rank"]}
         if extras:
             out["extra_configs"] = extras
@@ -488,7 +526,7 @@ def worker(args) -> int:
             # the host's free memory and says so in `sample`
             full = args.cpu_sample is None
             n_cpu = (args.nobs or spec["N"]) if full else (args.cpu_sample if args.nobs is None else min(args.cpu_sample, args.nobs))
-            out["cpu_baseline"] = cpu_baseline(args.workload, n_cpu, args.cpu_steps or (5 if full else 3), full)
+            out["cpu_baseline"] = cpu_baseline_child(args.workload, n_cpu, args.cpu_steps or (5 if full else 3), full)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -505,6 +543,9 @@ def worker(args) -> int:
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
+    if len(argv) == 2 and argv[0] == "--cpu-child":          # the CPU baseline's own process (cpu_baseline_child)
+        print(json.dumps(cpu_baseline(*json.loads(argv[1]))), flush=True)
+        return 0
     args = parse(argv)
     have_ranks = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not have_ranks:

@@ -1204,7 +1204,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
         }
     }
     __syncthreads();
-    float* __restrict__ part = A.partials + (size_t)blockIdx.x * Ptot;
+    float* __restrict__ part = kernargs_again()->partials + (size_t)blockIdx.x * Ptot;       // (re-read: not held across the tile loop)
     for (int idx = tid; idx < Ptot; idx += 512) part[idx] = smem[idx];
 
     if (MODE == 0) {
@@ -1219,9 +1219,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
             double t = 0.0;
             for (int k = 0; k < CL_NW; ++k) t += (double)smem[k];
 #if CL_DET
-            A.nll_part[blockIdx.x] = t;          // (every workgroup of the launch writes its slot: workgroups without tiles write 0)
+            kernargs_again()->nll_part[blockIdx.x] = t;          // (every workgroup of the launch writes its slot: workgroups without tiles write 0)
 #else
-            atomicAdd(A.scalars + CL_SC_NLL, t);
+            atomicAdd(kernargs_again()->scalars + CL_SC_NLL, t);
 #endif
         }
         if (use_ev11) {
@@ -1230,12 +1230,19 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                 ev_g0 += __shfl_xor(ev_g0, off); ev_g1 += __shfl_xor(ev_g1, off); ev_g2 += __shfl_xor(ev_g2, off);
             }
             if (lane == 0) {                         // d softplus(raw)/d raw = sigmoid(raw)
-                const float e0 = ev_g0 * cl_sigmoid(A.ev11[0]), e1 = ev_g1 * cl_sigmoid(A.ev11[1]), e2 = ev_g2 * cl_sigmoid(A.ev11[2]);
-                if (A.ev11_part != nullptr) {        // deterministic mode: this wave's slot, summed in index order by cl_det_reduce
-                    float* slot = A.ev11_part + 3 * (CL_EV11_WAVES * (size_t)blockIdx.x + wv);
+                // (the flush's pointers are re-read from the kernel-argument block HERE: read through `A` they are loaded at the top of the
+                // kernel and held in scalar registers across the tile loop -- three more spilled registers of each kind in the 64-wide
+                // instance, 0.2 - 0.6 % of the headline step: profiles/r5_mlp_r3_vs_r4_ab.txt)
+                cl_args_p F = kernargs_again();
+                const float* ev = F->ev11;
+                const float e0 = ev_g0 * cl_sigmoid(ev[0]), e1 = ev_g1 * cl_sigmoid(ev[1]), e2 = ev_g2 * cl_sigmoid(ev[2]);
+                float* part = F->ev11_part;
+                if (part != nullptr) {               // deterministic mode: this wave's slot, summed in index order by cl_det_reduce
+                    float* slot = part + 3 * (CL_EV11_WAVES * (size_t)blockIdx.x + wv);
                     slot[0] = e0; slot[1] = e1; slot[2] = e2;
                 } else {
-                    atomicAdd(A.d_ev11 + 0, e0); atomicAdd(A.d_ev11 + 1, e1); atomicAdd(A.d_ev11 + 2, e2);
+                    float* dst = F->d_ev11;
+                    atomicAdd(dst + 0, e0); atomicAdd(dst + 1, e1); atomicAdd(dst + 2, e2);
                 }
             }
         }

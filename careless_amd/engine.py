@@ -160,6 +160,10 @@ class ElboEngine(WidePath):
         self.model = model
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.process_group = process_group
+        # CARELESS_FORCE_DIST=1 (careless.py: _data_parallel): a one-rank run makes every collective call of the multi-GPU step
+        if os.environ.get("CARELESS_FORCE_DIST", "0") == "1":
+            import torch.distributed as dist
+            self.force_allreduce = dist.is_available() and dist.is_initialized()
         dev = self.device
 
         from careless_amd.models.merging.surrogate_posteriors import TruncatedNormal

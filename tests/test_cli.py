@@ -181,7 +181,7 @@ def test_data_parallel_cli_two_ranks_match_one(tmp_path, split):
     """`python -m careless_amd mono ...` as two one-process-per-GPU ranks (here: both on this GPU, gloo backend) writes the same
     merged amplitudes and history as the single-process run: observations sharded, one all-reduce per step, in-kernel noise keyed
     by global indices, rank 0 writes the files (careless_amd/careless.py: _data_parallel).  Both splits: rows (what two ranks run
-    by default) and reflection owners (the default from four ranks on: every rank updates its own reflections' q(F) only, the ranks
+    by default) and reflection owners (opt-in since round 5, CARELESS_HIP_OWNER_SHARD=1: every rank updates its own reflections' q(F) only, the ranks
     exchange them after training, the validation rows follow their reflection's owner); and the row split with its message in two
     pieces (round 4: the scaler's part all-reduced beside cl_tn_backward, a and b after it)."""
     import socket
