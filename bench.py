@@ -147,7 +147,7 @@ def cpu_baseline(workload: str, n_sample: int, steps: int, full: bool = False):
     S = spec["S"]
 
     def problem(n):
-        data = O.make_synthetic(n, d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"])
+        data = O.make_synthetic(n, d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], posenc_keys=spec.get("posenc_keys", 2))
         x = O.inputs_from_numpy(data, dtype=dt)
         p = O.init_params(data, cfg, spec["L"], spec["w"], dtype=dt)
         st = O.AdamState.zeros_like(p.tensors())

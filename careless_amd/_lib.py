@@ -72,7 +72,7 @@ class MlpArgs(C.Structure):
         ("imgl", _vp), ("d_imgl", _vp), ("n_imgl", C.c_int), ("n_images", C.c_int), ("tile_img", _vp), ("row_map", _vp),
         ("gmeta", _vp), ("tile_gmax", _vp), ("noise_row", _vp),
         ("act_out", _vp), ("dH_ext", _vp), ("dX_out", _vp),
-        ("dzf_obs", _vp), ("dimg_obs", _vp), ("nll_part", _vp), ("det_slot", _vp), ("ev11_part", _vp),
+        ("dzf_obs", _vp), ("dimg_obs", _vp), ("nll_part", _vp), ("det_slot", _vp), ("dZ0_out", _vp), ("ev11_part", _vp),
     ]
 
 
@@ -174,6 +174,10 @@ EXPORTS = {
     "cl_owner_qnorm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "cl_step_finalize": (C.c_int, [_vp, C.c_float, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),
     "cl_adam_grid": (C.c_int, [C.POINTER(AdamArgs)]),
+    "cl_peel_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "cl_peel_parts": (C.c_int, [C.c_longlong]),
+    "cl_peel_forward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "cl_peel_backward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "cl_tn_moments": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_float, _vp, _vp, _vp, _vp]),
     "cl_debug_noise": (C.c_int, [C.c_ulonglong, C.c_uint, C.c_int, C.c_longlong, C.c_longlong, C.c_int, _vp, _vp]),
 }

@@ -286,6 +286,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     const bool use_ev11 = FULL && A.ev11 != nullptr;
     const bool has_eta = FULL && A.eta != nullptr;          // injected scale noise (parity tests)
     const bool det = FULL && A.dzf_obs != nullptr;          // deterministic mode: stores per (observation, sample) instead of float atomics
+    // dL/d(pre-activations of layer 0) out (round 5: the launch behind a peeled first layer, cl_peel_*: a row per feature,
+    // [cl_mlp_meta_rows(w)][n_pad] like meta_t)
+    const bool has_dxo = FULL && A.dZ0_out != nullptr;
     if (use_ev11) { ev.sdfac = cl_softplus(A.ev11[0]); ev.sdadd = cl_softplus(A.ev11[1]); ev.sdb = cl_softplus(A.ev11[2]); }
 
     const int n_wt = (A.n_obs + WT - 1) / WT;                        // wave tiles
@@ -733,6 +736,16 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     });
                     dz_of(dzp[q ^ 1], hsp[l > 0 ? l - 1 : 0], dH);
                 }
+                if constexpr (l == 0) {
+                    if (has_dxo) {                                   // wave-uniform
+                        float* const dxo = A.dZ0_out + (size_t)(wt * WT) + lane;
+                        const size_t np = (size_t)A.n_pad;
+                        static_for<0, W>([&](auto fc_) {
+                            constexpr int f = decltype(fc_)::value;
+                            if (f < w) dxo[f * np] = DZ(0, f);
+                        });
+                    }
+                }
                 LFENCE();
                 // weight gradient of layer l; in the shadow of its MFMAs (two LDS instructions each are free for a lone wave) the
                 // staging writes, operand reads and dgrad weights of layer l - 1
@@ -894,7 +907,7 @@ static int launch_lane_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
 
 // the plain layout has a second instance without the optional inputs / outputs (the training step of a production run); the packed
 // layout (single-pass Laue) keeps the one full instance
-static inline bool lane_wants_full(const cl_mlp_args& a) { return a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr || a.dzf_obs != nullptr; }
+static inline bool lane_wants_full(const cl_mlp_args& a) { return a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr || a.dzf_obs != nullptr || a.dZ0_out != nullptr; }
 template <int W, int DMAX, bool PACKED>
 static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     if constexpr (PACKED) return launch_lane_inst<W, DMAX, true, true>(a, grid, st);

@@ -1374,6 +1374,11 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    // dZ0_out (the launch behind a peeled first layer, elbo_peel.hip) is stored by the default scaler's kernels only
+    if (a.dZ0_out != nullptr && !(mode == 0 && a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.n_imgl == 0 &&
+                                  (a.dzf_obs == nullptr || a.ev11 == nullptr || a.ev11_part != nullptr) &&
+                                  ((cl_lane_supports(a) && lane_enabled()) || (cl_narrow_supports(a) && narrow_enabled()))))
+        return -2;
     if (a.dzf_obs != nullptr && (mode == 0 || (a.act_out == nullptr && a.dH_ext == nullptr))) {
         // deterministic mode: the default scaler's shapes keep their own kernels (round 4: elbo_lane.hip / elbo_narrow.hip store per
         // observation when dzf_obs is given), every other width <= 64 runs the deterministic compilation of this file.  (The forward-only

@@ -542,6 +542,20 @@ void elbo_narrow_kernel(const cl_mlp_args A) {
                     if (l > 0) accd = mfma4(wd[0], dz[0], accd);
 #pragma unroll
                     for (int t = 0; t < KS; ++t) stw[t * PBW + 16 * g] = dz[t];                              // stage dZ_l
+                    if (l == 0) {
+                        // dL/d(pre-activations of layer 0) out (round 5: the launch behind a peeled first layer, elbo_peel.hip): lane (j, q),
+                        // step t = feature 4 t + q of observation 16 g + j; rows [cl_mlp_meta_rows(w)][n_pad] like meta_t.  Re-read per
+                        // tile: one scalar load.
+                        cl_args_p E3 = kernargs_again();
+                        float* const dxo = E3->dZ0_out;
+                        if (dxo != nullptr) {
+                            const size_t np = (size_t)E3->n_pad;
+                            float* const p0 = dxo + (size_t)(wt * WT + 16 * g + j);
+#pragma unroll
+                            for (int t = 0; t < KS; ++t)
+                                if (4 * t + q < w) p0[(size_t)(4 * t + q) * np] = dz[t];
+                        }
+                    }
                     NFENCE();
                     wa = mfma4(pa[g][1], pb[g][1], wa);
                     if (l > 0) accd = mfma4(wd[1], dz[1], accd);

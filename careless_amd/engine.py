@@ -241,6 +241,16 @@ class ElboEngine(WidePath):
         if not self.wide and imgl is None and self.L > max_plain:
             # deeper than one launch holds in registers: a chain of layer blocks, activations exchanged through HBM
             self.blocks = chain_plan(self.d, self.w, self.L, max_plain)
+        # The careless default scaler (20 layers, hidden width <= 10) on more metadata columns than its lane-per-observation kernel holds
+        # (31; four positionally encoded keys give 37): the first Dense layer is "peeled" -- its pre-activations come from
+        # cl_peel_forward, the fused kernel runs the same scaler with an identity first layer on them (w "metadata columns": the shape it
+        # is fastest at) and hands back dZ_0, cl_peel_backward takes W_0's and b_0's gradient (csrc/elbo_peel.hip).  Training
+        # launches only: forward-only / external-gradient launches (predictions, two-pass Laue) keep the original scaler.
+        # The same for every other scaler of hidden width <= 15 on more than 15 columns: elbo_narrow.hip holds <= 15 of them.
+        lane_shape = self.L == 20 and self.w <= 10 and os.environ.get("CARELESS_HIP_LANE", "1") != "0"
+        self.peel = (not self.wide and self.blocks is None and imgl is None and self.w <= 15 and self.L <= 20 and
+                     self.d > (31 if lane_shape else 15) and self.d > self.w and bool(self.lib.cl_peel_supported(self.d, self.w, self.L)) and
+                     os.environ.get("CARELESS_HIP_NARROW", "1") != "0")
         if imgl is not None:
             imgl.build(self.d)
             max_l = int(self.lib.cl_mlp_max_layers_imgl(self.w))
@@ -563,7 +573,9 @@ class ElboEngine(WidePath):
         """Name of the kernel instance the scaler launches of this engine run (`cl_mlp_kernel_name`: the library's own routing):
         what a rocprofv3 kernel trace lists for the dominant kernel."""
         if self.wide:
-            return "wide_gemm_kernel" + (" (slot likelihood: deterministic stores)" if self.deterministic else "")
+            sq = 65 <= self.w <= 128 and self.d <= 128          # (square layers of the streaming kernel's widths: cl_wide_head_bwd_supported's range)
+            return (("wide_sq_kernel + wide_gemm_kernel" if sq else "wide_gemm_kernel (+ wide_stream_kernel)") +
+                    (" (slot likelihood: deterministic stores)" if self.deterministic else ""))
         obs = self.obs.children[0] if isinstance(self.obs, ObsChunks) else self.obs
         ma = self._mlp_args(0, None, None, obs)
         if self.blocks is not None:
@@ -572,6 +584,8 @@ class ElboEngine(WidePath):
         elif self.laue and not obs.fused_laue:
             mode = 2 if mode == 0 else mode
             ma.dO_ext = ptr(obs.laue_dO)
+        elif self.peel and mode == 0:
+            ma = self._peel_args(ma, obs)
         buf = C.create_string_buffer(128)
         check(min(0, self.lib.cl_mlp_kernel_name(C.byref(ma), mode, buf, 128)), "cl_mlp_kernel_name")
         return buf.value.decode()
@@ -704,7 +718,7 @@ class ElboEngine(WidePath):
         if self.laue and obs.fused_laue:
             # single pass: the harmonic group sums happen inside the fused kernel; the padded slots (no rows, iconv = 0,
             # reference formatter.py:637-640 / laue.py:24) only add their constant -- and, with Ev11, its gradient
-            check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
+            self._fused_step_launch(ma, obs, st)
             npad = int(obs.pad_iobs.numel())
             if npad > 0:
                 obs.pad_iconv.zero_()
@@ -726,14 +740,60 @@ class ElboEngine(WidePath):
         else:
             # (deterministic mode: every workgroup of the launch STORES its NLL slot, det["grid"] slots per piece -- nothing to clear;
             #  the slots a short last piece leaves unwritten were zero-initialised and are never touched)
-            check(lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
-        if defer_reduce and not _piece and not self.deterministic:
+            self._fused_step_launch(ma, obs, st)
+        if self.peel and not (self.laue and not obs.fused_laue):
+            self._peel_reduce(obs, st, ma.n_obs)
+        elif defer_reduce and not _piece and not self.deterministic:
             self._pending_reduce = (ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp)
         else:
             check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, lay.P, self.grads.data_ptr() + 4 * lay.off_mlp,
                                          ptr(self.stop_flag), st), "cl_reduce_partials")
         if self.deterministic and not _piece:
             self._det_reduce(obs, st)
+
+    def _peel_bufs(self, obs: ObsData):
+        """Buffers of the peeled first layer for one observation set: its pre-activations and dZ_0 (feature-major, like meta_t), the
+        weight-gradient partials; per engine: the peeled scaler's parameters and reduced gradient."""
+        pb = getattr(obs, "peel", None)
+        if pb is None:
+            rows = int(self.lib.cl_mlp_meta_rows(self.w))
+            nparts = int(self.lib.cl_peel_parts(obs.n_pad))     # (packed layouts: every row of the padded axis may be a real one)
+            pb = obs.peel = dict(u=torch.zeros(rows * obs.n_pad, dtype=torch.float32, device=self.device),
+                                 dz0=torch.zeros(rows * obs.n_pad, dtype=torch.float32, device=self.device),
+                                 parts=torch.empty(nparts * (self.w * self.d + self.w), dtype=torch.float32, device=self.device), nparts=nparts)
+        if getattr(self, "peel_params", None) is None:
+            Pp = int(self.lib.cl_mlp_param_count(self.w, self.w, self.L))
+            self.peel_params = torch.zeros(Pp, dtype=torch.float32, device=self.device)
+            self.peel_grad = torch.zeros(Pp, dtype=torch.float32, device=self.device)
+        return pb
+
+    def _peel_args(self, ma: MlpArgs, obs: ObsData) -> MlpArgs:
+        """The fused launch behind the peeled first layer: the layer's pre-activations as metadata, identity first layer, dZ_0 out."""
+        pb = self._peel_bufs(obs)
+        a = MlpArgs()
+        C.memmove(C.byref(a), C.byref(ma), C.sizeof(MlpArgs))
+        a.meta_t, a.d, a.mlp, a.dZ0_out = ptr(pb["u"]), self.w, ptr(self.peel_params), ptr(pb["dz0"])
+        return a
+
+    def _fused_step_launch(self, ma: MlpArgs, obs: ObsData, st):
+        """cl_elbo_mono_fwd_bwd, behind cl_peel_forward when the first layer is peeled (self.peel)."""
+        if not self.peel:
+            check(self.lib.cl_elbo_mono_fwd_bwd(C.byref(ma), obs.grid, st), "cl_elbo_mono_fwd_bwd")
+            return
+        pb, lay = self._peel_bufs(obs), self.layout
+        check(self.lib.cl_peel_forward(ptr(obs.meta_t), ma.n_obs, obs.n_pad, self.d, self.w, self.L, self.params.data_ptr() + 4 * lay.off_mlp, ptr(pb["u"]),
+                                       ptr(self.peel_params), ptr(self.peel_grad), int(self.peel_grad.numel()), ptr(self.stop_flag), st), "cl_peel_forward")
+        a = self._peel_args(ma, obs)
+        check(self.lib.cl_elbo_mono_fwd_bwd(C.byref(a), obs.grid, st), "cl_elbo_mono_fwd_bwd")
+
+    def _peel_reduce(self, obs: ObsData, st, n_obs: int):
+        """Gradient of a step with a peeled first layer: the launch's partials -> the peeled scaler's gradient; layer 0's own gradient
+        from dZ_0 and the metadata, everything behind it copied over (cl_peel_backward)."""
+        pb, lay = obs.peel, self.layout
+        check(self.lib.cl_reduce_partials(ptr(obs.partials), obs.grid, int(self.peel_grad.numel()), ptr(self.peel_grad), ptr(self.stop_flag), st),
+              "cl_reduce_partials")
+        check(self.lib.cl_peel_backward(ptr(obs.meta_t), n_obs, obs.n_pad, self.d, self.w, self.L, ptr(pb["dz0"]), ptr(self.peel_grad),
+                                        self.grads.data_ptr() + 4 * lay.off_mlp, ptr(pb["parts"]), pb["nparts"], ptr(self.stop_flag), st), "cl_peel_backward")
 
     def _block_args(self, ma: MlpArgs, obs: ObsData, k: int) -> MlpArgs:
         """Arguments of block k of the chain: its slice of the parameters, its input (metadata or the previous block's output)."""

@@ -30,7 +30,7 @@ def standardize_metadata(m: np.ndarray) -> np.ndarray:
 
 
 def make_synthetic(N: int, R: Optional[int] = None, d0: int = 5, posenc: bool = False, posenc_L: int = 4,
-                   outliers: bool = False, seed: int = 1234, n_images: Optional[int] = None):
+                   outliers: bool = False, seed: int = 1234, n_images: Optional[int] = None, posenc_keys: int = 2):
     """Deterministic synthetic mono problem of SURVEY 8(d).  Returns a dict of numpy arrays in the reference's
     dtypes: ids int64, data float32 (io/formatter.py:382-394)."""
     rng = np.random.default_rng(seed)
@@ -52,7 +52,7 @@ def make_synthetic(N: int, R: Optional[int] = None, d0: int = 5, posenc: bool = 
     raw = np.concatenate([inv_d2[:, None], hkl, extra], axis=1)[:, :d0]
     meta = standardize_metadata(raw)
     if posenc:
-        xy = rng.uniform(0, 2048, size=(N, 2))
+        xy = rng.uniform(0, 2048, size=(N, posenc_keys))       # (2 keys: X, Y -- + 16 columns at L = 4; 4 keys: + 32)
         meta = np.concatenate([meta, positional_encoding(xy, posenc_L)], axis=1)
     g = np.exp(rng.normal(0.0, 0.2, size=M))
     K = np.exp(-5.0 * inv_d2) * g[image_id]

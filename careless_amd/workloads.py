@@ -26,6 +26,9 @@ WORKLOADS: Dict[str, dict] = {
     # configs[2]'s data (Student-T, positional encodings of X, Y: 5 + 16 metadata columns, mc-samples 8) on the CLI-default scaler:
     # what `careless mono --positional-encoding-keys X,Y --studentt-likelihood-dof 16 --mc-samples 8` runs
     "mono_10M_studentt_posenc_20x10_S8": dict(N=10_000_000, d0=5, posenc=True, L=20, w=10, S=8, dof=16.0, outliers=True),
+    # FOUR positionally encoded keys (5 + 32 = 37 metadata columns) on the CLI-default scaler: past the lane kernel's 31 columns, the
+    # first layer is peeled (csrc/elbo_peel.hip, round 5)
+    "mono_10M_studentt_posenc4_20x10_S8": dict(N=10_000_000, d0=5, posenc=True, posenc_keys=4, L=20, w=10, S=8, dof=16.0, outliers=True),
     # a scaler wider than the fused kernels hold (hidden width > 64): layer-by-layer GEMM kernels (csrc/wide_gemm.hip)
     "mono_2M_studentt_3x128_S4": dict(N=2_000_000, d0=5, posenc=False, L=3, w=128, S=4, dof=16.0, outliers=True),
     # half the default depth (register-pressure experiments on the narrow kernel)
@@ -95,7 +98,7 @@ def _generate(spec: dict, seed: int) -> dict:
         return make_synthetic_laue(spec["N"], seed=seed)
     if kind == "double_wilson":
         return make_synthetic_double_wilson(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
-    return make_synthetic(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed)
+    return make_synthetic(spec["N"], d0=spec["d0"], posenc=spec["posenc"], outliers=spec["outliers"], seed=seed, posenc_keys=spec.get("posenc_keys", 2))
 
 
 def _share_save(data: dict, path: str) -> None:

@@ -194,6 +194,9 @@ typedef struct cl_mlp_args {
     const int* det_slot;        /* optional [n_obs] (round 4): observation i's record goes to dzf_obs[det_slot[i]][S] instead of dzf_obs[i][S] --
                                    the caller's reflection-sorted position, so that cl_det_reduce (perm_refl NULL) reads every reflection's
                                    records contiguously instead of gathering them; the scattered STORES cost the kernel nothing it waits for */
+    float* dZ0_out;             /* optional [cl_mlp_meta_rows(w)][n_pad] (round 5): cl_elbo_mono_fwd_bwd also STORES dL/d(pre-activations of the FIRST Dense
+                                   layer), feature-major like meta_t -- what cl_peel_backward turns into a peeled first layer's weight gradient.
+                                   The default scaler's kernels only (elbo_lane.hip, elbo_narrow.hip): any other routing returns -2            */
     float* ev11_part;           /* deterministic mode with the Evans-2011 error model (round 4): every wave of the launch STORES its share of dL/d raw
                                    (Sdfac, Sdadd, SdB) at ev11_part[3 * (CL_EV11_WAVES * workgroup + wave)] instead of three float atomics on d_ev11;
                                    [3 * CL_EV11_WAVES * grid] floats, cl_det_reduce adds them in index order                                          */
@@ -427,6 +430,26 @@ int cl_step_finalize(double* scalars, float kl_weight_or_one, double* history, i
                      const double* norm_part, int n_norm_part, void* stream);
 /* workgroups cl_adam_step launches for these arguments (the length / 2 of norm_part) */
 int cl_adam_grid(const cl_adam_args* args);
+
+/* --- a wide first layer in front of the default scaler's kernels ("peeled" first layer, round 5) -----------------------------------
+ * replaces: the FIRST Dense layer of MetadataScaler / MLPScaler (careless/models/scaling/nn.py:55-68: tfk.layers.Dense on the metadata) and
+ *           its gradient (careless/models/merging/variational.py:197-202) when the metadata width exceeds what the lane / narrow kernels
+ *           hold -- e.g. 20 x 10 on the 37 columns of four positionally encoded keys (careless/args/positional_encoding.py:24-37).
+ * cl_peel_forward : u_t[k][i] = b_0[k] + sum_c W_0[k][c] x[c][i]  -- the layer's PRE-activations, feature-major [cl_mlp_meta_rows(w)][n_pad]
+ *                   like meta_t -- and mlp_peel = the scaler's parameters with layer 0 replaced by (identity w x w, zero bias)
+ *                   (cl_mlp_param_count(w, w, L) floats).  cl_elbo_mono_fwd_bwd on (meta_t = u_t, d = w, mlp = mlp_peel, dZ0_out = dz0_t)
+ *                   then computes the same step: LeakyReLU(I u + 0) is the original first activation, and dL/du = dZ_0 comes back in dZ0_out
+ *                   (elbo_lane.hip / elbo_narrow.hip store it).  zero_ptr[0 .. zero_n): cleared on the way (the caller's grad_peel).
+ * cl_peel_backward: grad_mlp[layer 0] += dZ_0^T X, sum dZ_0 (per-workgroup partials [nparts][w d + w], nparts <= cl_peel_parts(n_obs), summed
+ *                   in index order), grad_mlp[behind layer 0] += grad_peel[behind its layer 0] (grad_peel = cl_reduce_partials of the launch).
+ * `mlp` / `grad_mlp` point at the scaler's slice of the flat parameter / gradient vector (W^T layout).  cl_peel_supported: d > w, w <= 15,
+ * w (d + 1) <= 1280.                                                                                                                     */
+int cl_peel_supported(int d, int w, int L);
+int cl_peel_parts(long long n_obs);
+int cl_peel_forward(const float* meta_t, int n_obs, int n_pad, int d, int w, int L, const float* mlp, float* u_t, float* mlp_peel,
+                    float* zero_ptr, int zero_n, const int* stop_flag, void* stream);
+int cl_peel_backward(const float* meta_t, int n_obs, int n_pad, int d, int w, int L, const float* dz0_t, const float* grad_peel, float* grad_mlp,
+                     float* partials, int nparts, const int* stop_flag, void* stream);
 
 /* --- output step: merged amplitudes ---------------------------------------------------------------------------------
  * replaces: TruncatedNormal.mean / .stddev (tfd.TruncatedNormal moments behind SurrogatePosterior.mean / .stddev,

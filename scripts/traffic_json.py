@@ -21,6 +21,6 @@ for arg in sys.argv[1:]:
                "fetch_kib_reported": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "atomic_requests": vals.get("TCC_EA0_ATOMIC_sum"),
                "sources": source_hash(), "file": path,
                "launches_per_step": launches.get("FETCH_SIZE"),
-               "method": "2 x FETCH_SIZE + WRITE_SIZE summed over the dominant kernel(s)' launches of one step, separate rocprofv3 --pmc passes (scripts/r4_pmc_passes.sh)"}
+               "method": "2 x FETCH_SIZE + WRITE_SIZE summed over the dominant kernel(s)' launches of one step, separate rocprofv3 --pmc passes (scripts/pmc_passes_step.sh)"}
 json.dump(out, open(out_path, "w"), indent=1)
 print(json.dumps(out, indent=1))

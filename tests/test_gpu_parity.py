@@ -69,6 +69,22 @@ CASES = {
     "lane_laue_single_pass_20x10_S11": dict(N=700, R=40, L=20, w=10, S=11, laue=True, perturb=0.02, grid=2),
     "lane_laue_single_pass_20x8_d22_S3": dict(N=900, R=40, L=20, w=8, S=3, laue=True, extra_meta=16, perturb=0.02, grid=2),
     "lane_d21_three_observations": dict(N=3, R=2, d0=21, L=20, w=10, S=2, n_images=1, use_image_scales=False, perturb=0.02),
+    # ... with MORE than 31 metadata columns (round 5: four positionally encoded keys give 37): the first layer is peeled -- its
+    # pre-activations and its weight gradient come from csrc/elbo_peel.hip, the lane kernel runs the scaler with an identity first layer
+    "peel_20x10_d37_S1": dict(N=900, R=50, d0=37, L=20, w=10, S=1, perturb=0.02, grid=2),
+    "peel_20x10_d53_S8_studentt": dict(N=1100, R=50, d0=53, L=20, w=10, S=8, likelihood="studentt", dof=16.0, outliers=True, perturb=0.02, grid=2),
+    "peel_20x6_d64_S2_softplus_ev11": dict(N=600, R=40, d0=64, L=20, w=6, S=2, bijector="softplus", shift=1.5, ev11=True, perturb=0.02),
+    "peel_20x10_d32_S3_klweight_noimg": dict(N=500, R=40, d0=32, L=20, w=10, S=3, kl_weight=0.5, use_image_scales=False, perturb=0.02),
+    "peel_laue_single_pass_20x8_d38_S3": dict(N=900, R=40, L=20, w=8, S=3, laue=True, extra_meta=32, perturb=0.02, grid=2),
+    "peel_double_wilson_20x10_d40_S2": dict(N=600, R=60, d0=40, L=20, w=10, S=2, double_wilson=True, perturb=0.02),
+    "peel_rows_in_arbitrary_order_20x10_d37": dict(N=900, R=60, d0=37, L=20, w=10, S=2, n_images=9, shuffle_rows=True, perturb=0.02),
+    # ... and the same in front of the narrow kernel (any depth <= 20, hidden width <= 15, more than 15 columns)
+    "peel_narrow_7x12_d21_S2": dict(N=700, R=40, d0=5, posenc=True, L=7, w=12, S=2, perturb=0.03, grid=2),
+    "peel_narrow_20x15_d40_S3_studentt": dict(N=600, R=40, d0=40, L=20, w=15, S=3, likelihood="studentt", dof=8.0, perturb=0.02),
+    "peel_narrow_1x9_d16": dict(N=333, R=30, d0=16, L=1, w=9, S=1, perturb=0.03),
+    "peel_narrow_laue_single_pass_5x10_d22_ev11": dict(N=800, R=40, L=5, w=10, S=2, laue=True, extra_meta=16, ev11=True, perturb=0.03, grid=2),
+    "peel_narrow_12x13_d64_klweight": dict(N=500, R=40, d0=64, L=12, w=13, S=2, kl_weight=0.5, perturb=0.03),
+    "peel_d45_three_observations": dict(N=3, R=2, d0=45, L=20, w=10, S=2, n_images=1, use_image_scales=False, perturb=0.02),
     "narrow_one_layer_w9_d1": dict(N=333, R=30, d0=1, L=1, w=9, S=1, perturb=0.03),
     "narrow_laue_single_pass_7x6_S1_ev11": dict(N=600, R=40, L=7, w=6, S=1, laue=True, ev11=True, perturb=0.03),
     "image_layers2_3x8": dict(N=800, R=40, d0=5, L=3, w=8, S=2, n_images=5, image_layers=2, perturb=0.03),
@@ -418,11 +434,12 @@ def test_refl_gather_is_bit_exact():
     assert np.array_equal(ipred, expect * np.float32(1.0))
 
 
-@pytest.mark.parametrize("L,w", [(2, 32), (20, 10), (2, 96)], ids=["2x32", "cli_default_20x10", "wide_2x96"])
-def test_adam_trajectory_matches_oracle(L, w):
+@pytest.mark.parametrize("L,w,d0", [(2, 32, 5), (20, 10, 5), (2, 96, 5), (20, 10, 37)], ids=["2x32", "cli_default_20x10", "wide_2x96", "peel_20x10_d37"])
+def test_adam_trajectory_matches_oracle(L, w, d0):
     """20 Adam steps on injected noise: history and final parameters follow the oracle; also for the CLI-default geometry, which
-    runs on the narrow instance (permuted features, LDS-resident accumulators, bias gradient in column 15)"""
-    kw = dict(N=384, R=48, d0=5, L=L, w=w, S=2)
+    runs on the narrow instance (permuted features, LDS-resident accumulators, bias gradient in column 15), and for that geometry on 37
+    metadata columns (peeled first layer: its parameters are updated from cl_peel_backward's gradient)"""
+    kw = dict(N=384, R=48, d0=d0, L=L, w=w, S=2)
     data, cfg, params, x, u_f0, eta0 = util.make_problem(**kw)
     steps = 20
     rng = np.random.default_rng(11)
@@ -577,7 +594,7 @@ def test_wide_fused_backward_equals_the_separate_launches(monkeypatch, S, img):
         torch.cuda.synchronize()
         res.append((eng.loss_terms(), eng.grads.clone()))
     (ta, ga), (tb, gb) = res
-    assert abs(ta["nll"] - tb["nll"]) <= 1e-6 * abs(tb["nll"]) and ta["kl"] == tb["kl"]
+    assert abs(ta["nll"] - tb["nll"]) <= 5e-7 * abs(tb["nll"]) and ta["kl"] == tb["kl"]     # (round 5: the fused epilogue sums rows in fp64 like the separate launch)
     assert util.rel_err(ga.cpu().numpy(), gb.cpu().numpy()) < 2e-5
     for a, b in zip(eng._split(ga), eng._split(gb)):           # tensor by tensor: the head, every layer, the image scales
         assert util.rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-5
@@ -1150,11 +1167,13 @@ def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
                                 dict(N=900, R=50, d0=5, L=20, w=10, S=2, ev11=True, perturb=0.02),
                                 dict(N=800, R=40, d0=5, L=6, w=10, S=5, ev11=True, perturb=0.03, likelihood="studentt", dof=8.0),
                                 dict(N=700, R=40, L=3, w=32, S=2, laue=True, ev11=True),
-                                dict(N=900, R=50, d0=5, L=2, w=80, S=4, ev11=True)],
+                                dict(N=900, R=50, d0=5, L=2, w=80, S=4, ev11=True),
+                                # a peeled first layer (round 5): its weight gradient sums per-workgroup partials in index order
+                                dict(N=1100, R=50, d0=41, L=20, w=10, S=3, likelihood="studentt", dof=8.0, perturb=0.02, n_images=6)],
                          ids=["mono_5x64", "cli_default_20x10", "rows_in_arbitrary_order_S8", "no_image_scales_klweight",
                               "lane_posenc_d21_S8", "lane_20x8_S11", "narrow_6x10_S5", "narrow_9x13_d12", "laue_lane_20x10_S3", "laue_narrow_4x12", "laue_5x64_S3", "laue_3x32_d20_S9",
                               "double_wilson_5x64", "double_wilson_lane_20x10", "wide_3x128_S4", "wide_2x96_noimg", "deep_12x64_S3", "deep_25x10",
-                              "ev11_5x64", "ev11_lane_20x10", "ev11_narrow_6x10_S5", "ev11_laue_3x32", "ev11_wide_2x80_S4"])
+                              "ev11_5x64", "ev11_lane_20x10", "ev11_narrow_6x10_S5", "ev11_laue_3x32", "ev11_wide_2x80_S4", "peel_20x10_d41_S3"])
 def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypatch):
     """`model.deterministic = True` (or CARELESS_HIP_DETERMINISTIC=1): the fused kernel stores per-observation contributions instead of
     issuing float atomics and `cl_det_reduce` sums them in row order (include/careless_hip.h).  Same parity bar against the oracle,
