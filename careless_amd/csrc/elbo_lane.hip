@@ -152,7 +152,8 @@ struct LSmem {
 // training step of a production run uses none of them: its instance (FULL = false) carries neither their branches -- a lone wave
 // pays every one -- nor their scalar registers (the kernel spills ~90 of them into lanes of a vector register and reads them back
 // with v_readlane at the use).
-template <int W, int DMAX, bool PACKED, bool FULL>
+// DXO: a production instance (FULL = false) that also stores dZ_0 (cl_mlp_args.dZ0_out: the launch behind a peeled first layer).
+template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void elbo_lane_kernel(const cl_mlp_args A) {
     constexpr bool LX = (DMAX == 0);
@@ -288,7 +289,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     const bool det = FULL && A.dzf_obs != nullptr;          // deterministic mode: stores per (observation, sample) instead of float atomics
     // dL/d(pre-activations of layer 0) out (round 5: the launch behind a peeled first layer, cl_peel_*: a row per feature,
     // [cl_mlp_meta_rows(w)][n_pad] like meta_t)
-    const bool has_dxo = FULL && A.dZ0_out != nullptr;
+    const bool has_dxo = (FULL || DXO) && A.dZ0_out != nullptr;
     if (use_ev11) { ev.sdfac = cl_softplus(A.ev11[0]); ev.sdadd = cl_softplus(A.ev11[1]); ev.sdb = cl_softplus(A.ev11[2]); }
 
     const int n_wt = (A.n_obs + WT - 1) / WT;                        // wave tiles
@@ -887,12 +888,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #define CL_LANE_PART 0
 #endif
 
-template <int W, int DMAX, bool PACKED, bool FULL>
+template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false>
 static int launch_lane_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SM = LSmem<W, DMAX == 0>;
     const size_t sm = (size_t)SM::total(a.d) * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL>;
+    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL, DXO>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -907,11 +908,17 @@ static int launch_lane_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
 
 // the plain layout has a second instance without the optional inputs / outputs (the training step of a production run); the packed
 // layout (single-pass Laue) keeps the one full instance
-static inline bool lane_wants_full(const cl_mlp_args& a) { return a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr || a.dzf_obs != nullptr || a.dZ0_out != nullptr; }
+static inline bool lane_wants_full(const cl_mlp_args& a) { return a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr || a.dzf_obs != nullptr; }
 template <int W, int DMAX, bool PACKED>
 static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     if constexpr (PACKED) return launch_lane_inst<W, DMAX, true, true>(a, grid, st);
-    else return lane_wants_full(a) ? launch_lane_inst<W, DMAX, false, true>(a, grid, st) : launch_lane_inst<W, DMAX, false, false>(a, grid, st);
+    else {
+        if (lane_wants_full(a)) return launch_lane_inst<W, DMAX, false, true>(a, grid, st);
+        // the production step behind a peeled first layer: metadata = the peeled layer's w pre-activations, in registers (DMAX = 8 or 15)
+        if constexpr (DMAX != 0) { if (a.dZ0_out != nullptr) return launch_lane_inst<W, DMAX, false, false, true>(a, grid, st); }
+        else if (a.dZ0_out != nullptr) return launch_lane_inst<W, DMAX, false, true>(a, grid, st);
+        return launch_lane_inst<W, DMAX, false, false>(a, grid, st);
+    }
 }
 
 #ifndef CL_LANE_WMAX
@@ -959,8 +966,9 @@ int cl_lane_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
     const int W = a.w <= 4 ? 4 : (a.w <= 6 ? 6 : (a.w <= 8 ? 8 : 10));
     const int DM = a.d <= 8 ? 8 : (a.d <= DMAX_ALL ? DMAX_ALL : 0);
     const bool packed = a.row_map != nullptr;
-    return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s>%s", W, DM, packed ? "true" : "false", (packed || lane_wants_full(a)) ? "true" : "false",
-                    a.dzf_obs != nullptr ? " (deterministic stores)" : "");
+    const bool full = packed || lane_wants_full(a) || (DM == 0 && a.dZ0_out != nullptr);
+    return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s%s>%s", W, DM, packed ? "true" : "false", full ? "true" : "false",
+                    (!full && a.dZ0_out != nullptr) ? ", true" : "", a.dzf_obs != nullptr ? " (deterministic stores)" : "");
 }
 
 int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {

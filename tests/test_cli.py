@@ -253,3 +253,25 @@ def test_deterministic_command_line_runs_write_identical_files(tmp_path, monkeyp
         a, b = read_mtz(outs[0] + "_0.mtz"), read_mtz(outs[1] + "_0.mtz")
         for col in ("F", "SigF", "I", "SigI"):
             assert np.array_equal(a.columns[col], b.columns[col]), (tag, col)
+
+
+def test_default_scaler_on_four_positionally_encoded_keys(tmp_path):
+    """`--positional-encoding-keys` with four keys at the default `-L 4` gives 6 + 32 = 38 metadata columns on the default 20 x 10 scaler
+    (careless/args/positional_encoding.py:24-37, args/scaling.py:21-31): past the lane kernel's 31 columns the first layer is peeled
+    (csrc/elbo_peel.hip).  The run trains, validates, merges half datasets with the scaler frozen and writes every file; reloading its
+    weights and freezing the scaler leaves the first layer's parameters untouched."""
+    out = str(tmp_path / "a")
+    flags = (f"mono --iterations={niter} --disable-progress-bar --test-fraction 0.2 --merge-half-datasets --mc-samples 3 "
+             "--positional-encoding-keys X,Y,Hobs,Kobs dHKL,image_id,X,Y,Hobs,Kobs")
+    args, model, hist = _run(flags, [PYP], out, False)
+    eng = model._engine
+    assert eng.peel and eng.d == 38 and "elbo_lane_kernel" in eng.kernel_name()
+    assert "NLL_val" in hist and np.all(np.isfinite(hist["NLL_val"])) and os.path.exists(out + "_xval_0.mtz")
+    flat = lambda m: m._engine.mlp.flat.cpu().numpy()
+    w0 = flat(model)[: 10 * 38]
+    assert np.abs(w0 - np.eye(10, 38).reshape(-1)).max() > 0                  # the peeled layer's kernel was trained (identity-initialised, nn.py:62-67)
+    out2 = str(tmp_path / "b")
+    flags2 = (f"mono --iterations=3 --disable-progress-bar --scale-file {out}_scale --structure-factor-file {out}_structure_factor --freeze-scales "
+              "--mc-samples 3 --positional-encoding-keys X,Y,Hobs,Kobs dHKL,image_id,X,Y,Hobs,Kobs")
+    _, model2, _ = _run(flags2, [PYP], out2, False)
+    assert np.array_equal(flat(model2), flat(model))

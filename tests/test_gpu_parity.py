@@ -1019,9 +1019,11 @@ def test_freeze_flags_and_early_stop():
                                 dict(N=500, R=60, d0=5, L=2, w=32, S=2, double_wilson=True, optimize_dw_r=True),
                                 dict(N=600, R=40, d0=5, L=2, w=96, S=2),
                                 dict(N=600, R=50, L=2, w=32, S=2, laue=True, ev11=True),
-                                dict(N=700, R=40, d0=5, L=2, w=96, S=2, n_images=6, image_layers=1)],
+                                dict(N=700, R=40, d0=5, L=2, w=96, S=2, n_images=6, image_layers=1),
+                                dict(N=900, R=40, d0=37, L=20, w=10, S=3, perturb=0.02)],
                          ids=["mono", "laue", "double_wilson", "image_layers", "chained_scaler", "laue_image_layers", "cli_default_20x10",
-                              "cli_default_posenc_d21_S9", "ev11", "trainable_double_wilson_r", "wide_2x96", "laue_ev11", "wide_image_layers"])
+                              "cli_default_posenc_d21_S9", "ev11", "trainable_double_wilson_r", "wide_2x96", "laue_ev11", "wide_image_layers",
+                              "peeled_first_layer_d37"])
 @pytest.mark.parametrize("split", ["rows", "owners"])
 def test_rank_shards_sum_to_full_batch_on_gpu(kw, split):
     """Data-parallel decomposition on ONE GPU: the engines of rank 0 and rank 1 of a 2-rank world (all-reduce skipped) produce
@@ -1095,8 +1097,10 @@ def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch(o
 
 @pytest.mark.parametrize("kw", [dict(N=1500, R=60, d0=5, L=5, w=64, S=3, likelihood="studentt", dof=8.0),
                                 dict(N=1300, R=50, d0=5, posenc=True, L=20, w=10, S=2, perturb=0.02),
-                                dict(N=1100, R=50, d0=5, L=12, w=32, S=2)],
-                         ids=["mono_5x64", "cli_default_posenc_d21", "chained_12x32"])
+                                dict(N=1100, R=50, d0=5, L=12, w=32, S=2),
+                                dict(N=1200, R=50, d0=41, L=20, w=10, S=2, perturb=0.02),
+                                dict(N=1000, R=50, d0=5, posenc=True, L=9, w=13, S=2, perturb=0.03)],
+                         ids=["mono_5x64", "cli_default_posenc_d21", "chained_12x32", "peeled_lane_d41", "peeled_narrow_9x13_d21"])
 def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
     """A shard whose metadata image would pass 4 GiB runs as consecutive launches (engine.ObsChunks; the reference is full-batch at
     any N, variational.py:255-256).  With the bound lowered to a few hundred rows the same problem runs as 4 - 6 launches: loss,

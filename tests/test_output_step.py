@@ -17,6 +17,7 @@ CASES = {
     "mono_2x32": dict(N=500, R=40, d0=5, L=2, w=32, S=2),
     "mono_softplus_shift_noimg": dict(N=400, R=50, d0=6, L=3, w=20, S=1, bijector="softplus", shift=3.5, use_image_scales=False),
     "mono_cli_default_20x10": dict(N=600, R=50, d0=5, L=20, w=10, S=1, perturb=0.02),
+    "mono_peeled_first_layer_20x10_d37": dict(N=600, R=50, d0=37, L=20, w=10, S=2, perturb=0.02),
     "laue_2x32": dict(N=600, R=50, L=2, w=32, S=2, laue=True),
     "laue_groups_up_to_12_rows": dict(N=700, R=50, L=2, w=32, S=1, laue=True, regroup=4),
     "laue_rows_shuffled_softplus": dict(N=500, R=40, L=2, w=32, S=1, laue=True, bijector="softplus", shift=1.5, shuffle=True),
