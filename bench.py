@@ -331,7 +331,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
     # the dominant kernel is timed live with events on the stream it is launched on (torch's current stream):
     # the fused scaler kernel, one launch per step (mono, single-pass Laue), or forward + backward launches around the
     # harmonic sums (two-pass Laue fallback)
-    timed_names = ("cl_elbo_mono_fwd_bwd", "cl_mlp_forward", "cl_mlp_backward_ext")
+    timed_names = ("cl_elbo_mono_fwd_bwd", "cl_mlp_forward", "cl_mlp_backward_ext", "cl_peel_forward", "cl_peel_backward")      # (peeled first layer: its two calls count)
     if eng.wide:                    # width > 64: the layer-by-layer GEMM launches of csrc/wide_gemm.hip are the dominant kernels
         timed_names = ("cl_wide_dense_forward", "cl_wide_dense_forward_head", "cl_wide_dense_forward_head_lik", "cl_wide_dense2_forward", "cl_wide_dense_dgrad", "cl_wide_dense_dgrad_pre",
                        "cl_wide_dense_dgrad_pre_wgrad0", "cl_wide_dense_dgrad_head", "cl_wide_dense_wgrad", "cl_wide_dense_wgrad_pre", "cl_wide_dense_wgrad_head",
@@ -424,7 +424,7 @@ def run_workload(args, name, nobs, steps, warmup, rank, world, use_dist):
                    "parallelism": (("reflection-owner shard" if eng.owner else "obs-shard") + f" x{eng.shard.world}") if eng.shard.world > 1 else "single",
                    "loss_finite": finite, "final_loss": hist["loss"][-1] if hist["loss"] else None},
         "loss_history": [float(v) for v in hist["loss"]],
-        "roofline": {"bound": "mfma", "kernel": (kernel_name + " (" + ("cl_wide_* GEMM launches" if eng.wide else ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd")) + ")"),
+        "roofline": {"bound": "mfma", "kernel": (kernel_name + " (" + ("cl_wide_* GEMM launches" if eng.wide else ("cl_peel_forward + cl_elbo_mono_fwd_bwd + cl_peel_backward" if getattr(eng, "peel", False) else ("cl_mlp_forward + cl_mlp_backward_ext" if launches_per_step == 2 else "cl_elbo_mono_fwd_bwd"))) + ")"),
                      "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
                      "traffic": traffic_bytes(name, world)[0], "traffic_from": _traffic_from(name, world), "kernel_ms": kern_ms, "flops_per_obs": F, "obs_per_launch": eng.N,
                      "achieved_on_step_time": achieved_step, "frac_on_step_time": achieved_step / 157.3,
