@@ -37,7 +37,7 @@ int cl_mlp_default_grid(void) {
 
 int cl_mlp_max_layers(int w) {
     if (w < 1 || w > 64) return 0;
-    return w <= 15 ? CL_MLP_LMAX_W16 : (w <= 32 ? CL_MLP_LMAX_W32 : CL_MLP_LMAX_W64);
+    return w <= 16 ? CL_MLP_LMAX_W16 : (w <= 32 ? CL_MLP_LMAX_W32 : CL_MLP_LMAX_W64);      // (width 16: the 16-wide instance with explicit biases, round 5)
 }
 
 int cl_mlp_max_layers_imgl(int w) {

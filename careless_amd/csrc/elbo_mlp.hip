@@ -186,7 +186,10 @@ struct AccPlan {
 // (forward writes its last activations, A.act_out; backward starts from their gradient, A.dH_ext) and may return the gradient
 // w.r.t. its input (A.dX_out: the first layer gets a dgrad too).
 // ILAY: the packed unit is compiled with (ILAY) and without the per-image-layer code: single-pass Laue only needs the packed layout
-// KS: narrow kernel only -- number of 4-feature MFMA steps the hidden width needs (2, 3 or 4; see KPERM)
+// KS: narrow kernel only -- number of 4-feature MFMA steps the hidden width needs (2, 3 or 4; see KPERM); 5 = hidden width EXACTLY 16
+//     (round 5): four steps and NO constant-one feature -- slot 15 is a real feature, the bias gradient is the row sum of dZ as in the
+//     wider instances (`BONE` off).  Width 16 used to pad to the 32-wide instance: (16 / 32)^2 of its MFMAs useful, slower than width 15
+//     in absolute time and no faster than width 32 (profiles/r5_envelope_widths_16_64.txt).
 // DET: names the deterministic compilation's instances (their bodies differ by preprocessor: without a template argument of their own
 // they would be the same symbols as the plain unit's and the linker would keep one of the two)
 template <int WP, int DP, int LMAX, int MODE, bool IMGL, bool CHAIN = false, bool ILAY = IMGL, int KS = 4, bool DET = (CL_DET != 0)>
@@ -220,7 +223,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     // LeakyReLU(1) = 1), and nothing reads it: the next layer's weight column 15 is zero padding.  Column 15 of a layer's dW^T
     // accumulator is then sum_obs dZ[o][obs] * 1 = the BIAS gradient, for free inside the wgrad MFMAs: no LMAX bias registers, no
     // re-read of the dZ tile (a third of this kernel's LDS traffic), no row sums.  Layer 0 (metadata input) keeps its own sum.
-    constexpr bool BONE = WLOC;
+    constexpr bool BONE = WLOC && (KS != 5);
     // Narrow kernel: hidden feature f lives in accumulator row ("slot") 4 (f & 3) + (f >> 2) instead of row f (an involution; every
     // LDS image and the gradient flush use it consistently).  MFMA step t of a layer then contracts the features 4t .. 4t+3 rather
     // than {t, 4+t, 8+t, 12+t}, so for a width-w layer only ceil(w / 4) of the four forward and dgrad steps have anything to
@@ -326,7 +329,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     const int S = A.S;
     // MFMA steps of a hidden layer's forward / dgrad that hold real features: a template parameter, because a run-time test around
     // single MFMAs costs more than the skipped ones save (-8 % against +10 %)
-    constexpr int ks = KPERM ? KS : 4;     // MFMA steps of a hidden layer's forward / dgrad that hold real features
+    constexpr int ks = KPERM ? (KS == 5 ? 4 : KS) : 4;     // MFMA steps of a hidden layer's forward / dgrad that hold real features
 #ifdef CL_STAMPS
     unsigned long long st_acc[CL_NPH];
 #pragma unroll
@@ -875,6 +878,9 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
                     stz[t * PB] = dH[0][t];                                            // staging: dZ_l and H_{l-1}, this wave's columns
                     sth[t * PB] = hs[l > 0 ? l - 1 : 0][0][t];
                 }
+                // width 16 (no constant-one feature): layer l+1's bias gradient = row sums of its dZ -- the operand quad this lane just
+                // used is four observations of row j; the four lanes of a row add up in the flush
+                if (!BONE && l + 1 < LMAX) bacc[LP] += (pa4[0] + pa4[1]) + (pa4[2] + pa4[3]);
                 if (l + 1 < LMAX) { if (LP_LDS) acc_slot(LP) = accw; else wacc[LP < LREG ? LP : 0][0] = accw; }
                 CL_SCHED_FENCE();
                 // requested now, consumed one iteration from now: the operands (and LDS accumulator) of this layer's wgrad and the
@@ -898,6 +904,7 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) accw = mfma4(pa4[t], pb4[t], accw);
                     if (LP_LDS) acc_slot(LP) = accw; else wacc[LP < LREG ? LP : 0][0] = accw;
+                    if (!BONE) bacc[LP] += (pa4[0] + pa4[1]) + (pa4[2] + pa4[3]);     // (width 16: layer 1's bias gradient, as above)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) { pa4[t] = 0.0f; pb4[t] = 0.0f; }
                 }
@@ -1181,6 +1188,10 @@ void elbo_mlp_kernel(const cl_mlp_args A) {
     constexpr int SCRW = LMAX * WP + 2 * WP + 2;
     {
         float* mine = scr + wv * SCRW;
+        if (WLOC && !BONE) {             // width 16: the four lanes (j, q) of a row hold four observations' share each (layer 0: lanes q = 0 only)
+#pragma unroll
+            for (int l = 1; l < LMAX; ++l) { bacc[l] += __shfl_xor(bacc[l], 16); bacc[l] += __shfl_xor(bacc[l], 32); }
+        }
 #pragma unroll
         for (int l = 0; l < LMAX; ++l)
             if (l < Ld && lane < WP) mine[l * WP + lane] = (BONE && l > 0) ? 0.0f : bacc[l];
@@ -1319,6 +1330,9 @@ static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
         if (MODE != 1 && a.w <= 12) return launch_dp<16, L16, MODE, 3>(a, grid, st);
         return launch_dp<16, L16, MODE, 4>(a, grid, st);
     }
+#if CL_IMGL != 1
+    if (a.w == 16) return launch_dp<16, CL_MLP_LMAX_W16, MODE, 5>(a, grid, st);       // (per-image layers keep the 32-wide instance: cl_mlp_max_layers_imgl)
+#endif
     if (a.w <= 32) return (a.L + (CL_IMGL == 1 ? a.n_imgl : 0) <= 5) ? launch_dp<32, 5, MODE>(a, grid, st) : launch_dp<32, CL_MLP_LMAX_W32, MODE>(a, grid, st);
     return launch_dp<64, CL_MLP_LMAX_W64, MODE>(a, grid, st);
 }
@@ -1437,10 +1451,11 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     }
     if (a.w < 1 || a.w > 64 || a.d < 1 || a.d > 64) return snprintf(out, n, "(unsupported)");
     const int imgl = a.n_imgl > 0 ? a.n_imgl : 0;
-    const int WP = a.w <= 15 ? 16 : (a.w <= 32 ? 32 : 64);
+    const bool w16 = a.w == 16 && imgl == 0;                     // width exactly 16: the 16-wide instance without the constant-one feature (KS = 5)
+    const int WP = (a.w <= 15 || w16) ? 16 : (a.w <= 32 ? 32 : 64);
     const int DP = a.d <= 8 ? 8 : (a.d <= 32 ? 32 : 64);
-    const int LM = a.w <= 15 ? (imgl ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16) : (a.w <= 32 ? (a.L + imgl <= 5 ? 5 : CL_MLP_LMAX_W32) : CL_MLP_LMAX_W64);
-    const int KS = (a.w <= 15 && mode != 1) ? (a.w <= 8 ? 2 : (a.w <= 12 ? 3 : 4)) : 4;
+    const int LM = (a.w <= 15 || w16) ? (imgl ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16) : (a.w <= 32 ? (a.L + imgl <= 5 ? 5 : CL_MLP_LMAX_W32) : CL_MLP_LMAX_W64);
+    const int KS = w16 ? 5 : ((a.w <= 15 && mode != 1) ? (a.w <= 8 ? 2 : (a.w <= 12 ? 3 : 4)) : 4);
     return snprintf(out, n, "elbo_mlp_kernel<%d, %d, %d, %d%s, KS=%d>", WP, DP, LM, mode, unit, KS);
 }
 

@@ -248,7 +248,9 @@ class ElboEngine(WidePath):
         # launches only: forward-only / external-gradient launches (predictions, two-pass Laue) keep the original scaler.
         # The same for every other scaler of hidden width <= 15 on more than 15 columns: elbo_narrow.hip holds <= 15 of them.
         lane_shape = self.L == 20 and self.w <= 10 and os.environ.get("CARELESS_HIP_LANE", "1") != "0"
-        self.peel = (not self.wide and self.blocks is None and imgl is None and self.w <= 15 and self.L <= 20 and
+        # (widths 13 .. 15 -- the narrow kernel's four-step instance, ~90 spilled registers -- are no faster there than on the 16-wide
+        #  instance of elbo_mlp.hip, which takes up to 64 columns itself: profiles/r5_envelope.txt, 20 x 15 on 37 columns 2.02 against 2.19 ms)
+        self.peel = (not self.wide and self.blocks is None and imgl is None and self.w <= 12 and self.L <= 20 and
                      self.d > (31 if lane_shape else 15) and self.d > self.w and bool(self.lib.cl_peel_supported(self.d, self.w, self.L)) and
                      os.environ.get("CARELESS_HIP_NARROW", "1") != "0")
         if imgl is not None:

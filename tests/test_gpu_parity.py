@@ -91,6 +91,15 @@ CASES = {
     "laue_two_pass_narrow_8x5": dict(N=500, R=40, L=8, w=5, S=2, laue=True, two_pass=True, perturb=0.03),
     "mlp8x24_S2_studentt": dict(N=300, R=30, d0=5, L=8, w=24, S=2, likelihood="studentt", dof=4.0, perturb=0.03),
     "mlp12x16_d21_S3": dict(N=260, R=30, d0=5, posenc=True, L=12, w=16, S=3, perturb=0.02),
+    # width EXACTLY 16 (round 5): the 16-wide instance without the constant-one feature (slot 15 is feature 15, explicit bias gradient), up to
+    # 20 layers in one launch -- it used to pad to the 32-wide instance
+    "w16_20x16_S2_studentt": dict(N=700, R=40, d0=5, L=20, w=16, S=2, likelihood="studentt", dof=8.0, perturb=0.02, grid=2),
+    "w16_3x16_d40_S1_softplus_ev11": dict(N=500, R=40, d0=40, L=3, w=16, S=1, bijector="softplus", shift=0.5, ev11=True, perturb=0.03),
+    "w16_laue_single_pass_8x16_S3": dict(N=800, R=40, L=8, w=16, S=3, laue=True, perturb=0.03, grid=2),
+    "w16_laue_two_pass_5x16": dict(N=500, R=40, L=5, w=16, S=2, laue=True, two_pass=True, perturb=0.03),
+    "w16_deep_25x16_klweight": dict(N=500, R=40, d0=5, L=25, w=16, S=2, kl_weight=0.5, perturb=0.02),
+    "w16_double_wilson_6x16_d9": dict(N=400, R=60, d0=9, L=6, w=16, S=2, double_wilson=True, perturb=0.03),
+    "w16_image_layers1_3x16": dict(N=700, R=40, d0=5, L=3, w=16, S=2, n_images=5, image_layers=1, perturb=0.03),
     "ev11_normal_2x32_S3": dict(N=400, R=40, d0=5, L=2, w=32, S=3, ev11=True),
     "ev11_studentt_5x64_S8": dict(N=500, R=50, d0=5, L=5, w=64, S=8, ev11=True, likelihood="studentt", dof=8.0),
     "ev11_laue_normal_2x32_S2": dict(N=400, R=40, L=2, w=32, S=2, laue=True, ev11=True),
@@ -1173,11 +1182,12 @@ def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
                                 dict(N=700, R=40, L=3, w=32, S=2, laue=True, ev11=True),
                                 dict(N=900, R=50, d0=5, L=2, w=80, S=4, ev11=True),
                                 # a peeled first layer (round 5): its weight gradient sums per-workgroup partials in index order
-                                dict(N=1100, R=50, d0=41, L=20, w=10, S=3, likelihood="studentt", dof=8.0, perturb=0.02, n_images=6)],
+                                dict(N=1100, R=50, d0=41, L=20, w=10, S=3, likelihood="studentt", dof=8.0, perturb=0.02, n_images=6),
+                                dict(N=900, R=50, d0=5, L=12, w=16, S=3, perturb=0.02)],
                          ids=["mono_5x64", "cli_default_20x10", "rows_in_arbitrary_order_S8", "no_image_scales_klweight",
                               "lane_posenc_d21_S8", "lane_20x8_S11", "narrow_6x10_S5", "narrow_9x13_d12", "laue_lane_20x10_S3", "laue_narrow_4x12", "laue_5x64_S3", "laue_3x32_d20_S9",
                               "double_wilson_5x64", "double_wilson_lane_20x10", "wide_3x128_S4", "wide_2x96_noimg", "deep_12x64_S3", "deep_25x10",
-                              "ev11_5x64", "ev11_lane_20x10", "ev11_narrow_6x10_S5", "ev11_laue_3x32", "ev11_wide_2x80_S4", "peel_20x10_d41_S3"])
+                              "ev11_5x64", "ev11_lane_20x10", "ev11_narrow_6x10_S5", "ev11_laue_3x32", "ev11_wide_2x80_S4", "peel_20x10_d41_S3", "w16_12x16_S3"])
 def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypatch):
     """`model.deterministic = True` (or CARELESS_HIP_DETERMINISTIC=1): the fused kernel stores per-observation contributions instead of
     issuing float atomics and `cl_det_reduce` sums them in row order (include/careless_hip.h).  Same parity bar against the oracle,

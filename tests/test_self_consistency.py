@@ -17,6 +17,7 @@ CASES = {
     "cli_default_20x10": dict(N=600, R=40, d0=5, L=20, w=10, S=2, perturb=0.02),
     "peeled_first_layer_20x10_d37": dict(N=600, R=40, d0=37, L=20, w=10, S=2, perturb=0.02),
     "narrow_7x12": dict(N=500, R=40, d0=5, L=7, w=12, S=2, perturb=0.03),
+    "width_16_exactly_9x16": dict(N=500, R=40, d0=5, L=9, w=16, S=2, perturb=0.03),
     "laue_single_pass_2x32": dict(N=600, R=50, L=2, w=32, S=2, laue=True),
     "double_wilson_2x32": dict(N=500, R=60, d0=5, L=2, w=32, S=2, double_wilson=True),
     "chained_12x32": dict(N=500, R=40, d0=5, L=12, w=32, S=2),
