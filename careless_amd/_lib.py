@@ -231,7 +231,7 @@ def check(code: int, what: str) -> None:
     if code == -2:
         raise NotImplementedError(
             f"{what}: scaler geometry not supported by the fused gfx950 kernel "
-            "(needs mlp_width <= 64, metadata width <= 64 and mlp_layers <= 20 / 10 / 5 for width <= 15 / 32 / 64)")
+            "(needs mlp_width <= 64, metadata width <= 64 and mlp_layers <= 20 / 10 / 5 for width <= 16 / 32 / 64)")
     if code == -4:
         raise ValueError(f"{what}: one launch addresses < 4 GiB of metadata, z_f and per-(row, sample) arrays (32-bit lane offsets); the "
                          "engine cuts plain-layout shards into several launches (engine.ObsChunks) -- a packed layout (Laue, per-image "

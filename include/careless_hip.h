@@ -38,11 +38,11 @@ extern "C" {
 /* deepest scaler the fused kernel is instantiated for, by hidden width (cl_mlp_max_layers) */
 #ifndef CL_MLP_LMAX_W16
 #define CL_MLP_LMAX_W16 20
-#endif /* width <= 15 (the careless CLI default is 20 layers x width 10); padded feature 15 carries the bias gradient */
+#endif /* width <= 16 (the careless CLI default is 20 layers x width 10); width <= 15: padded feature 15 carries the bias gradient */
 #ifndef CL_MLP_LMAX_W16_IMGL
 #define CL_MLP_LMAX_W16_IMGL 24
 #endif /* width <= 15 with per-image layers: Dense + image layers (the default 20 + --image-layers <= 4) */
-#define CL_MLP_LMAX_W32 10 /* width <= 32 */
+#define CL_MLP_LMAX_W32 10 /* width 17 .. 32 */
 #define CL_MLP_LMAX_W64 5  /* width <= 64 */
 #define CL_HIST_STRIDE 8  /* doubles per history record: loss, F KLDiv, NLL, Grad Norm, skipped, 3 spare */
 
