@@ -81,3 +81,26 @@ def test_worker_refuses_a_world_that_is_not_gpus(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main(["--gpus", "8", "--no-cpu-baseline"])
     assert "WORLD_SIZE=1" in str(e.value)
+
+
+def test_cpu_baseline_runs_in_a_child_process_and_a_dead_child_only_drops_the_baseline(monkeypatch):
+    """`bench.py` times the CPU baseline in a FRESH child (`--cpu-child`, sized to the cgroup's memory): the child prints one JSON object; a
+    child that dies (the host killing it for memory) leaves a `cpu_baseline` that says so instead of taking the bench line with it."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-child", json.dumps(["mono_1M_normal_5x64_S1", 5000, 1, False])],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-1000:]
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["kind"] == "port" and d["n_obs"] == 5000 and d["value"] > 0 and d["cores"] >= 1
+    assert bench._host_free_bytes() > 0
+
+    class Dead:
+        returncode, stdout, stderr = -9, "", "Killed"
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: Dead())
+    out = bench.cpu_baseline_child("mono_1M_normal_5x64_S1", 10_000_000, 5, True)
+    assert out["value"] is None and "not measured" in out["sample"] and "-9" in out["sample"]
+
+
+def test_scale_curve_script_parses():
+    assert subprocess.run(["bash", "-n", os.path.join(ROOT, "scripts", "scale_curve.sh")]).returncode == 0
+    for s in ("profiles_all.sh", "pmc_passes_step.sh", "store_profiles.sh"):
+        assert subprocess.run(["bash", "-n", os.path.join(ROOT, "scripts", s)]).returncode == 0, s

@@ -1,0 +1,42 @@
+"""The library's routing, as DESIGN.md section 4 states it, held by a test: which kernel instance a training step of a given scaler shape
+runs (`engine.kernel_name()` = `cl_mlp_kernel_name`: the library's own routing restated next to `cl_launch_mlp`), whether the first
+layer is peeled, whether the scaler runs as a chain of layer blocks or layer by layer.  A shape that silently falls off its kernel
+costs 2 - 4 x (profiles/r5_envelope*.txt) and no parity test notices.  Reference flags that choose the shape: careless/args/scaling.py:21-31
+(--mlp-layers, --mlp-width), args/positional_encoding.py:24-37 (metadata columns)."""
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+#        L   w   d    kernel-name fragment                          peel   chain blocks   wide
+TABLE = [
+    (20, 10, 5,  "elbo_lane_kernel<10, 8, false, false",          False, None, False),      # the CLI default
+    (20, 10, 21, "elbo_lane_kernel<10, 0, false, false",          False, None, False),      # + two encoded keys: metadata as LDS rows
+    (20, 10, 37, "elbo_lane_kernel<10, 15, false, false, true",   True,  None, False),      # + four encoded keys: peeled first layer
+    (20, 8,  64, "elbo_lane_kernel<8, 8, false, false, true",     True,  None, False),
+    (20, 12, 5,  "elbo_narrow_kernel<2, 3, 8",                    False, None, False),
+    (10, 10, 21, "elbo_narrow_kernel<2, 3, 8",                    True,  None, False),      # other depths, more than 15 columns: peeled, narrow kernel
+    (7,  15, 5,  "elbo_narrow_kernel<2, 4, 8",                    False, None, False),
+    (7,  15, 40, "elbo_mlp_kernel<16, 64, 20, 0, KS=4",           False, None, False),      # widths 13 .. 15 on many columns: the 16-wide instance itself
+    (10, 16, 5,  "elbo_mlp_kernel<16, 8, 20, 0, KS=5",            False, None, False),      # width exactly 16: its own instance
+    (20, 16, 21, "elbo_mlp_kernel<16, 32, 20, 0, KS=5",           False, None, False),
+    (10, 20, 5,  "elbo_mlp_kernel<32, 8, 10, 0",                  False, None, False),
+    (5,  64, 21, "elbo_mlp_kernel<64, 32, 5, 0",                  False, None, False),      # the bench line's kernel
+    (24, 10, 5,  "elbo_mlp_kernel<16, 32, 20, 0, chain",          False, 2,    False),      # deeper than one launch: two layer blocks (the last one's input is 10 wide)
+    (12, 64, 5,  "elbo_mlp_kernel<64, 64, 5, 0, chain",           False, 3,    False),
+    (3,  128, 5, "wide_sq_kernel",                                False, None, True),       # layer by layer
+]
+
+
+@pytest.mark.parametrize("L,w,d,frag,peel,blocks,wide", TABLE, ids=[f"{r[0]}x{r[1]}_d{r[2]}" for r in TABLE])
+def test_training_step_runs_on_the_kernel_the_design_names(L, w, d, frag, peel, blocks, wide):
+    from careless_amd.engine import ElboEngine
+    data, cfg, params, x, u_f, eta = util.make_problem(N=300, R=30, d0=d, L=L, w=w, S=1, perturb=0.02)
+    eng = ElboEngine(util.build_model(data, cfg, params, L, w), util.reference_inputs(data), seed=1)
+    name = eng.kernel_name()
+    assert frag in name, name
+    assert bool(eng.peel) == peel and eng.wide == wide
+    assert (eng.blocks is None) == (blocks is None) and (blocks is None or len(eng.blocks) == blocks)
+    eng.alloc_history(1)
+    eng.train_step(0)                                           # ... and the step it names runs
