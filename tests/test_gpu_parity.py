@@ -1071,15 +1071,17 @@ def test_rank_shards_sum_to_full_batch_on_gpu(kw, split):
     assert util.rel_err(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("workload", ["mono_10M_cli_default_20x10_S1", "mono_10M_studentt_posenc4_20x10_S8"], ids=["d5", "four_encoded_keys_d37_peeled"])
 @pytest.mark.parametrize("owner", [True, False], ids=["reflection_owners", "rows"])
-def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch(owner):
+def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch(owner, workload):
     """1 M observations on the careless CLI's default scaler (20 x 10: the narrow kernel instance), in-kernel noise: the eight
     rank shards of an 8-GPU job -- reflection-owner split and row split --, run one after the other on this GPU without the
     all-reduce, add up to the single-GPU step: a size-independent property (every workgroup walks dozens of tiles, the accumulators
-    carry over in registers and LDS)."""
+    carry over in registers and LDS).  Also with four positionally encoded keys (37 columns, 8 samples: the peeled first layer's
+    kernels walk every shard's rows, round 5)."""
     from careless_amd.engine import ElboEngine, make_shard
     from careless_amd.workloads import make_workload
-    model, inputs, data, spec = make_workload("mono_10M_cli_default_20x10_S1", N=1_000_000)
+    model, inputs, data, spec = make_workload(workload, N=1_000_000)
     model.owner_shard = owner
     n, r = 1_000_000, int(model.surrogate_posterior.loc_raw.numel())
     full = ElboEngine(model, inputs, seed=7)
@@ -1108,8 +1110,8 @@ def test_full_size_rank_shards_of_the_cli_default_scaler_sum_to_the_full_batch(o
                                 dict(N=1300, R=50, d0=5, posenc=True, L=20, w=10, S=2, perturb=0.02),
                                 dict(N=1100, R=50, d0=5, L=12, w=32, S=2),
                                 dict(N=1200, R=50, d0=41, L=20, w=10, S=2, perturb=0.02),
-                                dict(N=1000, R=50, d0=5, posenc=True, L=9, w=13, S=2, perturb=0.03)],
-                         ids=["mono_5x64", "cli_default_posenc_d21", "chained_12x32", "peeled_lane_d41", "peeled_narrow_9x13_d21"])
+                                dict(N=1000, R=50, d0=5, posenc=True, L=9, w=12, S=2, perturb=0.03)],
+                         ids=["mono_5x64", "cli_default_posenc_d21", "chained_12x32", "peeled_lane_d41", "peeled_narrow_9x12_d21"])
 def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
     """A shard whose metadata image would pass 4 GiB runs as consecutive launches (engine.ObsChunks; the reference is full-batch at
     any N, variational.py:255-256).  With the bound lowered to a few hundred rows the same problem runs as 4 - 6 launches: loss,

@@ -29,13 +29,14 @@ def _problem(kind, N):
     if kind == "double_wilson":
         d = make_synthetic_double_wilson(N)
         return d, reference_inputs(d), dict(parents="None,0", dwr="0.,0.9"), dict(reflids=d["parent_ids"], root=d["root"], asu_ids=d["asu_ids"])
-    d = make_synthetic(N)
+    d = make_synthetic(N, posenc=(kind == "mono_posenc4"), posenc_keys=4)       # (posenc4: 5 + 32 = 37 metadata columns -- peeled first layer)
     return d, reference_inputs(d), {}, None
 
 
 @pytest.mark.parametrize("kind,N,L,w", [("mono", 1_000_000, 5, 64), ("laue", 200_000, 5, 64), ("double_wilson", 200_000, 5, 64),
-                                        ("mono", 300_000, 20, 10)],
-                         ids=["mono_1M_normal_5x64_S1", "laue_200k_5x64", "double_wilson_200k_5x64", "mono_300k_cli_default_20x10"])
+                                        ("mono", 300_000, 20, 10), ("mono_posenc4", 300_000, 20, 10), ("mono", 300_000, 10, 16)],
+                         ids=["mono_1M_normal_5x64_S1", "laue_200k_5x64", "double_wilson_200k_5x64", "mono_300k_cli_default_20x10",
+                              "mono_300k_four_encoded_keys_20x10_peeled", "mono_300k_10x16"])
 def test_training_recovers_the_true_amplitudes_and_half_datasets_agree(kind, N, L, w):
     from careless_amd.manager import DataManager, default_args, merge_half_datasets
     steps = 1500
