@@ -723,12 +723,14 @@ class ElboEngine(WidePath):
             self._fused_step_launch(ma, obs, st)
             npad = int(obs.pad_iobs.numel())
             if npad > 0:
-                obs.pad_iconv.zero_()
+                uniform = getattr(obs, "pad_uniform", False)            # all padded slots alike: one slot, weight x their number
+                nslot = 1 if uniform else npad
+                obs.pad_iconv[: nslot * self.S].zero_()
                 la = LaueArgs()
                 la.iobs, la.sig, la.iconv = ptr(obs.pad_iobs), ptr(obs.pad_sig), ptr(obs.pad_iconv)
-                la.n_obs, la.S = npad, self.S
+                la.n_obs, la.S = nslot, self.S
                 la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
-                la.w_ll = ma.w_ll
+                la.w_ll = ma.w_ll * (npad if uniform else 1)
                 la.scalars, la.stop_flag = ptr(self.scalars), ptr(self.stop_flag)
                 la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
                 if self.deterministic:      # the padded slots' workgroups store their NLL behind the fused launch's parts
