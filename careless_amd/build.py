@@ -28,7 +28,9 @@ UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=
          ("elbo_lane.hip", "elbo_lane2", ["-DCL_LANE_PART=2", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
          ("elbo_lane.hip", "elbo_lane3", ["-DCL_LANE_PART=3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", []), ("wide_gemm.hip", "wide_gemm", []),
-         ("elbo_peel.hip", "elbo_peel", [])]
+         ("elbo_peel.hip", "elbo_peel", []),
+         # host threads, no device code: the formatter's symmetry bookkeeping (exact products kept apart from their sums)
+         ("host_format.cpp", "host_format", ["-ffp-contract=off", "-pthread"])]
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["cl_math.h", "cl_kernels.h", os.path.join("..", "..", "include", "careless_hip.h")]
 ARCH = "gfx950"
@@ -64,7 +66,7 @@ def source_hash() -> str:
     import hashlib
     h = hashlib.sha256()
     inc = os.path.join(HERE, "..", "include", "careless_hip.h")
-    for f in sorted(os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith((".hip", ".h"))) + [inc, os.path.abspath(__file__)]:
+    for f in sorted(os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith((".hip", ".h", ".cpp"))) + [inc, os.path.abspath(__file__)]:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode() + b"\0" + fh.read())
     return h.hexdigest()[:12]
@@ -108,7 +110,7 @@ def _build(LIB: str, extra, verbose: bool) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -101,39 +101,39 @@ class SymmetryOps:
                     break
         return self._case
 
-    _CHUNK = 1 << 18          # rows mapped at a time: the orbit of a chunk is (2 nops, chunk, 3) int64, ~600 MB for 48 operators
+    def _map(self, hkl: np.ndarray, anomalous: bool, want_asu: bool, want_flags: bool):
+        """One pass of `cl_host_asu_map` (careless_amd/csrc/host_format.cpp; host threads) over the rows of `hkl`."""
+        import ctypes as C
+        from careless_amd._lib import check, get_lib
+        h = np.ascontiguousarray(np.asarray(hkl).reshape(-1, 3), dtype=np.int64)
+        if len(h) and np.abs(h).max() >= (1 << 19):
+            raise ValueError("Miller index beyond +-2^19")
+        h32 = np.ascontiguousarray(h, dtype=np.int32)
+        n = len(h32)
+        rot = np.ascontiguousarray(self.R, dtype=np.int32)
+        trans = np.ascontiguousarray(self.t, dtype=np.float64)
+        case = self.asu_case() if want_asu else None
+        hasu = np.empty((n, 3), dtype=np.int32) if want_asu else None
+        centric = np.empty(n, dtype=np.uint8) if want_flags else None
+        eps = np.empty(n, dtype=np.int32) if want_flags else None
+        absent = np.empty(n, dtype=np.uint8) if want_flags else None
+        p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        check(get_lib().cl_host_asu_map(p(h32), n, p(rot), p(trans), len(rot), -1 if case is None else int(case), int(bool(anomalous)),
+                                        p(hasu), p(centric), p(eps), p(absent), 0), "cl_host_asu_map")
+        return hasu, centric, eps, absent
 
     def to_asu(self, hkl: np.ndarray, anomalous: bool = False) -> np.ndarray:
-        hkl = np.asarray(hkl, dtype=np.int64)
-        if len(hkl) > self._CHUNK:
-            return np.concatenate([self.to_asu(hkl[i:i + self._CHUNK], anomalous) for i in range(0, len(hkl), self._CHUNK)])
-        rot = self.orbit(hkl)
-        orb = np.concatenate([rot, -rot], axis=0)
-        case = self.asu_case()
-        if case is None:
-            best = np.argmax(_key(orb), axis=0)
-        else:
-            best = np.argmax(_CCP4_ASU[case](orb[..., 0], orb[..., 1], orb[..., 2]), axis=0)   # first member inside
-        rep = np.take_along_axis(orb, best[None, :, None], axis=0)[0]
-        if anomalous:
-            # Friedel-minus: the representative is not among the rotation images (so the reflection is acentric)
-            minus = ~np.any(np.all(rot == rep[None], axis=2), axis=0)
-            rep = np.where(minus[:, None], -rep, rep)
-        return rep
+        return self._map(hkl, anomalous, True, False)[0].astype(np.int64)
 
     def describe(self, hkl: np.ndarray):
         """centric (N,) bool, epsilon (N,) int, absent (N,) bool."""
-        h = np.asarray(hkl, dtype=np.int64)
-        if len(h) > self._CHUNK:
-            parts = [self.describe(h[i:i + self._CHUNK]) for i in range(0, len(h), self._CHUNK)]
-            return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
-        orb = self.orbit(h)
-        same = np.all(orb == h[None], axis=2)
-        eps = same.sum(0)
-        phase = np.einsum("ni,oi->on", h.astype(np.float64), self.t)
-        absent = np.any(same & (np.abs(phase - np.round(phase)) > 1e-6), axis=0)
-        centric = np.any(np.all(orb == -h[None], axis=2), axis=0)
-        return centric, eps, absent
+        _, centric, eps, absent = self._map(hkl, False, False, True)
+        return centric.astype(bool), eps.astype(np.int64), absent.astype(bool)
+
+    def map_rows(self, hkl: np.ndarray, anomalous: bool = False):
+        """(ASU representative int64 (N, 3), centric, epsilon, absent) of every row in ONE pass (the formatter's per-observation call)."""
+        hasu, centric, eps, absent = self._map(hkl, anomalous, True, True)
+        return hasu.astype(np.int64), centric.astype(bool), eps.astype(np.int64), absent.astype(bool)
 
 
 class ReciprocalASU:

@@ -33,8 +33,34 @@ def standardize_metadata(metadata: np.ndarray, metadata_keys: Optional[Sequence[
 
 
 def _ngroup(*cols) -> np.ndarray:
-    """pandas `groupby(cols).ngroup()`: dense ids in sorted key order."""
-    keys = np.stack([np.asarray(c) for c in cols], axis=1)
+    """pandas `groupby(cols).ngroup()`: dense ids in sorted key order (reference formatter.py:203, 617).  Integer columns fold into ONE
+    int64 key whose order is the columns' lexicographic order; a key range of the order of the row count is ranked through a presence
+    table (`cl_host_dense_ids`, careless_amd/csrc/host_format.cpp: no sort -- the image ids), a larger one by sorting the key."""
+    cols = [np.asarray(c).reshape(-1) for c in cols]
+    n = len(cols[0])
+    if n == 0:
+        return np.zeros(0, dtype=np.int64)
+    if all(np.issubdtype(c.dtype, np.integer) for c in cols):
+        lo = [int(c.min()) for c in cols]
+        span = [int(c.max()) - l + 1 for c, l in zip(cols, lo)]
+        total = 1
+        for v in span:
+            total *= v
+        if total < (1 << 62):
+            key = np.zeros(n, dtype=np.int64)
+            for c, l, v in zip(cols, lo, span):
+                key *= v
+                key += c.astype(np.int64) - l
+            if total <= max(1 << 22, 4 * n):
+                import ctypes as C
+                from careless_amd._lib import check, get_lib
+                ids = np.empty(n, dtype=np.int64)
+                check(get_lib().cl_host_dense_ids(key.ctypes.data_as(C.c_void_p), n, 0, total - 1, ids.ctypes.data_as(C.c_void_p), None, 0),
+                      "cl_host_dense_ids")
+                return ids
+            _, inv = np.unique(key, return_inverse=True)
+            return inv.reshape(-1).astype(np.int64)
+    keys = np.stack(cols, axis=1)
     _, inv = np.unique(keys, axis=0, return_inverse=True)
     return inv.reshape(-1).astype(np.int64)
 
@@ -125,11 +151,13 @@ class DataFormatter:
     def _common_prep(self, cols: Dict[str, np.ndarray], mtz: Mtz, keys) -> Dict[str, np.ndarray]:
         ops = SymmetryOps(mtz.symops)
         H = np.stack([cols["H"], cols["K"], cols["L"]], axis=1).astype(np.int64)
-        _, _, absent = ops.describe(H)                                   # ds.remove_absences
-        cols = {k: np.asarray(v)[~absent] for k, v in cols.items()}
-        H = H[~absent]
+        Hasu, _, _, absent = ops.map_rows(H, self.anomalous)            # ds.remove_absences + ds.hkl_to_asu in one native pass
+        if absent.any():
+            keep = ~absent
+            cols = {k: np.asarray(v)[keep] for k, v in cols.items()}
+            H, Hasu = H[keep], Hasu[keep]
+        cols = dict(cols)
         cols["Hobs"], cols["Kobs"], cols["Lobs"] = H.T.astype(np.float32)
-        Hasu = ops.to_asu(H, self.anomalous)                              # ds.hkl_to_asu
         cols["H"], cols["K"], cols["L"] = Hasu.T
         cols["dHKL"] = (1.0 / np.sqrt(inv_d2(Hasu, mtz.cell))).astype(np.float32)
         image_key, intensity_key, uncertainty_key = keys
@@ -138,7 +166,8 @@ class DataFormatter:
         cols["image_id"] = np.asarray(cols[image_key]).astype(np.int64)
         if self.isigi_cutoff is not None:
             keep = ~(cols["intensity"] / cols["uncertainty"] < self.isigi_cutoff)
-            cols = {k: v[keep] for k, v in cols.items()}
+            if not keep.all():
+                cols = {k: v[keep] for k, v in cols.items()}
         return cols
 
     # -- all files ----------------------------------------------------------------------------------------
@@ -225,7 +254,8 @@ class MonoFormatter(DataFormatter):
         cols = dict(mtz.columns)
         d = 1.0 / np.sqrt(inv_d2(mtz.hkl(), mtz.cell))
         keep = ~(d < self.dmin)                                           # resolution cut (formatter.py:296-297)
-        cols = {k: v[keep] for k, v in cols.items()}
+        if not keep.all():
+            cols = {k: v[keep] for k, v in cols.items()}
         return self._common_prep(cols, mtz, keys)
 
     def finalize(self, data, rac):

@@ -464,6 +464,29 @@ int cl_peel_backward(const float* meta_t, int n_obs, int n_pad, int d, int w, in
 int cl_tn_moments(const float* q_loc_raw, const float* q_scale_raw, const float* low, int R, double high_moments, double high_m4, float eps,
                   float* mean, float* std, double* m4, void* stream);
 
+/* --- formatting step: symmetry bookkeeping of the reflection tables (HOST pointers, host threads; no stream) ---------------------------
+ * replaces: DataSet.remove_absences(), DataSet.hkl_to_asu(anomalous=...) and the centric / multiplicity labels the reference takes from
+ *           reciprocalspaceship / gemmi (C++) while formatting -- careless/io/formatter.py:285-302, 319 (MonoFormatter.prep_dataset),
+ *           :540-562 (LaueFormatter), careless/io/asu.py:27-56 (ReciprocalASU) -- and pandas' groupby(...).ngroup() behind the image ids
+ *           (careless/io/formatter.py:203).
+ * cl_host_asu_map: for every Miller index hkl[i] (int32 [n][3]) under the operators rot[o] (int32 [nops][3][3], acting on row vectors:
+ *           h' = h R) and trans[o] (fractions of the cell, [nops][3]):
+ *             eps[i]     = number of operators with h R = h                              (multiplicity of the reflection)
+ *             absent[i]  = any such operator with h . t not an integer (tolerance 1e-6)   (systematic absence)
+ *             centric[i] = any operator with h R = -h
+ *             hasu[i]    = the reciprocal-ASU representative: the first member of (h R_0 .. h R_{nops-1}, -h R_0 .. -h R_{nops-1}) inside
+ *                          the CCP4 inequality set `asu_case` (0 .. 9: -1, 2/m, mmm, 4/m and 6/m, 4/mmm and 6/mmm, -3, -31m, -3m1, m-3, m-3m
+ *                          in their reference settings; gemmi's ReciprocalAsu::is_in), or with asu_case = -1 the member with the largest
+ *                          (h, k, l) in lexicographic order; anomalous != 0: a representative that no ROTATION image reaches is a
+ *                          Friedel-minus and is stored negated, as hkl_to_asu(anomalous=True) does.
+ *           Any output pointer may be NULL (absent needs trans).  nthreads <= 0: the cores the process may run on, at most 32.
+ * cl_host_dense_ids: ids[i] = rank of key[i] among the DISTINCT keys in ascending order (groupby(...).ngroup() of one integer key),
+ *           *n_groups = their number; all keys inside [key_min, key_max].  A presence table over the range: returns -2 when the range
+ *           exceeds 2^31 slots (the caller sorts then).                                                                                  */
+int cl_host_asu_map(const int32_t* hkl, long long n, const int32_t* rot, const double* trans, int nops, int asu_case, int anomalous,
+                    int32_t* hasu, uint8_t* centric, int32_t* eps, uint8_t* absent, int nthreads);
+int cl_host_dense_ids(const int64_t* key, long long n, int64_t key_min, int64_t key_max, int64_t* ids, long long* n_groups, int nthreads);
+
 /* --- diagnostics -------------------------------------------------------------------------------------------------- */
 const char* cl_version(void);
 /* sizeof(cl_tn_args), sizeof(cl_mlp_args), sizeof(cl_adam_args), sizeof(cl_laue_args), sizeof(cl_det_args): lets a binding verify its mirrors */
