@@ -214,6 +214,8 @@ class ReciprocalASUCollection:
     def to_refl_id(self, asu_ids, H) -> np.ndarray:
         asu_ids = np.asarray(asu_ids, dtype=np.int64).reshape(-1)
         H = np.asarray(H, dtype=np.int64)
+        if len(self.reciprocal_asus) == 1 and (len(asu_ids) == 0 or (asu_ids.min() == 0 and asu_ids.max() == 0)):
+            return self.reciprocal_asus[0].to_refl_id(H)                 # (one ASU: no row selection, no copies)
         out = np.empty(len(asu_ids), dtype=np.int64)
         for i, a in enumerate(self.reciprocal_asus):
             m = asu_ids == i

@@ -204,7 +204,7 @@ class DataFormatter:
             metadata = standardize_metadata(metadata, self.metadata_keys)
         if self.positional_encoding_keys is not None:
             enc = np.stack([np.asarray(data[k], dtype=np.float32) for k in self.positional_encoding_keys], axis=1)
-            metadata = np.concatenate([metadata, positional_encoding(enc, self.encoding_bit_depth).astype(np.float32)], axis=1)
+            metadata = np.concatenate([metadata, positional_encoding(enc, self.encoding_bit_depth, dtype=np.float32)], axis=1)
         return metadata.astype(np.float32)
 
     @staticmethod
