@@ -142,10 +142,10 @@ class VariationalMergingModel(BaseModel):
             return self.likelihood(inputs).convolve
         return None
 
-    def scale_mean_stddev(self, inputs):
+    def scale_mean_stddev(self, inputs, scale_dist=None):
         """Moments of the posterior scale of every observation (reference variational.py:47-78).  Laue data: the moments of the
         rows of a harmonic group are summed into the group's slot (means add, variances add), slots without rows stay 0."""
-        dist = self.scaling_model(inputs)
+        dist = self.scaling_model(inputs) if scale_dist is None else scale_dist
         mean, stddev = dist.mean().cpu().numpy(), dist.stddev().cpu().numpy()
         convolve = self._convolved(inputs)
         if convolve is not None:
@@ -153,13 +153,14 @@ class VariationalMergingModel(BaseModel):
             stddev = np.sqrt(convolve(stddev * stddev))
         return mean, stddev
 
-    def prediction_mean_stddev(self, inputs):
+    def prediction_mean_stddev(self, inputs, scale_dist=None):
         """E[I] and sd[I] of every observation under the current model (reference variational.py:80-121); for Laue data
-        per harmonic slot: `iexp` and `ivar` of the member rows are summed before the square root (:113-119)."""
+        per harmonic slot: `iexp` and `ivar` of the member rows are summed before the square root (:113-119).  `scale_dist`: the
+        scaler's output on `inputs` when the caller already has it (the output step asks for the scale moments too)."""
         rid = self.get_refl_id(inputs)
         refl_id = torch.as_tensor(np.asarray(rid.cpu() if torch.is_tensor(rid) else rid).reshape(-1).astype(np.int64))
         q = self.surrogate_posterior
-        dist = self.scaling_model(inputs)
+        dist = self.scaling_model(inputs) if scale_dist is None else scale_dist
         smean, sstd = dist.mean().double().cpu(), dist.stddev().double().cpu()
         if hasattr(q, "loc_raw"):                           # truncated normal: mean, stddev and <F^4> from one `cl_tn_moments` launch
             from careless_amd.engine import tn_moments

@@ -49,7 +49,8 @@ def get_results(surrogate_posterior, inputs, output_parameters: bool = True, max
 def get_predictions(model, inputs) -> Dict[str, np.ndarray]:
     """Per-observation posterior predictive moments (reference manager.py:89-161 -> variational.py:80-121, 47-78):
     Ipred, SigIpred, Scale, SigScale."""
-    iexp, isd = model.prediction_mean_stddev(inputs)
-    smean, sstd = model.scale_mean_stddev(inputs)
+    dist = model.scaling_model(inputs)                       # ONE forward pass of the scaler serves both pairs of moments
+    iexp, isd = model.prediction_mean_stddev(inputs, scale_dist=dist)
+    smean, sstd = model.scale_mean_stddev(inputs, scale_dist=dist)
     return {"Ipred": np.asarray(iexp, dtype=np.float32), "SigIpred": np.asarray(isd, dtype=np.float32),
             "Scale": np.asarray(smean, dtype=np.float32), "SigScale": np.asarray(sstd, dtype=np.float32)}

@@ -36,6 +36,10 @@ WORKLOADS: Dict[str, dict] = {
     # --image-layers 1 on the headline configuration (one Dense layer traded for a per-image layer)
     "mono_10M_studentt_posenc_4x64_img1_S8": dict(N=10_000_000, d0=5, posenc=True, L=4, w=64, S=8, dof=16.0, outliers=True,
                                                   image_layers=1),
+    # the CLI-default scaler on the other data kinds a user runs it on (round 5: measured so that the table has no unmeasured default)
+    "laue_5M_normal_20x10_S1": dict(N=5_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, kind="laue"),
+    "dw_10M_normal_20x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, kind="double_wilson"),
+    "mono_10M_20x10_img2_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, image_layers=2),
 }
 
 
