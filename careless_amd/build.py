@@ -27,6 +27,7 @@ UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=
          ("elbo_lane.hip", "elbo_lane1", ["-DCL_LANE_PART=1", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
          ("elbo_lane.hip", "elbo_lane2", ["-DCL_LANE_PART=2", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
          ("elbo_lane.hip", "elbo_lane3", ["-DCL_LANE_PART=3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
+         ("elbo_lane.hip", "elbo_lane4", ["-DCL_LANE_PART=4", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),      # per-image layers (round 5)
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", []), ("wide_gemm.hip", "wide_gemm", []),
          ("elbo_peel.hip", "elbo_peel", []),
          # host threads, no device code: the formatter's symmetry bookkeeping (exact products kept apart from their sums)

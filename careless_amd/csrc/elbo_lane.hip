@@ -107,17 +107,23 @@ __device__ __forceinline__ T ld_uo(const T* base, unsigned byte_off) {       // 
 // row of the bias in block 0 -- reads the same rows back transposed.  The staging tiles of dZ / H then come in ONE copy instead of
 // one per layer parity (a wave's LDS operations execute in order, so the second copy only ever bought scheduling freedom): that
 // is what pays for the row buffers.
-template <int W, bool LX>
+// NI > 0 (round 5): per-image layers on top of the NL Dense ones (NeuralImageScaler): every WAVE holds the weight images of its current
+// image's layers (forward + transposed) and parks the activations of the top PK layers in LDS across the sampling epilogue, where the
+// register file is fullest; the staging tiles come in one copy (as for LX) to pay for both.
+template <int W, bool LX, int NI = 0>
 struct LSmem {
     static constexpr int NC = (W + 3) / 4;                    // 4-feature chunks of a layer's outputs
     static constexpr int IMG = NC * 64;                       // one layer's weight registers: [chunk][lane]
     static constexpr int NF = NL + 1 + (LX ? 1 : 0);          // forward images: layers 0 .. NL-1, the head (NL), LX: layer 0's second input block (NL + 1)
-    static constexpr int TPAR = LX ? 1 : 2;                   // copies of the dZ / H staging tiles
+    static constexpr int TPAR = (LX || NI > 0) ? 1 : 2;       // copies of the dZ / H staging tiles
+    static constexpr int PK = NI > 0 ? 4 : 0;                 // top layers whose activations wait in LDS during the epilogue
     static constexpr int oF = 0;
     static constexpr int oK = oF + NF * IMG;                  // transposed (dgrad) images, layers 0 .. NL-1 and the head
     static constexpr int oT = oK + (NL + 1) * IMG;            // per wave: sZ[TPAR], sH[TPAR] (by layer parity), sX (not LX)   [16][PIT] each
     static constexpr int oS = (2 * TPAR + (LX ? 0 : 1)) * 16 * PIT;   // (within a wave's region) sS: the lane's SPRE sampled amplitudes / amplitude gradients; sQ
-    static constexpr int oX = oS + (2 * SPRE + 1) * 64;       // (sS, sQ, sE: the batch's scale noise); LX: two buffers of `xrows` metadata rows [row][PIT]
+    static constexpr int oI = oS + (2 * SPRE + 1) * 64;       // (sS, sQ, sE: the batch's scale noise); NI: the wave's image-layer weight images [fwd | transposed][NI][IMG]
+    static constexpr int oP = oI + 2 * NI * IMG;              // NI: parked activations [PK][W][64]
+    static constexpr int oX = oP + PK * W * 64;               // LX: two buffers of `xrows` metadata rows [row][PIT]
     static constexpr int TWF = oX;                            // floats of a wave's region without the row buffers
     static constexpr int NACCB = NL + (LX ? 1 : 0);           // 16 x 16 accumulator blocks a wave parks in the flush
     static constexpr int REG = NACCB * 256;
@@ -153,12 +159,22 @@ struct LSmem {
 // pays every one -- nor their scalar registers (the kernel spills ~90 of them into lanes of a vector register and reads them back
 // with v_readlane at the use).
 // DXO: a production instance (FULL = false) that also stores dZ_0 (cl_mlp_args.dZ0_out: the launch behind a peeled first layer).
-template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false>
+// NI (round 5): per-image layers (NeuralImageScaler, careless/models/scaling/image.py:66-125: `--image-layers NI` on the default scaler) --
+// the NL Dense layers are followed by NI layers whose (w x w) kernel and bias belong to the IMAGE of the observation; same contract as the
+// IMGL instances of elbo_mlp.hip (A.imgl / d_imgl / n_imgl / n_images / tile_img: a 128-row tile of the packed layout holds one image).
+// A wave walks a CONTIGUOUS range of wave tiles, keeps its current image's weight images (forward + transposed) in its own LDS region and
+// the layers' weight-gradient sums in accumulator registers like any other layer's; on an image change it adds the sums to the image's
+// gradient (atomics) and reloads.  The activations of the top PK layers wait in LDS across the sampling epilogue (22 x 10 activations +
+// the epilogue's state do not fit the 512 registers; the compiler would spill to scratch, which a lone wave waits for in full).
+template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false, int NI = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void elbo_lane_kernel(const cl_mlp_args A) {
     constexpr bool LX = (DMAX == 0);
     constexpr int DREG = LX ? 1 : DMAX;               // metadata registers of the lane (LX: none; arrays keep one element)
-    using SM = LSmem<W, LX>;
+    constexpr int NLT = NL + NI;                      // hidden layers: Dense + per-image
+    static_assert(NI == 0 || (PACKED && !LX && !DXO), "per-image layers: packed layout, metadata in registers");
+    using SM = LSmem<W, LX, NI>;
+    constexpr int PK = SM::PK;
     constexpr int DGMAX = LX ? 8 : (DMAX + 3) / 4;
     constexpr int TPAR = SM::TPAR;
     constexpr int NC = SM::NC;
@@ -271,12 +287,22 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     unsigned* const sQ = reinterpret_cast<unsigned*>(sS + SPRE * 64);       // byte offset of the lane's reflection in dz_f (~0: none)
     float* const sE = sS + (SPRE + 1) * 64;            // the standard normals of the lane's observation for the samples of a batch   [sample][lane]
     float* const sXb = sZ + SM::oX;                    // LX: metadata rows of the current / the next tile: buffer (tile parity) x [xrows][PIT]
+    float* const sFi = sZ + SM::oI + lane;             // NI: forward weight register c of image layer li: sFi[li * IMG + c * 64]
+    float* const sKi = sFi + NI * IMG;                 //     transposed
+    float* const sP = sZ + SM::oP + lane;              // NI: activation f of parked layer p (= layer NLT - PK + p): sP[(p * W + f) * 64]
+    // transposed weight image of hidden layer l (l == NLT: the head)
+    auto kimg = [&](auto lc) -> const float* {
+        constexpr int l = decltype(lc)::value;
+        if constexpr (l < NL) return sK + l * IMG;
+        else if constexpr (l < NLT) return sKi + (l - NL) * IMG;
+        else return sK + NL * IMG;
+    };
     constexpr int PAR = (TPAR - 1) * 16 * PIT;         // second copy of sZ / sH (layers alternate between the two; LX: one copy)
 
     // ---- accumulators that live across all tiles of this wave ----------------------------------------------------------
-    f32x4 wacc[NL], wacd[NL];           // dW_l = wacc + wacd: lane (j, q), element t = dW_l[out 4 q + t][in j]  (in 15: the bias)
+    f32x4 wacc[NLT], wacd[NLT];         // dW_l = wacc + wacd: lane (j, q), element t = dW_l[out 4 q + t][in j]  (in 15: the bias)
 #pragma unroll
-    for (int l = 0; l < NL; ++l) { wacc[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; wacd[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    for (int l = 0; l < NLT; ++l) { wacc[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; wacd[l] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
     f32x4 wacc0b = {0.0f, 0.0f, 0.0f, 0.0f}, wacd0b = {0.0f, 0.0f, 0.0f, 0.0f};      // LX: layer 0's second input block (columns 15 .. 30)
     f32x2 hacc[W + 1];                  // head: per-lane sums of (dloc, draw) x top activation k; [W]: the bias
 #pragma unroll
@@ -344,8 +370,57 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         sgn = ld_uo(A.sig, ob);
         imgn = A.use_img ? ld_uo(A.image_id, ob) : 0;
     };
-    const int wt_begin = (int)blockIdx.x * NWV + wv;
-    if (wt_begin < n_wt) prefetch(wt_begin, 0);
+    // wave tiles of this wave: strided over all waves of the launch, or (NI) one contiguous range so that image changes are rare
+    const int gwv = (int)blockIdx.x * NWV + wv;
+    const int wt_begin = NI > 0 ? (int)((long long)gwv * n_wt / wt_step) : gwv;
+    const int wt_end = NI > 0 ? (int)((long long)(gwv + 1) * n_wt / wt_step) : n_wt;
+    const int wt_inc = NI > 0 ? 1 : wt_step;
+    if (wt_begin < wt_end) prefetch(wt_begin, 0);
+
+    // ---- per-image layers: this wave's gradient flush and weight reload on an image change ------------------------------------------
+    int cur_img = -1;
+    const size_t imgl_blk = NI > 0 ? (size_t)A.n_images * (size_t)(w * w + w) : 0;      // floats per image layer: [W: n_images x (w x w) | b: n_images x w]
+    auto imgl_flush = [&](int im) {
+        asm volatile("s_nop 15\n\ts_nop 15");      // (inline-assembly MFMAs: results land eight passes after the issue)
+#pragma unroll
+        for (int li = 0; li < NI; ++li) {
+            float* __restrict__ gW = A.d_imgl + (size_t)li * imgl_blk + (size_t)im * (size_t)(w * w);
+            float* __restrict__ gB = A.d_imgl + (size_t)li * imgl_blk + (size_t)A.n_images * (size_t)(w * w) + (size_t)im * w;
+            const f32x4 v = wacc[NL + li] + wacd[NL + li];
+            const int fi = lane & 15;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int fo = 4 * (lane >> 4) + t;
+                if (fo < w && fi < w) atomicAdd(gW + fo * w + fi, v[t]);
+                if (fo < w && fi == ONE) atomicAdd(gB + fo, v[t]);
+            }
+            wacc[NL + li] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            wacd[NL + li] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    auto imgl_load = [&](int im) {
+        const int b = lane >> 2, fq = lane & 3;
+#pragma unroll
+        for (int li = 0; li < NI; ++li) {
+            const float* __restrict__ Wg = A.imgl + (size_t)li * imgl_blk + (size_t)im * (size_t)(w * w);
+            const float* __restrict__ Bg = A.imgl + (size_t)li * imgl_blk + (size_t)A.n_images * (size_t)(w * w) + (size_t)im * w;
+            float vf[NC], vk[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int f = 4 * c + fq;
+                const bool okf = f < w && (b == ONE || b < w), okk = b < w && f < w;
+                const float xf = (b == ONE) ? Bg[f < w ? f : 0] : Wg[okf ? f * w + b : 0];
+                const float xk = Wg[okk ? b * w + f : 0];
+                vf[c] = okf ? xf : 0.0f;
+                vk[c] = okk ? xk : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                sFi[li * IMG + c * 64] = vf[c];
+                sKi[li * IMG + c * 64] = vk[c];
+            }
+        }
+    };
 
     const float ones = 1.0f;
     const int rr16 = lane & 15, kq = lane >> 4;
@@ -360,7 +435,15 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     st_acc[6] = st_last - st_t0;                                  // launch prologue: weight images, tile fill, first prefetch issue
 #endif
     int xcur = 0;                                             // LX: buffer of the current tile's metadata rows
-    for (int wt = wt_begin; wt < n_wt; wt += wt_step, xcur ^= 1) {
+    for (int wt = wt_begin; wt < wt_end; wt += wt_inc, xcur ^= 1) {
+        if constexpr (NI > 0) {
+            const int im = uniform(A.tile_img[(wt * WT) / CL_MLP_TILE]);
+            if (im != cur_img) {                 // wave-uniform
+                if (cur_img >= 0) imgl_flush(cur_img);
+                imgl_load(im);
+                cur_img = im;
+            }
+        }
         float x0[DREG];
 #pragma unroll
         for (int k = 0; k < DREG; ++k) x0[k] = xn[k];          // (rows >= d of meta_t are zero by contract, groups past them were never loaded)
@@ -415,11 +498,15 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         // ================= forward ==========================================================================================
         // (activations and dZ in aligned register pairs: the packed fp32 instructions of the backward pass take them as they stand)
         static_assert(W % 2 == 0, "feature pairs");
-        f32x2 hsp[NL][W / 2];
+        f32x2 hsp[NLT][W / 2];
 #define HS(l, f) hsp[l][(f) >> 1][(f) & 1]
         float wan[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) wan[c] = sF[c * 64];
+        // (The Dense layers keep this loop exactly as the instances without per-image layers had it before round 5: rewritten as a
+        //  static_for over all NLT layers, the dZ_0-storing production instance -- 511 registers -- came out of hipcc giving results that
+        //  changed from run to run, with nothing in the source to explain it; profiles/r5_lane_imgl.txt.  The per-image layers follow
+        //  in a loop of their own.)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             {
@@ -428,7 +515,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 for (int c = 0; c < NC; ++c) wa[c] = wan[c];
                 // the next layer's weight registers, in flight under this layer's MFMAs (after the top layer: the head's)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) wan[c] = sF[(l + 1) * IMG + c * 64];
+                for (int c = 0; c < NC; ++c) wan[c] = (NI > 0 && l + 1 == NL) ? sFi[c * 64] : sF[(l + 1) * IMG + c * 64];
                 f32x4 acc[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -483,9 +570,44 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #pragma unroll
                     for (int f = 0; f < W; ++f) HS(l, f) = lrelu2(acc[f >> 2][f & 3], lk[f >> 2][f & 3]);
                 }
+                if (PK > 0 && l >= NLT - PK) {       // parked: the registers are free from the head on, the backward pass reads the copy
+#pragma unroll
+                    for (int f = 0; f < W; ++f) sP[((l - (NLT - PK)) * W + f) * 64] = HS(l, f);
+                }
             }
         }
-#define TOP(k) HS(NL - 1, k)                             /* the head's input */
+        if constexpr (NI > 0) {
+            // the per-image layers: the same chain on the wave's own weight images (after the last one: the head's, as above)
+#pragma unroll
+            for (int li = 0; li < NI; ++li) {
+                const int l = NL + li;
+                float wa[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) wa[c] = wan[c];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) wan[c] = (li + 1 < NI) ? sFi[(li + 1) * IMG + c * 64] : sF[NL * IMG + c * 64];
+                f32x4 acc[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                static_for<0, W>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[c] = mfma_bk<k>(wa[c], HS(l - 1, k), acc[c]);
+                });
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = mfma_bk<ONE>(wa[c], ones, acc[c]);
+                f32x4 lk[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) lk[c] = acc[c] * leak;
+#pragma unroll
+                for (int f = 0; f < W; ++f) HS(l, f) = lrelu2(acc[f >> 2][f & 3], lk[f >> 2][f & 3]);
+                if (l >= NLT - PK) {
+#pragma unroll
+                    for (int f = 0; f < W; ++f) sP[((l - (NLT - PK)) * W + f) * 64] = HS(l, f);
+                }
+            }
+        }
+#define TOP(k) HS(NLT - 1, k)                            /* the head's input */
         LSTAMP(1);
         // Dense(2) head: outputs 0, 1 of one more chunk
         float o0, o1;
@@ -652,10 +774,24 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 
         LSTAMP(2);
         // next tile's inputs: their latency hides under the backward pass
-        if (wt + wt_step < n_wt) prefetch(wt + wt_step, xcur ^ 1);
+        if (wt + wt_inc < wt_end) prefetch(wt + wt_inc, xcur ^ 1);
         LSTAMP(3);
 
         // ================= backward =========================================================================================
+        // NI: a parked layer's activations come back from LDS right before their first use on the way down (through an offset the
+        // compiler cannot see through: it would otherwise keep the registers across the epilogue instead of the copy)
+        auto unpark = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            if constexpr (PK > 0 && l >= NLT - PK && l < NLT) {
+                int zero = 0;
+                asm volatile("" : "+v"(zero));
+                const float* const sp = sP + zero;
+#pragma unroll
+                for (int f = 0; f < W; ++f) HS(l, f) = sp[((l - (NLT - PK)) * W + f) * 64];
+            }
+        };
+        unpark(std::integral_constant<int, NLT - 1>{});
+        unpark(std::integral_constant<int, (NLT >= 2 ? NLT - 2 : 0)>{});
         // head: its weight gradient is per-lane sums; its dgrad two steps (dloc, draw) per input chunk
         {
             const f32x2 dd2 = {dloc, draw};
@@ -718,14 +854,15 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     if constexpr ((j & 1) == 0) pa[q][c] = *reinterpret_cast<const f32x4*>(rdZ + q * PAR + 16 * c);
                     else pb[q][c] = *reinterpret_cast<const f32x4*>((ll == 0 ? rdX + xoff : rdH + q * PAR) + 16 * c);
                 } else if constexpr (i < NOPS + NC) {
-                    if constexpr (ll > 0) wk[q][i - NOPS] = sK[ll * IMG + (i - NOPS) * 64];       // dgrad weights of layer ll (input side: layer ll - 1)
+                    if constexpr (ll > 0) wk[q][i - NOPS] = kimg(llc)[(i - NOPS) * 64];       // dgrad weights of layer ll (input side: layer ll - 1)
                 }
             };
             // top layer: nothing to hide behind
-            dz_of(dzp[(NL - 1) & 1], hsp[NL - 1], dH);
-            static_for<0, NOPS + NC>([&](auto ic_) { lds_op(std::integral_constant<int, NL - 1>{}, ic_); });
-            static_for<0, NL>([&](auto lc) {
-                constexpr int l = NL - 1 - decltype(lc)::value, q = l & 1;
+            dz_of(dzp[(NLT - 1) & 1], hsp[NLT - 1], dH);
+            static_for<0, NOPS + NC>([&](auto ic_) { lds_op(std::integral_constant<int, NLT - 1>{}, ic_); });
+            static_for<0, NLT>([&](auto lc) {
+                constexpr int l = NLT - 1 - decltype(lc)::value, q = l & 1;
+                if constexpr (l >= 2) unpark(std::integral_constant<int, (l >= 2 ? l - 2 : 0)>{});      // (layer l - 1's staging, issued under this layer's MFMAs, reads layer l - 2's activations)
                 if constexpr (l > 0) {
                     // dgrad of layer l: dH of layer l - 1, then its dZ
 #pragma unroll
@@ -752,7 +889,13 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 // staging writes, operand reads and dgrad weights of layer l - 1
                 static_for<0, 16>([&](auto ic_) {
                     constexpr int i = decltype(ic_)::value, c = (i >> 3) * 2, t = (i >> 1) & 3;
-                    if constexpr ((i & 1) == 0) mfma16_acc(wacc[l], pa[q][c][t], pb[q][c][t]);
+                    if constexpr (l >= NL) {
+                        // per-image layers: their sums are read and cleared at every image change, and around that branch the register
+                        // allocator copies the accumulators; behind an inline-assembly MFMA such a copy reads before the result has
+                        // landed (it does not know the instruction) -- the builtin lets it place the wait states
+                        if constexpr ((i & 1) == 0) wacc[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[q][c][t], pb[q][c][t], wacc[l], 0, 0, 0);
+                        else wacd[l] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[q][c + 1][t], pb[q][c + 1][t], wacd[l], 0, 0, 0);
+                    } else if constexpr ((i & 1) == 0) mfma16_acc(wacc[l], pa[q][c][t], pb[q][c][t]);
                     else mfma16_acc(wacd[l], pa[q][c + 1][t], pb[q][c + 1][t]);
                     if constexpr (l > 0) {
                         lds_op(std::integral_constant<int, (l > 0 ? l - 1 : 0)>{}, std::integral_constant<int, 2 * i>{});
@@ -777,6 +920,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         LSTAMP(5);
     }
     // ================= flush: sum the waves' accumulators, scatter into the flat W^T layout of this workgroup's partial ====
+    if constexpr (NI > 0) { if (cur_img >= 0) imgl_flush(cur_img); }        // the last image's layers of this wave
     asm volatile("s_nop 15\n\ts_nop 15");     // (the compiler does not know that the inline-assembly MFMAs' results take eight passes to land)
     __syncthreads();
     const int offWo = w * d + w + (L - 1) * (w * w + w);
@@ -888,12 +1032,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #define CL_LANE_PART 0
 #endif
 
-template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false>
+template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false, int NI = 0>
 static int launch_lane_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
-    using SM = LSmem<W, DMAX == 0>;
+    using SM = LSmem<W, DMAX == 0, NI>;
     const size_t sm = (size_t)SM::total(a.d) * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL, DXO>;
+    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL, DXO, NI>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -924,6 +1068,7 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #ifndef CL_LANE_WMAX
 #define CL_LANE_WMAX 10
 #endif
+#define CL_LANE_IMGL_MAX 2          /* per-image layers of the lane instances */
 
 // the instance whose compile-time width is the smallest one that holds the scaler (zero-padded features cost MFMA steps)
 #define CL_LANE_WIDTHS(CASE)      \
@@ -936,6 +1081,7 @@ int cl_launch_lane_plain_reg(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_packed_reg(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_packed_rows(const cl_mlp_args& a, int grid, hipStream_t st);
+int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st);
 
 #if CL_LANE_PART == 0
 int cl_launch_lane_plain_reg(const cl_mlp_args& a, int grid, hipStream_t st) {
@@ -959,6 +1105,26 @@ int cl_lane_supports(const cl_mlp_args& a) {
           a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr)))
         return 0;
     return a.d <= DMAX_ALL || lane_rows_lds(a.w, a.d) <= 160 * 1024;
+}
+
+// 1 = the training step of a NeuralImageScaler runs on the lane-per-observation kernel (round 5): the default depth and width (NL Dense layers,
+// w <= 10) on up to 15 metadata columns with one or two per-image layers (`careless mono --image-layers 1|2`), monochromatic data in the
+// packed-by-image layout; everything else with per-image layers stays on the IMGL instances of elbo_mlp.hip.
+int cl_lane_imgl_supports(const cl_mlp_args& a) {
+    return a.n_imgl >= 1 && a.n_imgl <= CL_LANE_IMGL_MAX && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && a.L == NL &&
+           a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.dZ0_out == nullptr && a.dzf_obs == nullptr && a.row_map != nullptr &&
+           a.gmeta == nullptr && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
+}
+
+int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st) {
+    if (!cl_lane_imgl_supports(a)) return -2;
+    if (a.n_pad % CL_MLP_TILE != 0 || a.n_pad <= 0 || a.n_obs != a.n_pad) return -1;
+    if (4ull * (unsigned long long)((a.d + 3) & ~3) * (unsigned long long)a.n_pad >= (1ull << 32) ||
+        4ull * (unsigned long long)a.R * (unsigned long long)a.S >= (1ull << 32))
+        return -4;
+    if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+    if (grid < 1) return -1;
+    return cl_launch_lane_imgl_inst(a, grid, st);
 }
 
 // name of the instance cl_launch_lane runs (cl_mlp_kernel_name)
@@ -1003,6 +1169,16 @@ int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_CASE(WW) launch_lane_one<WW, 0, false>(a, grid, st)
     CL_LANE_WIDTHS(CL_LANE_CASE)
 #undef CL_LANE_CASE
+}
+#elif CL_LANE_PART == 4
+// per-image layers: the widest instance serves every w <= 10 (a narrower scaler pays the padded MFMA steps: --image-layers on a
+// non-default width is rare); with and without the optional inputs / outputs, as the plain layout
+int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
+    const bool full = lane_wants_full(a);
+#define CL_LANE_IMGL_CASE(DM, NI_) (full ? launch_lane_inst<CL_LANE_WMAX, DM, true, true, false, NI_>(a, grid, st) : launch_lane_inst<CL_LANE_WMAX, DM, true, false, false, NI_>(a, grid, st))
+    if (a.n_imgl == 1) return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 1) : CL_LANE_IMGL_CASE(DMAX_ALL, 1);
+    return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 2) : CL_LANE_IMGL_CASE(DMAX_ALL, 2);
+#undef CL_LANE_IMGL_CASE
 }
 #else
 int cl_launch_lane_packed_rows(const cl_mlp_args& a, int grid, hipStream_t st) {

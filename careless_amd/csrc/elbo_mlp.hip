@@ -1407,7 +1407,12 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
         return cl_launch_mlp_det(a, mode, grid, st);
     }
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
-    if (a.n_imgl > 0) return cl_launch_mlp_imgl(a, mode, grid, st);            // packed layout + per-image layers
+    if (a.n_imgl > 0) {                                                        // packed layout + per-image layers
+        // the default scaler's depth and width with one or two per-image layers: the lane-per-observation kernel (elbo_lane.hip, round 5)
+        if (mode == 0 && cl_lane_imgl_supports(a) && lane_enabled() && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1)
+            return cl_launch_lane_imgl(a, grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid, st);
+        return cl_launch_mlp_imgl(a, mode, grid, st);
+    }
     if (a.row_map != nullptr && !(mode == 0 && ((cl_narrow_supports(a) && narrow_enabled()) || (cl_lane_supports(a) && lane_enabled()))))
         return cl_launch_mlp_packed(a, mode, grid, st);                          // packed layout (single-pass Laue)
 #endif
@@ -1443,8 +1448,12 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
         if (mode == 0 && (a.ev11 == nullptr || a.ev11_part != nullptr) && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
         unit = (mode == 0 && a.dX_out != nullptr) ? ", chain deterministic" : ((a.row_map != nullptr && a.n_imgl == 0) ? ", packed deterministic" : ", deterministic");
     } else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
-    else if (a.n_imgl > 0) unit = ", image layers";
-    else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }
+    else if (a.n_imgl > 0) {
+        if (mode == 0 && cl_lane_imgl_supports(a) && lane_enabled())
+            return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, false, %d> (image layers)", 10, a.d <= 8 ? 8 : 15,
+                            (a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr) ? "true" : "false", a.n_imgl);
+        unit = ", image layers";
+    } else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }
     if (a.dzf_obs == nullptr && (unit[0] == 0 || packed)) {
         if (mode == 0 && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
         if (mode == 0 && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);

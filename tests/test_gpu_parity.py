@@ -113,6 +113,16 @@ CASES = {
     "image_layers2_4x10_softplus": dict(N=900, R=50, d0=5, L=4, w=10, S=2, n_images=6, image_layers=2, bijector="softplus",
                                         shift=0.7),
     "image_layers2_on_the_cli_default_20x10": dict(N=600, R=40, d0=5, L=20, w=10, S=2, n_images=4, image_layers=2),
+    # `--image-layers 1|2` on the default scaler: the lane-per-observation kernel with per-image top layers (elbo_lane.hip, round 5);
+    # many images per wave (flush + reload at every change), a narrower scaler on the widest instance, 12 columns (DMAX = 15), two
+    # sample batches, the Evans-2011 error model, Student-T
+    "lane_image_layers1_20x10_many_images": dict(N=3000, R=120, d0=5, L=20, w=10, S=1, n_images=37, image_layers=1, perturb=0.03),
+    "lane_image_layers2_20x8_d12_S3_studentt": dict(N=1500, R=80, d0=12, L=20, w=8, S=3, n_images=9, image_layers=2, likelihood="studentt", dof=8.0,
+                                                    perturb=0.03),
+    "lane_image_layers2_20x10_S11_softplus": dict(N=900, R=50, d0=5, L=20, w=10, S=11, n_images=6, image_layers=2, bijector="softplus", perturb=0.03),
+    "lane_image_layers1_20x6_ev11": dict(N=800, R=50, d0=7, L=20, w=6, S=2, n_images=5, image_layers=1, ev11=True, perturb=0.03),
+    "lane_image_layers2_20x10_rows_in_arbitrary_order": dict(N=1200, R=60, d0=5, L=20, w=10, S=2, n_images=11, image_layers=2, shuffle_rows=True,
+                                                             perturb=0.03),
     "laue_image_layers1_2x32": dict(N=600, R=60, L=2, w=32, S=3, laue=True, n_images=4, image_layers=1),
     # the two Laue code paths: single pass (group sums inside the fused kernel; the default) and two passes around the group sums
     "laue_two_pass_2x32_S3": dict(N=400, R=40, L=2, w=32, S=3, laue=True, two_pass=True),
@@ -662,6 +672,60 @@ def test_image_layers_philox_noise_is_keyed_by_the_callers_rows():
     assert util.rel_err(ipred, out["ipred"].numpy()) < 1e-4
     errs = [util.rel_err(a.cpu().numpy(), b.numpy()) for a, b in zip(eng.grad_tensors(), grads)]
     assert len(errs) == len(grads) and max(errs) < RTOL_GRAD, errs
+
+
+@pytest.mark.parametrize("kw", [dict(N=2500, R=60, d0=5, L=20, w=10, S=2, n_images=13, image_layers=2, perturb=0.03),
+                                dict(N=1800, R=50, d0=11, L=20, w=8, S=1, n_images=9, image_layers=1, likelihood="studentt", dof=8.0, perturb=0.03)],
+                         ids=["20x10_img2", "20x8_d11_img1_studentt"])
+def test_lane_image_layers_production_instance_on_in_kernel_noise(kw):
+    """`--image-layers` on the default scaler, as a production step runs it (round 5: elbo_lane_kernel<.., NI> without the optional
+    inputs / outputs, in-kernel Philox noise keyed by the caller's rows through the by-image packing): the dumped noise replayed through
+    the oracle gives the same loss and gradients, per-image tensors included."""
+    from careless_amd.engine import ElboEngine, debug_noise
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    perm = np.random.default_rng(3).permutation(kw["N"])
+    for k in ("refl_id", "image_id", "file_id", "metadata", "iobs", "sigiobs"):
+        data[k] = np.asarray(data[k])[perm]
+    x = O.inputs_from_numpy(data)
+    eng = ElboEngine(util.build_model(data, cfg, params, kw["L"], kw["w"]), util.reference_inputs(data), seed=77)
+    eng.forward_backward(5)
+    torch.cuda.synchronize()
+    name = eng.kernel_name()
+    assert name.startswith("elbo_lane_kernel<10, ") and f"true, false, false, {kw['image_layers']}>" in name, name
+    u = debug_noise(77, 5, kw["S"], kw["R"], 0, kind=0).t().cpu().numpy()
+    e = debug_noise(77, 5, kw["S"], kw["N"], 0, kind=1).t().cpu().numpy()
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(out["loss"])) <= RTOL_LOSS * abs(float(out["loss"]))
+    _assert_grads([g.cpu().numpy() for g in eng.grad_tensors()], grads, (data, cfg, params, u, e), name="lane image layers, in-kernel noise")
+
+
+@pytest.mark.parametrize("kw", [dict(N=5000, R=40, d0=37, L=20, w=10, S=3, perturb=0.02),
+                                dict(N=5000, R=40, d0=5, L=20, w=10, S=3, perturb=0.02, image_layers=2, n_images=23),
+                                dict(N=5000, R=40, d0=12, L=20, w=8, S=2, perturb=0.02, image_layers=1, n_images=11),
+                                dict(N=5000, R=40, d0=5, L=20, w=10, S=1, perturb=0.02)],
+                         ids=["peeled_dZ0_out", "image_layers2", "image_layers1_d12", "cli_default"])
+def test_lane_production_instances_repeat_from_run_to_run(kw):
+    """Guards the one-wave-per-SIMD instances at the 512-register wall against a code generation accident (round 5: a rewrite of the
+    forward loop that changed nothing in the source's meaning left the dZ_0-storing instance with results that moved from run to run;
+    NOTEBOOK R5.8): eight fresh engines on the same inputs and seed give ONE loss, and gradients that differ by the order of their float
+    atomics only."""
+    from careless_amd.engine import ElboEngine
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    inputs = util.reference_inputs(data)
+    losses, g0 = set(), None
+    for _ in range(8):
+        eng = ElboEngine(util.build_model(data, cfg, params, kw["L"], kw["w"]), inputs, seed=99)
+        eng.forward_backward(3)
+        torch.cuda.synchronize()
+        assert eng.kernel_name().startswith("elbo_lane_kernel")
+        losses.add(round(eng.loss_terms()["nll"], 6))
+        g = eng.grads.clone()
+        if g0 is None:
+            g0 = g
+        assert float((g - g0).abs().max()) <= 2e-6 * float(g0.abs().max())
+        del eng
+    assert len(losses) == 1, losses
 
 
 def test_image_layers_adam_trajectory_and_scaler_call():
