@@ -1108,12 +1108,13 @@ int cl_lane_supports(const cl_mlp_args& a) {
 }
 
 // 1 = the training step of a NeuralImageScaler runs on the lane-per-observation kernel (round 5): the default depth and width (NL Dense layers,
-// w <= 10) on up to 15 metadata columns with one or two per-image layers (`careless mono --image-layers 1|2`), monochromatic data in the
-// packed-by-image layout; everything else with per-image layers stays on the IMGL instances of elbo_mlp.hip.
+// w <= 10) on up to 15 metadata columns with one or two per-image layers (`careless mono | poly --image-layers 1|2`) in the packed-by-image
+// layout (Laue data: harmonic groups inside 16-row granules, single pass, as without per-image layers); everything else with per-image
+// layers stays on the IMGL instances of elbo_mlp.hip.
 int cl_lane_imgl_supports(const cl_mlp_args& a) {
     return a.n_imgl >= 1 && a.n_imgl <= CL_LANE_IMGL_MAX && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && a.L == NL &&
            a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.dZ0_out == nullptr && a.dzf_obs == nullptr && a.row_map != nullptr &&
-           a.gmeta == nullptr && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
+           (a.gmeta == nullptr || a.tile_gmax != nullptr) && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
 }
 
 int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st) {

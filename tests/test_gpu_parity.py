@@ -121,6 +121,9 @@ CASES = {
                                                     perturb=0.03),
     "lane_image_layers2_20x10_S11_softplus": dict(N=900, R=50, d0=5, L=20, w=10, S=11, n_images=6, image_layers=2, bijector="softplus", perturb=0.03),
     "lane_image_layers1_20x6_ev11": dict(N=800, R=50, d0=7, L=20, w=6, S=2, n_images=5, image_layers=1, ev11=True, perturb=0.03),
+    "lane_laue_image_layers1_20x10": dict(N=900, R=60, L=20, w=10, S=1, laue=True, n_images=6, image_layers=1, perturb=0.03),
+    "lane_laue_image_layers2_20x6_S3_studentt": dict(N=700, R=50, L=20, w=6, S=3, laue=True, n_images=4, image_layers=2, likelihood="studentt", dof=8.0,
+                                                     perturb=0.03),
     "lane_image_layers2_20x10_rows_in_arbitrary_order": dict(N=1200, R=60, d0=5, L=20, w=10, S=2, n_images=11, image_layers=2, shuffle_rows=True,
                                                              perturb=0.03),
     "laue_image_layers1_2x32": dict(N=600, R=60, L=2, w=32, S=3, laue=True, n_images=4, image_layers=1),
