@@ -169,7 +169,7 @@ EXPORTS = {
     "cl_laue_backward": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_slot_rows": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_reduce_partials": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
-    "cl_grad_sqnorm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "cl_grad_sqnorm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cl_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
     "cl_owner_qnorm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "cl_step_finalize": (C.c_int, [_vp, C.c_float, _vp, C.c_int, _vp, _vp, C.c_int, _vp]),

@@ -129,10 +129,10 @@ int cl_dw_prior_forward(const cl_tn_args* a, void* stream) {
 }
 
 int cl_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
-                   const int* stop_flag, void* stream) {
+                   const unsigned char* frozen, const int* stop_flag, void* stream) {
     if (g == nullptr || scalars == nullptr || n < 1) return -1;
-    if (seg_sq != nullptr && (seg_off == nullptr || nseg < 1)) return -1;
-    return cl_launch_grad_sqnorm(g, n, seg_off, nseg, seg_sq, scalars, stop_flag, (hipStream_t)stream);
+    if ((seg_sq != nullptr || frozen != nullptr) && (seg_off == nullptr || nseg < 1)) return -1;
+    return cl_launch_grad_sqnorm(g, n, seg_off, nseg, seg_sq, scalars, frozen, stop_flag, (hipStream_t)stream);
 }
 
 int cl_adam_step(const cl_adam_args* a, void* stream) {

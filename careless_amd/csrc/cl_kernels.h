@@ -27,7 +27,7 @@ int cl_launch_tn_forward(const cl_tn_args& a, hipStream_t st);
 int cl_launch_tn_backward(const cl_tn_args& a, hipStream_t st);
 int cl_launch_dw_forward(const cl_tn_args& a, hipStream_t st);
 int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
-                          const int* stop_flag, hipStream_t st);
+                          const unsigned char* frozen, const int* stop_flag, hipStream_t st);
 int cl_launch_adam(const cl_adam_args& a, hipStream_t st);
 int cl_launch_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* out, double* scratch, const int* stop_flag, hipStream_t st);
 int cl_launch_finalize(double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,

@@ -222,10 +222,13 @@ __device__ __forceinline__ int seg_of(const int* __restrict__ seg_off, int nseg,
 
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, int n, const int* __restrict__ seg_off,
                                                           int nseg, double* __restrict__ seg_sq, double* scalars,
-                                                          const int* stop_flag) {
+                                                          const unsigned char* __restrict__ frozen, const int* stop_flag) {
     if (stop_flag != nullptr && *stop_flag != 0) return;
     double acc = 0.0, sane = 0.0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        // (a tensor that is not trainable is not among the gradients the reference takes the norm of: tape.gradient(loss,
+        //  self.trainable_variables), variational.py:201-205)
+        if (frozen != nullptr && frozen[seg_of(seg_off, nseg, i)] != 0) continue;
         const float v = g[i];
         const double v2 = (double)v * (double)v;
         acc += v2;                                           // raw: a NaN gradient gives a NaN norm (variational.py:205)
@@ -324,12 +327,13 @@ __global__ __launch_bounds__(256) void adam_kernel(const cl_adam_args A) {
             if (!on[u]) continue;
             const int i = ii[u];
             float g = g_[u];
+            // (a frozen tensor is neither updated nor part of the norm: the reference's gradients are those of trainable_variables)
+            if (A.frozen != nullptr && A.frozen[seg_of(A.seg_off, A.nseg, i)] != 0) continue;
             if (A.norm_out != nullptr && rk[u] >= A.norm_skip_ranges) {    // fused tf.linalg.global_norm (variational.py:205)
                 const double v2 = (double)g * (double)g;
                 acc += v2;
                 sane += isfinite(g) ? v2 : 0.0;
             }
-            if (A.frozen != nullptr && A.frozen[seg_of(A.seg_off, A.nseg, i)] != 0) continue;
             if (!isfinite(g)) g = 0.0f;                                   // variational.py:208
             if (A.clipnorm > 0.0f) {                                      // per-tensor tf.clip_by_norm [3P]
                 const float nrm = (float)sqrt(A.seg_sq[seg_of(A.seg_off, A.nseg, i)]);
@@ -492,12 +496,12 @@ int cl_launch_dw_forward(const cl_tn_args& a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 int cl_launch_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
-                          const int* stop_flag, hipStream_t st) {
+                          const unsigned char* frozen, const int* stop_flag, hipStream_t st) {
     if (n <= 0) return -1;
     int grid = (n + 255) / 256;
     if (grid > 1024) grid = 1024;
     (void)hipGetLastError();   // drop any stale error of an unrelated earlier runtime call
-    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, seg_off, nseg, seg_sq, scalars, stop_flag);
+    hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, st, g, n, seg_off, nseg, seg_sq, scalars, frozen, stop_flag);
     return (int)hipGetLastError();
 }
 int cl_adam_grid_of(const cl_adam_args& a) {

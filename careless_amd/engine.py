@@ -334,6 +334,16 @@ class ElboEngine(WidePath):
             if osh is not None:
                 self.shard = osh
         self.owner = bool(self.shard.owner)
+        # A frozen scaling model (`--freeze-scales`; the half-dataset trainings of `--merge-half-datasets`, reference careless.py:102-128):
+        # its output (loc, sigma) per observation does not change from step to step, so a step needs neither its forward nor its backward
+        # pass -- only the sampling / likelihood part (`_data_term_frozen`).  An engine built around a frozen scaler lays its observations out
+        # for that (plain rows in the caller's order: no packing by image or harmonic group).
+        want_ff = getattr(model, "frozen_scaler_fast_path", None)
+        self.frozen_fast = (os.environ.get("CARELESS_HIP_FROZEN_FAST", "1") != "0") if want_ff is None else bool(want_ff)
+        self._grid_arg = grid
+        self._frozen_layout = self.frozen_fast and not model.scaling_model.trainable and not (self.deterministic and self.laue)
+        self._frozen_epoch = 0
+        self.scaler_frozen = False
         self.obs = self._build_obs(inputs, self.shard.start, self.shard.stop, grid, self.laue_groups, rows=self.shard.rows if self.owner else None)
         if self.blocks is not None:
             self.obs.alloc_chain(self.lib, self.blocks, self.w, dev)
@@ -373,6 +383,8 @@ class ElboEngine(WidePath):
         kw = dict(grid=grid, n_refl=self.R, n_images=self._max_images(), laue_groups=laue_groups, pack_images=self.imgl is not None and not self.wide,
                   sort_images=self.imgl is not None and self.wide,
                   laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None and not self.wide, wide=self.wide)
+        if getattr(self, "_frozen_layout", False):
+            kw.update(pack_images=False, sort_images=False, laue_single_pass=False)
         n_total = int(_np(BaseModel.get_refl_id(inputs)).reshape(-1).shape[0])
         stop = n_total if stop is None else stop
         per = launch_row_limit(self.d, self.S if self.deterministic else 0)
@@ -380,6 +392,7 @@ class ElboEngine(WidePath):
             start, stop = 0, len(rows)
         if self.laue or self.imgl is not None or self.wide or stop - start <= per:
             o = ObsData(self.lib, inputs, start, stop, self.S, self.layout.P, self.device, rows=rows, **kw)
+            o.host_inputs = inputs                        # (a reference: the frozen-scaler path reads the rows' metadata once per training)
             if self.deterministic:
                 self._det_attach(o, [o])
             return o
@@ -388,6 +401,7 @@ class ElboEngine(WidePath):
             b = min(stop, a + per)
             pieces.append(ObsData(self.lib, inputs, a, b, self.S, self.layout.P, self.device, rows=None if rows is None else rows[a:b], **kw))
             pieces[-1].row0 = a - start                   # first row of the piece inside the shard's eta / ipred arrays
+            pieces[-1].host_inputs = inputs
             kw["n_refl"] = kw["n_images"] = None          # (the id ranges were checked over the whole input by the first piece)
             if len(pieces) > 1:
                 pieces[-1].partials = pieces[0].partials  # launches are serialised on one stream: one partial buffer
@@ -468,6 +482,16 @@ class ElboEngine(WidePath):
                 fr[k] = 1
         self.any_frozen = bool(fr.any())
         self.frozen.copy_(torch.as_tensor(fr))
+        self.scaler_frozen = not m.scaling_model.trainable
+        self._frozen_epoch += 1                          # (loc, sigma) of a frozen scaler are taken again at every train_model call
+        if self._frozen_layout and not self.scaler_frozen:
+            # the scaler was frozen when the engine laid its observations out and is trainable now: the fused kernels' layouts again
+            self._frozen_layout = False
+            first = self.obs.children[0] if isinstance(self.obs, ObsChunks) else self.obs
+            self.obs = self._build_obs(first.host_inputs, self.shard.start, self.shard.stop, self._grid_arg, self.laue_groups,
+                                       rows=self.shard.rows if self.owner else None)
+            if self.blocks is not None:
+                self.obs.alloc_chain(self.lib, self.blocks, self.w, self.device)
         opt = m.optimizer
         self.opt = opt
         S, N, R = self.S, self.N_total, self.R
@@ -706,6 +730,11 @@ class ElboEngine(WidePath):
             if self.deterministic:
                 self._det_reduce(obs, st)
             return
+        if self.scaler_frozen and self.frozen_fast and self._frozen_ok(obs):
+            self._data_term_frozen(obs, step, eta, ipred_out, st)
+            if self.deterministic and not _piece:
+                self._det_reduce(obs, st)
+            return
         if self.wide:
             self._data_term_wide(obs, step, eta, ipred_out, st)
             if self.deterministic and not _piece:
@@ -754,6 +783,39 @@ class ElboEngine(WidePath):
                                          ptr(self.stop_flag), st), "cl_reduce_partials")
         if self.deterministic and not _piece:
             self._det_reduce(obs, st)
+
+    def _frozen_ok(self, obs: ObsData) -> bool:
+        """The sampling / likelihood kernels take this observation image as it is: rows in the caller's order (not packed by image or
+        harmonic group, not sorted by image), and -- deterministic mode -- rows that are their own slot."""
+        if obs.row_map is not None or obs.fused_laue or getattr(obs, "perm", None) is not None or getattr(obs, "host_inputs", None) is None:
+            return False
+        if self.imgl is not None and not self._frozen_layout:
+            return False
+        return not (self.deterministic and obs.laue)
+
+    def _data_term_frozen(self, obs: ObsData, step: int, eta, ipred_out, st):
+        """The data term of a step whose scaling model is frozen (round 5): (loc, sigma) of every row once per `train_model` call -- any
+        scaler the package runs, through `scaler_forward` -- then per step only what depends on the sampled amplitudes: sample the scale,
+        predict, log-prob and its gradient to dz_f (and the Evans-2011 terms) on the slot kernels of the two-pass path
+        (`cl_slot_rows`, or `cl_laue_predict / _likelihood / _backward` for harmonic groups).  The scaler's own gradient is not computed at
+        all: the reference takes gradients of `trainable_variables` only (variational.py:201), so its "Grad Norm" does not see it either."""
+        if getattr(obs, "locsig_epoch", None) != self._frozen_epoch:
+            sl = obs.rows if obs.rows is not None else slice(obs.start, obs.start + obs.N)
+            md = _np(BaseModel.get_metadata(obs.host_inputs))
+            md = md.reshape(md.shape[0], -1)[sl]
+            ids = _np(BaseModel.get_image_id(obs.host_inputs)).reshape(-1)[sl] if self.imgl is not None else None
+            obs.laue_loc, obs.laue_sig = scaler_forward(self.mlp, md, self.imgl, ids)
+            if getattr(obs, "laue_dO", None) is None:
+                obs.laue_dO = torch.empty(obs.N * 2, dtype=torch.float32, device=self.device)
+            if not hasattr(obs, "harmonic_id"):
+                obs.harmonic_id = None
+            if getattr(obs, "laue_iconv", None) is None:      # (rows that are their own slot never touch it; the entry point wants a pointer)
+                obs.laue_iconv = torch.empty(obs.N * self.S if obs.harmonic_id is not None else 4, dtype=torch.float32, device=self.device)
+            if obs.rows is not None and getattr(obs, "row_index", None) is None:
+                obs.row_index = torch.as_tensor(np.asarray(obs.rows, dtype=np.int64), device=self.device)     # the noise key of every row
+            obs.locsig_epoch = self._frozen_epoch
+        ma = self._mlp_args(step, eta, ipred_out, obs)
+        self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
 
     def _peel_bufs(self, obs: ObsData):
         """Buffers of the peeled first layer for one observation set: its pre-activations and dZ_0 (feature-major, like meta_t), the
@@ -955,7 +1017,7 @@ class ElboEngine(WidePath):
         norm_first = use_seg or float(opt.global_clipnorm or 0.0) > 0.0
         if norm_first:
             check(lib.cl_grad_sqnorm(ptr(self.grads), n, ptr(self.seg_off), self.nseg, ptr(self.seg_sq) if use_seg else None,
-                                     ptr(self.scalars), ptr(self.stop_flag), st), "cl_grad_sqnorm")
+                                     ptr(self.scalars), ptr(self.frozen) if self.any_frozen else None, ptr(self.stop_flag), st), "cl_grad_sqnorm")
             if self.owner:
                 # the pass above saw this rank's own q gradients (the others' entries are zero here) and the all-reduced tail: trade
                 # the own share (cl_owner_qnorm's double accumulators) for the sum over the ranks that came back in the message

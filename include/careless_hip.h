@@ -414,8 +414,10 @@ typedef struct cl_adam_args {
                                    workgroup) instead of added to norm_out by same-address atomics, and cl_step_finalize adds them up     */
 } cl_adam_args;
 
+/* frozen (optional [nseg], as cl_adam_args.frozen): tensors that are not trainable stay out of the norm -- the reference takes
+ * tf.linalg.global_norm of tape.gradient(loss, self.trainable_variables) (variational.py:201-205); cl_adam_step's fused norm does the same */
 int cl_grad_sqnorm(const float* g, int n, const int* seg_off, int nseg, double* seg_sq, double* scalars,
-                   const int* stop_flag, void* stream);
+                   const unsigned char* frozen, const int* stop_flag, void* stream);
 int cl_adam_step(const cl_adam_args* args, void* stream);
 /* Reflection-owner data parallelism (no reference counterpart; the reference is single-process): the squared norm of THIS rank's
  * part of the surrogate-posterior gradient -- g[r_begin .. r_end) (d a) and g[R + r_begin .. R + r_end) (d b) -- as four floats the

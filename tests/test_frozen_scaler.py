@@ -1,0 +1,124 @@
+"""A frozen scaling model (`--freeze-scales`; the half-dataset trainings of `--merge-half-datasets`: reference careless/careless.py:48-50,
+102-128): the engine takes (loc, sigma) of every observation once and runs only the sampling / likelihood part per step
+(`ElboEngine._data_term_frozen`, round 5).  Held here against the fused step of the same engine with the short cut switched off -- same
+in-kernel noise, same loss, same gradients of everything that is trainable -- for every data kind and scaler family, against the oracle on
+injected noise, and over a short Adam trajectory."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import elbo_oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "cli_default_20x10_S3": dict(N=2000, R=60, d0=5, L=20, w=10, S=3, perturb=0.02),
+    "mono_5x64_studentt_posenc_S2": dict(N=1500, R=50, d0=5, posenc=True, L=5, w=64, S=2, likelihood="studentt", dof=8.0),
+    "laue_2x32_S2": dict(N=900, R=60, L=2, w=32, S=2, laue=True),
+    "laue_20x10_ev11": dict(N=900, R=60, L=20, w=10, S=1, laue=True, ev11=True, perturb=0.02),
+    "double_wilson_2x32": dict(N=800, R=60, d0=5, L=2, w=32, S=2, double_wilson=True),
+    "image_layers2_20x10": dict(N=1200, R=50, d0=5, L=20, w=10, S=2, n_images=7, image_layers=2, perturb=0.03),
+    "image_layers1_2x32": dict(N=700, R=40, d0=5, L=2, w=32, S=3, n_images=5, image_layers=1),
+    "wide_2x96": dict(N=600, R=40, d0=5, L=2, w=96, S=2),
+    "chained_12x32": dict(N=600, R=40, d0=5, L=12, w=32, S=2),
+    "peeled_20x10_d37_ev11": dict(N=900, R=40, d0=37, L=20, w=10, S=2, ev11=True, perturb=0.02),
+}
+
+
+def _engine(kw, fast, shard=None, seed=31):
+    from careless_amd.engine import ElboEngine
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    model = util.build_model(data, cfg, params, kw["L"], kw["w"])
+    model.scaling_model.trainable = False
+    model.frozen_scaler_fast_path = fast
+    eng = ElboEngine(model, util.reference_inputs(data), seed=seed, shard=shard)
+    if shard is not None:
+        eng.local_only = True
+    return eng, model
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_frozen_step_equals_the_fused_step(name):
+    kw = CASES[name]
+    fast, _ = _engine(kw, True)
+    full, _ = _engine(kw, False)
+    assert fast.scaler_frozen and fast._frozen_layout and not full._frozen_layout
+    for eng in (fast, full):
+        eng.forward_backward(4)
+    torch.cuda.synchronize()
+    tf, tu = fast.loss_terms(), full.loss_terms()
+    assert abs(tf["nll"] - tu["nll"]) <= 2e-5 * abs(tu["nll"]) and abs(tf["kl"] - tu["kl"]) <= 1e-6 * max(abs(tu["kl"]), 1.0)
+    lay, R = fast.layout, fast.R
+    gq_f, gq_u = fast.grads[: 2 * R].cpu().numpy(), full.grads[: 2 * R].cpu().numpy()
+    assert util.rel_err(gq_f, gq_u) < 2e-5                                  # d a, d b of every reflection
+    if lay.n_ev11 > 0:                                                     # the Evans-2011 parameters stay trainable
+        e_f, e_u = fast.grads[lay.off_ev11: lay.off_ev11 + 3].cpu().numpy(), full.grads[lay.off_ev11: lay.off_ev11 + 3].cpu().numpy()
+        assert util.rel_err(e_f, e_u) < 5e-5
+    # the scaler's own gradient is not computed (the reference does not take it either: trainable_variables only)
+    # (the image scales' gradient falls out of the likelihood kernel; it is neither applied nor part of the norm: `frozen`)
+    assert float(fast.grads[lay.off_mlp: lay.off_img].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["cli_default_20x10_S3", "laue_2x32_S2", "image_layers2_20x10", "double_wilson_2x32"])
+def test_frozen_step_matches_the_oracle_on_injected_noise(name):
+    kw = CASES[name]
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u_f, dtype=torch.float64), torch.as_tensor(eta, dtype=torch.float64))
+    model = util.build_model(data, cfg, params, kw["L"], kw["w"])
+    model.scaling_model.trainable = False
+    ipred = model(util.reference_inputs(data), u_f=u_f, eta=eta)
+    eng = model._engine
+    torch.cuda.synchronize()
+    assert eng.scaler_frozen and eng._frozen_layout
+    t = eng.loss_terms()
+    assert abs(t["loss"] - float(out["loss"])) <= 1e-4 * abs(float(out["loss"]))
+    assert util.rel_err(ipred.cpu().numpy(), out["ipred"].numpy()) < 1e-4
+    g = eng.grad_tensors()
+    for k in (0, 1):                                                       # q's two tensors lead both lists
+        assert util.rel_err(g[k].cpu().numpy(), grads[k].numpy()) < 2e-4
+
+
+def test_frozen_rank_shards_sum_to_the_full_batch():
+    from careless_amd.engine import make_shard
+    kw = dict(N=1500, R=60, d0=5, L=20, w=10, S=2, perturb=0.02)
+    full, _ = _engine(kw, True)
+    full.forward_backward(3)
+    torch.cuda.synchronize()
+    g, nll = torch.zeros_like(full.grads), 0.0
+    for r in range(2):
+        eng, _ = _engine(kw, True, shard=make_shard(kw["N"], kw["R"], r, 2))
+        eng.forward_backward(3)
+        torch.cuda.synchronize()
+        g += eng.grads
+        nll += eng.loss_terms()["nll"]
+    assert abs(nll - full.loss_terms()["nll"]) <= 1e-5 * abs(nll)
+    assert util.rel_err(g.cpu().numpy(), full.grads.cpu().numpy()) < 2e-5
+
+
+def test_frozen_trajectory_and_unfreezing():
+    """Ten Adam steps with the scaler frozen: the same q(F) as with the short cut off; the "Grad Norm" of the history is the norm over
+    the trainable tensors alone in both (reference variational.py:201-205); unfreezing afterwards lays the observations out for the
+    fused kernels again and trains the scaler."""
+    kw = dict(N=1500, R=60, d0=5, L=20, w=10, S=2, n_images=6, image_layers=1, perturb=0.03)
+    hist, q = {}, {}
+    for fast in (True, False):
+        data, cfg, params, x, _, _ = util.make_problem(**kw)
+        model = util.build_model(data, cfg, params, kw["L"], kw["w"])
+        model.scaling_model.trainable = False
+        model.frozen_scaler_fast_path = fast
+        model.seed = 5
+        inputs = util.reference_inputs(data)
+        w0 = model.scaling_model.mlp_scaler.flat.clone() if hasattr(model.scaling_model, "mlp_scaler") else None
+        hist[fast] = model.train_model(inputs, 10, progress=False)
+        q[fast] = model.surrogate_posterior.loc_raw.cpu().numpy().copy()
+        if fast:
+            model.scaling_model.trainable = True
+            before = model._engine.params.clone()
+            model.train_model(inputs, 2, progress=False)
+            assert not model._engine._frozen_layout and model._engine.obs.row_map is not None       # packed by image again
+            lay = model._engine.layout
+            assert not torch.equal(before[lay.off_mlp:], model._engine.params[lay.off_mlp:])        # the scaler moved
+    assert util.rel_err(q[True], q[False]) < 1e-4
+    for k in ("loss", "NLL", "Grad Norm"):
+        assert np.allclose(hist[True][k], hist[False][k], rtol=2e-4), k
