@@ -167,6 +167,14 @@ int cl_tn_moments(const float* q_loc_raw, const float* q_scale_raw, const float*
     return cl_launch_tn_moments(q_loc_raw, q_scale_raw, low, R, high_moments, high_m4, eps, mean, std, m4, (hipStream_t)stream);
 }
 
+int cl_predict_moments(const float* scale_mean, const float* scale_std, const int* refl_id, long long n, const float* f_mean, const float* f_std,
+                       const double* f_m4, int R, double* iexp, double* ivar, void* stream) {
+    if (scale_mean == nullptr || scale_std == nullptr || refl_id == nullptr || f_mean == nullptr || f_std == nullptr || f_m4 == nullptr ||
+        iexp == nullptr || ivar == nullptr || n < 1 || R < 1)
+        return -1;
+    return cl_launch_predict_moments(scale_mean, scale_std, refl_id, n, f_mean, f_std, f_m4, R, iexp, ivar, (hipStream_t)stream);
+}
+
 int cl_debug_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,
                    void* stream) {
     if (out == nullptr || S < 1 || n < 1) return -1;

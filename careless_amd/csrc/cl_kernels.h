@@ -33,6 +33,8 @@ int cl_launch_owner_qnorm(const float* g, int R, int r_begin, int r_end, float* 
 int cl_launch_finalize(double* scalars, float klw, double* history, int step_index, int hist_stride, int* stop_flag,
                        const double* norm_part, int n_norm_part, hipStream_t st);
 int cl_adam_grid_of(const cl_adam_args& a);
+int cl_launch_predict_moments(const float* smean, const float* sstd, const int* refl_id, long long n, const float* fmean, const float* fstd,
+                              const double* fm4, int R, double* iexp, double* ivar, hipStream_t st);      // elbo_elem.hip: output step, per observation
 int cl_launch_tn_moments(const float* a, const float* b, const float* low, int R, double high, double high4, float eps, float* mean, float* sd,
                          double* m4, hipStream_t st);                                // elbo_elem.hip: moments of q for the output step
 int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,

@@ -436,6 +436,23 @@ __global__ __launch_bounds__(256) void tn_moments_kernel(const float* __restrict
     }
 }
 
+// Output step, per observation (reference VariationalMergingModel.prediction_mean_stddev, careless/models/merging/variational.py:80-121): with
+// the scale's moments (smean, sstd) of the row and <F^2> = mean^2 + std^2, <F^4> of its reflection, E[I] = smean <F^2> and
+// var[I] = <F^4> (smean^2 + sstd^2) - E[I]^2, in fp64 (the subtraction cancels).  HBM-bound: 12 bytes in, 16 out per row + two gathers.
+__global__ __launch_bounds__(256) void predict_moments_kernel(const float* __restrict__ smean, const float* __restrict__ sstd, const int* __restrict__ refl_id,
+                                                              long long n, const float* __restrict__ fmean, const float* __restrict__ fstd,
+                                                              const double* __restrict__ fm4, int R, double* __restrict__ iexp, double* __restrict__ ivar) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int r = refl_id[i];
+        const bool ok = r >= 0 && r < R;
+        const double m = ok ? (double)fmean[r] : 0.0, s = ok ? (double)fstd[r] : 0.0, m4 = ok ? fm4[r] : 0.0;
+        const double sm = (double)smean[i], ss = (double)sstd[i];
+        const double e = sm * (m * m + s * s);
+        iexp[i] = e;
+        ivar[i] = m4 * (sm * sm + ss * ss) - e * e;
+    }
+}
+
 // debug / test aid: the noise the kernels would draw for (seed, step)
 __global__ void noise_kernel(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind,
                              float* out) {
@@ -545,6 +562,14 @@ int cl_launch_tn_moments(const float* a, const float* b, const float* low, int R
                          double* m4, hipStream_t st) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(tn_moments_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, a, b, low, R, high, high4, eps, mean, sd, m4);
+    return (int)hipGetLastError();
+}
+int cl_launch_predict_moments(const float* smean, const float* sstd, const int* refl_id, long long n, const float* fmean, const float* fstd,
+                              const double* fm4, int R, double* iexp, double* ivar, hipStream_t st) {
+    long long blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(predict_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, st, smean, sstd, refl_id, n, fmean, fstd, fm4, R, iexp, ivar);
     return (int)hipGetLastError();
 }
 int cl_launch_noise(unsigned long long seed, unsigned step, int S, long long n, long long offset, int kind, float* out,

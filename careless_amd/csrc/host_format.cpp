@@ -64,11 +64,18 @@ void parallel_rows(long long n, int nthreads, F&& body) {
     std::vector<std::thread> pool;
     pool.reserve(nthreads);
     const long long per = (n + nthreads - 1) / nthreads;
+    long long done = 0;                       // rows handed to a thread so far
     for (int t = 0; t < nthreads; ++t) {
         const long long a = t * per, b = a + per < n ? a + per : n;
         if (a >= b) break;
-        pool.emplace_back([&body, a, b] { body(a, b); });
+        try {
+            pool.emplace_back([&body, a, b] { body(a, b); });
+            done = b;
+        } catch (...) {                       // (no more threads to be had: the caller's thread takes the rest -- nothing may unwind through the C-ABI)
+            break;
+        }
     }
+    if (done < n) body(done, n);
     for (auto& th : pool) th.join();
 }
 
@@ -141,7 +148,8 @@ int cl_host_dense_ids(const int64_t* key, long long n, int64_t key_min, int64_t 
     if (n < 0 || (n > 0 && (key == nullptr || ids == nullptr)) || key_max < key_min) return -1;
     const unsigned long long range = (unsigned long long)(key_max - key_min) + 1ULL;
     if (range > (1ULL << 31)) return -2;                // the caller sorts instead
-    std::vector<int64_t> slot((size_t)range, 0);
+    std::vector<int32_t> slot;                          // (ranks fit 31 bits: at most `range` distinct keys)
+    try { slot.assign((size_t)range, 0); } catch (...) { return -3; }      // no memory for the table: the caller sorts instead
     bool bad = false;
     for (long long i = 0; i < n; ++i) {                // presence (serial: 8 bytes per row, and the table is shared)
         const int64_t k = key[i];
@@ -150,8 +158,8 @@ int cl_host_dense_ids(const int64_t* key, long long n, int64_t key_min, int64_t 
     }
     if (bad) return -1;
     int64_t next = 0;
-    for (size_t s = 0; s < (size_t)range; ++s) { const int64_t present = slot[s]; slot[s] = next; next += present; }
-    const int64_t* sl = slot.data();
+    for (size_t s = 0; s < (size_t)range; ++s) { const int32_t present = slot[s]; slot[s] = (int32_t)next; next += present; }
+    const int32_t* sl = slot.data();
     parallel_rows(n, nthreads, [=](long long a, long long b) {
         for (long long i = a; i < b; ++i) ids[i] = sl[(size_t)(key[i] - key_min)];
     });

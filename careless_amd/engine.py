@@ -1193,6 +1193,24 @@ def tn_moments(q, high_m4=np.inf, want=("mean", "std", "m4")):
     return out
 
 
+def predict_moments(scale_mean, scale_std, refl_id, mom):
+    """E[I] and var[I] of every observation (fp64 numpy arrays) via `cl_predict_moments` (reference variational.py:80-121) from the scale's
+    moments per row (device tensors), the rows' reflection ids and `tn_moments(q)`."""
+    dev = require_gpu("prediction_mean_stddev")
+    lib = _lib.get_lib()
+    sm = scale_mean.to(dev, torch.float32).contiguous().reshape(-1)
+    ss = scale_std.to(dev, torch.float32).contiguous().reshape(-1)
+    n = int(sm.numel())
+    rid = torch.as_tensor(_np(refl_id).reshape(-1).astype(np.int32), device=dev)
+    if int(rid.numel()) != n or int(ss.numel()) != n:
+        raise ValueError("scale moments and refl_id differ in length")
+    iexp = torch.empty(n, dtype=torch.float64, device=dev)
+    ivar = torch.empty(n, dtype=torch.float64, device=dev)
+    check(lib.cl_predict_moments(ptr(sm), ptr(ss), ptr(rid), n, ptr(mom["mean"]), ptr(mom["std"]), ptr(mom["m4"]), int(mom["mean"].numel()),
+                                 ptr(iexp), ptr(ivar), _stream()), "cl_predict_moments")
+    return iexp.cpu().numpy(), ivar.cpu().numpy()
+
+
 def scaler_forward(mlp, metadata, imgl=None, image_id=None):
     """loc, sigma of the scaler's Normal for every row of `metadata` via `cl_mlp_forward`; `imgl` + `image_id` add the
     per-image layers of a `NeuralImageScaler`."""

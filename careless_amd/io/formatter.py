@@ -55,9 +55,11 @@ def _ngroup(*cols) -> np.ndarray:
                 import ctypes as C
                 from careless_amd._lib import check, get_lib
                 ids = np.empty(n, dtype=np.int64)
-                check(get_lib().cl_host_dense_ids(key.ctypes.data_as(C.c_void_p), n, 0, total - 1, ids.ctypes.data_as(C.c_void_p), None, 0),
-                      "cl_host_dense_ids")
-                return ids
+                rc = get_lib().cl_host_dense_ids(key.ctypes.data_as(C.c_void_p), n, 0, total - 1, ids.ctypes.data_as(C.c_void_p), None, 0)
+                if rc == 0:
+                    return ids
+                if rc not in (-2, -3):                     # (-2 / -3: no table of that size -- the key is sorted below)
+                    check(rc, "cl_host_dense_ids")
             _, inv = np.unique(key, return_inverse=True)
             return inv.reshape(-1).astype(np.int64)
     keys = np.stack(cols, axis=1)

@@ -161,6 +161,15 @@ class VariationalMergingModel(BaseModel):
         refl_id = torch.as_tensor(np.asarray(rid.cpu() if torch.is_tensor(rid) else rid).reshape(-1).astype(np.int64))
         q = self.surrogate_posterior
         dist = self.scaling_model(inputs) if scale_dist is None else scale_dist
+        if hasattr(q, "loc_raw") and dist.mean().is_cuda:
+            # truncated normal (what the command line builds): the posterior's moments from one `cl_tn_moments` launch, the rows' from one
+            # `cl_predict_moments` launch -- nothing per observation is computed on the host
+            from careless_amd.engine import predict_moments, tn_moments
+            iexp, ivar = predict_moments(dist.mean(), dist.stddev(), refl_id, tn_moments(q))
+            convolve = self._convolved(inputs)
+            if convolve is not None:
+                iexp, ivar = convolve(iexp), convolve(ivar)
+            return iexp.astype(np.float32), np.sqrt(ivar).astype(np.float32)
         smean, sstd = dist.mean().double().cpu(), dist.stddev().double().cpu()
         if hasattr(q, "loc_raw"):                           # truncated normal: mean, stddev and <F^4> from one `cl_tn_moments` launch
             from careless_amd.engine import tn_moments

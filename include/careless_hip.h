@@ -466,6 +466,16 @@ int cl_peel_backward(const float* meta_t, int n_obs, int n_pad, int d, int w, in
 int cl_tn_moments(const float* q_loc_raw, const float* q_scale_raw, const float* low, int R, double high_moments, double high_m4, float eps,
                   float* mean, float* std, double* m4, void* stream);
 
+/* --- output step: posterior predictive moments per observation -------------------------------------------------------------------
+ * replaces: VariationalMergingModel.prediction_mean_stddev (careless/models/merging/variational.py:80-121), consumed by
+ *           DataManager.get_predictions (careless/io/manager.py:89-161): per observation i of reflection r = refl_id[i], with the scale's
+ *           moments of the row (scale_mean, scale_std: the scaler's forward pass) and the posterior's per reflection (cl_tn_moments),
+ *             iexp[i] = scale_mean[i] (f_mean[r]^2 + f_std[r]^2),   ivar[i] = f_m4[r] (scale_mean[i]^2 + scale_std[i]^2) - iexp[i]^2
+ *           in fp64 (Ipred = iexp, SigIpred = sqrt(ivar); Laue data: the caller sums both over a harmonic group's rows first, :113-119).
+ *           refl_id outside [0, R): zeros.                                                                                              */
+int cl_predict_moments(const float* scale_mean, const float* scale_std, const int* refl_id, long long n, const float* f_mean, const float* f_std,
+                       const double* f_m4, int R, double* iexp, double* ivar, void* stream);
+
 /* --- formatting step: symmetry bookkeeping of the reflection tables (HOST pointers, host threads; no stream) ---------------------------
  * replaces: DataSet.remove_absences(), DataSet.hkl_to_asu(anomalous=...) and the centric / multiplicity labels the reference takes from
  *           reciprocalspaceship / gemmi (C++) while formatting -- careless/io/formatter.py:285-302, 319 (MonoFormatter.prep_dataset),
@@ -483,8 +493,8 @@ int cl_tn_moments(const float* q_loc_raw, const float* q_scale_raw, const float*
  *                          Friedel-minus and is stored negated, as hkl_to_asu(anomalous=True) does.
  *           Any output pointer may be NULL (absent needs trans).  nthreads <= 0: the cores the process may run on, at most 32.
  * cl_host_dense_ids: ids[i] = rank of key[i] among the DISTINCT keys in ascending order (groupby(...).ngroup() of one integer key),
- *           *n_groups = their number; all keys inside [key_min, key_max].  A presence table over the range: returns -2 when the range
- *           exceeds 2^31 slots (the caller sorts then).                                                                                  */
+ *           *n_groups = their number; all keys inside [key_min, key_max].  A presence table over the range (4 bytes per slot): returns -2 when
+ *           the range exceeds 2^31 slots, -3 when the table cannot be allocated (the caller sorts then).                                                                                  */
 int cl_host_asu_map(const int32_t* hkl, long long n, const int32_t* rot, const double* trans, int nops, int asu_case, int anomalous,
                     int32_t* hasu, uint8_t* centric, int32_t* eps, uint8_t* absent, int nthreads);
 int cl_host_dense_ids(const int64_t* key, long long n, int64_t key_min, int64_t key_max, int64_t* ids, long long* n_groups, int nthreads);

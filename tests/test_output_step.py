@@ -198,3 +198,26 @@ def test_get_results_matches_scipy_moments():
     assert res["N"].sum() == 120 and res["N"][29] == 0 and not res["observed"][29] and res["observed"][:29].all()
     assert set(["high", "loc", "low", "scale"]) <= set(res) and np.allclose(res["loc"], loc, rtol=1e-6)
     assert np.all(res["high"] == np.float32(1e10))
+
+
+def test_cl_predict_moments_matches_the_fp64_formula():
+    """`cl_predict_moments` (reference variational.py:80-121: E[I] = <Sigma><F^2>, var[I] = <F^4><Sigma^2> - E[I]^2 per observation) against
+    numpy in fp64, reflection ids outside [0, R) included."""
+    from careless_amd.engine import predict_moments
+    rng = np.random.default_rng(2)
+    R, n = 300, 20_000
+    mom = {"mean": torch.as_tensor(rng.gamma(2.0, 3.0, R).astype(np.float32), device="cuda"),
+           "std": torch.as_tensor(rng.gamma(1.0, 0.5, R).astype(np.float32), device="cuda"),
+           "m4": torch.as_tensor(rng.gamma(2.0, 500.0, R), device="cuda")}
+    sm = torch.as_tensor(rng.gamma(3.0, 1.0, n).astype(np.float32), device="cuda")
+    ss = torch.as_tensor(rng.gamma(1.0, 0.2, n).astype(np.float32), device="cuda")
+    rid = rng.integers(0, R, n)
+    rid[:5] = [-1, R, R + 7, 0, R - 1]
+    iexp, ivar = predict_moments(sm, ss, rid, mom)
+    ok = (rid >= 0) & (rid < R)
+    r = np.clip(rid, 0, R - 1)
+    m, s, m4 = (mom[k].cpu().numpy().astype(np.float64)[r] * ok for k in ("mean", "std", "m4"))
+    a, b = sm.cpu().numpy().astype(np.float64), ss.cpu().numpy().astype(np.float64)
+    e = a * (m * m + s * s)
+    assert np.allclose(iexp, e, rtol=1e-14, atol=0.0)
+    assert np.allclose(ivar, m4 * (a * a + b * b) - e * e, rtol=1e-12, atol=1e-9)
