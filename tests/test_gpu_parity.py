@@ -423,8 +423,41 @@ def _random_engine_cases(n=12, seed=11):
     return cases
 
 
+def _random_lane_image_layer_cases(n=10, seed=23):
+    """Seeded random draws over what the lane kernel's per-image-layer instances take (round 5: 20 Dense layers, width 1 .. 10, 1 .. 15 metadata
+    columns, one or two per-image layers, mono and single-pass Laue, any sample count, every likelihood / bijector / reduction switch)."""
+    rng = np.random.default_rng(seed)
+    cases = {}
+    for i in range(n):
+        laue = rng.random() < 0.3
+        kw = dict(N=int(rng.integers(60, 2500)), R=int(rng.integers(4, 90)), L=20, w=int(rng.integers(1, 11)), S=int(rng.integers(1, 13)),
+                  image_layers=int(rng.integers(1, 3)), n_images=int(rng.integers(2, 30)), perturb=0.03)
+        if laue:
+            kw["laue"] = True
+            kw["N"] = max(kw["N"], 150)
+            kw["n_images"] = min(kw["n_images"], 8)
+        else:
+            kw["d0"] = int(rng.integers(1, 16))
+            if rng.random() < 0.3:
+                kw["shuffle_rows"] = True
+        if rng.random() < 0.5:
+            kw.update(likelihood="studentt", dof=float(rng.choice([3.0, 8.0, 32.0])))
+        if rng.random() < 0.3:
+            kw["ev11"] = True
+        if rng.random() < 0.3:
+            kw.update(bijector="softplus", shift=float(rng.choice([0.0, 1.5])))
+        if rng.random() < 0.25:
+            kw["kl_weight"] = 0.5
+        if rng.random() < 0.4:
+            kw["grid"] = int(rng.integers(1, 4))
+        kw["R"] = min(kw["R"], kw["N"])
+        cases[f"random_lane_imgl_{i:02d}_{'laue' if laue else 'mono'}_20x{kw['w']}_K{kw['image_layers']}_S{kw['S']}"] = kw
+    return cases
+
+
 # (a longer sweep on demand: ENGINE_RANDOM_N=150 ENGINE_RANDOM_SEED=3 python -m pytest tests/test_gpu_parity.py -k random_engine)
 RANDOM_ENGINE_CASES = _random_engine_cases(int(os.environ.get("ENGINE_RANDOM_N", "12")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")))
+RANDOM_ENGINE_CASES.update(_random_lane_image_layer_cases(int(os.environ.get("LANE_IMGL_RANDOM_N", "10")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")) + 12))
 
 
 @pytest.mark.parametrize("name", list(RANDOM_ENGINE_CASES))
