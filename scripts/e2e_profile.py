@@ -4,12 +4,14 @@ import cProfile, os, pstats, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 n, its = int(sys.argv[1]), sys.argv[2]
 tmp = os.environ.get("E2E_TMP", "/tmp/e2e"); os.makedirs(tmp, exist_ok=True)
-mtz = os.path.join(tmp, f"big_{n}.mtz")
+mode = os.environ.get("E2E_MODE", "mono")            # poly: a synthetic Laue file (scripts/gen_big_laue_mtz.py), metadata keys BATCH,X,Y,Wavelength
+mtz = os.path.join(tmp, f"big_{mode}_{n}.mtz")
 if not os.path.exists(mtz):
-    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(__file__), "gen_big_mtz.py"), str(n), mtz])
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(__file__), "gen_big_mtz.py" if mode == "mono" else "gen_big_laue_mtz.py"), str(n), mtz])
 from careless_amd.parser import parser
 from careless_amd import careless
-args = parser.parse_args(["mono", "--iterations", its, "--disable-progress-bar"] + sys.argv[3:] + ["BATCH,XDET,YDET", mtz, os.path.join(tmp, "out")])
+args = parser.parse_args([mode, "--iterations", its, "--disable-progress-bar"] + sys.argv[3:] +
+                         ["BATCH,XDET,YDET" if mode == "mono" else "BATCH,X,Y,Wavelength", mtz, os.path.join(tmp, "out")])
 pr = cProfile.Profile(); t = time.time(); pr.enable()
 careless.run_careless(args)
 pr.disable(); print("TOTAL wall s", round(time.time() - t, 2))
