@@ -181,6 +181,8 @@ EXPORTS = {
     "cl_tn_moments": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_float, _vp, _vp, _vp, _vp]),
     "cl_host_asu_map": (C.c_int, [_vp, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cl_host_dense_ids": (C.c_int, [_vp, C.c_longlong, C.c_int64, C.c_int64, _vp, C.POINTER(C.c_longlong), C.c_int]),
+    "cl_host_crystfel_count": (C.c_longlong, [_vp, C.c_longlong, C.POINTER(C.c_longlong), C.c_int]),
+    "cl_host_crystfel_parse": (C.c_int, [_vp, C.c_longlong, C.c_longlong, _vp, C.c_int]),
     "cl_predict_moments": (C.c_int, [_vp, _vp, _vp, C.c_longlong, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "cl_debug_noise": (C.c_int, [C.c_ulonglong, C.c_uint, C.c_int, C.c_longlong, C.c_longlong, C.c_int, _vp, _vp]),
 }

@@ -498,6 +498,14 @@ int cl_predict_moments(const float* scale_mean, const float* scale_std, const in
 int cl_host_asu_map(const int32_t* hkl, long long n, const int32_t* rot, const double* trans, int nops, int asu_case, int anomalous,
                     int32_t* hasu, uint8_t* centric, int32_t* eps, uint8_t* absent, int nthreads);
 int cl_host_dense_ids(const int64_t* key, long long n, int64_t key_min, int64_t key_max, int64_t* ids, long long* n_groups, int nthreads);
+/* CrystFEL `.stream` files (replaces: rs.read_crystfel behind careless/io/formatter.py:179-184 -- serial-crystallography input, text files of
+ * 10^7 .. 10^8 reflection lines): the indexed reflection lists of every crystal in the buffer `buf` (the file's bytes, e.g. a read-only
+ * memory map) as one table.  cl_host_crystfel_count returns the number of rows (list lines with at least nine blank-separated fields; < 0:
+ * error) and the number of "--- Begin crystal" lines; cl_host_crystfel_parse fills cols[10][n_rows] (column-major, fp32):
+ * h, k, l, I, sigma(I), peak, background, fs/px, ss/px, BATCH = number of the crystal (0-based).  Integers as int(), reals as float() of the
+ * field (strtoll / strtod) stored as fp32; -5: a field that is not a number.  Lists are parsed in parallel on host threads.              */
+long long cl_host_crystfel_count(const char* buf, long long nbytes, long long* n_crystals, int nthreads);
+int cl_host_crystfel_parse(const char* buf, long long nbytes, long long n_rows, float* cols, int nthreads);
 
 /* --- diagnostics -------------------------------------------------------------------------------------------------- */
 const char* cl_version(void);
