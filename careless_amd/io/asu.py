@@ -105,8 +105,8 @@ class SymmetryOps:
         """One pass of `cl_host_asu_map` (careless_amd/csrc/host_format.cpp; host threads) over the rows of `hkl`."""
         import ctypes as C
         from careless_amd._lib import check, get_lib
-        h = np.ascontiguousarray(np.asarray(hkl).reshape(-1, 3), dtype=np.int64)
-        if len(h) and np.abs(h).max() >= (1 << 19):
+        h = np.asarray(hkl).reshape(-1, 3)
+        if len(h) and (int(h.max()) >= (1 << 19) or int(h.min()) <= -(1 << 19)):
             raise ValueError("Miller index beyond +-2^19")
         h32 = np.ascontiguousarray(h, dtype=np.int32)
         n = len(h32)
@@ -131,9 +131,9 @@ class SymmetryOps:
         return centric.astype(bool), eps.astype(np.int64), absent.astype(bool)
 
     def map_rows(self, hkl: np.ndarray, anomalous: bool = False):
-        """(ASU representative int64 (N, 3), centric, epsilon, absent) of every row in ONE pass (the formatter's per-observation call)."""
+        """(ASU representative int32 (N, 3), centric, epsilon, absent) of every row in ONE pass (the formatter's per-observation call)."""
         hasu, centric, eps, absent = self._map(hkl, anomalous, True, True)
-        return hasu.astype(np.int64), centric.astype(bool), eps.astype(np.int64), absent.astype(bool)
+        return hasu, centric.view(bool), eps, absent.view(bool)
 
 
 class ReciprocalASU:

@@ -152,7 +152,9 @@ class DataFormatter:
 
     def _common_prep(self, cols: Dict[str, np.ndarray], mtz: Mtz, keys) -> Dict[str, np.ndarray]:
         ops = SymmetryOps(mtz.symops)
-        H = np.stack([cols["H"], cols["K"], cols["L"]], axis=1).astype(np.int64)
+        H = np.empty((len(cols["H"]), 3), dtype=np.int32)                 # (filled column by column: no int64 / float64 copies of the table)
+        for j, k in enumerate(("H", "K", "L")):
+            H[:, j] = cols[k]
         Hasu, _, _, absent = ops.map_rows(H, self.anomalous)            # ds.remove_absences + ds.hkl_to_asu in one native pass
         if absent.any():
             keep = ~absent
@@ -185,7 +187,8 @@ class DataFormatter:
         common = set(tables[0])
         for t in tables[1:]:
             common &= set(t)
-        data = {k: np.concatenate([t[k] for t in tables]) for k in tables[0] if k in common}
+        data = ({k: v for k, v in tables[0].items() if k in common} if len(tables) == 1 else
+                {k: np.concatenate([t[k] for t in tables]) for k in tables[0] if k in common})
         dmin = float(data["dHKL"].min())
         if self.separate_outputs:
             asus = [ReciprocalASU(c, s, dmin, self.anomalous, *g) for c, s, g in zip(cells, syms, sgs)]
@@ -254,10 +257,11 @@ class MonoFormatter(DataFormatter):
     def prep_dataset(self, mtz: Mtz):
         keys = self._guess_keys(mtz)
         cols = dict(mtz.columns)
-        d = 1.0 / np.sqrt(inv_d2(mtz.hkl(), mtz.cell))
-        keep = ~(d < self.dmin)                                           # resolution cut (formatter.py:296-297)
-        if not keep.all():
-            cols = {k: v[keep] for k, v in cols.items()}
+        if self.dmin is not None and self.dmin > 0.0:                     # resolution cut (formatter.py:296-297); no d < 0 without one
+            d = 1.0 / np.sqrt(inv_d2(mtz.hkl(), mtz.cell))
+            keep = ~(d < self.dmin)
+            if not keep.all():
+                cols = {k: v[keep] for k, v in cols.items()}
         return self._common_prep(cols, mtz, keys)
 
     def finalize(self, data, rac):
