@@ -163,6 +163,9 @@ class ReciprocalASU:
         k = _key(self.Hall)
         self._sort = np.argsort(k)
         self._keys = k[self._sort]
+        # reflection id by direct lookup over the index box (|h_i| <= lim_i): one gather per observation instead of a binary search
+        self._lim = np.asarray(lim, dtype=np.int64)
+        self._lut = None                                   # (built at the first lookup; never pickled)
 
     @property
     def centric(self):
@@ -179,8 +182,37 @@ class ReciprocalASU:
     def __len__(self):
         return len(self.Hall)
 
+    def _flat(self, H: np.ndarray) -> np.ndarray:
+        """Position of every Miller index (inside the box) in the lookup table."""
+        lh, lk, ll = (int(v) for v in self._lim)
+        H = np.asarray(H)
+        return ((H[:, 0].astype(np.int64) + lh) * (2 * lk + 1) + (H[:, 1] + lk)) * (2 * ll + 1) + (H[:, 2] + ll)
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_lut"] = None                               # (a table over the index box: rebuilt on demand, not shipped with the pickle)
+        return state
+
+    def _table(self):
+        if self._lut is None and int((2 * self._lim + 1).prod()) <= (1 << 25):
+            self._lut = np.full(int((2 * self._lim + 1).prod()), -1, dtype=np.int32)
+            self._lut[self._flat(self.Hall)] = np.arange(len(self.Hall), dtype=np.int32)
+        return self._lut
+
     def to_refl_id(self, H: np.ndarray) -> np.ndarray:
         """Reflection ids of Miller indices that are already ASU representatives; raises KeyError for anything else."""
+        if self._table() is not None:
+            H = np.asarray(H)
+            H = H.reshape(-1, 3)
+            inside = np.ones(len(H), dtype=bool)
+            for j in range(3):
+                inside &= (H[:, j] >= -self._lim[j]) & (H[:, j] <= self._lim[j])
+            if not inside.all():
+                raise KeyError("Miller index outside the reciprocal asymmetric unit (absent, beyond dmin, or not mapped to the ASU)")
+            ids = self._lut[self._flat(H)]
+            if len(ids) and int(ids.min()) < 0:
+                raise KeyError("Miller index outside the reciprocal asymmetric unit (absent, beyond dmin, or not mapped to the ASU)")
+            return ids.astype(np.int64)
         k = _key(np.asarray(H, dtype=np.int64))
         pos = np.searchsorted(self._keys, k)
         pos = np.clip(pos, 0, len(self._keys) - 1)
