@@ -275,3 +275,20 @@ def test_default_scaler_on_four_positionally_encoded_keys(tmp_path):
               "--mc-samples 3 --positional-encoding-keys X,Y,Hobs,Kobs dHKL,image_id,X,Y,Hobs,Kobs")
     _, model2, _ = _run(flags2, [PYP], out2, False)
     assert np.array_equal(flat(model2), flat(model))
+
+
+@pytest.mark.parametrize("mode", ["mono", "poly"])
+def test_default_scaler_with_image_layers_and_half_datasets(tmp_path, mode):
+    """`careless mono|poly --image-layers 2 --merge-half-datasets` with the default scaler (reference careless/args/scaling.py:21-40,
+    careless.py:102-128): the main training runs the lane kernel's per-image-layer instance (round 5), the half-dataset trainings -- scaler
+    frozen -- the sampling / likelihood kernels only; every output file is written."""
+    out = str(tmp_path / "a")
+    flags = f"{mode} --iterations={niter} --disable-progress-bar --image-layers 2 --merge-half-datasets --test-fraction 0.1 dHKL,image_id"
+    args, model, hist = _run(flags, [PYP], out, False)
+    eng = model._engine
+    name = eng.kernel_name()
+    assert name.startswith("elbo_lane_kernel<10, 8, true, ") and name.rstrip().endswith("2> (image layers)"), name
+    assert not eng.scaler_frozen and eng.obs.row_map is not None                   # trained on the packed-by-image layout
+    x = read_mtz(out + "_xval_0.mtz")
+    assert set(np.unique(x.columns["half"])) == {0.0, 1.0} and np.all(np.isfinite(x.columns["F"]))
+    assert "NLL_val" in hist and np.all(np.isfinite(hist["NLL_val"]))
