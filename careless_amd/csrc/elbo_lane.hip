@@ -1113,7 +1113,7 @@ int cl_lane_supports(const cl_mlp_args& a) {
 // layers stays on the IMGL instances of elbo_mlp.hip.
 int cl_lane_imgl_supports(const cl_mlp_args& a) {
     return a.n_imgl >= 1 && a.n_imgl <= CL_LANE_IMGL_MAX && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && a.L == NL &&
-           a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.dZ0_out == nullptr && a.dzf_obs == nullptr && a.row_map != nullptr &&
+           a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.dzf_obs == nullptr && a.row_map != nullptr &&
            (a.gmeta == nullptr || a.tile_gmax != nullptr) && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
 }
 
@@ -1175,7 +1175,11 @@ int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st) {
 // per-image layers: the widest instance serves every w <= 10 (a narrower scaler pays the padded MFMA steps: --image-layers on a
 // non-default width is rare); with and without the optional inputs / outputs, as the plain layout
 int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
-    const bool full = lane_wants_full(a);
+    // Behind a peeled first layer (more than 15 metadata columns) the FULL instance stores dZ_0.  A production instance with that store
+    // (<.., false, true, NI>) was built and withdrawn: hipcc's code for <10, 15, true, false, true, 2> gave results that changed from run to
+    // run (tests: ..._repeat_from_run_to_run, ..._production_instance_on_in_kernel_noise) -- the second dZ_0-storing instance at the register
+    // wall to do so (NOTEBOOK R5.9 / R5.12); 4.02 against 4.44 ms per step at 10 M observations was not worth an instance nobody can trust.
+    const bool full = lane_wants_full(a) || a.dZ0_out != nullptr;
 #define CL_LANE_IMGL_CASE(DM, NI_) (full ? launch_lane_inst<CL_LANE_WMAX, DM, true, true, false, NI_>(a, grid, st) : launch_lane_inst<CL_LANE_WMAX, DM, true, false, false, NI_>(a, grid, st))
     if (a.n_imgl == 1) return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 1) : CL_LANE_IMGL_CASE(DMAX_ALL, 1);
     return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 2) : CL_LANE_IMGL_CASE(DMAX_ALL, 2);

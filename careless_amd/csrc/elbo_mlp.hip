@@ -1389,9 +1389,10 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     // dZ0_out (the launch behind a peeled first layer, elbo_peel.hip) is stored by the default scaler's kernels only
-    if (a.dZ0_out != nullptr && !(mode == 0 && a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.n_imgl == 0 &&
+    if (a.dZ0_out != nullptr && !(mode == 0 && a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr &&
                                   (a.dzf_obs == nullptr || a.ev11 == nullptr || a.ev11_part != nullptr) &&
-                                  ((cl_lane_supports(a) && lane_enabled()) || (cl_narrow_supports(a) && narrow_enabled()))))
+                                  ((a.n_imgl == 0 && ((cl_lane_supports(a) && lane_enabled()) || (cl_narrow_supports(a) && narrow_enabled()))) ||
+                                   (a.n_imgl > 0 && cl_lane_imgl_supports(a) && lane_enabled()))))
         return -2;
     if (a.dzf_obs != nullptr && (mode == 0 || (a.act_out == nullptr && a.dH_ext == nullptr))) {
         // deterministic mode: the default scaler's shapes keep their own kernels (round 4: elbo_lane.hip / elbo_narrow.hip store per
@@ -1451,7 +1452,7 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     else if (a.n_imgl > 0) {
         if (mode == 0 && cl_lane_imgl_supports(a) && lane_enabled())
             return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, false, %d> (image layers)", 10, a.d <= 8 ? 8 : 15,
-                            (a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr) ? "true" : "false", a.n_imgl);
+                            (a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr || a.dZ0_out != nullptr) ? "true" : "false", a.n_imgl);
         unit = ", image layers";
     } else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }
     if (a.dzf_obs == nullptr && (unit[0] == 0 || packed)) {

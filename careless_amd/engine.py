@@ -253,6 +253,11 @@ class ElboEngine(WidePath):
         self.peel = (not self.wide and self.blocks is None and imgl is None and self.w <= 12 and self.L <= 20 and
                      self.d > (31 if lane_shape else 15) and self.d > self.w and bool(self.lib.cl_peel_supported(self.d, self.w, self.L)) and
                      os.environ.get("CARELESS_HIP_NARROW", "1") != "0")
+        # ... and (round 5) the default scaler with one or two per-image layers on more than the 15 columns its lane instances hold
+        # (`--image-layers 2 --positional-encoding-keys X,Y`: 21): the peeled layer's w pre-activations are the lane kernel's "metadata"
+        if (not self.wide and imgl is not None and lane_shape and imgl.n_image_layers <= 2 and self.d > 15 and self.d > self.w and
+                not self.laue and bool(self.lib.cl_peel_supported(self.d, self.w, self.L))):
+            self.peel = True
         if imgl is not None:
             imgl.build(self.d)
             max_l = int(self.lib.cl_mlp_max_layers_imgl(self.w))

@@ -40,6 +40,7 @@ WORKLOADS: Dict[str, dict] = {
     "laue_5M_normal_20x10_S1": dict(N=5_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, kind="laue"),
     "dw_10M_normal_20x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, kind="double_wilson"),
     "mono_10M_20x10_img2_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, image_layers=2),
+    "mono_10M_studentt_posenc_20x10_img2_S8": dict(N=10_000_000, d0=5, posenc=True, L=20, w=10, S=8, dof=16.0, outliers=True, image_layers=2),
     "laue_5M_normal_20x10_img2_S1": dict(N=5_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, kind="laue", image_layers=2),
 }
 

@@ -121,6 +121,10 @@ CASES = {
                                                     perturb=0.03),
     "lane_image_layers2_20x10_S11_softplus": dict(N=900, R=50, d0=5, L=20, w=10, S=11, n_images=6, image_layers=2, bijector="softplus", perturb=0.03),
     "lane_image_layers1_20x6_ev11": dict(N=800, R=50, d0=7, L=20, w=6, S=2, n_images=5, image_layers=1, ev11=True, perturb=0.03),
+    # ... on more than the 15 columns the lane instances hold: the first layer peeled in front of them (`--image-layers 2 --positional-encoding-keys X,Y`)
+    "lane_image_layers2_20x10_posenc_d21_peeled": dict(N=1500, R=60, d0=5, posenc=True, L=20, w=10, S=2, n_images=8, image_layers=2, perturb=0.03),
+    "lane_image_layers1_20x8_d30_peeled_studentt_S9": dict(N=1200, R=50, d0=30, L=20, w=8, S=9, n_images=11, image_layers=1, likelihood="studentt", dof=8.0,
+                                                           perturb=0.03),
     "lane_laue_image_layers1_20x10": dict(N=900, R=60, L=20, w=10, S=1, laue=True, n_images=6, image_layers=1, perturb=0.03),
     "lane_laue_image_layers2_20x6_S3_studentt": dict(N=700, R=50, L=20, w=6, S=3, laue=True, n_images=4, image_layers=2, likelihood="studentt", dof=8.0,
                                                      perturb=0.03),
@@ -711,8 +715,9 @@ def test_image_layers_philox_noise_is_keyed_by_the_callers_rows():
 
 
 @pytest.mark.parametrize("kw", [dict(N=2500, R=60, d0=5, L=20, w=10, S=2, n_images=13, image_layers=2, perturb=0.03),
-                                dict(N=1800, R=50, d0=11, L=20, w=8, S=1, n_images=9, image_layers=1, likelihood="studentt", dof=8.0, perturb=0.03)],
-                         ids=["20x10_img2", "20x8_d11_img1_studentt"])
+                                dict(N=1800, R=50, d0=11, L=20, w=8, S=1, n_images=9, image_layers=1, likelihood="studentt", dof=8.0, perturb=0.03),
+                                dict(N=2000, R=60, d0=5, posenc=True, L=20, w=10, S=2, n_images=9, image_layers=2, perturb=0.03)],
+                         ids=["20x10_img2", "20x8_d11_img1_studentt", "20x10_img2_posenc_d21_peeled"])
 def test_lane_image_layers_production_instance_on_in_kernel_noise(kw):
     """`--image-layers` on the default scaler, as a production step runs it (round 5: elbo_lane_kernel<.., NI> without the optional
     inputs / outputs, in-kernel Philox noise keyed by the caller's rows through the by-image packing): the dumped noise replayed through
@@ -727,7 +732,8 @@ def test_lane_image_layers_production_instance_on_in_kernel_noise(kw):
     eng.forward_backward(5)
     torch.cuda.synchronize()
     name = eng.kernel_name()
-    assert name.startswith("elbo_lane_kernel<10, ") and f"true, false, false, {kw['image_layers']}>" in name, name
+    peeled = np.asarray(data["metadata"]).shape[1] > 15          # (behind a peeled first layer the instance that stores dZ_0 runs: the full one)
+    assert name.startswith("elbo_lane_kernel<10, ") and f"true, {'true' if peeled else 'false'}, false, {kw['image_layers']}>" in name, name
     u = debug_noise(77, 5, kw["S"], kw["R"], 0, kind=0).t().cpu().numpy()
     e = debug_noise(77, 5, kw["S"], kw["N"], 0, kind=1).t().cpu().numpy()
     out, grads = O.elbo_value_and_grads(params, x, cfg, torch.as_tensor(u, dtype=torch.float64), torch.as_tensor(e, dtype=torch.float64))
@@ -739,8 +745,13 @@ def test_lane_image_layers_production_instance_on_in_kernel_noise(kw):
 @pytest.mark.parametrize("kw", [dict(N=5000, R=40, d0=37, L=20, w=10, S=3, perturb=0.02),
                                 dict(N=5000, R=40, d0=5, L=20, w=10, S=3, perturb=0.02, image_layers=2, n_images=23),
                                 dict(N=5000, R=40, d0=12, L=20, w=8, S=2, perturb=0.02, image_layers=1, n_images=11),
-                                dict(N=5000, R=40, d0=5, L=20, w=10, S=1, perturb=0.02)],
-                         ids=["peeled_dZ0_out", "image_layers2", "image_layers1_d12", "cli_default"])
+                                dict(N=5000, R=40, d0=5, L=20, w=10, S=1, perturb=0.02),
+                                dict(N=5000, R=40, d0=5, posenc=True, L=20, w=10, S=2, perturb=0.02, image_layers=2, n_images=17),
+                                dict(N=5000, R=40, d0=37, L=20, w=8, S=2, perturb=0.02), dict(N=5000, R=40, d0=41, L=20, w=6, S=1, perturb=0.02),
+                                dict(N=5000, R=40, d0=33, L=20, w=4, S=3, perturb=0.02), dict(N=5000, R=40, d0=21, L=20, w=10, S=8, perturb=0.02),
+                                dict(N=5000, R=60, L=20, w=10, S=1, laue=True, perturb=0.02)],
+                         ids=["peeled_dZ0_out", "image_layers2", "image_layers1_d12", "cli_default", "image_layers2_peeled_d21",
+                              "peeled_w8", "peeled_w6", "peeled_w4", "lds_rows_d21_S8", "laue_packed"])
 def test_lane_production_instances_repeat_from_run_to_run(kw):
     """Guards the one-wave-per-SIMD instances at the 512-register wall against a code generation accident (round 5: a rewrite of the
     forward loop that changed nothing in the source's meaning left the dZ_0-storing instance with results that moved from run to run;
