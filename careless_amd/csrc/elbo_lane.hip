@@ -172,7 +172,11 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     constexpr bool LX = (DMAX == 0);
     constexpr int DREG = LX ? 1 : DMAX;               // metadata registers of the lane (LX: none; arrays keep one element)
     constexpr int NLT = NL + NI;                      // hidden layers: Dense + per-image
+#ifdef CL_EXP_DXO_NI      /* diagnostic builds only (NOTEBOOK R5.12): the withdrawn dZ_0-storing production instance with per-image layers */
+    static_assert(NI == 0 || (PACKED && !LX), "per-image layers: packed layout, metadata in registers");
+#else
     static_assert(NI == 0 || (PACKED && !LX && !DXO), "per-image layers: packed layout, metadata in registers");
+#endif
     using SM = LSmem<W, LX, NI>;
     constexpr int PK = SM::PK;
     constexpr int DGMAX = LX ? 8 : (DMAX + 3) / 4;
@@ -878,10 +882,28 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     if (has_dxo) {                                   // wave-uniform
                         float* const dxo = A.dZ0_out + (size_t)(wt * WT) + lane;
                         const size_t np = (size_t)A.n_pad;
+#ifndef CL_EXP_DXO_NOSTORE
+#ifdef CL_EXP_DXO_NOP         /* wait states in front of the stores: their data / address registers come out of inline-assembly VALU code */
+                        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+#ifdef CL_EXP_DXO_COPY        /* the stored value passes through a VALU instruction the compiler knows */
+                        float one_ = 1.0f;
+                        asm volatile("" : "+v"(one_));
+#endif
                         static_for<0, W>([&](auto fc_) {
                             constexpr int f = decltype(fc_)::value;
+#ifdef CL_EXP_DXO_COPY
+                            if (f < w) dxo[f * np] = DZ(0, f) * one_;
+#else
                             if (f < w) dxo[f * np] = DZ(0, f);
+#endif
                         });
+#else
+                        (void)dxo; (void)np;
+#endif
+#ifdef CL_EXP_DXO_WAIT
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                     }
                 }
                 LFENCE();
@@ -1179,8 +1201,15 @@ int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
     // (<.., false, true, NI>) was built and withdrawn: hipcc's code for <10, 15, true, false, true, 2> gave results that changed from run to
     // run (tests: ..._repeat_from_run_to_run, ..._production_instance_on_in_kernel_noise) -- the second dZ_0-storing instance at the register
     // wall to do so (NOTEBOOK R5.9 / R5.12); 4.02 against 4.44 ms per step at 10 M observations was not worth an instance nobody can trust.
+#ifdef CL_EXP_DXO_NI
+    const bool full = lane_wants_full(a);
+#define CL_LANE_IMGL_CASE(DM, NI_) (full ? launch_lane_inst<CL_LANE_WMAX, DM, true, true, false, NI_>(a, grid, st) : \
+                                    (a.dZ0_out != nullptr ? launch_lane_inst<CL_LANE_WMAX, DM, true, false, true, NI_>(a, grid, st) : \
+                                                            launch_lane_inst<CL_LANE_WMAX, DM, true, false, false, NI_>(a, grid, st)))
+#else
     const bool full = lane_wants_full(a) || a.dZ0_out != nullptr;
 #define CL_LANE_IMGL_CASE(DM, NI_) (full ? launch_lane_inst<CL_LANE_WMAX, DM, true, true, false, NI_>(a, grid, st) : launch_lane_inst<CL_LANE_WMAX, DM, true, false, false, NI_>(a, grid, st))
+#endif
     if (a.n_imgl == 1) return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 1) : CL_LANE_IMGL_CASE(DMAX_ALL, 1);
     return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 2) : CL_LANE_IMGL_CASE(DMAX_ALL, 2);
 #undef CL_LANE_IMGL_CASE
