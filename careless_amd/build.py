@@ -14,20 +14,25 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcareless_hip.so")
+# The fused scaler kernels' LeakyReLU is fmaxf(x, leak x); with NaNs honoured hipcc puts a canonicalising v_max_f32 x, x in front of
+# every one of them, without it emits the one v_max_f32 -- an instruction it KNOWS, so that its hazard recognizer pads the two wait
+# states gfx950 wants in front of an MFMA that reads the result (until round 6 the bare instruction was inline assembly, which it does
+# not see: NOTEBOOK R6.1).  Nothing in these units tests for NaN (the non-finite stop is taken on the gradient norm, in elbo_elem.hip).
+NNAN = ["-fno-honor-nans"]
 # (source, object stem, extra flags): elbo_mlp.hip is compiled twice -- Dense-only scalers and the per-image-layer variant
-UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=0"]), ("elbo_mlp.hip", "elbo_mlp_imgl", ["-DCL_IMGL=1"]),
-         ("elbo_mlp.hip", "elbo_mlp_packed", ["-DCL_IMGL=2"]),
-         ("elbo_mlp.hip", "elbo_mlp_chain", ["-DCL_CHAIN=1"]),
-         ("elbo_mlp.hip", "elbo_mlp_det", ["-DCL_DET=1"]),               # deterministic mode: the epilogue's atomics as stores
-         ("elbo_mlp.hip", "elbo_mlp_packed_det", ["-DCL_IMGL=2", "-DCL_DET=1"]),    # ... in the packed layout (single-pass Laue)
-         ("elbo_mlp.hip", "elbo_mlp_chain_det", ["-DCL_CHAIN=1", "-DCL_DET=1"]),    # ... for the last block of a layer-block chain
-         ("elbo_narrow.hip", "elbo_narrow", ["-fno-slp-vectorize"]),     # (packed fp32 math costs more than it saves beside MFMAs)
+UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=0"] + NNAN), ("elbo_mlp.hip", "elbo_mlp_imgl", ["-DCL_IMGL=1"] + NNAN),
+         ("elbo_mlp.hip", "elbo_mlp_packed", ["-DCL_IMGL=2"] + NNAN),
+         ("elbo_mlp.hip", "elbo_mlp_chain", ["-DCL_CHAIN=1"] + NNAN),
+         ("elbo_mlp.hip", "elbo_mlp_det", ["-DCL_DET=1"] + NNAN),               # deterministic mode: the epilogue's atomics as stores
+         ("elbo_mlp.hip", "elbo_mlp_packed_det", ["-DCL_IMGL=2", "-DCL_DET=1"] + NNAN),    # ... in the packed layout (single-pass Laue)
+         ("elbo_mlp.hip", "elbo_mlp_chain_det", ["-DCL_CHAIN=1", "-DCL_DET=1"] + NNAN),    # ... for the last block of a layer-block chain
+         ("elbo_narrow.hip", "elbo_narrow", ["-fno-slp-vectorize"] + NNAN),     # (packed fp32 math costs more than it saves beside MFMAs)
          # (4x4x1 results feed vector code: no accumulator-register detour); four parts = four groups of instances, compiled in parallel
-         ("elbo_lane.hip", "elbo_lane0", ["-DCL_LANE_PART=0", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-         ("elbo_lane.hip", "elbo_lane1", ["-DCL_LANE_PART=1", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-         ("elbo_lane.hip", "elbo_lane2", ["-DCL_LANE_PART=2", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-         ("elbo_lane.hip", "elbo_lane3", ["-DCL_LANE_PART=3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-         ("elbo_lane.hip", "elbo_lane4", ["-DCL_LANE_PART=4", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]),      # per-image layers (round 5)
+         ("elbo_lane.hip", "elbo_lane0", ["-DCL_LANE_PART=0", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),
+         ("elbo_lane.hip", "elbo_lane1", ["-DCL_LANE_PART=1", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),
+         ("elbo_lane.hip", "elbo_lane2", ["-DCL_LANE_PART=2", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),
+         ("elbo_lane.hip", "elbo_lane3", ["-DCL_LANE_PART=3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),
+         ("elbo_lane.hip", "elbo_lane4", ["-DCL_LANE_PART=4", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),      # per-image layers (round 5)
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", []), ("wide_gemm.hip", "wide_gemm", []),
          ("elbo_peel.hip", "elbo_peel", []),
          # host threads, no device code: the formatter's symmetry bookkeeping (exact products kept apart from their sums)
@@ -92,6 +97,9 @@ def build(force: bool = False, verbose: bool = True, stamps: bool = False) -> st
 
 
 def _build(LIB: str, extra, verbose: bool) -> str:
+    """Objects go to a directory of this process' own and the library is moved into place when it is complete: two builds at once (a
+    test session that finds the library stale while `python -m careless_amd.build` runs) do not tread on each other."""
+    import tempfile
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     objs = []
@@ -99,25 +107,55 @@ def _build(LIB: str, extra, verbose: bool) -> str:
     lane_ok = _lane_flag_ok(hipcc)
     if not lane_ok and verbose:
         print("hipcc rejects " + " ".join(LANE_FLAG) + ": building elbo_lane.hip without it", flush=True)
-    for s, stem, flags in UNITS:
-        if not lane_ok:
-            flags = [f for f in flags if f not in LANE_FLAG]
-        o = os.path.join(LIBDIR, stem + ".o" + ("s" if extra else ""))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + list(extra) + flags + ["-c", os.path.join(CSRC, s), "-o", o]
+    work = tempfile.mkdtemp(prefix=".build_", dir=LIBDIR)
+    try:
+        for s, stem, flags in UNITS:
+            if not lane_ok:
+                flags = [f for f in flags if f not in LANE_FLAG]
+            o = os.path.join(work, stem + ".o")
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + list(extra) + flags + ["-c", os.path.join(CSRC, s), "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(o)
+        for cmd, p in procs:
+            if p.wait() != 0:
+                raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        tmp = os.path.join(work, os.path.basename(LIB))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-pthread", "-o", tmp] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(o)
-    for cmd, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed: " + " ".join(cmd))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    for o in objs:
-        os.remove(o)
+        subprocess.check_call(cmd)
+        if os.environ.get("CARELESS_HIP_SKIP_ISA_CHECK") != "1":
+            _isa_gate(tmp, verbose)
+        os.replace(tmp, LIB)
+    finally:
+        for _, p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(work, ignore_errors=True)
     return LIB
+
+
+def _isa_gate(lib: str, verbose: bool) -> None:
+    """Build-time assertion (round 6): no kernel of the library may hold a pair of instructions closer than the gfx950 wait-state rules
+    allow -- hipcc pads only the pairs it can see, and the kernels carry inline assembly (scripts/check_lane_isa.py; NOTEBOOK R6.1).  A
+    library that fails is not installed."""
+    import importlib.util
+    path = os.path.join(HERE, "..", "scripts", "check_lane_isa.py")
+    if not os.path.exists(path):          # (an installed copy without the scripts directory: the check is the repository's)
+        return
+    spec = importlib.util.spec_from_file_location("check_lane_isa", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules.setdefault("check_lane_isa", mod)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.OBJDUMP):
+        return
+    n, bad = mod.check_library(lib)
+    if verbose:
+        print(f"check_lane_isa: {n} kernels, {len(bad)} violations", flush=True)
+    if bad:
+        raise RuntimeError("gfx950 wait-state violations in the built library (scripts/check_lane_isa.py):\n" + "\n".join(bad[:20]))
 
 
 if __name__ == "__main__":

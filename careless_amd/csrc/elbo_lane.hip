@@ -70,14 +70,37 @@ __device__ __forceinline__ f32x4 mfma_bk(float a, float b, f32x4 c) { return __b
 // (two per layer, so that consecutive MFMAs never depend on each other): written as inline assembly, because with the compiler's
 // own choice every layer of every tile pays copies between the two register files.  (Same-destination MFMAs need no software
 // wait states between them; the only other reader is the flush, a barrier later.)
+// Diagnostic switches of round 6 (scripts/probe/build_lane_variants.py; NOTEBOOK R6.1): CL_LANE_MFMA_BUILTIN / CL_LANE_SEL_C replace one
+// kind of inline-assembly statement by code the compiler knows, CL_LANE_LRELU_ASM brings the inline-assembly LeakyReLU back; CL_LANE_PAD_PRE / CL_LANE_PAD_POST pad the MFMA statement.
+#ifndef CL_LANE_PAD_PRE
+#define CL_LANE_PAD_PRE ""
+#endif
+#ifndef CL_LANE_PAD_POST
+#define CL_LANE_PAD_POST ""
+#endif
 __device__ __forceinline__ void mfma16_acc(f32x4& acc, float a, float b) {
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#ifdef CL_LANE_MFMA_BUILTIN
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#else
+    asm volatile(CL_LANE_PAD_PRE "v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" CL_LANE_PAD_POST : "+a"(acc) : "v"(a), "v"(b));
+#endif
 }
 
-__device__ __forceinline__ float lrelu2(float x, float lx) {          // max(x, leak x), leak x given
+// max(x, leak x), leak x given.  ONE v_max_f32 that the compiler KNOWS: this unit is compiled with -fno-honor-nans (build.py), under
+// which fmaxf needs no canonicalising v_max_f32 x, x in front (signalling NaNs are the only inputs that would tell the difference).
+// Until round 6 this was an inline-assembly v_max_f32 -- opaque to hipcc's hazard recognizer.  Its result is the B operand of the next
+// layer's MFMAs, gfx950 wants two wait states between a vector-ALU write and an MFMA reading it, and hipcc pads them only between
+// instructions it knows: wherever the scheduler left ONE instruction between the two, the MFMA read the register's old content on
+// some launches (NOTEBOOK R6.1: the run-to-run defect of round 5's two withdrawn dZ_0-storing instances, and four latent sites in
+// shipped ones).  scripts/check_lane_isa.py holds every code object of the library to the rule; -DCL_LANE_LRELU_ASM rebuilds the old form.
+__device__ __forceinline__ float lrelu2(float x, float lx) {
+#ifdef CL_LANE_LRELU_ASM
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lx));
     return r;
+#else
+    return __builtin_fmaxf(x, lx);
+#endif
 }
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -172,11 +195,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     constexpr bool LX = (DMAX == 0);
     constexpr int DREG = LX ? 1 : DMAX;               // metadata registers of the lane (LX: none; arrays keep one element)
     constexpr int NLT = NL + NI;                      // hidden layers: Dense + per-image
-#ifdef CL_EXP_DXO_NI      /* diagnostic builds only (NOTEBOOK R5.12): the withdrawn dZ_0-storing production instance with per-image layers */
     static_assert(NI == 0 || (PACKED && !LX), "per-image layers: packed layout, metadata in registers");
-#else
-    static_assert(NI == 0 || (PACKED && !LX && !DXO), "per-image layers: packed layout, metadata in registers");
-#endif
     using SM = LSmem<W, LX, NI>;
     constexpr int PK = SM::PK;
     constexpr int DGMAX = LX ? 8 : (DMAX + 3) / 4;
@@ -507,10 +526,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         float wan[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) wan[c] = sF[c * 64];
-        // (The Dense layers keep this loop exactly as the instances without per-image layers had it before round 5: rewritten as a
-        //  static_for over all NLT layers, the dZ_0-storing production instance -- 511 registers -- came out of hipcc giving results that
-        //  changed from run to run, with nothing in the source to explain it; profiles/r5_lane_imgl.txt.  The per-image layers follow
-        //  in a loop of their own.)
+        // (The Dense layers in one loop, the per-image layers in a loop of their own behind it: round 5 kept them apart because a single
+        //  static_for over all NLT layers "made" the dZ_0-storing instance unrepeatable -- it had only moved the inline-assembly LeakyReLU
+        //  next to an MFMA, NOTEBOOK R6.1; the split stays because the instruction streams are the measured ones.)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             {
@@ -820,6 +838,11 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 f32x4 lk[NC];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) lk[c] = dh[c] * leak;
+#ifdef CL_LANE_SEL_C
+#pragma unroll
+                for (int f = 0; f < W; ++f) dzp[f >> 1][f & 1] = hp[f >> 1][f & 1] > 0.0f ? dh[f >> 2][f & 3] : lk[f >> 2][f & 3];
+                if (true) return;
+#endif
 #pragma unroll
                 for (int f0 = 0; f0 < W; f0 += SELG) {
                     unsigned long long m[SELG];
@@ -882,28 +905,10 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     if (has_dxo) {                                   // wave-uniform
                         float* const dxo = A.dZ0_out + (size_t)(wt * WT) + lane;
                         const size_t np = (size_t)A.n_pad;
-#ifndef CL_EXP_DXO_NOSTORE
-#ifdef CL_EXP_DXO_NOP         /* wait states in front of the stores: their data / address registers come out of inline-assembly VALU code */
-                        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-#ifdef CL_EXP_DXO_COPY        /* the stored value passes through a VALU instruction the compiler knows */
-                        float one_ = 1.0f;
-                        asm volatile("" : "+v"(one_));
-#endif
                         static_for<0, W>([&](auto fc_) {
                             constexpr int f = decltype(fc_)::value;
-#ifdef CL_EXP_DXO_COPY
-                            if (f < w) dxo[f * np] = DZ(0, f) * one_;
-#else
                             if (f < w) dxo[f * np] = DZ(0, f);
-#endif
                         });
-#else
-                        (void)dxo; (void)np;
-#endif
-#ifdef CL_EXP_DXO_WAIT
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
                     }
                 }
                 LFENCE();
@@ -1197,19 +1202,14 @@ int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st) {
 // per-image layers: the widest instance serves every w <= 10 (a narrower scaler pays the padded MFMA steps: --image-layers on a
 // non-default width is rare); with and without the optional inputs / outputs, as the plain layout
 int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
-    // Behind a peeled first layer (more than 15 metadata columns) the FULL instance stores dZ_0.  A production instance with that store
-    // (<.., false, true, NI>) was built and withdrawn: hipcc's code for <10, 15, true, false, true, 2> gave results that changed from run to
-    // run (tests: ..._repeat_from_run_to_run, ..._production_instance_on_in_kernel_noise) -- the second dZ_0-storing instance at the register
-    // wall to do so (NOTEBOOK R5.9 / R5.12); 4.02 against 4.44 ms per step at 10 M observations was not worth an instance nobody can trust.
-#ifdef CL_EXP_DXO_NI
+    // Behind a peeled first layer (more than 15 metadata columns) the launch stores dZ_0: the production instance <.., false, true, NI>.
+    // (Round 5 built it, saw results that moved from run to run and withdrew it for the FULL instance; round 6 found the cause -- the
+    //  inline-assembly LeakyReLU one wait state in front of an MFMA, NOTEBOOK R6.1 -- and it is back: 4.44 -> 4.0 ms per step at 10 M
+    //  observations and 8 samples.)
     const bool full = lane_wants_full(a);
 #define CL_LANE_IMGL_CASE(DM, NI_) (full ? launch_lane_inst<CL_LANE_WMAX, DM, true, true, false, NI_>(a, grid, st) : \
                                     (a.dZ0_out != nullptr ? launch_lane_inst<CL_LANE_WMAX, DM, true, false, true, NI_>(a, grid, st) : \
                                                             launch_lane_inst<CL_LANE_WMAX, DM, true, false, false, NI_>(a, grid, st)))
-#else
-    const bool full = lane_wants_full(a) || a.dZ0_out != nullptr;
-#define CL_LANE_IMGL_CASE(DM, NI_) (full ? launch_lane_inst<CL_LANE_WMAX, DM, true, true, false, NI_>(a, grid, st) : launch_lane_inst<CL_LANE_WMAX, DM, true, false, false, NI_>(a, grid, st))
-#endif
     if (a.n_imgl == 1) return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 1) : CL_LANE_IMGL_CASE(DMAX_ALL, 1);
     return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 2) : CL_LANE_IMGL_CASE(DMAX_ALL, 2);
 #undef CL_LANE_IMGL_CASE

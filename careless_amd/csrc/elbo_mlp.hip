@@ -114,12 +114,19 @@ __device__ __forceinline__ int opaque_uniform(int v) {
     return v;
 }
 
-// LeakyReLU as max(x, leak x) with a bare v_max_f32: fmaxf() makes hipcc canonicalise x first (a second v_max per element)
+// LeakyReLU as max(x, leak x) with a bare v_max_f32: fmaxf() makes hipcc canonicalise x first (a second v_max per element) -- unless
+// the unit is compiled with -fno-honor-nans (build.py), which it is since round 6.  Before that the bare instruction was inline assembly:
+// opaque to hipcc's hazard recognizer, while its result is an MFMA operand of the next layer and gfx950 wants two wait states between a
+// vector-ALU write and an MFMA reading it (NOTEBOOK R6.1; scripts/check_lane_isa.py holds the library to the rule).
 __device__ __forceinline__ float lrelu(float x, float leak) {
     const float m = leak * x;
+#ifdef CL_LRELU_ASM
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
     return r;
+#else
+    return __builtin_fmaxf(x, m);
+#endif
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -1388,11 +1395,13 @@ int cl_launch_mlp_imgl(const cl_mlp_args& a, int mode, int grid, hipStream_t st)
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
 #else
 int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    // per-image layers on the lane kernel: ONE predicate for the dZ0_out guard below and for the dispatch (a launch that fell through
+    // to the IMGL instances of this file would ignore dZ0_out and leave the peeled layer a zero gradient without any error)
+    const bool lane_imgl_route = a.n_imgl > 0 && mode == 0 && cl_lane_imgl_supports(a) && lane_enabled() && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1;
     // dZ0_out (the launch behind a peeled first layer, elbo_peel.hip) is stored by the default scaler's kernels only
     if (a.dZ0_out != nullptr && !(mode == 0 && a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr &&
                                   (a.dzf_obs == nullptr || a.ev11 == nullptr || a.ev11_part != nullptr) &&
-                                  ((a.n_imgl == 0 && ((cl_lane_supports(a) && lane_enabled()) || (cl_narrow_supports(a) && narrow_enabled()))) ||
-                                   (a.n_imgl > 0 && cl_lane_imgl_supports(a) && lane_enabled()))))
+                                  ((a.n_imgl == 0 && ((cl_lane_supports(a) && lane_enabled()) || (cl_narrow_supports(a) && narrow_enabled()))) || lane_imgl_route)))
         return -2;
     if (a.dzf_obs != nullptr && (mode == 0 || (a.act_out == nullptr && a.dH_ext == nullptr))) {
         // deterministic mode: the default scaler's shapes keep their own kernels (round 4: elbo_lane.hip / elbo_narrow.hip store per
@@ -1410,8 +1419,7 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
     if (a.n_imgl > 0) {                                                        // packed layout + per-image layers
         // the default scaler's depth and width with one or two per-image layers: the lane-per-observation kernel (elbo_lane.hip, round 5)
-        if (mode == 0 && cl_lane_imgl_supports(a) && lane_enabled() && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1)
-            return cl_launch_lane_imgl(a, grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid, st);
+        if (lane_imgl_route) return cl_launch_lane_imgl(a, grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid, st);
         return cl_launch_mlp_imgl(a, mode, grid, st);
     }
     if (a.row_map != nullptr && !(mode == 0 && ((cl_narrow_supports(a) && narrow_enabled()) || (cl_lane_supports(a) && lane_enabled()))))
@@ -1451,8 +1459,11 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     } else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
     else if (a.n_imgl > 0) {
         if (mode == 0 && cl_lane_imgl_supports(a) && lane_enabled())
-            return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, false, %d> (image layers)", 10, a.d <= 8 ? 8 : 15,
-                            (a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr || a.dZ0_out != nullptr) ? "true" : "false", a.n_imgl);
+        {
+            const bool full = a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr;
+            return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d> (image layers)", 10, a.d <= 8 ? 8 : 15, full ? "true" : "false",
+                            (!full && a.dZ0_out != nullptr) ? "true" : "false", a.n_imgl);
+        }
         unit = ", image layers";
     } else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }
     if (a.dzf_obs == nullptr && (unit[0] == 0 || packed)) {

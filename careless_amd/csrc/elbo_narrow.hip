@@ -41,11 +41,16 @@ __device__ __forceinline__ int slot_of(int f) { return ((f & 3) << 2) | (f >> 2)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// (one v_max_f32 the compiler knows: -fno-honor-nans, see elbo_mlp.hip)
 __device__ __forceinline__ float lrelu(float x, float leak) {
     const float m = leak * x;
+#ifdef CL_LRELU_ASM
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(m));
     return r;
+#else
+    return __builtin_fmaxf(x, m);
+#endif
 }
 
 // dZ = dH * lrelu'(h): dH where h > 0, leak dH otherwise (h == 0 takes the leak branch, like `h > 0 ? ... : ...`; -0.0 cannot
