@@ -497,6 +497,7 @@ def worker(args) -> int:
             if ex is not None:
                 extras[extra_name] = {"value": ex["value"], "unit": "reflections/s", "n_gpus": world, "ms_per_step": ex["ms_per_step"],
                                       "config": ex["config"], "roofline": ex["roofline"], "obs_per_rank": ex["obs_per_rank"],
+                                      "loss_history": ex["loss_history"],
                                       "host_peak_rss_gib_per_rank": ex["host_peak_rss_gib_per_rank"]}
         except Exception as e:                   # noqa: BLE001  (BuildFailed is raised on every rank alike: nobody waits in a collective)
             extras[extra_name] = {"error": repr(e)}

@@ -105,6 +105,25 @@ class LaueArgs(C.Structure):
     ]
 
 
+class FrozenArgs(C.Structure):
+    """mirror of `cl_frozen_args` (include/careless_hip.h)"""
+    _fields_ = [
+        ("refl_id", _vp), ("loc", _vp), ("sigma", _vp), ("aim", _vp), ("iobs", _vp), ("sig", _vp), ("key", _vp),
+        ("obs_offset", C.c_longlong), ("n", C.c_longlong),
+        ("R", C.c_int), ("S", C.c_int),
+        ("z_f", _vp), ("dz_f", _vp),
+        ("accumulate", C.c_int),
+        ("lik_kind", C.c_int), ("dof", C.c_float), ("lik_const", C.c_float),
+        ("shift", C.c_float), ("w_ll", C.c_float),
+        ("eta", _vp),
+        ("seed", C.c_ulonglong), ("step", C.c_uint),
+        ("scalars", _vp), ("ipred_out", _vp), ("stop_flag", _vp),
+        ("ev11", _vp), ("d_ev11", _vp),
+        ("edge_rid", _vp), ("edge_val", _vp),
+        ("nll_part", _vp), ("ev11_part", _vp),
+    ]
+
+
 class AdamArgs(C.Structure):
     """mirror of `cl_adam_args` (include/careless_hip.h)"""
     _fields_ = [
@@ -168,6 +187,10 @@ EXPORTS = {
     "cl_laue_likelihood": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_laue_backward": (C.c_int, [C.POINTER(LaueArgs), _vp]),
     "cl_slot_rows": (C.c_int, [C.POINTER(LaueArgs), _vp]),
+    "cl_frozen_rows": (C.c_int, [C.POINTER(FrozenArgs), _vp]),
+    "cl_frozen_edge_floats": (C.c_int, [C.c_longlong, C.c_int]),
+    "cl_frozen_grid": (C.c_int, [C.c_longlong]),
+    "cl_frozen_args_size": (C.c_size_t, []),
     "cl_reduce_partials": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "cl_grad_sqnorm": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "cl_adam_step": (C.c_int, [C.POINTER(AdamArgs), _vp]),
@@ -222,6 +245,8 @@ def get_lib() -> C.CDLL:
     mine = (C.sizeof(TnArgs), C.sizeof(MlpArgs), C.sizeof(AdamArgs), C.sizeof(LaueArgs), C.sizeof(DetArgs))
     if tuple(sizes) != mine:
         raise CarelessHipError(f"ABI mismatch between careless_amd/_lib.py {mine} and the library {tuple(sizes)}")
+    if int(lib.cl_frozen_args_size()) != C.sizeof(FrozenArgs):
+        raise CarelessHipError(f"ABI mismatch: cl_frozen_args is {int(lib.cl_frozen_args_size())} bytes in the library, {C.sizeof(FrozenArgs)} in careless_amd/_lib.py")
     _lib = lib
     return lib
 

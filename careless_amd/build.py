@@ -9,6 +9,7 @@ import os
 import shutil
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -33,8 +34,10 @@ UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=
          ("elbo_lane.hip", "elbo_lane2", ["-DCL_LANE_PART=2", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),
          ("elbo_lane.hip", "elbo_lane3", ["-DCL_LANE_PART=3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),
          ("elbo_lane.hip", "elbo_lane4", ["-DCL_LANE_PART=4", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),      # per-image layers (round 5)
+         # ... and the widest instances once more per depth below the default (round 6: `--mlp-layers 2 .. 19` at widths 7 .. 10; 16 - 25 s each)
+         *[("elbo_lane.hip", f"elbo_lane_d{D}", ["-DCL_LANE_PART=7", f"-DCL_LANE_NL={D}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN) for D in range(2, 20)],
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", []), ("wide_gemm.hip", "wide_gemm", []),
-         ("elbo_peel.hip", "elbo_peel", []),
+         ("elbo_peel.hip", "elbo_peel", []), ("elbo_frozen.hip", "elbo_frozen", []),
          # host threads, no device code: the formatter's symmetry bookkeeping (exact products kept apart from their sums)
          ("host_format.cpp", "host_format", ["-ffp-contract=off", "-pthread"])]
 SOURCES = sorted({u[0] for u in UNITS})
@@ -109,6 +112,7 @@ def _build(LIB: str, extra, verbose: bool) -> str:
         print("hipcc rejects " + " ".join(LANE_FLAG) + ": building elbo_lane.hip without it", flush=True)
     work = tempfile.mkdtemp(prefix=".build_", dir=LIBDIR)
     try:
+        jobs = max(2, min(int(os.environ.get("CARELESS_HIP_BUILD_JOBS", "0")) or (os.cpu_count() or 4) + 2, 16))
         for s, stem, flags in UNITS:
             if not lane_ok:
                 flags = [f for f in flags if f not in LANE_FLAG]
@@ -116,6 +120,8 @@ def _build(LIB: str, extra, verbose: bool) -> str:
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + list(extra) + flags + ["-c", os.path.join(CSRC, s), "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
+            while sum(1 for _, p in procs if p.poll() is None) >= jobs:      # (38 units: not all compilers at once on a small box)
+                time.sleep(0.2)
             procs.append((cmd, subprocess.Popen(cmd)))
             objs.append(o)
         for cmd, p in procs:

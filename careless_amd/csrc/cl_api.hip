@@ -27,6 +27,8 @@ int cl_laue_predict(const cl_laue_args* a, void* stream) { return a ? cl_launch_
 int cl_laue_likelihood(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_likelihood(*a, (hipStream_t)stream) : -1; }
 int cl_laue_backward(const cl_laue_args* a, void* stream) { return a ? cl_launch_laue_backward(*a, (hipStream_t)stream) : -1; }
 int cl_slot_rows(const cl_laue_args* a, void* stream) { return a ? cl_launch_slot_rows(*a, (hipStream_t)stream) : -1; }
+int cl_frozen_rows(const cl_frozen_args* a, void* stream) { return a ? cl_launch_frozen_rows(*a, (hipStream_t)stream) : -1; }
+size_t cl_frozen_args_size(void) { return sizeof(cl_frozen_args); }
 
 int cl_mlp_default_grid(void) {
     int dev = 0, cus = 0;

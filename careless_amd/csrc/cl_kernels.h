@@ -43,6 +43,7 @@ int cl_launch_laue_predict(const cl_laue_args& a, hipStream_t st);
 int cl_launch_laue_likelihood(const cl_laue_args& a, hipStream_t st);
 int cl_launch_laue_backward(const cl_laue_args& a, hipStream_t st);
 int cl_launch_slot_rows(const cl_laue_args& a, hipStream_t st);
+int cl_launch_frozen_rows(const cl_frozen_args& a, hipStream_t st);      // elbo_frozen.hip (round 6)
 
 // The kernel arguments, re-read from the kernarg segment behind an opaque pointer.  hipcc loads every field of a by-value argument
 // struct at kernel entry and keeps it in SGPRs for the whole kernel (more than the ~100 there are: it then parks them in VGPR lanes

@@ -42,7 +42,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int NL = CL_MLP_LMAX_W16;   // Dense layers one launch holds
+// Dense layers of the scaler: a compile-time constant of the unit.  The default build has the careless default depth (20 = the most one
+// launch holds); round 6 compiles the file again with -DCL_LANE_NL=2 .. 19 (build.py: one part per depth, 16 - 25 s each, the widest
+// instances only) for `--mlp-layers` below the default -- a run-time depth test per unrolled layer costs this one-wave-per-SIMD kernel its
+// register allocation (NOTEBOOK R6.3: 120 - 380 spilled registers and accumulator copies behind the inline-assembly MFMAs).
+#ifndef CL_LANE_NL
+#define CL_LANE_NL CL_MLP_LMAX_W16
+#endif
+constexpr int NL = CL_LANE_NL;
 constexpr int NWV = 4;                // waves of a workgroup (one per SIMD)
 constexpr int NT = 64 * NWV;
 constexpr int WT = 64;                // observations of a wave tile
@@ -189,9 +196,11 @@ struct LSmem {
 // the layers' weight-gradient sums in accumulator registers like any other layer's; on an image change it adds the sums to the image's
 // gradient (atomics) and reloads.  The activations of the top PK layers wait in LDS across the sampling epilogue (22 x 10 activations +
 // the epilogue's state do not fit the 512 registers; the compiler would spill to scratch, which a lone wave waits for in full).
-template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false, int NI = 0>
+// DEPTH: the unit's NL again, as a template argument -- the instances of the units compiled for other depths need names of their own.
+template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false, int NI = 0, int DEPTH = NL>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void elbo_lane_kernel(const cl_mlp_args A) {
+    static_assert(DEPTH == NL, "one depth per compilation unit");
     constexpr bool LX = (DMAX == 0);
     constexpr int DREG = LX ? 1 : DMAX;               // metadata registers of the lane (LX: none; arrays keep one element)
     constexpr int NLT = NL + NI;                      // hidden layers: Dense + per-image
@@ -1064,7 +1073,7 @@ static int launch_lane_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SM = LSmem<W, DMAX == 0, NI>;
     const size_t sm = (size_t)SM::total(a.d) * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL, DXO, NI>;
+    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL, DXO, NI, NL>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -1096,6 +1105,9 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_WMAX 10
 #endif
 #define CL_LANE_IMGL_MAX 2          /* per-image layers of the lane instances */
+#ifndef CL_LANE_DEPTH_WMIN
+#define CL_LANE_DEPTH_WMIN 5        /* narrowest scaler the other-depth instances (compiled at widths 8 and 10) take */
+#endif
 
 // the instance whose compile-time width is the smallest one that holds the scaler (zero-padded features cost MFMA steps)
 #define CL_LANE_WIDTHS(CASE)      \
@@ -1109,6 +1121,17 @@ int cl_launch_lane_packed_reg(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_packed_rows(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st);
+// other depths than the default (round 6): one compilation per depth, CL_LANE_PART = 7
+#define CL_LANE_DEPTHS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19)
+#define CL_LANE_DEPTH_DECL(D) int cl_launch_lane_depth##D(const cl_mlp_args& a, int grid, hipStream_t st);
+CL_LANE_DEPTHS(CL_LANE_DEPTH_DECL)
+#undef CL_LANE_DEPTH_DECL
+static inline bool lane_has_depth(int L) {
+#define CL_LANE_DEPTH_TEST(D) if (L == D) return true;
+    CL_LANE_DEPTHS(CL_LANE_DEPTH_TEST)
+#undef CL_LANE_DEPTH_TEST
+    return false;
+}
 
 #if CL_LANE_PART == 0
 int cl_launch_lane_plain_reg(const cl_mlp_args& a, int grid, hipStream_t st) {
@@ -1128,9 +1151,14 @@ static size_t lane_rows_lds(int w, int d) {
 // are rows of an LDS buffer (LX); any number of MC samples (batches of SPRE).  4 M observations, 20 x 10, Student-T, ms per step
 // here / on elbo_narrow.hip (scripts/narrow_samples.py): S = 1 0.96 / 1.11, 2: 1.01 / 1.12, 4: 1.07 / 1.19, 8: 1.16 / 1.34.
 int cl_lane_supports(const cl_mlp_args& a) {
-    if (!(a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_LX && a.L == NL && a.n_imgl == 0 && a.act_out == nullptr &&
+    if (!(a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_LX && (a.L == NL || lane_has_depth(a.L)) && a.n_imgl == 0 && a.act_out == nullptr &&
           a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr)))
         return 0;
+    // the other depths (round 6): instances at widths 8 and 10 (a narrower scaler pays the padded steps: from width CL_LANE_DEPTH_WMIN on it still
+    // beats elbo_narrow.hip), metadata in registers, no dZ_0 out
+    // (CARELESS_HIP_LANE_DEPTHS=0: A/B runs against the narrow kernel these shapes ran on until round 5)
+    static const bool depths_on = [] { const char* e = getenv("CARELESS_HIP_LANE_DEPTHS"); return !(e != nullptr && e[0] == '0'); }();
+    if (a.L != NL) return depths_on && a.w >= CL_LANE_DEPTH_WMIN && a.d <= DMAX_ALL && a.dZ0_out == nullptr;
     return a.d <= DMAX_ALL || lane_rows_lds(a.w, a.d) <= 160 * 1024;
 }
 
@@ -1161,6 +1189,9 @@ int cl_lane_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
     const int DM = a.d <= 8 ? 8 : (a.d <= DMAX_ALL ? DMAX_ALL : 0);
     const bool packed = a.row_map != nullptr;
     const bool full = packed || lane_wants_full(a) || (DM == 0 && a.dZ0_out != nullptr);
+    if (a.L != NL)
+        return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s, false, 0, %d>%s", a.w <= 8 ? 8 : CL_LANE_WMAX, DM, packed ? "true" : "false", full ? "true" : "false", a.L,
+                        a.dzf_obs != nullptr ? " (deterministic stores)" : "");
     return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s%s>%s", W, DM, packed ? "true" : "false", full ? "true" : "false",
                     (!full && a.dZ0_out != nullptr) ? ", true" : "", a.dzf_obs != nullptr ? " (deterministic stores)" : "");
 }
@@ -1176,6 +1207,16 @@ int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {
         if (a.ev11 != nullptr && a.ev11_part == nullptr) return -2;      // (the Evans-2011 gradients need their per-wave slots)
         if (a.nll_part == nullptr || (a.use_img && a.dimg_obs == nullptr)) return -1;
         if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+    }
+    if (a.L != NL) {
+        if (a.row_map != nullptr) {
+            if (a.n_obs != a.n_pad || (a.gmeta != nullptr && a.tile_gmax == nullptr)) return -1;
+            if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+        }
+#define CL_LANE_DEPTH_CALL(D) if (a.L == D) return cl_launch_lane_depth##D(a, grid, st);
+        CL_LANE_DEPTHS(CL_LANE_DEPTH_CALL)
+#undef CL_LANE_DEPTH_CALL
+        return -2;
     }
     // metadata as LDS rows from DMAX_ALL + 1 columns on (from 9 on it measured slower than the register instances, round 3)
     const bool rows = a.d > DMAX_ALL;
@@ -1197,6 +1238,21 @@ int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_CASE(WW) launch_lane_one<WW, 0, false>(a, grid, st)
     CL_LANE_WIDTHS(CL_LANE_CASE)
 #undef CL_LANE_CASE
+}
+#elif CL_LANE_PART == 7
+// another depth than the default (-DCL_LANE_NL=D): widths 8 and 10, metadata in registers -- plain layout (production / full) and packed
+#define CL_LANE_DEPTH_FN2(D) cl_launch_lane_depth##D
+#define CL_LANE_DEPTH_FN(D) CL_LANE_DEPTH_FN2(D)
+template <int WW>
+static int launch_lane_depth_w(const cl_mlp_args& a, int grid, hipStream_t st) {
+    if (a.row_map != nullptr)
+        return a.d <= 8 ? launch_lane_inst<WW, 8, true, true>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, true, true>(a, grid, st);
+    if (lane_wants_full(a))
+        return a.d <= 8 ? launch_lane_inst<WW, 8, false, true>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, true>(a, grid, st);
+    return a.d <= 8 ? launch_lane_inst<WW, 8, false, false>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, false>(a, grid, st);
+}
+int CL_LANE_DEPTH_FN(CL_LANE_NL)(const cl_mlp_args& a, int grid, hipStream_t st) {
+    return a.w <= 8 ? launch_lane_depth_w<8>(a, grid, st) : launch_lane_depth_w<CL_LANE_WMAX>(a, grid, st);
 }
 #elif CL_LANE_PART == 4
 // per-image layers: the widest instance serves every w <= 10 (a narrower scaler pays the padded MFMA steps: --image-layers on a

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void laue_backward_kernel(const cl_laue_args A
         dsig = dt * eta;
         da = dzs * tq;
     }
+    if (A.dO == nullptr) return;          // (wave-uniform) a frozen scaling model: nobody takes dL/d(loc, sigma) or the image scales' gradient (round 6)
     // segmented sums over the lanes of one row (they are consecutive)
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -328,11 +329,14 @@ int cl_launch_slot_rows(const cl_laue_args& a, hipStream_t st) {
 }
 int cl_launch_laue_backward(const cl_laue_args& a, hipStream_t st) {
     if (int e = laue_check(a)) return e;
-    if (a.dz_f == nullptr || a.dO == nullptr || (a.use_img && a.d_img == nullptr)) return -1;
+    if (a.dz_f == nullptr || (a.dO != nullptr && a.use_img && a.d_img == nullptr)) return -1;
     (void)hipGetLastError();
-    // dO receives the rows' sums by atomics: cleared here, on the same stream (part of the call)
-    hipError_t e = hipMemsetAsync(a.dO, 0, sizeof(float) * 2 * (size_t)a.n_obs, st);
-    if (e != hipSuccess) return (int)e;
+    // dO receives the rows' sums by atomics: cleared here, on the same stream (part of the call).  dO NULL (round 6): the scaling model
+    // is frozen -- only dz_f is taken, no clearing, no per-row reductions
+    if (a.dO != nullptr) {
+        hipError_t e = hipMemsetAsync(a.dO, 0, sizeof(float) * 2 * (size_t)a.n_obs, st);
+        if (e != hipSuccess) return (int)e;
+    }
     const long long n = (long long)a.n_obs * a.S;
     hipLaunchKernelGGL(laue_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     return (int)hipGetLastError();

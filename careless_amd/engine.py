@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from careless_amd import _lib
-from careless_amd._lib import AdamArgs, DetArgs, LaueArgs, MlpArgs, TnArgs, check, ptr
+from careless_amd._lib import AdamArgs, DetArgs, FrozenArgs, LaueArgs, MlpArgs, TnArgs, check, ptr
 from careless_amd.models.base import BaseModel
 # (re-exported: the tests, bench.py and scripts import the sharding / layout names from here)
 from careless_amd.obs import (GRANULE, ObsChunks, ObsData, Shard, _EmptyObs, _ShardRows, _np, laue_group_shard, launch_row_limit,  # noqa: F401
@@ -152,6 +152,7 @@ def chain_plan(d: int, w: int, L: int, max_layers: int) -> List[LayerBlock]:
 # the engine
 # ------------------------------------------------------------------------------------------------------------
 class ElboEngine(WidePath):
+    FROZEN_SORTED_ROWS = True        # a frozen scaler's monochromatic rows: sorted by reflection, `cl_frozen_rows` (round 6; tests flip it to compare with `cl_slot_rows`)
     SLOT_ROWS_ONE_LAUNCH = True      # rows that are their own slot: predict + log-prob + gradient in one `cl_slot_rows` launch (tests flip it)
     def __init__(self, model, inputs, seed: int = 1234, shard: Optional[Shard] = None, process_group=None,
                  grid: Optional[int] = None):
@@ -406,6 +407,7 @@ class ElboEngine(WidePath):
             b = min(stop, a + per)
             pieces.append(ObsData(self.lib, inputs, a, b, self.S, self.layout.P, self.device, rows=None if rows is None else rows[a:b], **kw))
             pieces[-1].row0 = a - start                   # first row of the piece inside the shard's eta / ipred arrays
+            pieces[-1].is_piece = True                    # (several launches share dz_f: `cl_frozen_rows` adds instead of storing)
             pieces[-1].host_inputs = inputs
             kw["n_refl"] = kw["n_images"] = None          # (the id ranges were checked over the whole input by the first piece)
             if len(pieces) > 1:
@@ -820,7 +822,59 @@ class ElboEngine(WidePath):
                 obs.row_index = torch.as_tensor(np.asarray(obs.rows, dtype=np.int64), device=self.device)     # the noise key of every row
             obs.locsig_epoch = self._frozen_epoch
         ma = self._mlp_args(step, eta, ipred_out, obs)
-        self._slot_likelihood(ma, obs, step, eta, ipred_out, st)
+        keyed = getattr(obs, "row_index", None) is not None and (eta is not None or ipred_out is not None)      # (injected noise on rows that are not a contiguous range: the slot kernels index it by local row)
+        if obs.harmonic_id is None and not self.deterministic and self.FROZEN_SORTED_ROWS and not keyed:
+            self._frozen_rows(ma, obs, step, eta, ipred_out, st)
+            return
+        self._slot_likelihood(ma, obs, step, eta, ipred_out, st, frozen=True)
+
+    def _frozen_rows(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
+        """Monochromatic rows behind a frozen scaler (round 6, `cl_frozen_rows`): the rows sorted by reflection ONCE per training -- the
+        scaler's output is a constant, so no layout constraint binds their order -- with (loc, sigma), the image scale and the global row
+        number (the noise key) of every row beside them; per step one row-per-thread launch that sums the amplitude gradients of a
+        reflection's rows inside the wave and stores them (no float atomics into dz_f), plus the small launch for the runs that cross a
+        wave border.  The image scales are part of the frozen scaling model: their gradient is not computed either."""
+        fz = getattr(obs, "frozen_sorted", None)
+        if fz is None or fz["epoch"] != self._frozen_epoch:
+            dev = self.device
+            rid = obs.refl_id[: obs.N]
+            order = torch.argsort(rid, stable=True)
+            take = lambda t: t[: obs.N].index_select(0, order).contiguous()
+            if ma.use_img:
+                img_id = obs.image_id[: obs.N].long()
+                scales = torch.cat([torch.ones(1, dtype=torch.float32, device=dev), self.params[self.layout.off_img: self.layout.off_img + self.layout.n_img].detach()])
+                aim = scales.index_select(0, img_id).index_select(0, order).contiguous()      # (image 0 is pinned to 1: image.py:23-25)
+            else:
+                aim = None
+            if getattr(obs, "row_index", None) is not None:
+                key = obs.row_index[: obs.N].index_select(0, order).to(torch.int32).contiguous()
+            else:
+                key = (order + int(obs.start)).to(torch.int32).contiguous()
+            n_waves = (obs.N + 63) // 64
+            fz = obs.frozen_sorted = dict(
+                epoch=self._frozen_epoch, refl=take(rid).to(torch.int32), loc=take(obs.laue_loc), sigma=take(obs.laue_sig), aim=aim,
+                iobs=take(obs.iobs), sig=take(obs.sig), key=key,
+                edge_rid=torch.empty(2 * n_waves, dtype=torch.int32, device=dev),
+                edge_val=torch.empty(max(int(self.lib.cl_frozen_edge_floats(obs.N, self.S)), 1), dtype=torch.float32, device=dev))
+        fa = FrozenArgs()
+        fa.refl_id, fa.loc, fa.sigma, fa.aim = ptr(fz["refl"]), ptr(fz["loc"]), ptr(fz["sigma"]), ptr(fz["aim"])
+        fa.iobs, fa.sig, fa.key = ptr(fz["iobs"]), ptr(fz["sig"]), ptr(fz["key"])
+        fa.obs_offset, fa.n = int(obs.start), int(obs.N)
+        fa.R, fa.S = self.R, self.S
+        fa.z_f, fa.dz_f = ptr(self.z_f), ptr(self.dz_f)
+        # (several launches into one dz_f -- the pieces of a chunked shard -- and the double-Wilson prior, whose dlog p / dz is in dz_f
+        #  before the data term: add with atomics instead of storing)
+        fa.accumulate = 1 if (getattr(obs, "is_piece", False) or self.double_wilson) else 0
+        fa.lik_kind, fa.dof, fa.lik_const = self.lik_kind, self.dof, self.lik_const
+        fa.shift, fa.w_ll = ma.shift, ma.w_ll
+        row0 = getattr(obs, "row0", 0)                  # piece of a chunked shard: its rows inside the shard's eta / ipred arrays
+        fa.eta = None if eta is None else eta.data_ptr() + 4 * self.S * row0
+        fa.seed, fa.step = self.seed, step & 0xFFFFFFFF
+        fa.scalars, fa.stop_flag = ptr(self.scalars), ptr(self.stop_flag)
+        fa.ipred_out = None if ipred_out is None else ipred_out.data_ptr() + 4 * self.S * row0
+        fa.ev11, fa.d_ev11 = ma.ev11, ma.d_ev11
+        fa.edge_rid, fa.edge_val = ptr(fz["edge_rid"]), ptr(fz["edge_val"])
+        check(self.lib.cl_frozen_rows(C.byref(fa), st), "cl_frozen_rows")
 
     def _peel_bufs(self, obs: ObsData):
         """Buffers of the peeled first layer for one observation set: its pre-activations and dZ_0 (feature-major, like meta_t), the
@@ -970,7 +1024,7 @@ class ElboEngine(WidePath):
         la.row_index = off(obs.row_index, 8)
         return la
 
-    def _slot_likelihood(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
+    def _slot_likelihood(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st, frozen: bool = False):
         """From (loc, sigma) per row in obs.laue_loc / laue_sig: sample, predict, group sums, slot likelihood (NLL into the
         scalars), its gradient back on the rows -> dz_f, d(image scales), obs.laue_dO = dL/d(loc, sigma) per row."""
         lib = self.lib
@@ -993,6 +1047,8 @@ class ElboEngine(WidePath):
             return
         check(lib.cl_laue_predict(C.byref(la), st), "cl_laue_predict")
         check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
+        if frozen:
+            la.dO = None                # nobody takes dL/d(loc, sigma) of a frozen scaler: amplitude gradients only (no clearing, no row sums)
         check(lib.cl_laue_backward(C.byref(la), st), "cl_laue_backward")
 
     def _allreduce(self):

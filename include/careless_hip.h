@@ -6,8 +6,9 @@
  * from Python with ctypes.
  *
  * Conventions
- *   - all pointers are DEVICE pointers (hipMalloc'ed / torch.Tensor.data_ptr()), row-major, contiguous, owned by the
- *     caller and never retained after the call returns;
+ *   - all pointers are DEVICE pointers (hipMalloc'ed / torch.Tensor.data_ptr()), row-major, contiguous, owned by the caller and never
+ *     retained after the call returns -- EXCEPT in the cl_host_* group at the end of this file (the formatting step: HOST pointers, host
+ *     threads, no stream, no device);
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); every call only enqueues;
  *   - return value: 0 = ok, < 0 = invalid argument (-1 shape, -2 unsupported scaler geometry, -3 LDS budget, -4 shard >= 4 GiB),
  *     > 0 = hipError_t from the launch;  nothing throws, nothing allocates persistent device memory;
@@ -359,7 +360,8 @@ typedef struct cl_laue_args {
                                    them with dNLL/diconv                     */
     float* dz_f;                /* [R][S] +=                                 */
     float* d_img;               /* [M-1] +=                                  */
-    float* dO;                  /* [n_obs][2] dL/d(loc, sigma) for cl_mlp_backward_ext */
+    float* dO;                  /* [n_obs][2] dL/d(loc, sigma) for cl_mlp_backward_ext; cl_laue_backward takes NULL (a frozen scaling model:
+                                   dz_f only, d_img untouched) */
     double* scalars;
     float* ipred_out;           /* optional [n_obs][S]                       */
     const int* stop_flag;
@@ -385,6 +387,50 @@ int cl_laue_backward(const cl_laue_args* args, void* stream);
  * careless/models/likelihoods/mono.py:10-73 on the layer-by-layer path of scalers wider than 64): predict, log-prob and its gradient back to
  * dz_f / d_img / dO per (row, sample) with nothing in between; iconv is not touched.  -2 when harmonic_id is set.                    */
 int cl_slot_rows(const cl_laue_args* args, void* stream);
+
+/* --- the data term of a step whose scaling model is frozen (round 6) -------------------------------------------------------------------
+ * replaces: VariationalMergingModel.call + the likelihood's log_prob + tape.gradient over the TRAINABLE variables only
+ *           (careless/models/merging/variational.py:156-181, 197-202; models/likelihoods/mono.py:10-73) in the trainings whose scaling
+ *           model has trainable = False: `--freeze-scales` and the half-dataset trainings of `--merge-half-datasets`
+ *           (careless/careless.py:48-50, 102-128).  The scaler's output is then a constant of the training: the caller takes (loc, sigma)
+ *           and the image scale of every row once and SORTS THE ROWS BY REFLECTION (any order is as good as another for a constant).
+ * Per step: sample the scale (Philox keyed by the row's global number `key`: the fused kernels' draws), predict, log-prob into
+ * scalars[NLL], amplitude gradient into dz_f -- equal-reflection runs are summed inside the wave and leave as ONE plain store per
+ * (reflection, sample); runs that cross a wave border go through `edge_val / edge_rid` and a second small launch of the same call.  No
+ * float atomic touches dz_f: the result does not depend on the run (accumulate = 1 -- several calls share dz_f, e.g. the pieces of a
+ * shard -- adds with atomics instead of storing).  Rows with refl_id < 0 are skipped; monochromatic rows only (every row its own slot). */
+typedef struct cl_frozen_args {
+    const int* refl_id;         /* [n] ascending                                                                   */
+    const float* loc;           /* [n] scaler mean per row (cl_mlp_forward / the wide path), in the sorted order   */
+    const float* sigma;         /* [n] scaler sigma per row                                                        */
+    const float* aim;           /* [n] image scale per row, or NULL (= 1): image.py:53-63 with the scale frozen    */
+    const float* iobs;          /* [n]                                                                             */
+    const float* sig;           /* [n]                                                                             */
+    const int* key;             /* [n] global row number of every row: noise key, row of eta / ipred_out (minus obs_offset); NULL: obs_offset + i */
+    long long obs_offset;
+    long long n;
+    int R, S;
+    const float* z_f;           /* [R][S]                                                                          */
+    float* dz_f;                /* [R][S] stored (accumulate = 0) or += (accumulate = 1) for the reflections that have rows */
+    int accumulate;
+    int lik_kind; float dof, lik_const;
+    float shift, w_ll;
+    const float* eta;           /* optional [rows][S] injected normals (parity tests)                              */
+    unsigned long long seed; unsigned step;
+    double* scalars;
+    float* ipred_out;           /* optional [rows][S]                                                              */
+    const int* stop_flag;
+    const float* ev11;          /* [3] raw Sdfac, Sdadd, SdB or NULL (mono.py:39-73)                               */
+    float* d_ev11;              /* [3] +=                                                                          */
+    int* edge_rid;              /* [2 * ceil(n / 64)] workspace                                                    */
+    float* edge_val;            /* [cl_frozen_edge_floats(n, S)] workspace                                         */
+    double* nll_part;           /* optional [cl_frozen_grid(n)]: every workgroup STORES its NLL (no fp64 atomic)   */
+    float* ev11_part;           /* optional [3 * 4 * cl_frozen_grid(n)]: every wave stores its Evans-2011 terms    */
+} cl_frozen_args;
+int cl_frozen_rows(const cl_frozen_args* args, void* stream);
+int cl_frozen_edge_floats(long long n, int S);     /* floats of edge_val */
+int cl_frozen_grid(long long n);                   /* workgroups of the launch (nll_part / ev11_part slots) */
+size_t cl_frozen_args_size(void);                  /* sizeof(cl_frozen_args) as the library was compiled (binding check, like cl_abi_sizes) */
 
 /* --- gradient norm, sanitise, clip, Adam -------------------------------------------------------------------------
  * replaces: tf.linalg.global_norm, tf.where(is_finite), optimizer.apply_gradients (variational.py:202-209)

@@ -122,3 +122,61 @@ def test_frozen_trajectory_and_unfreezing():
     assert util.rel_err(q[True], q[False]) < 1e-4
     for k in ("loss", "NLL", "Grad Norm"):
         assert np.allclose(hist[True][k], hist[False][k], rtol=2e-4), k
+
+
+# ---- round 6: rows sorted by reflection, `cl_frozen_rows` (no float atomics into dz_f) -----------------------------------------------------
+SORTED_CASES = {
+    "cli_default_S1": dict(N=5000, R=60, d0=5, L=20, w=10, S=1, perturb=0.02),
+    "studentt_S8": dict(N=4000, R=50, d0=5, posenc=True, L=5, w=64, S=8, likelihood="studentt", dof=8.0),
+    "S11_few_reflections": dict(N=3000, R=7, d0=5, L=2, w=32, S=11),                 # runs of ~430 rows: chains over several waves; two sample batches
+    "many_reflections": dict(N=3000, R=2500, d0=5, L=2, w=32, S=3),                  # most runs a single row
+    "ev11_no_image_scales": dict(N=2500, R=40, d0=5, L=20, w=10, S=2, ev11=True, use_image_scales=False, perturb=0.02),
+    "double_wilson": dict(N=2000, R=60, d0=5, L=2, w=32, S=2, double_wilson=True),
+}
+
+
+@pytest.mark.parametrize("name", list(SORTED_CASES))
+def test_sorted_rows_kernel_equals_the_slot_kernel_and_repeats_bit_for_bit(name):
+    """The frozen step on `cl_frozen_rows` against round 5's `cl_slot_rows` on the same engine configuration (same in-kernel noise: the
+    noise key is the row's global number in both), and twice on fresh engines: no float atomic touches dz_f, so the amplitude gradients
+    are bit-identical from run to run."""
+    from careless_amd.engine import ElboEngine
+    kw = SORTED_CASES[name]
+    runs = []
+    for sorted_rows in (True, True, False):
+        eng, _ = _engine(kw, True)
+        eng.FROZEN_SORTED_ROWS = sorted_rows
+        eng.forward_backward(4)
+        torch.cuda.synchronize()
+        runs.append((eng.grads.clone(), eng.dz_f.clone(), eng.loss_terms()))
+        assert (getattr(eng.obs, "frozen_sorted", None) is not None) == sorted_rows
+    (g1, z1, t1), (g2, z2, t2), (g0, z0, t0) = runs
+    R, lay = eng.R, eng.layout
+    assert torch.equal(z1, z2) and torch.equal(g1[: 2 * R], g2[: 2 * R])     # (the NLL is a sum of fp64 workgroup atomics, the three Evans-2011 terms
+    #                                                                          of per-wave float atomics: equal to rounding)
+    assert float((g1 - g2).abs().max()) <= 2e-6 * float(g1.abs().max())
+    assert abs(t1["nll"] - t2["nll"]) <= 1e-12 * abs(t1["nll"])
+    assert abs(t1["nll"] - t0["nll"]) <= 1e-6 * abs(t0["nll"])
+    assert util.rel_err(z1.cpu().numpy(), z0.cpu().numpy()) < 2e-6
+    assert util.rel_err(g1[: 2 * R].cpu().numpy(), g0[: 2 * R].cpu().numpy()) < 1e-5
+    if lay.n_ev11 > 0:
+        assert util.rel_err(g1[lay.off_ev11: lay.off_ev11 + 3].cpu().numpy(), g0[lay.off_ev11: lay.off_ev11 + 3].cpu().numpy()) < 2e-5
+
+
+def test_sorted_rows_kernel_on_a_chunked_shard_adds_its_pieces():
+    """A shard cut into several launches (`ObsChunks`) shares dz_f between its pieces: `accumulate` (atomics) instead of stores."""
+    from careless_amd import engine as E
+    kw = dict(N=6000, R=40, d0=5, L=20, w=10, S=2, perturb=0.02)
+    one, _ = _engine(kw, True)
+    one.forward_backward(2)
+    old = E.launch_row_limit
+    try:
+        E.launch_row_limit = lambda d, S=0: 2560
+        cut, _ = _engine(kw, True)
+    finally:
+        E.launch_row_limit = old
+    assert isinstance(cut.obs, E.ObsChunks) and len(cut.obs.children) == 3
+    cut.forward_backward(2)
+    torch.cuda.synchronize()
+    assert util.rel_err(cut.dz_f.cpu().numpy(), one.dz_f.cpu().numpy()) < 2e-6
+    assert abs(cut.loss_terms()["nll"] - one.loss_terms()["nll"]) <= 1e-9 * abs(one.loss_terms()["nll"])

@@ -32,7 +32,12 @@ CASES = {
     "mlp2x32_S12_studentt": dict(N=300, R=40, d0=5, L=2, w=32, S=12, likelihood="studentt", dof=8.0),       # more than 8 MC samples
     "laue_2x32_S11": dict(N=400, R=40, L=2, w=32, S=11, laue=True),
     # narrow instance, all three MFMA-step counts (hidden width <= 8 / <= 12 / <= 15)
-    "mlp9x7_d6_S2": dict(N=700, R=40, d0=6, L=9, w=7, S=2, perturb=0.03, grid=2),
+    "mlp9x7_d6_S2": dict(N=700, R=40, d0=6, L=9, w=7, S=2, perturb=0.03, grid=2),         # (since round 6 on the lane kernel's depth-9 instance: widths 7 .. 10 at any depth)
+    "narrow_9x4_d6_S2": dict(N=700, R=40, d0=6, L=9, w=4, S=2, perturb=0.03, grid=2),     # ... the narrow kernel's two-step instance keeps widths <= 4
+    "lane_depth12_studentt_12x10_d12_S3": dict(N=800, R=50, d0=12, L=12, w=10, S=3, likelihood="studentt", dof=6.0, perturb=0.03, grid=2),
+    "lane_depth2_2x9_S2": dict(N=500, R=40, d0=5, L=2, w=9, S=2, perturb=0.05),
+    "lane_depth19_19x8_S1": dict(N=600, R=40, d0=7, L=19, w=8, S=1, perturb=0.02, grid=2),
+    "lane_depth10_laue_single_pass_10x10_S3": dict(N=900, R=40, L=10, w=10, S=3, laue=True, perturb=0.03, grid=2),
     "mlp7x12_S3_studentt": dict(N=500, R=40, d0=5, L=7, w=12, S=3, likelihood="studentt", dof=6.0, perturb=0.03),
     "mlp5x13_softplus": dict(N=400, R=30, d0=5, L=5, w=13, S=2, bijector="softplus", shift=1.5, perturb=0.03),
     # the narrow kernel (csrc/elbo_narrow.hip: width <= 15, metadata <= 15 columns, plain mono layout) beyond the CLI default

@@ -4,7 +4,7 @@ Round 5 shipped a guard over ten instances at 5 000 rows, because two instances 
 nothing in the source to explain it.  Round 6 named the cause (an inline-assembly v_max_f32 one wait state in front of an MFMA reading
 its result: gfx950 wants two, hipcc pads only pairs it knows -- NOTEBOOK R6.1), removed it at the source and holds the code objects to
 the rule without a GPU (tests/test_lane_isa.py).  This is the run-time half: every (width, metadata, layout, optional-input, dZ_0,
-per-image-layer) instance `cl_mlp_kernel_name` can name, eight runs on identical inputs --
+per-image-layer) instance `cl_mlp_kernel_name` can name at the default depth, and a sample of the instances compiled for other depths, eight runs on identical inputs --
 
   * the scaler's gradient is BIT-identical (its partials are summed in index order in every mode: any operand read early shows here);
   * where the deterministic mode exists (no float atomics at all) the whole flat gradient and the NLL are bit-identical;
@@ -54,6 +54,14 @@ for w in (4, 6, 8, 10):
         CASES[f"packed_laue_w{w}_dm{dm}"] = _packed(w, dm)
     CASES[f"dz0_out_w{w}"] = _plain(w, 15 if w == 10 else 8, dxo=True)
 CASES["packed_laue_atomics_w10_dm8"] = _packed(10, 8, det=False)
+# the instances compiled for other depths (round 6: widths 7 .. 10, metadata in registers)
+for depth in (2, 5, 10, 16, 19):
+    for tag, base in (("plain", _plain(10, 8)), ("plain_full_det", _plain(10, 15, full=True)), ("packed_laue", _packed(10, 8))):
+        kw = dict(base["kw"], L=depth, w=10 if depth != 5 else 7)
+        packed = "true" if "laue" in tag else "false"
+        full = "false" if tag == "plain" else "true"
+        dm = 15 if tag == "plain_full_det" else 8
+        CASES[f"depth{depth}_{tag}"] = dict(kw=kw, det=base["det"], name=f"elbo_lane_kernel<{10 if kw['w'] > 8 else 8}, {dm}, {packed}, {full}, false, 0, {depth}>" + (" (deterministic stores)" if base["det"] else ""))
 for ni in (1, 2):
     for dm in (8, 15):
         CASES[f"image_layers{ni}_dm{dm}"] = _imgl(ni, dm)
