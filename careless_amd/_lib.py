@@ -201,6 +201,7 @@ EXPORTS = {
     "cl_peel_parts": (C.c_int, [C.c_longlong]),
     "cl_peel_forward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
     "cl_peel_backward": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "cl_chain_dx": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "cl_tn_moments": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_double, C.c_float, _vp, _vp, _vp, _vp]),
     "cl_host_asu_map": (C.c_int, [_vp, C.c_longlong, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int]),
     "cl_host_dense_ids": (C.c_int, [_vp, C.c_longlong, C.c_int64, C.c_int64, _vp, C.POINTER(C.c_longlong), C.c_int]),

@@ -137,9 +137,44 @@ __global__ __launch_bounds__(256) void peel_tail_kernel(const float* __restrict_
     if (e < n_tail) grad_tail[e] += grad_peel[e];
 }
 
+// dX = W^T dZ per observation, both feature-major like meta_t (rows of four-row groups, n_pad columns): the step from dL/d(pre-activations
+// of a block's first layer) -- what the default scaler's kernels store as dZ_0 -- to dL/d(the block's input activations), which the block
+// in front of it in a layer-block chain takes as dH_ext (round 6: the last block of a deep narrow scaler on elbo_lane.hip).  One thread per
+// observation, the layer's weights through LDS; reads 4 w_out and writes 4 w_in bytes per observation: HBM-bound by construction.
+__global__ __launch_bounds__(256) void chain_dx_kernel(const float* __restrict__ dz, const float* __restrict__ Wt, int n_obs, int n_pad, int w_out,
+                                                        int w_in, float* __restrict__ dx, const int* __restrict__ stop_flag) {
+    if (stop_flag != nullptr && *stop_flag != 0) return;
+    __shared__ float sW[16 * 16];
+    for (int i = threadIdx.x; i < w_out * w_in; i += 256) sW[i] = Wt[i];         // Wt[out][in]
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_pad) return;
+    float z[16], x[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) z[o] = (o < w_out && n < n_obs) ? dz[(size_t)o * n_pad + n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = 0.0f;
+    for (int o = 0; o < w_out; ++o) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = fmaf(i < w_in ? sW[o * w_in + i] : 0.0f, z[o], x[i]);
+    }
+    const int rows = (w_in + 3) & ~3;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < rows) dx[(size_t)i * n_pad + n] = i < w_in ? x[i] : 0.0f;
+}
+
 }  // namespace
 
 extern "C" {
+
+int cl_chain_dx(const float* dz0_t, const float* Wt, int n_obs, int n_pad, int w_out, int w_in, float* dx_t, const int* stop_flag, void* stream) {
+    if (dz0_t == nullptr || Wt == nullptr || dx_t == nullptr || n_obs < 1 || n_pad < n_obs) return -1;
+    if (w_out < 1 || w_out > 15 || w_in < 1 || w_in > 15) return -2;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(chain_dx_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dz0_t, Wt, n_obs, n_pad, w_out, w_in, dx_t, stop_flag);
+    return (int)hipGetLastError();
+}
 
 int cl_peel_supported(int d, int w, int L) {
     return d >= 1 && d <= 79 && w >= 1 && w <= 15 && L >= 1 && d > w;          // (five 16-column blocks hold 79 columns + the ones)

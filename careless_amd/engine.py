@@ -131,11 +131,17 @@ class LayerBlock:
     final: bool
 
 
-def chain_plan(d: int, w: int, L: int, max_layers: int) -> List[LayerBlock]:
+def chain_plan(d: int, w: int, L: int, max_layers: int, last: int = 0) -> List[LayerBlock]:
     """Split a scaler of L Dense layers into the fewest, evenly sized blocks of at most `max_layers` layers (one block = one
-    launch of the fused kernel, include/careless_hip.h: act_out / dH_ext / dX_out)."""
-    K = -(-L // max_layers)
-    sizes = [L // K + (1 if i < L % K else 0) for i in range(K)]
+    launch of the fused kernel, include/careless_hip.h: act_out / dH_ext / dX_out).  `last` > 0: the last block has exactly that many
+    layers (round 6: 20 of them on the default scaler's lane kernel), the layers in front of it are split evenly."""
+    if last > 0 and L > last:
+        K = -(-(L - last) // max_layers)
+        sizes = [(L - last) // K + (1 if i < (L - last) % K else 0) for i in range(K)] + [last]
+        K += 1
+    else:
+        K = -(-L // max_layers)
+        sizes = [L // K + (1 if i < L % K else 0) for i in range(K)]
     off_of = lambda l: 0 if l == 0 else w * d + w + (l - 1) * (w * w + w)
     blocks, l0 = [], 0
     for k, n in enumerate(sizes):
@@ -232,6 +238,7 @@ class ElboEngine(WidePath):
         self.dw_trainable = self.double_wilson and prior.r_raw is not None
         n_dwr = int(prior.r_raw.numel()) if self.dw_trainable else 0
         self.blocks = None
+        self.chain_lane = False                      # (a chained scaler whose last 20 layers run on the lane kernel: set with the plan below)
         # hidden or metadata width beyond 64: the activations of a layer no longer fit a wave's registers next to the weight-gradient
         # blocks, so the scaler runs unfused -- one fp32-MFMA GEMM launch (csrc/wide_gemm.hip) per layer and direction, activations
         # through HBM -- around the same HIP likelihood kernels (_data_term_wide)
@@ -241,7 +248,12 @@ class ElboEngine(WidePath):
         max_plain = 1 if self.wide else int(self.lib.cl_mlp_max_layers(self.w))
         if not self.wide and imgl is None and self.L > max_plain:
             # deeper than one launch holds in registers: a chain of layer blocks, activations exchanged through HBM
-            self.blocks = chain_plan(self.d, self.w, self.L, max_plain)
+            # width <= 10 (round 6): the LAST 20 layers and the head run on the lane-per-observation kernel -- the default scaler's own, with its
+            # input = the activations of the block in front (w "metadata columns") and dZ_0 out; `cl_chain_dx` turns dZ_0 into the gradient
+            # of those activations.  24 x 10 at 4 M observations: 3.13 -> 1.4 ms per step (two blocks of the 16-wide kernel before).
+            self.chain_lane = (self.w <= 10 and not self.laue and max_plain == 20 and os.environ.get("CARELESS_HIP_LANE", "1") != "0" and
+                               os.environ.get("CARELESS_HIP_CHAIN_LANE", "1") != "0")
+            self.blocks = chain_plan(self.d, self.w, self.L, max_plain, last=20 if self.chain_lane else 0)
         # The careless default scaler (20 layers, hidden width <= 10) on more metadata columns than its lane-per-observation kernel holds
         # (31; four positionally encoded keys give 37): the first Dense layer is "peeled" -- its pre-activations come from
         # cl_peel_forward, the fused kernel runs the same scaler with an identity first layer on them (w "metadata columns": the shape it
@@ -613,7 +625,10 @@ class ElboEngine(WidePath):
         ma = self._mlp_args(0, None, None, obs)
         if self.blocks is not None:
             ma = self._block_args(ma, obs, len(self.blocks) - 1)
-            ma.dX_out = ptr(obs.chain_dact[len(self.blocks) - 2])
+            if getattr(self, "chain_lane", False):
+                ma.dZ0_out = ptr(obs.chain_dact[len(self.blocks) - 2])
+            else:
+                ma.dX_out = ptr(obs.chain_dact[len(self.blocks) - 2])
         elif self.laue and not obs.fused_laue:
             mode = 2 if mode == 0 else mode
             ma.dO_ext = ptr(obs.laue_dO)
@@ -941,11 +956,19 @@ class ElboEngine(WidePath):
             a.act_out = ptr(obs.chain_act[k])
             check(lib.cl_mlp_forward(C.byref(a), obs.grid, st), "cl_mlp_forward")
         a = self._block_args(ma, obs, K - 1)
-        a.dX_out = ptr(obs.chain_dact[K - 2])
-        if self.laue:
-            self._laue_passes(a, obs, step, eta, ipred_out, st)
-        else:
+        if getattr(self, "chain_lane", False):
+            # the last block on the lane kernel: dZ_0 of its first layer out (into a buffer of the boundary's shape), then dX = W_0^T dZ_0
+            if getattr(obs, "chain_dz0", None) is None:
+                obs.chain_dz0 = torch.zeros_like(obs.chain_dact[K - 2])
+            a.dZ0_out = ptr(obs.chain_dz0)
             check(lib.cl_elbo_mono_fwd_bwd(C.byref(a), obs.grid, st), "cl_elbo_mono_fwd_bwd")
+            check(lib.cl_chain_dx(ptr(obs.chain_dz0), a.mlp, a.n_obs, obs.n_pad, self.w, self.w, ptr(obs.chain_dact[K - 2]), ptr(self.stop_flag), st), "cl_chain_dx")
+        else:
+            a.dX_out = ptr(obs.chain_dact[K - 2])
+            if self.laue:
+                self._laue_passes(a, obs, step, eta, ipred_out, st)
+            else:
+                check(lib.cl_elbo_mono_fwd_bwd(C.byref(a), obs.grid, st), "cl_elbo_mono_fwd_bwd")
         check(lib.cl_reduce_partials(ptr(obs.partials), obs.grid, self.blocks[K - 1].P, gptr(K - 1), ptr(self.stop_flag), st),
               "cl_reduce_partials")
         for k in range(K - 2, -1, -1):

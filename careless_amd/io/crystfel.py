@@ -31,8 +31,10 @@ def _unit_cell(buf) -> dict:
                 break
             pos = a + 1
             continue
-        b = buf.find(b"\n----- End unit cell", a)
-        b = len(buf) if b < 0 else b
+        # (a unit-cell block is a dozen short lines: the end marker is looked for in the 4 KiB behind the begin marker, so that a header cut
+        #  off before it does not make this copy and split a stream of tens of GB)
+        b = buf.find(b"\n----- End unit cell", a, a + 4096)
+        b = min(len(buf), a + 4096) if b < 0 else b
         for line in buf[a:b].split(b"\n")[1:]:
             m = _CELL_LINE.match(line)
             if m:

@@ -154,7 +154,10 @@ class DataFormatter:
         ops = SymmetryOps(mtz.symops)
         H = np.empty((len(cols["H"]), 3), dtype=np.int32)                 # (filled column by column: no int64 / float64 copies of the table)
         for j, k in enumerate(("H", "K", "L")):
-            H[:, j] = cols[k]
+            c = np.asarray(cols[k])
+            if c.dtype.kind == "f" and not np.isfinite(c).all():       # (a NaN cast to int32 is INT_MIN: say which column, not "index beyond 2^19")
+                raise ValueError(f"{getattr(mtz, 'path', 'reflection file')}: column {k} holds {int((~np.isfinite(c)).sum())} missing / non-finite Miller indices")
+            H[:, j] = c
         Hasu, _, _, absent = ops.map_rows(H, self.anomalous)            # ds.remove_absences + ds.hkl_to_asu in one native pass
         if absent.any():
             keep = ~absent

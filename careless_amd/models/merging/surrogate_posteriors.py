@@ -33,6 +33,13 @@ class SurrogatePosterior:
 
 
 class TruncatedNormal(SurrogatePosterior):
+    """q(F): one truncated normal per reflection (reference surrogate_posteriors.py:12-131).  `sample`, `mean`, `stddev`, `variance` and
+    `moment_4` run on the GPU through the C-ABI (`cl_tn_forward`, `cl_tn_moments`: fp64 closed forms on the device) and return CUDA tensors
+    without autograd history; without the library or a GPU they raise `CarelessHipError` (there is no CPU path: `engine.require_gpu`).  A
+    host-side reader of a saved posterior (a pickle opened on a login node) takes the moments from the written MTZ columns, or from
+    `scipy.stats.truncnorm((low - loc) / scale, (high - loc) / scale, loc, scale)` on `loc` / `scale`, which are plain tensors.
+    `log_prob` is torch arithmetic on the parameters' device."""
+
     def __init__(self, loc_raw, scale_raw, low, high=1e10, scale_shift=1e-7):
         """Holds the *raw* trainable vectors a = log(loc), b = log(scale - scale_shift)."""
         self.loc_raw = _t(loc_raw)

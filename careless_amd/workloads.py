@@ -33,6 +33,8 @@ WORKLOADS: Dict[str, dict] = {
     "mono_2M_studentt_3x128_S4": dict(N=2_000_000, d0=5, posenc=False, L=3, w=128, S=4, dof=16.0, outliers=True),
     # half the default depth (register-pressure experiments on the narrow kernel)
     "mono_10M_10x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=10, w=10, S=1, dof=None, outliers=False),
+    # (round 6) more layers than one launch holds at the default width: 4 layers on the 16-wide kernel's chain modes + 20 on the lane kernel
+    "mono_10M_24x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=24, w=10, S=1, dof=None, outliers=False),
     # --image-layers 1 on the headline configuration (one Dense layer traded for a per-image layer)
     "mono_10M_studentt_posenc_4x64_img1_S8": dict(N=10_000_000, d0=5, posenc=True, L=4, w=64, S=8, dof=16.0, outliers=True,
                                                   image_layers=1),

@@ -498,6 +498,12 @@ int cl_peel_forward(const float* meta_t, int n_obs, int n_pad, int d, int w, int
                     float* zero_ptr, int zero_n, const int* stop_flag, void* stream);
 int cl_peel_backward(const float* meta_t, int n_obs, int n_pad, int d, int w, int L, const float* dz0_t, const float* grad_peel, float* grad_mlp,
                      float* partials, int nparts, const int* stop_flag, void* stream);
+/* The last block of a layer-block chain on the default scaler's kernels (round 6): a scaler of more than 20 layers at width <= 10 runs its
+ * last 20 layers on elbo_lane.hip, which stores dZ_0 = dL/d(pre-activations of the block's first layer) (cl_mlp_args.dZ0_out); the block in
+ * front takes dL/d(its output activations) as dH_ext: dX = W_0^T dZ_0 per observation.  dz0_t [cl_mlp_meta_rows(w_out)][n_pad] and dx_t
+ * [cl_mlp_meta_rows(w_in)][n_pad] feature-major like meta_t, Wt [w_out][w_in] as in the flat layout; widths <= 15 (-2 beyond).
+ * replaces: the tape's step through the first Dense kernel of the block (careless/models/scaling/nn.py:55-68, variational.py:197-202).        */
+int cl_chain_dx(const float* dz0_t, const float* Wt, int n_obs, int n_pad, int w_out, int w_in, float* dx_t, const int* stop_flag, void* stream);
 
 /* --- output step: merged amplitudes ---------------------------------------------------------------------------------
  * replaces: TruncatedNormal.mean / .stddev (tfd.TruncatedNormal moments behind SurrogatePosterior.mean / .stddev,

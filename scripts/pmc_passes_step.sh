@@ -1,4 +1,5 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT}" || exit 1
 # usage: bash scripts/pmc_passes_step.sh WORKLOAD   -- PMC passes (separate runs) over the dominant kernel(s) of one bench workload.  Output lines
 # "<pass> <counter> <launches per step> <value per STEP>": the counter summed over the dominant kernels' launches of one step (4 steps run).
 T=$1

@@ -21,3 +21,12 @@ def pytest_sessionstart(session):
             b.build(verbose=False)
         except Exception as e:  # pragma: no cover - no hipcc on this machine
             print(f"[conftest] could not build libcareless_hip.so: {e}", file=sys.stderr)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How many parity cases of this session needed the LeakyReLU branch-flip resolver (tests/test_gpu_parity.py: `_assert_grads`) -- the
+    escape hatch of the main gate is counted where everybody sees it (profiles/r6_gpu_suite.txt keeps the line)."""
+    mod = sys.modules.get("tests.test_gpu_parity") or sys.modules.get("test_gpu_parity")
+    if mod is not None and hasattr(mod, "FLIP_CASES"):
+        cases = mod.FLIP_CASES
+        terminalreporter.write_line(f"branch-flip resolutions this session: {len(cases)}" + (": " + ", ".join(f"{n} {list(s)}" for n, s, _ in cases) if cases else ""))

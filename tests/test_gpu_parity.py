@@ -150,6 +150,10 @@ CASES = {
     # scalers deeper than one launch holds: chains of layer blocks (activations through HBM, forward recomputed per block)
     "deep_12x64_studentt_S4": dict(N=700, R=50, d0=5, posenc=True, L=12, w=64, S=4, likelihood="studentt", dof=8.0),
     "deep_25x10_softplus": dict(N=500, R=40, d0=5, L=25, w=10, S=2, bijector="softplus", shift=0.5),
+    # (round 6: at width <= 10 the last 20 layers of a chained scaler run on the lane kernel, cl_chain_dx hands dZ_0 back as the gradient of the boundary activations)
+    "deep_24x10_d12_studentt_S3": dict(N=700, R=40, d0=12, L=24, w=10, S=3, likelihood="studentt", dof=6.0, perturb=0.02, grid=2),
+    "deep_45x8_three_blocks": dict(N=500, R=40, d0=5, L=45, w=8, S=2, perturb=0.01),
+    "deep_22x6_double_wilson": dict(N=600, R=40, d0=5, L=22, w=6, S=2, double_wilson=True, perturb=0.02),
     "deep_11x32_noimg": dict(N=400, R=40, d0=5, L=11, w=32, S=3, use_image_scales=False),
     "deep_laue_7x64": dict(N=500, R=50, L=7, w=64, S=2, laue=True, two_pass=True),
     "deep_double_wilson_6x64": dict(N=400, R=60, d0=5, L=6, w=64, S=2, double_wilson=True),
