@@ -121,6 +121,7 @@ class FrozenArgs(C.Structure):
         ("ev11", _vp), ("d_ev11", _vp),
         ("edge_rid", _vp), ("edge_val", _vp),
         ("nll_part", _vp), ("ev11_part", _vp),
+        ("gmeta", _vp), ("gbuf", _vp), ("src", _vp),
     ]
 
 

@@ -1155,10 +1155,10 @@ int cl_lane_supports(const cl_mlp_args& a) {
           a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr)))
         return 0;
     // the other depths (round 6): instances at widths 8 and 10 (a narrower scaler pays the padded steps: from width CL_LANE_DEPTH_WMIN on it still
-    // beats elbo_narrow.hip), metadata in registers, no dZ_0 out
+    // beats elbo_narrow.hip), metadata in registers (more columns: behind the engine's peeled first layer, dZ_0 out in the plain layout)
     // (CARELESS_HIP_LANE_DEPTHS=0: A/B runs against the narrow kernel these shapes ran on until round 5)
     static const bool depths_on = [] { const char* e = getenv("CARELESS_HIP_LANE_DEPTHS"); return !(e != nullptr && e[0] == '0'); }();
-    if (a.L != NL) return depths_on && a.w >= CL_LANE_DEPTH_WMIN && a.d <= DMAX_ALL && a.dZ0_out == nullptr;
+    if (a.L != NL) return depths_on && a.w >= CL_LANE_DEPTH_WMIN && a.d <= DMAX_ALL && (a.dZ0_out == nullptr || a.row_map == nullptr);
     return a.d <= DMAX_ALL || lane_rows_lds(a.w, a.d) <= 160 * 1024;
 }
 
@@ -1190,8 +1190,8 @@ int cl_lane_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
     const bool packed = a.row_map != nullptr;
     const bool full = packed || lane_wants_full(a) || (DM == 0 && a.dZ0_out != nullptr);
     if (a.L != NL)
-        return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s, false, 0, %d>%s", a.w <= 8 ? 8 : CL_LANE_WMAX, DM, packed ? "true" : "false", full ? "true" : "false", a.L,
-                        a.dzf_obs != nullptr ? " (deterministic stores)" : "");
+        return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s, %s, 0, %d>%s", a.w <= 8 ? 8 : CL_LANE_WMAX, DM, packed ? "true" : "false", full ? "true" : "false",
+                        (!full && a.dZ0_out != nullptr) ? "true" : "false", a.L, a.dzf_obs != nullptr ? " (deterministic stores)" : "");
     return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s%s>%s", W, DM, packed ? "true" : "false", full ? "true" : "false",
                     (!full && a.dZ0_out != nullptr) ? ", true" : "", a.dzf_obs != nullptr ? " (deterministic stores)" : "");
 }
@@ -1249,6 +1249,9 @@ static int launch_lane_depth_w(const cl_mlp_args& a, int grid, hipStream_t st) {
         return a.d <= 8 ? launch_lane_inst<WW, 8, true, true>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, true, true>(a, grid, st);
     if (lane_wants_full(a))
         return a.d <= 8 ? launch_lane_inst<WW, 8, false, true>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, true>(a, grid, st);
+    // behind a peeled first layer (more than 15 metadata columns: the engine hands over the layer's w pre-activations): dZ_0 out
+    if (a.dZ0_out != nullptr)
+        return a.d <= 8 ? launch_lane_inst<WW, 8, false, false, true>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, false, true>(a, grid, st);
     return a.d <= 8 ? launch_lane_inst<WW, 8, false, false>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, false>(a, grid, st);
 }
 int CL_LANE_DEPTH_FN(CL_LANE_NL)(const cl_mlp_args& a, int grid, hipStream_t st) {

@@ -158,6 +158,7 @@ def chain_plan(d: int, w: int, L: int, max_layers: int, last: int = 0) -> List[L
 # the engine
 # ------------------------------------------------------------------------------------------------------------
 class ElboEngine(WidePath):
+    FROZEN_LAUE_PACKED = True        # ... harmonic groups: packed order + the two-call form of `cl_frozen_rows` (tests flip it to compare with the three slot launches)
     FROZEN_SORTED_ROWS = True        # a frozen scaler's monochromatic rows: sorted by reflection, `cl_frozen_rows` (round 6; tests flip it to compare with `cl_slot_rows`)
     SLOT_ROWS_ONE_LAUNCH = True      # rows that are their own slot: predict + log-prob + gradient in one `cl_slot_rows` launch (tests flip it)
     def __init__(self, model, inputs, seed: int = 1234, shard: Optional[Shard] = None, process_group=None,
@@ -402,7 +403,10 @@ class ElboEngine(WidePath):
                   sort_images=self.imgl is not None and self.wide,
                   laue_single_pass=not getattr(self.model, "laue_two_pass", False) and self.blocks is None and not self.wide, wide=self.wide)
         if getattr(self, "_frozen_layout", False):
-            kw.update(pack_images=False, sort_images=False, laue_single_pass=False)
+            # plain rows for a frozen scaler (its output is a constant: no tile / image constraint) -- except Laue data, which keeps the packed
+            # order of the single-pass kernels (a group inside a 16-row granule) for `cl_frozen_rows`' group sums (round 6)
+            kw.update(pack_images=False, sort_images=False,
+                      laue_single_pass=bool(self.laue and self.FROZEN_LAUE_PACKED and not self.deterministic and not getattr(self.model, "laue_two_pass", False)))
         n_total = int(_np(BaseModel.get_refl_id(inputs)).reshape(-1).shape[0])
         stop = n_total if stop is None else stop
         per = launch_row_limit(self.d, self.S if self.deterministic else 0)
@@ -772,24 +776,7 @@ class ElboEngine(WidePath):
             # single pass: the harmonic group sums happen inside the fused kernel; the padded slots (no rows, iconv = 0,
             # reference formatter.py:637-640 / laue.py:24) only add their constant -- and, with Ev11, its gradient
             self._fused_step_launch(ma, obs, st)
-            npad = int(obs.pad_iobs.numel())
-            if npad > 0:
-                uniform = getattr(obs, "pad_uniform", False)            # all padded slots alike: one slot, weight x their number
-                nslot = 1 if uniform else npad
-                obs.pad_iconv[: nslot * self.S].zero_()
-                la = LaueArgs()
-                la.iobs, la.sig, la.iconv = ptr(obs.pad_iobs), ptr(obs.pad_sig), ptr(obs.pad_iconv)
-                la.n_obs, la.S = nslot, self.S
-                la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
-                la.w_ll = ma.w_ll * (npad if uniform else 1)
-                la.scalars, la.stop_flag = ptr(self.scalars), ptr(self.stop_flag)
-                la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
-                if self.deterministic:      # the padded slots' workgroups store their NLL behind the fused launch's parts
-                    det = obs.det_parent.det
-                    la.nll_part = det["nll"].data_ptr() + 8 * det["pieces"] * det["grid"]
-                    if self.ev11:
-                        la.ev11_part = det["ev11"].data_ptr() + 4 * 3 * _lib.CL_EV11_WAVES * det["pieces"] * det["grid"]
-                check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
+            self._laue_pad_slots(ma, obs, st)
         elif self.laue:
             self._laue_passes(ma, obs, step, eta, ipred_out, st)
         else:
@@ -806,10 +793,40 @@ class ElboEngine(WidePath):
         if self.deterministic and not _piece:
             self._det_reduce(obs, st)
 
+    def _laue_pad_slots(self, ma: MlpArgs, obs: ObsData, st):
+        """The padded slots of a packed Laue observation set (no rows, iconv = 0: reference formatter.py:637-640 / laue.py:24) add their
+        constant to the NLL -- and, with Ev11, its gradient -- through one small `cl_laue_likelihood` launch."""
+        lib = self.lib
+        npad = int(obs.pad_iobs.numel())
+        if npad <= 0:
+            return
+        uniform = getattr(obs, "pad_uniform", False)            # all padded slots alike: one slot, weight x their number
+        nslot = 1 if uniform else npad
+        obs.pad_iconv[: nslot * self.S].zero_()
+        la = LaueArgs()
+        la.iobs, la.sig, la.iconv = ptr(obs.pad_iobs), ptr(obs.pad_sig), ptr(obs.pad_iconv)
+        la.n_obs, la.S = nslot, self.S
+        la.lik_kind, la.dof, la.lik_const = self.lik_kind, self.dof, self.lik_const
+        la.w_ll = ma.w_ll * (npad if uniform else 1)
+        la.scalars, la.stop_flag = ptr(self.scalars), ptr(self.stop_flag)
+        la.ev11, la.d_ev11 = ma.ev11, ma.d_ev11
+        if self.deterministic:      # the padded slots' workgroups store their NLL behind the fused launch's parts
+            det = obs.det_parent.det
+            la.nll_part = det["nll"].data_ptr() + 8 * det["pieces"] * det["grid"]
+            if self.ev11:
+                la.ev11_part = det["ev11"].data_ptr() + 4 * 3 * _lib.CL_EV11_WAVES * det["pieces"] * det["grid"]
+        check(lib.cl_laue_likelihood(C.byref(la), st), "cl_laue_likelihood")
+
     def _frozen_ok(self, obs: ObsData) -> bool:
         """The sampling / likelihood kernels take this observation image as it is: rows in the caller's order (not packed by image or
         harmonic group, not sorted by image), and -- deterministic mode -- rows that are their own slot."""
-        if obs.row_map is not None or obs.fused_laue or getattr(obs, "perm", None) is not None or getattr(obs, "host_inputs", None) is None:
+        if getattr(obs, "host_inputs", None) is None:
+            return False
+        if obs.fused_laue:
+            # harmonic groups in the packed order of the single-pass kernels (round 6): `cl_frozen_rows` in its two-call form -- an engine
+            # built around a frozen scaler keeps that layout for Laue data (_build_obs)
+            return self._frozen_layout and self.FROZEN_LAUE_PACKED and not self.deterministic and obs.tile_img is None
+        if obs.row_map is not None or getattr(obs, "perm", None) is not None:
             return False
         if self.imgl is not None and not self._frozen_layout:
             return False
@@ -829,14 +846,17 @@ class ElboEngine(WidePath):
             obs.laue_loc, obs.laue_sig = scaler_forward(self.mlp, md, self.imgl, ids)
             if getattr(obs, "laue_dO", None) is None:
                 obs.laue_dO = torch.empty(obs.N * 2, dtype=torch.float32, device=self.device)
-            if not hasattr(obs, "harmonic_id"):
+            if not hasattr(obs, "harmonic_id") and not obs.fused_laue:
                 obs.harmonic_id = None
-            if getattr(obs, "laue_iconv", None) is None:      # (rows that are their own slot never touch it; the entry point wants a pointer)
+            if getattr(obs, "laue_iconv", None) is None and not obs.fused_laue:      # (rows that are their own slot never touch it; the entry point wants a pointer)
                 obs.laue_iconv = torch.empty(obs.N * self.S if obs.harmonic_id is not None else 4, dtype=torch.float32, device=self.device)
             if obs.rows is not None and getattr(obs, "row_index", None) is None:
                 obs.row_index = torch.as_tensor(np.asarray(obs.rows, dtype=np.int64), device=self.device)     # the noise key of every row
             obs.locsig_epoch = self._frozen_epoch
         ma = self._mlp_args(step, eta, ipred_out, obs)
+        if obs.fused_laue:
+            self._frozen_laue(ma, obs, step, eta, ipred_out, st)
+            return
         keyed = getattr(obs, "row_index", None) is not None and (eta is not None or ipred_out is not None)      # (injected noise on rows that are not a contiguous range: the slot kernels index it by local row)
         if obs.harmonic_id is None and not self.deterministic and self.FROZEN_SORTED_ROWS and not keyed:
             self._frozen_rows(ma, obs, step, eta, ipred_out, st)
@@ -890,6 +910,63 @@ class ElboEngine(WidePath):
         fa.ev11, fa.d_ev11 = ma.ev11, ma.d_ev11
         fa.edge_rid, fa.edge_val = ptr(fz["edge_rid"]), ptr(fz["edge_val"])
         check(self.lib.cl_frozen_rows(C.byref(fa), st), "cl_frozen_rows")
+
+    def _frozen_laue(self, ma: MlpArgs, obs: ObsData, step: int, eta, ipred_out, st):
+        """Harmonic groups behind a frozen scaler (round 6): `cl_frozen_rows` twice -- in the packed order of the single-pass kernels the group
+        sums, the likelihood and every row's amplitude gradient (stored per row: the rows of a group belong to different reflections), then
+        the same rows in reflection order, gathered and summed per reflection like monochromatic rows -- and the padded slots' constant."""
+        fz = getattr(obs, "frozen_sorted", None)
+        dev = self.device
+        if obs.noise_row is not None and (eta is not None or ipred_out is not None):
+            raise NotImplementedError("injected noise / ipred_out on a shard of harmonic groups behind a frozen scaler (a parity-test input: "
+                                      "set model.frozen_scaler_fast_path = False)")
+        if fz is None or fz["epoch"] != self._frozen_epoch:
+            rm = obs.row_map.long()
+            valid = rm >= 0
+            rmc = rm.clamp(min=0)
+            loc_p = obs.laue_loc.index_select(0, rmc).contiguous()
+            sig_p = obs.laue_sig.index_select(0, rmc).contiguous()
+            if ma.use_img:
+                scales = torch.cat([torch.ones(1, dtype=torch.float32, device=dev), self.params[self.layout.off_img: self.layout.off_img + self.layout.n_img].detach()])
+                aim = scales.index_select(0, obs.image_id.long().clamp(min=0)).contiguous()
+            else:
+                aim = None
+            key = obs.noise_row if obs.noise_row is not None else (rmc + int(obs.start)).to(torch.int32).contiguous()
+            active = torch.nonzero(valid & (obs.refl_id >= 0)).flatten()
+            order = torch.argsort(obs.refl_id.index_select(0, active), stable=True)
+            src = active.index_select(0, order).to(torch.int32).contiguous()
+            refl_sorted = obs.refl_id.index_select(0, src.long()).to(torch.int32).contiguous()
+            n2 = int(src.numel())
+            fz = obs.frozen_sorted = dict(
+                epoch=self._frozen_epoch, loc=loc_p, sigma=sig_p, aim=aim, key=key, src=src, refl_sorted=refl_sorted, n2=n2,
+                gbuf=torch.zeros(obs.n_pad * self.S, dtype=torch.float32, device=dev),
+                edge_rid=torch.empty(2 * ((n2 + 63) // 64) + 2, dtype=torch.int32, device=dev),
+                edge_val=torch.empty(max(int(self.lib.cl_frozen_edge_floats(n2, self.S)), 1), dtype=torch.float32, device=dev))
+        row0 = getattr(obs, "row0", 0)
+        fa = FrozenArgs()
+        fa.refl_id, fa.loc, fa.sigma, fa.aim = ptr(obs.refl_id), ptr(fz["loc"]), ptr(fz["sigma"]), ptr(fz["aim"])
+        fa.iobs, fa.sig, fa.key = ptr(obs.iobs), ptr(obs.sig), ptr(fz["key"])
+        fa.obs_offset, fa.n = int(obs.start), int(obs.n_pad)
+        fa.R, fa.S = self.R, self.S
+        fa.z_f, fa.dz_f = ptr(self.z_f), ptr(self.dz_f)
+        fa.lik_kind, fa.dof, fa.lik_const = self.lik_kind, self.dof, self.lik_const
+        fa.shift, fa.w_ll = ma.shift, ma.w_ll
+        fa.eta = None if eta is None else eta.data_ptr() + 4 * self.S * row0
+        fa.seed, fa.step = self.seed, step & 0xFFFFFFFF
+        fa.scalars, fa.stop_flag = ptr(self.scalars), ptr(self.stop_flag)
+        fa.ipred_out = None if ipred_out is None else ipred_out.data_ptr() + 4 * self.S * row0
+        fa.ev11, fa.d_ev11 = ma.ev11, ma.d_ev11
+        fa.gmeta, fa.gbuf = ptr(obs.gmeta), ptr(fz["gbuf"])
+        check(self.lib.cl_frozen_rows(C.byref(fa), st), "cl_frozen_rows (harmonic groups)")
+        if fz["n2"] > 0:
+            fb = FrozenArgs()
+            fb.refl_id, fb.src, fb.gbuf = ptr(fz["refl_sorted"]), ptr(fz["src"]), ptr(fz["gbuf"])
+            fb.n, fb.R, fb.S = fz["n2"], self.R, self.S
+            fb.dz_f, fb.stop_flag = ptr(self.dz_f), ptr(self.stop_flag)
+            fb.accumulate = 1 if (getattr(obs, "is_piece", False) or self.double_wilson) else 0
+            fb.edge_rid, fb.edge_val = ptr(fz["edge_rid"]), ptr(fz["edge_val"])
+            check(self.lib.cl_frozen_rows(C.byref(fb), st), "cl_frozen_rows (per-reflection sums)")
+        self._laue_pad_slots(ma, obs, st)
 
     def _peel_bufs(self, obs: ObsData):
         """Buffers of the peeled first layer for one observation set: its pre-activations and dZ_0 (feature-major, like meta_t), the

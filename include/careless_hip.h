@@ -426,6 +426,16 @@ typedef struct cl_frozen_args {
     float* edge_val;            /* [cl_frozen_edge_floats(n, S)] workspace                                         */
     double* nll_part;           /* optional [cl_frozen_grid(n)]: every workgroup STORES its NLL (no fp64 atomic)   */
     float* ev11_part;           /* optional [3 * 4 * cl_frozen_grid(n)]: every wave stores its Evans-2011 terms    */
+    /* Harmonic groups (Laue data, careless/models/likelihoods/laue.py:9-47: the predictions of a group's rows sum before the likelihood) take
+     * TWO calls, because the rows of a group belong to different reflections:
+     *   1. gmeta != NULL: rows in the packed order of the single-pass kernels (a group inside a 16-row granule; gmeta[i] = member index |
+     *      group size << 8; padding rows refl_id < 0; iobs / sig of the group replicated on its rows): group sums over shuffles, likelihood,
+     *      NLL (member 0), the row's amplitude gradient STORED at gbuf[i][s].  refl_id need not be sorted; dz_f / edge_* unused.
+     *   2. src != NULL: refl_id ascending over the same rows, src[i] = the row's index in gbuf: the gradients are gathered, summed per
+     *      reflection and stored into dz_f as for monochromatic rows (loc / sigma / iobs / sig / z_f / scalars unused).             */
+    const int* gmeta;
+    float* gbuf;                /* [rows][S]                                                                        */
+    const int* src;
 } cl_frozen_args;
 int cl_frozen_rows(const cl_frozen_args* args, void* stream);
 int cl_frozen_edge_floats(long long n, int S);     /* floats of edge_val */

@@ -180,3 +180,59 @@ def test_sorted_rows_kernel_on_a_chunked_shard_adds_its_pieces():
     torch.cuda.synchronize()
     assert util.rel_err(cut.dz_f.cpu().numpy(), one.dz_f.cpu().numpy()) < 2e-6
     assert abs(cut.loss_terms()["nll"] - one.loss_terms()["nll"]) <= 1e-9 * abs(one.loss_terms()["nll"])
+
+
+LAUE_CASES = {
+    "laue_S1": dict(N=3000, R=60, L=2, w=32, S=1, laue=True),
+    "laue_S3_studentt": dict(N=2500, R=40, L=20, w=10, S=3, laue=True, likelihood="studentt", dof=8.0, perturb=0.02),
+    "laue_S9_ev11_few_reflections": dict(N=2000, R=9, L=2, w=32, S=9, laue=True, ev11=True),
+    "laue_double_wilson_like_noimg": dict(N=1500, R=50, L=5, w=64, S=2, laue=True, use_image_scales=False),
+}
+
+
+@pytest.mark.parametrize("name", list(LAUE_CASES))
+def test_frozen_harmonic_groups_two_call_form_equals_the_slot_launches_and_repeats(name):
+    """Laue data behind a frozen scaler (round 6): `cl_frozen_rows` twice (group sums in packed order, per-reflection sums in reflection
+    order) against round 5's `cl_laue_predict / _likelihood / _backward` on plain rows -- same in-kernel noise -- and twice on fresh engines:
+    dz_f bit-identical (no float atomics)."""
+    kw = LAUE_CASES[name]
+    runs = []
+    for packed in (True, True, False):
+        from careless_amd.engine import ElboEngine
+        old = ElboEngine.FROZEN_LAUE_PACKED
+        ElboEngine.FROZEN_LAUE_PACKED = packed
+        try:
+            eng, _ = _engine(kw, True)
+            eng.forward_backward(4)
+            torch.cuda.synchronize()
+        finally:
+            ElboEngine.FROZEN_LAUE_PACKED = old
+        assert bool(eng.obs.fused_laue) == packed and (getattr(eng.obs, "frozen_sorted", None) is not None) == packed
+        runs.append((eng.grads.clone(), eng.dz_f.clone(), eng.loss_terms(), eng))
+    (g1, z1, t1, e1), (g2, z2, t2, _), (g0, z0, t0, _) = runs
+    R, lay = e1.R, e1.layout
+    assert torch.equal(z1, z2) and torch.equal(g1[: 2 * R], g2[: 2 * R])
+    assert abs(t1["nll"] - t0["nll"]) <= 2e-6 * abs(t0["nll"])
+    assert util.rel_err(z1.cpu().numpy(), z0.cpu().numpy()) < 5e-6
+    assert util.rel_err(g1[: 2 * R].cpu().numpy(), g0[: 2 * R].cpu().numpy()) < 1e-5
+    if lay.n_ev11 > 0:
+        assert util.rel_err(g1[lay.off_ev11: lay.off_ev11 + 3].cpu().numpy(), g0[lay.off_ev11: lay.off_ev11 + 3].cpu().numpy()) < 2e-5
+
+
+def test_frozen_laue_rank_shards_sum_to_the_full_batch():
+    """Shards of whole harmonic groups (the rows of a rank are not a contiguous range: the noise key is the global row number)."""
+    from careless_amd.engine import make_shard
+    kw = dict(N=2400, R=60, L=20, w=10, S=2, laue=True, perturb=0.02)
+    full, _ = _engine(kw, True)
+    full.forward_backward(3)
+    torch.cuda.synchronize()
+    assert full.obs.fused_laue and full.obs.frozen_sorted is not None
+    g, nll = torch.zeros_like(full.grads), 0.0
+    for r in range(3):
+        eng, _ = _engine(kw, True, shard=make_shard(kw["N"], kw["R"], r, 3))
+        eng.forward_backward(3)
+        torch.cuda.synchronize()
+        g += eng.grads
+        nll += eng.loss_terms()["nll"]
+    assert abs(nll - full.loss_terms()["nll"]) <= 1e-5 * abs(nll)
+    assert util.rel_err(g.cpu().numpy(), full.grads.cpu().numpy()) < 2e-5

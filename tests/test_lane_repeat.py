@@ -62,6 +62,7 @@ for depth in (2, 5, 10, 16, 19):
         full = "false" if tag == "plain" else "true"
         dm = 15 if tag == "plain_full_det" else 8
         CASES[f"depth{depth}_{tag}"] = dict(kw=kw, det=base["det"], name=f"elbo_lane_kernel<{10 if kw['w'] > 8 else 8}, {dm}, {packed}, {full}, false, 0, {depth}>" + (" (deterministic stores)" if base["det"] else ""))
+    CASES[f"depth{depth}_dz0_out"] = dict(kw=dict(_plain(10, 15, dxo=True)["kw"], L=depth), det=False, name=f"elbo_lane_kernel<10, 15, false, false, true, 0, {depth}>")
 for ni in (1, 2):
     for dm in (8, 15):
         CASES[f"image_layers{ni}_dm{dm}"] = _imgl(ni, dm)
