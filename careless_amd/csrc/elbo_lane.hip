@@ -197,10 +197,15 @@ struct LSmem {
 // gradient (atomics) and reloads.  The activations of the top PK layers wait in LDS across the sampling epilogue (22 x 10 activations +
 // the epilogue's state do not fit the 512 registers; the compiler would spill to scratch, which a lone wave waits for in full).
 // DEPTH: the unit's NL again, as a template argument -- the instances of the units compiled for other depths need names of their own.
-template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false, int NI = 0, int DEPTH = NL>
+// MODE (round 6): 0 = the fused step; the two launches of a head-less layer block in front of another one (a scaler deeper than one launch:
+// include/careless_hip.h, act_out / dH_ext) -- 1 = forward only, the top layer's activations stored feature-major at act_out;
+// 2 = backward from an external dL/d(top activations) (dH_ext), the forward pass recomputed, weight-gradient partials as in the fused step
+// (no head, no sampling epilogue, nothing per reflection).
+template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false, int NI = 0, int DEPTH = NL, int MODE = 0>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void elbo_lane_kernel(const cl_mlp_args A) {
     static_assert(DEPTH == NL, "one depth per compilation unit");
+    static_assert(MODE == 0 || (!PACKED && !FULL && !DXO && NI == 0 && DMAX != 0), "layer-block launches: plain layout, metadata in registers");
     constexpr bool LX = (DMAX == 0);
     constexpr int DREG = LX ? 1 : DMAX;               // metadata registers of the lane (LX: none; arrays keep one element)
     constexpr int NLT = NL + NI;                      // hidden layers: Dense + per-image
@@ -262,9 +267,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 } else if (l < NL) {
                     off = b == ONE ? base + w * in_dim + f : base + f * in_dim + b;
                     ok = f < w && (b == ONE || b < in_dim);
-                } else {                                              // the Dense(2) head
+                } else {                                              // the Dense(2) head (a head-less block has none)
                     off = b == ONE ? offWo + 2 * w + f : offWo + f * w + b;
-                    ok = f < 2 && (b == ONE || b < w);
+                    ok = MODE == 0 && f < 2 && (b == ONE || b < w);
                 }
             } else {
                 if (l < NL) {
@@ -272,7 +277,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                     ok = l > 0 && b < w && f < w;
                 } else {
                     off = offWo + b * w + f;
-                    ok = b < 2 && f < w;
+                    ok = MODE == 0 && b < 2 && f < w;
                 }
             }
             ok = ok && rho < NROW;
@@ -396,11 +401,13 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             }
         }
         // (no arithmetic on the loaded values here: it would wait for them; observations past the end are masked at the use)
-        const unsigned ob = 4u * (unsigned)min(base + lane, last_obs);
-        ridn = ld_uo(A.refl_id, ob);
-        ion = ld_uo(A.iobs, ob);
-        sgn = ld_uo(A.sig, ob);
-        imgn = A.use_img ? ld_uo(A.image_id, ob) : 0;
+        if constexpr (MODE == 0) {
+            const unsigned ob = 4u * (unsigned)min(base + lane, last_obs);
+            ridn = ld_uo(A.refl_id, ob);
+            ion = ld_uo(A.iobs, ob);
+            sgn = ld_uo(A.sig, ob);
+            imgn = A.use_img ? ld_uo(A.image_id, ob) : 0;
+        }
     };
     // wave tiles of this wave: strided over all waves of the launch, or (NI) one contiguous range so that image changes are rare
     const int gwv = (int)blockIdx.x * NWV + wv;
@@ -497,10 +504,10 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         // Gathers that depend on the prefetched ids: issued now, consumed in the epilogue.  Every lane loads from a valid (clamped)
         // address and nothing is done with the values here: a select or a merge under a divergent branch would make this lone wave
         // wait for each gather in turn.
-        float aim_raw = 1.0f, zf0;
+        float aim_raw = 1.0f, zf0 = 0.0f;
         int rme = 0, gm = 0;                 // PACKED: the caller's row of this lane's packed row; (member index | group size << 8)
         long long nkey = 0;                  // PACKED: noise key of this lane's row
-        {
+        if constexpr (MODE == 0) {
             const unsigned zb = 4u * (unsigned)max(rid, 0) * (unsigned)A.S;
             if (A.use_img) aim_raw = ld_uo(A.img, 4u * (unsigned)max(img - 1, 0));
             zf0 = ld_uo(A.z_f, zb);
@@ -640,6 +647,19 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         }
 #define TOP(k) HS(NLT - 1, k)                            /* the head's input */
         LSTAMP(1);
+        float dloc = 0.0f, draw = 0.0f;
+        if constexpr (MODE == 1) {
+            // a head-less block, forward only: the top layer's activations out (feature-major like meta_t: the next block's "metadata")
+            float* const ao = A.act_out + (size_t)(wt * WT) + lane;
+            const size_t np = (size_t)A.n_pad;
+            static_for<0, W>([&](auto fc_) {
+                constexpr int f = decltype(fc_)::value;
+                if (f < w) ao[f * np] = TOP(f);
+            });
+            if (wt + wt_inc < wt_end) prefetch(wt + wt_inc, xcur ^ 1);
+            continue;
+        }
+        if constexpr (MODE == 0) {
         // Dense(2) head: outputs 0, 1 of one more chunk
         float o0, o1;
         {
@@ -801,7 +821,9 @@ void elbo_lane_kernel(const cl_mlp_args A) {
                 cl_image_grad_segments(A.d_img, img, pda, rid >= 0 && img > 0, lane);
             }
         }
-        const float dloc = pdl, draw = pds * dsig_draw;              // zero for padding observations
+        dloc = pdl;
+        draw = pds * dsig_draw;              // zero for padding observations
+        }   // MODE == 0
 
         LSTAMP(2);
         // next tile's inputs: their latency hides under the backward pass
@@ -823,6 +845,18 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         };
         unpark(std::integral_constant<int, NLT - 1>{});
         unpark(std::integral_constant<int, (NLT >= 2 ? NLT - 2 : 0)>{});
+        f32x4 dH[NC];
+        if constexpr (MODE == 2) {
+            // a head-less block: dL/d(top activations) comes from the block behind it (feature-major, like act_out)
+            const float* const dh = A.dH_ext + (size_t)(wt * WT) + lane;
+            const size_t np = (size_t)A.n_pad;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dH[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            static_for<0, W>([&](auto fc_) {
+                constexpr int f = decltype(fc_)::value;
+                if (f < w) dH[f >> 2][f & 3] = in_range ? dh[f * np] : 0.0f;
+            });
+        } else {
         // head: its weight gradient is per-lane sums; its dgrad two steps (dloc, draw) per input chunk
         {
             const f32x2 dd2 = {dloc, draw};
@@ -830,7 +864,6 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             for (int k = 0; k < W; ++k) hacc[k] += dd2 * f32x2{TOP(k), TOP(k)};
             hacc[W] += dd2;
         }
-        f32x4 dH[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float wk = sK[NL * IMG + c * 64];
@@ -838,6 +871,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             a = mfma_bk<0>(wk, dloc, a);
             a = mfma_bk<1>(wk, draw, a);
             dH[c] = a;
+        }
         }
         LSTAMP(4);
             // dZ of a layer: dH where the activation is positive, leak dH otherwise.  As the compiler writes the select (compare
@@ -955,12 +989,13 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             });
         LSTAMP(5);
     }
+    if constexpr (MODE == 1) return;                             // (forward only: nothing accumulated)
     // ================= flush: sum the waves' accumulators, scatter into the flat W^T layout of this workgroup's partial ====
     if constexpr (NI > 0) { if (cur_img >= 0) imgl_flush(cur_img); }        // the last image's layers of this wave
     asm volatile("s_nop 15\n\ts_nop 15");     // (the compiler does not know that the inline-assembly MFMAs' results take eight passes to land)
     __syncthreads();
     const int offWo = w * d + w + (L - 1) * (w * w + w);
-    const int Ptot = offWo + 2 * w + 2;
+    const int Ptot = offWo + (MODE == 0 ? 2 * w + 2 : 0);        // (a head-less block's partial ends with its last Dense layer)
     // fixed binary tree over the waves (deterministic): at stride s the waves with (wv & (2s - 1)) == s park their sums in the
     // region of wave wv - s, which adds them to its own
     constexpr int REG = SM::REG;
@@ -1016,7 +1051,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
             if (fo < w && fi == ONE) part[off + w * in_dim + fo] = v;                     // bias gradient: the ones column
         }
     }
-    if (tid < 32) {
+    if (MODE == 0 && tid < 32) {
         const int c = tid >> 4, k = tid & 15;                      // head: row c (loc / raw sigma), input feature k; k == W: the bias
         float v = 0.0f;
         for (int q = 0; q < NWV; ++q) v += sHead[q * 32 + tid];
@@ -1024,7 +1059,7 @@ void elbo_lane_kernel(const cl_mlp_args A) {
         if (k == W) part[offWo + 2 * w + c] = v;
     }
 
-    {
+    if constexpr (MODE == 0) {
         float v = cl_wave_sum(nll_acc);
         __syncthreads();
         if (lane == 0) smem[wv] = v;
@@ -1068,12 +1103,12 @@ void elbo_lane_kernel(const cl_mlp_args A) {
 #define CL_LANE_PART 0
 #endif
 
-template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false, int NI = 0>
+template <int W, int DMAX, bool PACKED, bool FULL, bool DXO = false, int NI = 0, int MODE = 0>
 static int launch_lane_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
     using SM = LSmem<W, DMAX == 0, NI>;
     const size_t sm = (size_t)SM::total(a.d) * sizeof(float);
     if (sm > 160 * 1024) return -3;
-    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL, DXO, NI, NL>;
+    auto kern = elbo_lane_kernel<W, DMAX, PACKED, FULL, DXO, NI, NL, MODE>;
     static std::atomic<size_t> configured{0};
     size_t have = configured.load(std::memory_order_acquire);
     if (have < sm) {
@@ -1126,6 +1161,11 @@ int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st);
 #define CL_LANE_DEPTH_DECL(D) int cl_launch_lane_depth##D(const cl_mlp_args& a, int grid, hipStream_t st);
 CL_LANE_DEPTHS(CL_LANE_DEPTH_DECL)
 #undef CL_LANE_DEPTH_DECL
+// ... and the two launches of a head-less layer block (MODE 1 / 2) at every depth 2 .. 20: the blocks in front of the last one of a chained scaler
+#define CL_LANE_BLOCK_DECL(D) int cl_launch_lane_block##D(const cl_mlp_args& a, int mode, int grid, hipStream_t st);
+CL_LANE_DEPTHS(CL_LANE_BLOCK_DECL)
+CL_LANE_BLOCK_DECL(20)
+#undef CL_LANE_BLOCK_DECL
 static inline bool lane_has_depth(int L) {
 #define CL_LANE_DEPTH_TEST(D) if (L == D) return true;
     CL_LANE_DEPTHS(CL_LANE_DEPTH_TEST)
@@ -1170,6 +1210,29 @@ int cl_lane_imgl_supports(const cl_mlp_args& a) {
     return a.n_imgl >= 1 && a.n_imgl <= CL_LANE_IMGL_MAX && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && a.L == NL &&
            a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.dzf_obs == nullptr && a.row_map != nullptr &&
            (a.gmeta == nullptr || a.tile_gmax != nullptr) && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
+}
+
+// 1 = this launch of a head-less layer block (mode 1: forward with act_out; mode 2: backward from dH_ext) runs on the lane kernel (round 6):
+// 2 .. 20 Dense layers of width 5 .. 10 on <= 15 input columns in the plain layout, the FIRST block of a chain (no dX_out)
+int cl_lane_block_supports(const cl_mlp_args& a, int mode) {
+    static const bool on = [] { const char* e = getenv("CARELESS_HIP_LANE_BLOCKS"); return !(e != nullptr && e[0] == '0'); }();
+    if (!on || !(mode == 1 || mode == 2)) return 0;
+    if (!(a.w >= CL_LANE_DEPTH_WMIN && a.w <= CL_LANE_WMAX && a.d >= 1 && a.d <= DMAX_ALL && (a.L == NL || lane_has_depth(a.L)) && a.n_imgl == 0 &&
+          a.row_map == nullptr && a.gmeta == nullptr && a.dX_out == nullptr && a.dO_ext == nullptr && a.dZ0_out == nullptr))
+        return 0;
+    if (mode == 1) return a.act_out != nullptr && a.dH_ext == nullptr && a.loc_out == nullptr && a.sig_out == nullptr;
+    return a.dH_ext != nullptr && a.act_out == nullptr && a.partials != nullptr;
+}
+
+int cl_launch_lane_block(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (!cl_lane_block_supports(a, mode)) return -2;
+    if (a.n_pad % CL_MLP_TILE != 0 || a.n_pad <= 0 || grid < 1) return -1;
+    if (4ull * (unsigned long long)((a.d + 3) & ~3) * (unsigned long long)a.n_pad >= (1ull << 32)) return -4;
+#define CL_LANE_BLOCK_CALL(D) if (a.L == D) return cl_launch_lane_block##D(a, mode, grid, st);
+    CL_LANE_DEPTHS(CL_LANE_BLOCK_CALL)
+    CL_LANE_BLOCK_CALL(20)
+#undef CL_LANE_BLOCK_CALL
+    return -2;
 }
 
 int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st) {
@@ -1257,7 +1320,21 @@ static int launch_lane_depth_w(const cl_mlp_args& a, int grid, hipStream_t st) {
 int CL_LANE_DEPTH_FN(CL_LANE_NL)(const cl_mlp_args& a, int grid, hipStream_t st) {
     return a.w <= 8 ? launch_lane_depth_w<8>(a, grid, st) : launch_lane_depth_w<CL_LANE_WMAX>(a, grid, st);
 }
-#elif CL_LANE_PART == 4
+#endif
+#if CL_LANE_PART == 7 || CL_LANE_PART == 8
+// the two launches of a head-less layer block of this depth (part 8: the default depth)
+template <int WW, int MODE>
+static int launch_lane_block_w(const cl_mlp_args& a, int grid, hipStream_t st) {
+    return a.d <= 8 ? launch_lane_inst<WW, 8, false, false, false, 0, MODE>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, false, false, 0, MODE>(a, grid, st);
+}
+#define CL_LANE_BLOCK_FN2(D) cl_launch_lane_block##D
+#define CL_LANE_BLOCK_FN(D) CL_LANE_BLOCK_FN2(D)
+int CL_LANE_BLOCK_FN(CL_LANE_NL)(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    if (mode == 1) return a.w <= 8 ? launch_lane_block_w<8, 1>(a, grid, st) : launch_lane_block_w<CL_LANE_WMAX, 1>(a, grid, st);
+    return a.w <= 8 ? launch_lane_block_w<8, 2>(a, grid, st) : launch_lane_block_w<CL_LANE_WMAX, 2>(a, grid, st);
+}
+#endif
+#if CL_LANE_PART == 4
 // per-image layers: the widest instance serves every w <= 10 (a narrower scaler pays the padded MFMA steps: --image-layers on a
 // non-default width is rare); with and without the optional inputs / outputs, as the plain layout
 int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
@@ -1273,7 +1350,7 @@ int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st) {
     return a.d <= 8 ? CL_LANE_IMGL_CASE(8, 2) : CL_LANE_IMGL_CASE(DMAX_ALL, 2);
 #undef CL_LANE_IMGL_CASE
 }
-#else
+#elif CL_LANE_PART == 3
 int cl_launch_lane_packed_rows(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_CASE(WW) launch_lane_one<WW, 0, true>(a, grid, st)
     CL_LANE_WIDTHS(CL_LANE_CASE)

@@ -1416,6 +1416,9 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
         if (a.row_map != nullptr && a.n_imgl == 0) return cl_launch_mlp_packed_det(a, mode, grid, st);      // single-pass Laue, wider than 15
         return cl_launch_mlp_det(a, mode, grid, st);
     }
+    // the first block of a chained narrow scaler: the lane kernel's forward-only / external-gradient instances (round 6)
+    if ((a.act_out != nullptr || a.dH_ext != nullptr) && cl_lane_block_supports(a, mode) && lane_enabled() && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1)
+        return cl_launch_lane_block(a, mode, grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid, st);
     if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) return cl_launch_mlp_chain(a, mode, grid, st);
     if (a.n_imgl > 0) {                                                        // packed layout + per-image layers
         // the default scaler's depth and width with one or two per-image layers: the lane-per-observation kernel (elbo_lane.hip, round 5)
