@@ -269,8 +269,9 @@ class ElboEngine(WidePath):
                      os.environ.get("CARELESS_HIP_NARROW", "1") != "0")
         # ... and (round 5) the default scaler with one or two per-image layers on more than the 15 columns its lane instances hold
         # (`--image-layers 2 --positional-encoding-keys X,Y`: 21): the peeled layer's w pre-activations are the lane kernel's "metadata"
+        # (round 6: Laue data too -- the per-image-layer instances are packed-layout kernels either way, and their dZ_0-storing form is back)
         if (not self.wide and imgl is not None and lane_shape and imgl.n_image_layers <= 2 and self.d > 15 and self.d > self.w and
-                not self.laue and bool(self.lib.cl_peel_supported(self.d, self.w, self.L))):
+                bool(self.lib.cl_peel_supported(self.d, self.w, self.L))):
             self.peel = True
         if imgl is not None:
             imgl.build(self.d)

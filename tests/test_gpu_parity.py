@@ -62,6 +62,7 @@ CASES = {
     "lane_20x9_d1_three_observations": dict(N=3, R=2, d0=1, L=20, w=9, S=1, n_images=1, use_image_scales=False, perturb=0.02),
     "lane_laue_single_pass_20x10_S2": dict(N=900, R=40, L=20, w=10, S=2, laue=True, perturb=0.02, grid=2),
     "lane_laue_single_pass_20x6_S1_ev11": dict(N=600, R=40, L=20, w=6, S=1, laue=True, ev11=True, perturb=0.02),
+    "lane_laue_image_layers2_peeled_d21_S2": dict(N=900, R=40, L=20, w=10, S=2, laue=True, image_layers=2, n_images=7, extra_meta=15, perturb=0.02),   # (round 6: Laue + per-image layers behind the peeled first layer)
     # ... with 16 .. 31 metadata columns (positional encodings: + 16 columns; the rows of a tile then live in LDS, layer 0 has two
     # input blocks) and with more than eight MC samples (batches of eight through LDS)
     "lane_20x10_d21_S8_studentt": dict(N=900, R=50, d0=5, posenc=True, L=20, w=10, S=8, likelihood="studentt", dof=16.0, outliers=True, perturb=0.02, grid=2),

@@ -69,6 +69,9 @@ for ni in (1, 2):
         CASES[f"image_layers{ni}_full_ev11_dm{dm}"] = _imgl(ni, dm, full=True)
     CASES[f"image_layers{ni}_dz0_out_dm15"] = _imgl(ni, 15, dxo=True)
     CASES[f"image_layers{ni}_dz0_out_dm8"] = _imgl(ni, 8, dxo=True, w=8)
+laue_il = _imgl(2, 15, dxo=True)
+laue_il["kw"] = dict(R=40, L=20, w=10, S=2, perturb=0.02, image_layers=2, n_images=17, laue=True, extra_meta=15)      # Laue data on 21 columns (round 6)
+CASES["image_layers2_dz0_out_laue_d21"] = laue_il
 
 
 def _run(case, N, engines, n_images=None, R=None, launches=1):
