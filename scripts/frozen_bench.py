@@ -17,6 +17,9 @@ ap.add_argument("--slot", action="store_true")
 a = ap.parse_args()
 model, inputs, data, spec = make_workload(a.workload)
 model.scaling_model.trainable = False
+if a.slot:
+    from careless_amd.engine import ElboEngine
+    ElboEngine.FROZEN_LAUE_PACKED = False              # (harmonic groups: round 5's three slot launches on plain rows)
 eng = model.engine(inputs)
 if a.slot:
     eng.FROZEN_SORTED_ROWS = False
@@ -43,5 +46,7 @@ torch.cuda.synchronize()
 dms = d0.elapsed_time(d1) / a.steps
 N, S, R = int(eng.obs.N) if hasattr(eng.obs, "N") else spec["N"], eng.S, eng.R
 alg = 28.0 * N + 8.0 * R * S          # rows once (refl, loc, sigma, image scale, iobs, sig, key) + z_f read and dz_f written once per (reflection, sample)
+if getattr(eng.obs, "fused_laue", False) or spec.get("kind") == "laue":
+    alg += (4.0 + 8.0 * S + 8.0) * N  # harmonic groups: gmeta, the per-row gradient written and read once, (refl, src) of the second pass
 print(json.dumps(dict(workload=a.workload, path="cl_slot_rows" if a.slot else "cl_frozen_rows", ms_per_step=ms, data_term_ms=dms, rows=N, S=S, R=R,
                       algorithmic_GB=alg / 1e9, data_term_TBps=alg / dms / 1e9, frac_of_8TBps=alg / dms / 1e9 / 8.0, loss_finite=bool(torch.isfinite(eng.grads).all()))))

@@ -9,12 +9,12 @@ mkdir -p gpurun_out/r6
 bash scripts/profiles_all.sh 2>&1 | tail -90
 timeout 1500 python3 bench.py > gpurun_out/r6/bench_default.json 2> gpurun_out/r6/bench_default.err; tail -c 900 gpurun_out/r6/bench_default.json
 : > gpurun_out/r6/frozen_step.jsonl
-for W in mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_5x64_S8 laue_5M_normal_5x64_S1 mono_10M_20x10_img2_S1 dw_10M_normal_20x10_S1; do
+for W in mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_5x64_S8 laue_5M_normal_5x64_S1 laue_5M_normal_20x10_S1 mono_10M_20x10_img2_S1 dw_10M_normal_20x10_S1; do
   timeout 600 python3 scripts/frozen_bench.py $W 2>/dev/null | tail -1 >> gpurun_out/r6/frozen_step.jsonl
   timeout 600 python3 scripts/frozen_bench.py $W --slot 2>/dev/null | tail -1 >> gpurun_out/r6/frozen_step.jsonl
 done
 cut -c1-230 gpurun_out/r6/frozen_step.jsonl
-for W in mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_5x64_S8; do
+for W in mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_5x64_S8 laue_5M_normal_5x64_S1; do
   rm -rf gpurun_out/fz_$W gpurun_out/fzC_$W gpurun_out/fzD_$W
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fz_$W -- python3 scripts/frozen_bench.py $W --steps 20 > gpurun_out/r6/fz_trace.log 2>&1
   f=$(ls gpurun_out/fz_$W/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f gpurun_out/r6/kernel_stats_frozen_$W.csv
@@ -27,7 +27,7 @@ for d in "CD":
     for f in glob.glob(f"gpurun_out/fz{d}_{W}/*/*counter_collection.csv"):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'frozen_rows' in r['Kernel_Name'] or 'frozen_edges' in r['Kernel_Name']:
+            if 'frozen_' in r['Kernel_Name']:
                 acc[(r['Kernel_Name'].split('(')[0], r['Counter_Name'])].append(float(r['Counter_Value']))
         for (k, c), v in sorted(acc.items()):
             print(d, k, c, "launches", len(v), "per launch", sum(v) / len(v))
@@ -36,7 +36,7 @@ PY
   cat gpurun_out/r6/pmc_frozen_$W.txt
   rm -rf gpurun_out/fz_$W gpurun_out/fzC_$W gpurun_out/fzD_$W
 done
-N=4000000 LS=2,5,8,10,12,16,19,20,24 WS=5,6,8,10 DS=5,12 SS=1,8 timeout 2400 python3 scripts/envelope.py 2>/dev/null > gpurun_out/r6/envelope.txt
-CARELESS_HIP_LANE_DEPTHS=0 CARELESS_HIP_CHAIN_LANE=0 N=4000000 LS=2,5,8,10,12,16,19,20,24 WS=5,6,8,10 DS=5,12 SS=1,8 timeout 2400 python3 scripts/envelope.py 2>/dev/null > gpurun_out/r6/envelope_before.txt
+N=4000000 LS=2,5,8,10,12,16,19,20,24,40 WS=5,6,8,10 DS=5,12,21 SS=1,8 timeout 2400 python3 scripts/envelope.py 2>/dev/null > gpurun_out/r6/envelope.txt
+CARELESS_HIP_LANE_DEPTHS=0 CARELESS_HIP_CHAIN_LANE=0 CARELESS_HIP_LANE_BLOCKS=0 N=4000000 LS=2,5,8,10,12,16,19,20,24,40 WS=5,6,8,10 DS=5,12,21 SS=1,8 timeout 2400 python3 scripts/envelope.py 2>/dev/null > gpurun_out/r6/envelope_before.txt
 paste -d'\n' gpurun_out/r6/envelope.txt gpurun_out/r6/envelope_before.txt | grep "S=1" | cut -c1-170 | head -40
 bash scripts/r6_rehearsal.sh 2>&1 | tail -12
