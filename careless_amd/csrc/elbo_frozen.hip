@@ -58,7 +58,7 @@ __global__ __launch_bounds__(FB) void frozen_rows_kernel(const cl_frozen_args A)
     // two dependent loads deep and a thread has ~20 chunks to walk
     // `src` given (harmonic groups, second pass): the row's amplitude gradients were made by frozen_laue_kernel and wait in gbuf[src]: this
     // launch only sums them per reflection
-    const bool gather = A.src != nullptr;
+    const bool gather = A.gbuf != nullptr;                 // (this kernel is only launched without gmeta: the second pass of harmonic groups)
     struct Row { int rid, rid_before, rid_after; float loc, sigma, io, sg, aim; long long key; };
     auto fetch = [&](long long c) -> Row {
         Row r;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(FB) void frozen_rows_kernel(const cl_frozen_args A)
         r.rid = A.refl_id[rc];
         if (gather) {
             r.loc = r.sigma = r.io = 0.0f; r.sg = r.aim = 1.0f;
-            r.key = (long long)A.src[rc];
+            r.key = A.src != nullptr ? (long long)A.src[rc] : rc;
         } else {
             r.loc = A.loc[rc]; r.sigma = A.sigma[rc]; r.io = A.iobs[rc]; r.sg = A.sig[rc];
             r.aim = A.aim != nullptr ? A.aim[rc] : 1.0f;
@@ -240,6 +240,9 @@ __global__ __launch_bounds__(FB) void frozen_laue_kernel(const cl_frozen_args A)
         const float loc = A.loc[rc], sigma = A.sigma[rc], io = A.iobs[rc], sg = A.sig[rc];
         const float aim = A.aim != nullptr ? A.aim[rc] : 1.0f;
         const long long key = A.key != nullptr ? (long long)A.key[rc] : A.obs_offset + row;
+        // where this row's gradients go in gbuf: its position in REFLECTION order when the caller gives one (src: the second pass then reads
+        // gbuf front to back -- a scattered 4 S-byte write per row here instead of a gathered 128-byte line per row there), else its own row
+        const long long gdst = !in ? -1 : (A.src != nullptr ? (long long)A.src[rc] : row);
         const int gm = act ? A.gmeta[rc] : (1 << 8);
         const int mem = gm & 0xff, cnt = gm >> 8;
         int gmax = cnt;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(FB) void frozen_laue_kernel(const cl_frozen_args A)
                         if (mem == 0) nll -= (double)ll * (double)A.w_ll;
                         gj = -dll * A.w_ll * aim * tq * 2.0f * zf;
                     }
-                    if (in) A.gbuf[(size_t)row * S + s] = gj;
+                    if (gdst >= 0) A.gbuf[(size_t)gdst * S + s] = gj;
                 }
             }
         }
@@ -371,7 +374,7 @@ int cl_launch_frozen_rows(const cl_frozen_args& a, hipStream_t st) {
     if (a.gmeta != nullptr) {
         // harmonic groups, first pass: per-row amplitude gradients into gbuf (no sums, no edges)
         if (a.n <= 0 || a.S <= 0 || a.refl_id == nullptr || a.loc == nullptr || a.sigma == nullptr || a.iobs == nullptr || a.sig == nullptr ||
-            a.z_f == nullptr || a.gbuf == nullptr || a.scalars == nullptr || a.src != nullptr)
+            a.z_f == nullptr || a.gbuf == nullptr || a.scalars == nullptr)
             return -1;
         if (a.n >= (1ll << 31) - 64) return -4;
         if (a.ev11 != nullptr && a.d_ev11 == nullptr && a.ev11_part == nullptr) return -1;
@@ -380,8 +383,8 @@ int cl_launch_frozen_rows(const cl_frozen_args& a, hipStream_t st) {
         else hipLaunchKernelGGL(frozen_laue_kernel<8>, dim3((unsigned)frozen_blocks<1>(frozen_laue_kernel<8>, a.n)), dim3(FB), 0, st, a);
         return (int)hipGetLastError();
     }
-    if (a.src != nullptr) {
-        // ... second pass: the gradients gathered in reflection order and summed (refl_id ascending, src = the row of gbuf)
+    if (a.gbuf != nullptr) {
+        // ... second pass: the gradients in reflection order summed per reflection (refl_id ascending; gbuf row i, or src[i] when given)
         if (a.n <= 0 || a.S <= 0 || a.refl_id == nullptr || a.gbuf == nullptr || a.dz_f == nullptr || a.edge_rid == nullptr || a.edge_val == nullptr) return -1;
     } else if (a.n <= 0 || a.S <= 0 || a.refl_id == nullptr || a.loc == nullptr || a.sigma == nullptr || a.iobs == nullptr || a.sig == nullptr ||
                a.z_f == nullptr || a.dz_f == nullptr || a.scalars == nullptr || a.edge_rid == nullptr || a.edge_val == nullptr)

@@ -935,12 +935,15 @@ class ElboEngine(WidePath):
             key = obs.noise_row if obs.noise_row is not None else (rmc + int(obs.start)).to(torch.int32).contiguous()
             active = torch.nonzero(valid & (obs.refl_id >= 0)).flatten()
             order = torch.argsort(obs.refl_id.index_select(0, active), stable=True)
-            src = active.index_select(0, order).to(torch.int32).contiguous()
-            refl_sorted = obs.refl_id.index_select(0, src.long()).to(torch.int32).contiguous()
+            src = active.index_select(0, order)
+            refl_sorted = obs.refl_id.index_select(0, src).to(torch.int32).contiguous()
             n2 = int(src.numel())
+            # the first pass writes a row's gradients at its position in reflection order (a 4 S-byte store per row), the second reads them front to back
+            dst = torch.full((obs.n_pad,), -1, dtype=torch.int32, device=dev)
+            dst[src] = torch.arange(n2, dtype=torch.int32, device=dev)
             fz = obs.frozen_sorted = dict(
-                epoch=self._frozen_epoch, loc=loc_p, sigma=sig_p, aim=aim, key=key, src=src, refl_sorted=refl_sorted, n2=n2,
-                gbuf=torch.zeros(obs.n_pad * self.S, dtype=torch.float32, device=dev),
+                epoch=self._frozen_epoch, loc=loc_p, sigma=sig_p, aim=aim, key=key, dst=dst, refl_sorted=refl_sorted, n2=n2,
+                gbuf=torch.zeros(max(n2, 1) * self.S, dtype=torch.float32, device=dev),
                 edge_rid=torch.empty(2 * ((n2 + 63) // 64) + 2, dtype=torch.int32, device=dev),
                 edge_val=torch.empty(max(int(self.lib.cl_frozen_edge_floats(n2, self.S)), 1), dtype=torch.float32, device=dev))
         row0 = getattr(obs, "row0", 0)
@@ -957,11 +960,11 @@ class ElboEngine(WidePath):
         fa.scalars, fa.stop_flag = ptr(self.scalars), ptr(self.stop_flag)
         fa.ipred_out = None if ipred_out is None else ipred_out.data_ptr() + 4 * self.S * row0
         fa.ev11, fa.d_ev11 = ma.ev11, ma.d_ev11
-        fa.gmeta, fa.gbuf = ptr(obs.gmeta), ptr(fz["gbuf"])
+        fa.gmeta, fa.gbuf, fa.src = ptr(obs.gmeta), ptr(fz["gbuf"]), ptr(fz["dst"])
         check(self.lib.cl_frozen_rows(C.byref(fa), st), "cl_frozen_rows (harmonic groups)")
         if fz["n2"] > 0:
             fb = FrozenArgs()
-            fb.refl_id, fb.src, fb.gbuf = ptr(fz["refl_sorted"]), ptr(fz["src"]), ptr(fz["gbuf"])
+            fb.refl_id, fb.gbuf = ptr(fz["refl_sorted"]), ptr(fz["gbuf"])
             fb.n, fb.R, fb.S = fz["n2"], self.R, self.S
             fb.dz_f, fb.stop_flag = ptr(self.dz_f), ptr(self.stop_flag)
             fb.accumulate = 1 if (getattr(obs, "is_piece", False) or self.double_wilson) else 0

@@ -430,9 +430,10 @@ typedef struct cl_frozen_args {
      * TWO calls, because the rows of a group belong to different reflections:
      *   1. gmeta != NULL: rows in the packed order of the single-pass kernels (a group inside a 16-row granule; gmeta[i] = member index |
      *      group size << 8; padding rows refl_id < 0; iobs / sig of the group replicated on its rows): group sums over shuffles, likelihood,
-     *      NLL (member 0), the row's amplitude gradient STORED at gbuf[i][s].  refl_id need not be sorted; dz_f / edge_* unused.
-     *   2. src != NULL: refl_id ascending over the same rows, src[i] = the row's index in gbuf: the gradients are gathered, summed per
-     *      reflection and stored into dz_f as for monochromatic rows (loc / sigma / iobs / sig / z_f / scalars unused).             */
+     *      NLL (member 0), the row's amplitude gradients STORED at gbuf[src ? src[i] : i][s] (src[i] < 0: nowhere) -- with src[i] = the row's
+     *      position in reflection order the second call reads gbuf front to back.  refl_id need not be sorted; dz_f / edge_* unused.
+     *   2. gmeta == NULL, gbuf != NULL: refl_id ascending over the rows that have a reflection; row i's gradients at gbuf[src ? src[i] : i]: summed
+     *      per reflection and stored into dz_f as for monochromatic rows (loc / sigma / iobs / sig / z_f / scalars unused).             */
     const int* gmeta;
     float* gbuf;                /* [rows][S]                                                                        */
     const int* src;

@@ -10,7 +10,6 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from careless_amd.workloads import WORKLOADS, bytes_per_obs  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 P = "profiles"
@@ -41,10 +40,9 @@ for f in sorted(os.listdir(P)):
                     top = row["Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
                     steps_traced = int(row["Calls"]) if "elbo_" in row["Name"] else steps_traced
         per_step = tot / steps_traced / 1e6
-    spec = WORKLOADS.get(wl, {})
     alg = None
     try:
-        alg = bytes_per_obs(spec) * spec["N"] / 1e9
+        alg = r["hbm_secondary"]["bytes_per_obs"] * r["obs_per_launch"] / 1e9        # 4 (d + 3) + 4 + 8 S bytes per observation
     except Exception:      # noqa: BLE001
         pass
     t = traffic.get(wl)
