@@ -469,8 +469,52 @@ def _random_lane_image_layer_cases(n=10, seed=23):
     return cases
 
 
+def _random_lane_depth_cases(n=16, seed=61):
+    """Seeded random draws over round 6's routes around the default scaler: widths 5 .. 10 at any depth 2 .. 40 (the lane kernel compiled per
+    depth, chains of lane blocks past 20 layers), 1 .. 40 metadata columns (past 15: the peeled first layer in front of the depth's dZ_0-storing
+    instance), mono / single-pass Laue / double-Wilson, any sample count, every likelihood / bijector / reduction switch."""
+    rng = np.random.default_rng(seed)
+    cases = {}
+    for i in range(n):
+        kind = str(rng.choice(["mono", "laue", "double_wilson"], p=[0.6, 0.25, 0.15]))
+        L = int(rng.choice([rng.integers(2, 20), rng.integers(21, 41)], p=[0.75, 0.25]))
+        kw = dict(N=int(rng.integers(40, 1500)), R=int(rng.integers(4, 70)), L=L, w=int(rng.integers(5, 11)), S=int(rng.integers(1, 13)),
+                  perturb=0.02 if L > 8 else 0.04)
+        if L > 20:
+            kw["perturb"] = 0.01
+        if kind == "laue":
+            kw["laue"] = True
+            kw["L"] = min(kw["L"], 20)
+            kw["N"] = max(kw["N"], 150)
+            if rng.random() < 0.4:
+                kw["extra_meta"] = int(rng.integers(1, 9))
+        else:
+            kw["d0"] = int(rng.integers(1, 41)) if rng.random() < 0.6 else 5
+        if kind == "double_wilson":
+            kw["double_wilson"] = True
+            kw["R"] = max(kw["R"], 8)
+            kw["R"] += kw["R"] % 2
+            kw["N"] = max(kw["N"], kw["R"])
+        if rng.random() < 0.5:
+            kw.update(likelihood="studentt", dof=float(rng.choice([3.0, 8.0, 32.0])))
+        if rng.random() < 0.25 and kind != "double_wilson":
+            kw["ev11"] = True
+        if rng.random() < 0.3:
+            kw.update(bijector="softplus", shift=float(rng.choice([0.0, 1.5])))
+        if rng.random() < 0.25:
+            kw["kl_weight"] = 0.5
+        if rng.random() < 0.25:
+            kw["use_image_scales"] = False
+        if rng.random() < 0.4:
+            kw["grid"] = int(rng.integers(1, 4))
+        kw["R"] = min(kw["R"], kw["N"])
+        cases[f"random_lane_depth_{i:02d}_{kind}_{kw['L']}x{kw['w']}_S{kw['S']}"] = kw
+    return cases
+
+
 # (a longer sweep on demand: ENGINE_RANDOM_N=150 ENGINE_RANDOM_SEED=3 python -m pytest tests/test_gpu_parity.py -k random_engine)
 RANDOM_ENGINE_CASES = _random_engine_cases(int(os.environ.get("ENGINE_RANDOM_N", "12")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")))
+RANDOM_ENGINE_CASES.update(_random_lane_depth_cases(int(os.environ.get("LANE_DEPTH_RANDOM_N", "16")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")) + 50))
 RANDOM_ENGINE_CASES.update(_random_lane_image_layer_cases(int(os.environ.get("LANE_IMGL_RANDOM_N", "10")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")) + 12))
 
 
