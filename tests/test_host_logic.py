@@ -334,3 +334,23 @@ def test_wide_path_envelope_queries():
     assert lib.cl_wide_dense_dgrad_head(None, 128, None, None, None, None, 100, 128, 128, None, 128, 0.01, None, 128, None, None) == -1
     assert lib.cl_wide_dense_wgrad_head(None, 128, None, None, None, 0.01, None, 128, 100, 128, 128, None, None, 1, None, None) == -1
     assert lib.cl_wide_dense_dgrad_pre_wgrad0(None, 128, None, 100, 128, 128, None, 8, 5, None, None, 0.01, None, None, None) == -1
+
+
+def test_round6_entry_points_host_side():
+    """`cl_frozen_rows` / `cl_chain_dx` (round 6): workspace queries and argument checks answer without a device."""
+    import ctypes as C
+    lib = _lib.get_lib()
+    # two edge records per 64-row wave, S floats each; at most CL_LAUE_LIK_MAX_BLOCKS workgroups of 256 rows
+    assert lib.cl_frozen_edge_floats(0, 3) == 0 and lib.cl_frozen_edge_floats(1, 3) == 6 and lib.cl_frozen_edge_floats(64, 1) == 2
+    assert lib.cl_frozen_edge_floats(65, 8) == 32 and lib.cl_frozen_edge_floats(10_000_000, 8) == 2 * 156250 * 8
+    assert lib.cl_frozen_grid(1) == 1 and lib.cl_frozen_grid(257) == 2 and lib.cl_frozen_grid(10_000_000) == _lib.CL_LAUE_LIK_MAX_BLOCKS
+    assert int(lib.cl_frozen_args_size()) == C.sizeof(_lib.FrozenArgs)
+    assert lib.cl_frozen_rows(None, None) == -1
+    fa = _lib.FrozenArgs()
+    fa.n, fa.S = 100, 2
+    assert lib.cl_frozen_rows(C.byref(fa), None) == -1                    # no buffers
+    fa.gmeta = 1                                                          # (harmonic groups, first call: still no buffers)
+    assert lib.cl_frozen_rows(C.byref(fa), None) == -1
+    assert lib.cl_chain_dx(None, None, 10, 128, 10, 10, None, None, None) == -1
+    assert lib.cl_chain_dx(1, 1, 10, 128, 16, 10, 1, None, None) == -2    # widths beyond 15
+    assert lib.cl_chain_dx(1, 1, 200, 128, 10, 10, 1, None, None) == -1   # n_pad < n_obs
