@@ -96,6 +96,32 @@ def test_frozen_rank_shards_sum_to_the_full_batch():
     assert util.rel_err(g.cpu().numpy(), full.grads.cpu().numpy()) < 2e-5
 
 
+def test_frozen_reflection_owner_shards_sum_to_the_full_batch():
+    """The reflection-owner split behind a frozen scaler: a rank's rows are not a contiguous range (the noise key is the global row number
+    the sorted-rows kernel carries per row), its reflections are its own."""
+    from careless_amd.engine import ElboEngine, make_shard
+    kw = dict(N=3000, R=60, d0=5, L=20, w=10, S=3, perturb=0.02)
+    full, _ = _engine(kw, True)
+    full.forward_backward(3)
+    torch.cuda.synchronize()
+    data, cfg, params, x, _, _ = util.make_problem(**kw)
+    g, nll = torch.zeros_like(full.grads), 0.0
+    for r in range(3):
+        model = util.build_model(data, cfg, params, kw["L"], kw["w"])
+        model.scaling_model.trainable = False
+        model.owner_shard = True
+        eng = ElboEngine(model, util.reference_inputs(data), seed=31, shard=make_shard(kw["N"], kw["R"], r, 3))
+        eng.local_only = True
+        assert eng.owner and eng.scaler_frozen
+        eng.forward_backward(3)
+        torch.cuda.synchronize()
+        assert getattr(eng.obs, "frozen_sorted", None) is not None
+        g += eng.grads
+        nll += eng.loss_terms()["nll"]
+    assert abs(nll - full.loss_terms()["nll"]) <= 1e-5 * abs(nll)
+    assert util.rel_err(g[: 2 * full.R].cpu().numpy(), full.grads[: 2 * full.R].cpu().numpy()) < 2e-5
+
+
 def test_frozen_trajectory_and_unfreezing():
     """Ten Adam steps with the scaler frozen: the same q(F) as with the short cut off; the "Grad Norm" of the history is the norm over
     the trainable tensors alone in both (reference variational.py:201-205); unfreezing afterwards lays the observations out for the
