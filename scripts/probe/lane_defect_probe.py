@@ -27,6 +27,11 @@ CONFIGS = {
     "peeled_dZ0_out": dict(R=40, d0=37, L=20, w=10, S=3, perturb=0.02),
     "image_layers2": dict(R=40, d0=5, L=20, w=10, S=2, perturb=0.02, image_layers=2, n_images=23),
     "cli_default": dict(R=40, d0=5, L=20, w=10, S=1, perturb=0.02),
+    # (the other fused kernels carried the same inline-assembly LeakyReLU until round 6: soak them as well)
+    "headline_5x64": dict(R=40, d0=5, posenc=True, L=5, w=64, S=8, likelihood="studentt", dof=16.0),
+    "narrow_12x12": dict(R=40, d0=5, L=12, w=12, S=2, perturb=0.03),
+    "depth10_10x10": dict(R=40, d0=5, L=10, w=10, S=1, perturb=0.03),
+    "chain_24x10": dict(R=40, d0=5, L=24, w=10, S=1, perturb=0.01),
 }
 
 
