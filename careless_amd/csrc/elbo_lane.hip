@@ -1150,6 +1150,15 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.w <= 6) return CASE(6); \
     if (a.w <= 8) return CASE(8); \
     return CASE(10);
+// ... with the metadata in registers also widths 11 and 12 (round 6: three output chunks like width 10, two more activation registers per
+// layer -- 22 .. 72 spilled registers at the default depth, none from 16 layers down; still ahead of elbo_narrow.hip: profiles/r6_envelope_w12.txt)
+#define CL_LANE_W12 12
+#define CL_LANE_WIDTHS_REG(CASE)   \
+    if (a.w <= 4) return CASE(4);  \
+    if (a.w <= 6) return CASE(6);  \
+    if (a.w <= 8) return CASE(8);  \
+    if (a.w <= 10) return CASE(10); \
+    return CASE(CL_LANE_W12);
 
 int cl_launch_lane_plain_reg(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_packed_reg(const cl_mlp_args& a, int grid, hipStream_t st);
@@ -1175,8 +1184,8 @@ static inline bool lane_has_depth(int L) {
 
 #if CL_LANE_PART == 0
 int cl_launch_lane_plain_reg(const cl_mlp_args& a, int grid, hipStream_t st) {
-#define CL_LANE_CASE(WW) (a.d <= 8 ? launch_lane_one<WW, 8, false>(a, grid, st) : launch_lane_one<WW, DMAX_ALL, false>(a, grid, st))
-    CL_LANE_WIDTHS(CL_LANE_CASE)
+#define CL_LANE_CASE(WW) (a.d <= 8 ? launch_lane_one<WW, 8, false>(a, grid, st) : (WW <= CL_LANE_WMAX ? launch_lane_one<(WW <= CL_LANE_WMAX ? WW : 4), DMAX_ALL, false>(a, grid, st) : -2))
+    CL_LANE_WIDTHS_REG(CL_LANE_CASE)
 #undef CL_LANE_CASE
 }
 
@@ -1191,7 +1200,10 @@ static size_t lane_rows_lds(int w, int d) {
 // are rows of an LDS buffer (LX); any number of MC samples (batches of SPRE).  4 M observations, 20 x 10, Student-T, ms per step
 // here / on elbo_narrow.hip (scripts/narrow_samples.py): S = 1 0.96 / 1.11, 2: 1.01 / 1.12, 4: 1.07 / 1.19, 8: 1.16 / 1.34.
 int cl_lane_supports(const cl_mlp_args& a) {
-    if (!(a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_LX && (a.L == NL || lane_has_depth(a.L)) && a.n_imgl == 0 && a.act_out == nullptr &&
+    // (CARELESS_HIP_LANE_W12=0: A/B runs of widths 11 and 12 against the narrow kernel they ran on until round 6)
+    static const bool w12_on = [] { const char* e = getenv("CARELESS_HIP_LANE_W12"); return !(e != nullptr && e[0] == '0'); }();
+    const int wtop = (w12_on && a.d <= DMAX_ALL) ? CL_LANE_W12 : CL_LANE_WMAX;
+    if (!(a.w >= 1 && a.w <= wtop && a.S >= 1 && a.d >= 1 && a.d <= DMAX_LX && (a.L == NL || lane_has_depth(a.L)) && a.n_imgl == 0 && a.act_out == nullptr &&
           a.dH_ext == nullptr && a.dX_out == nullptr && (a.row_map != nullptr || a.gmeta == nullptr)))
         return 0;
     // the other depths (round 6): instances at widths 8 and 10 (a narrower scaler pays the padded steps: from width CL_LANE_DEPTH_WMIN on it still
@@ -1199,6 +1211,9 @@ int cl_lane_supports(const cl_mlp_args& a) {
     // (CARELESS_HIP_LANE_DEPTHS=0: A/B runs against the narrow kernel these shapes ran on until round 5)
     static const bool depths_on = [] { const char* e = getenv("CARELESS_HIP_LANE_DEPTHS"); return !(e != nullptr && e[0] == '0'); }();
     if (a.L != NL) return depths_on && a.w >= CL_LANE_DEPTH_WMIN && a.d <= DMAX_ALL && (a.dZ0_out == nullptr || a.row_map == nullptr);
+    // widths 11, 12 at the default depth: 22 .. 72 spilled registers -- ahead of the narrow kernel on <= 8 columns (1.05 against 1.11 ms at
+    // 4 M observations), behind it on 9 .. 15 (1.17 against 1.12)
+    if (a.w > CL_LANE_WMAX) return a.d <= 8;
     return a.d <= DMAX_ALL || lane_rows_lds(a.w, a.d) <= 160 * 1024;
 }
 
@@ -1248,12 +1263,12 @@ int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st) {
 
 // name of the instance cl_launch_lane runs (cl_mlp_kernel_name)
 int cl_lane_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
-    const int W = a.w <= 4 ? 4 : (a.w <= 6 ? 6 : (a.w <= 8 ? 8 : 10));
-    const int DM = a.d <= 8 ? 8 : (a.d <= DMAX_ALL ? DMAX_ALL : 0);
+    const int W = a.w <= 4 ? 4 : (a.w <= 6 ? 6 : (a.w <= 8 ? 8 : (a.w <= 10 ? 10 : CL_LANE_W12)));
+    const int DM = (a.d <= 8 && a.L == NL) ? 8 : (a.d <= DMAX_ALL ? DMAX_ALL : 0);       // (the other depths: one metadata capacity)
     const bool packed = a.row_map != nullptr;
     const bool full = packed || lane_wants_full(a) || (DM == 0 && a.dZ0_out != nullptr);
     if (a.L != NL)
-        return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s, %s, 0, %d>%s", a.w <= 8 ? 8 : CL_LANE_WMAX, DM, packed ? "true" : "false", full ? "true" : "false",
+        return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s, %s, 0, %d>%s", a.w <= 8 ? 8 : (a.w <= 10 ? CL_LANE_WMAX : CL_LANE_W12), DM, packed ? "true" : "false", full ? "true" : "false",
                         (!full && a.dZ0_out != nullptr) ? "true" : "false", a.L, a.dzf_obs != nullptr ? " (deterministic stores)" : "");
     return snprintf(out, n, "elbo_lane_kernel<%d, %d, %s, %s%s>%s", W, DM, packed ? "true" : "false", full ? "true" : "false",
                     (!full && a.dZ0_out != nullptr) ? ", true" : "", a.dzf_obs != nullptr ? " (deterministic stores)" : "");
@@ -1292,8 +1307,8 @@ int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st) {
 }
 #elif CL_LANE_PART == 1
 int cl_launch_lane_packed_reg(const cl_mlp_args& a, int grid, hipStream_t st) {
-#define CL_LANE_CASE(WW) (a.d <= 8 ? launch_lane_one<WW, 8, true>(a, grid, st) : launch_lane_one<WW, DMAX_ALL, true>(a, grid, st))
-    CL_LANE_WIDTHS(CL_LANE_CASE)
+#define CL_LANE_CASE(WW) (a.d <= 8 ? launch_lane_one<WW, 8, true>(a, grid, st) : (WW <= CL_LANE_WMAX ? launch_lane_one<(WW <= CL_LANE_WMAX ? WW : 4), DMAX_ALL, true>(a, grid, st) : -2))
+    CL_LANE_WIDTHS_REG(CL_LANE_CASE)
 #undef CL_LANE_CASE
 }
 #elif CL_LANE_PART == 2
@@ -1303,29 +1318,29 @@ int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st) {
 #undef CL_LANE_CASE
 }
 #elif CL_LANE_PART == 7
-// another depth than the default (-DCL_LANE_NL=D): widths 8 and 10, metadata in registers -- plain layout (production / full) and packed
+// another depth than the default (-DCL_LANE_NL=D): widths 8, 10 and 12, metadata in registers -- plain layout (production / full) and packed
 #define CL_LANE_DEPTH_FN2(D) cl_launch_lane_depth##D
 #define CL_LANE_DEPTH_FN(D) CL_LANE_DEPTH_FN2(D)
+// (one metadata capacity -- 15 columns in registers -- for every depth below the default: the eight-column instances of the default depth buy
+//  back registers the shallower units do not miss, and would double the 19 units' compile time)
 template <int WW>
 static int launch_lane_depth_w(const cl_mlp_args& a, int grid, hipStream_t st) {
-    if (a.row_map != nullptr)
-        return a.d <= 8 ? launch_lane_inst<WW, 8, true, true>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, true, true>(a, grid, st);
-    if (lane_wants_full(a))
-        return a.d <= 8 ? launch_lane_inst<WW, 8, false, true>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, true>(a, grid, st);
+    if (a.row_map != nullptr) return launch_lane_inst<WW, DMAX_ALL, true, true>(a, grid, st);
+    if (lane_wants_full(a)) return launch_lane_inst<WW, DMAX_ALL, false, true>(a, grid, st);
     // behind a peeled first layer (more than 15 metadata columns: the engine hands over the layer's w pre-activations): dZ_0 out
-    if (a.dZ0_out != nullptr)
-        return a.d <= 8 ? launch_lane_inst<WW, 8, false, false, true>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, false, true>(a, grid, st);
-    return a.d <= 8 ? launch_lane_inst<WW, 8, false, false>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, false>(a, grid, st);
+    if (a.dZ0_out != nullptr) return launch_lane_inst<WW, DMAX_ALL, false, false, true>(a, grid, st);
+    return launch_lane_inst<WW, DMAX_ALL, false, false>(a, grid, st);
 }
 int CL_LANE_DEPTH_FN(CL_LANE_NL)(const cl_mlp_args& a, int grid, hipStream_t st) {
-    return a.w <= 8 ? launch_lane_depth_w<8>(a, grid, st) : launch_lane_depth_w<CL_LANE_WMAX>(a, grid, st);
+    return a.w <= 8 ? launch_lane_depth_w<8>(a, grid, st) : (a.w <= 10 ? launch_lane_depth_w<CL_LANE_WMAX>(a, grid, st) : launch_lane_depth_w<CL_LANE_W12>(a, grid, st));
 }
 #endif
 #if CL_LANE_PART == 7 || CL_LANE_PART == 8
 // the two launches of a head-less layer block of this depth (part 8: the default depth)
 template <int WW, int MODE>
 static int launch_lane_block_w(const cl_mlp_args& a, int grid, hipStream_t st) {
-    return a.d <= 8 ? launch_lane_inst<WW, 8, false, false, false, 0, MODE>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, false, false, 0, MODE>(a, grid, st);
+    if constexpr (NL == CL_MLP_LMAX_W16) return a.d <= 8 ? launch_lane_inst<WW, 8, false, false, false, 0, MODE>(a, grid, st) : launch_lane_inst<WW, DMAX_ALL, false, false, false, 0, MODE>(a, grid, st);
+    else return launch_lane_inst<WW, DMAX_ALL, false, false, false, 0, MODE>(a, grid, st);
 }
 #define CL_LANE_BLOCK_FN2(D) cl_launch_lane_block##D
 #define CL_LANE_BLOCK_FN(D) CL_LANE_BLOCK_FN2(D)

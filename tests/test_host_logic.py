@@ -298,13 +298,17 @@ def test_kernel_name_follows_the_librarys_routing():
     assert name(d=32, w=10, L=20, S=1).startswith("elbo_mlp_kernel<16, 32, 20, 0")
     assert name(d=5, w=13, L=12, S=8) == "elbo_narrow_kernel<2, 4, 8, false>"
     # other depths than the default at widths 7 .. 10 (round 6): the lane kernel compiled for that depth, widest instance
-    assert name(d=5, w=10, L=12, S=1) == "elbo_lane_kernel<10, 8, false, false, false, 0, 12>"
+    assert name(d=5, w=10, L=12, S=1) == "elbo_lane_kernel<10, 15, false, false, false, 0, 12>"
     assert name(d=12, w=7, L=2, S=3, eta=1) == "elbo_lane_kernel<8, 15, false, true, false, 0, 2>"
-    assert name(d=6, w=9, L=19, S=1, row_map=1) == "elbo_lane_kernel<10, 8, true, true, false, 0, 19>"
-    assert name(d=5, w=6, L=12, S=1) == "elbo_lane_kernel<8, 8, false, false, false, 0, 12>"
+    assert name(d=6, w=9, L=19, S=1, row_map=1) == "elbo_lane_kernel<10, 15, true, true, false, 0, 19>"
+    assert name(d=5, w=6, L=12, S=1) == "elbo_lane_kernel<8, 15, false, false, false, 0, 12>"
     assert name(d=5, w=4, L=12, S=1).startswith("elbo_narrow_kernel<")                 # narrower than 5: the narrow kernel's two-step instance
     assert name(d=21, w=10, L=12, S=1).startswith("elbo_mlp_kernel<16, 32, 20, 0")     # (more than 15 columns without the engine's peeled first layer)
     assert name(d=5, w=10, L=1, S=1).startswith("elbo_narrow_kernel<")
+    # widths 11 and 12 with the metadata in registers (round 6): the twelve-wide instances; on 16 .. 31 columns the next kernel down
+    assert name(d=5, w=12, L=20, S=1) == "elbo_lane_kernel<12, 8, false, false>"
+    assert name(d=12, w=11, L=14, S=2, row_map=1) == "elbo_lane_kernel<12, 15, true, true, false, 0, 14>"
+    assert name(d=21, w=12, L=20, S=1).startswith("elbo_mlp_kernel<16, 32, 20, 0")
     assert name(d=21, w=64, L=5, S=8) == "elbo_mlp_kernel<64, 32, 5, 0, KS=4>"
     assert name(d=21, w=64, L=5, S=8, mode=1) == "elbo_mlp_kernel<64, 32, 5, 1, KS=4>"
     assert name(d=5, w=10, L=20, S=1, act_out=1, mode=1).startswith("elbo_mlp_kernel<16, 8, 20, 1, chain")

@@ -60,7 +60,7 @@ for depth in (2, 5, 10, 16, 19):
         kw = dict(base["kw"], L=depth, w=10 if depth != 5 else 7)
         packed = "true" if "laue" in tag else "false"
         full = "false" if tag == "plain" else "true"
-        dm = 15 if tag == "plain_full_det" else 8
+        dm = 15                                     # (the per-depth units have one metadata capacity)
         CASES[f"depth{depth}_{tag}"] = dict(kw=kw, det=base["det"], name=f"elbo_lane_kernel<{10 if kw['w'] > 8 else 8}, {dm}, {packed}, {full}, false, 0, {depth}>" + (" (deterministic stores)" if base["det"] else ""))
     CASES[f"depth{depth}_dz0_out"] = dict(kw=dict(_plain(10, 15, dxo=True)["kw"], L=depth), det=False, name=f"elbo_lane_kernel<10, 15, false, false, true, 0, {depth}>")
 for ni in (1, 2):

@@ -15,12 +15,14 @@ TABLE = [
     (20, 10, 21, "elbo_lane_kernel<10, 0, false, false",          False, None, False),      # + two encoded keys: metadata as LDS rows
     (20, 10, 37, "elbo_lane_kernel<10, 15, false, false, true",   True,  None, False),      # + four encoded keys: peeled first layer
     (20, 8,  64, "elbo_lane_kernel<8, 8, false, false, true",     True,  None, False),
-    (20, 12, 5,  "elbo_narrow_kernel<2, 3, 8",                    False, None, False),
-    (10, 10, 5,  "elbo_lane_kernel<10, 8, false, false, false, 0, 10>",  False, None, False),   # other depths at widths 7 .. 10 (round 6): the lane kernel compiled for the depth
+    (20, 12, 5,  "elbo_lane_kernel<12, 8, false, false",          False, None, False),      # widths 11, 12 (round 6): the lane kernel's twelve-wide register instances
+    (20, 12, 12, "elbo_narrow_kernel<2, 3, 8",                    False, None, False),      # ... at the default depth only up to 8 columns (spilled registers beyond: the narrow kernel is ahead)
+    (20, 13, 5,  "elbo_narrow_kernel<2, 4, 8",                    False, None, False),
+    (10, 10, 5,  "elbo_lane_kernel<10, 15, false, false, false, 0, 10>",  False, None, False),   # other depths at widths 7 .. 10 (round 6): the lane kernel compiled for the depth
     (16, 8,  12, "elbo_lane_kernel<8, 15, false, false, false, 0, 16>",  False, None, False),
     (12, 4,  5,  "elbo_narrow_kernel<2, 2, 8",                    False, None, False),      # narrower than 5: the narrow kernel
     (10, 10, 21, "elbo_lane_kernel<10, 15, false, false, true, 0, 10>", True, None, False),  # other depths, more than 15 columns: peeled, the depth's dZ_0-storing lane instance (round 6)
-    (9,  12, 21, "elbo_narrow_kernel<2, 3, 8",                    True,  None, False),      # ... widths 11, 12: peeled, narrow kernel
+    (9,  12, 21, "elbo_lane_kernel<12, 15, false, false, true, 0, 9>", True, None, False),
     (7,  15, 5,  "elbo_narrow_kernel<2, 4, 8",                    False, None, False),
     (7,  15, 40, "elbo_mlp_kernel<16, 64, 20, 0, KS=4",           False, None, False),      # widths 13 .. 15 on many columns: the 16-wide instance itself
     (10, 16, 5,  "elbo_mlp_kernel<16, 8, 20, 0, KS=5",            False, None, False),      # width exactly 16: its own instance
