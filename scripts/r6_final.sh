@@ -36,7 +36,7 @@ PY
   cat gpurun_out/r6/pmc_frozen_$W.txt
   rm -rf gpurun_out/fz_$W gpurun_out/fzC_$W gpurun_out/fzD_$W
 done
-N=4000000 LS=2,5,8,10,12,16,19,20,24,40 WS=5,6,8,10 DS=5,12,21 SS=1,8 timeout 2400 python3 scripts/envelope.py 2>/dev/null > gpurun_out/r6/envelope.txt
-CARELESS_HIP_LANE_DEPTHS=0 CARELESS_HIP_CHAIN_LANE=0 CARELESS_HIP_LANE_BLOCKS=0 N=4000000 LS=2,5,8,10,12,16,19,20,24,40 WS=5,6,8,10 DS=5,12,21 SS=1,8 timeout 2400 python3 scripts/envelope.py 2>/dev/null > gpurun_out/r6/envelope_before.txt
+N=4000000 LS=2,5,8,10,12,16,19,20,24,40 WS=5,6,8,10,12 DS=5,12,21 SS=1,8 timeout 2400 python3 scripts/envelope.py 2>/dev/null > gpurun_out/r6/envelope.txt
+CARELESS_HIP_LANE_DEPTHS=0 CARELESS_HIP_CHAIN_LANE=0 CARELESS_HIP_LANE_BLOCKS=0 CARELESS_HIP_LANE_W12=0 N=4000000 LS=2,5,8,10,12,16,19,20,24,40 WS=5,6,8,10,12 DS=5,12,21 SS=1,8 timeout 2400 python3 scripts/envelope.py 2>/dev/null > gpurun_out/r6/envelope_before.txt
 paste -d'\n' gpurun_out/r6/envelope.txt gpurun_out/r6/envelope_before.txt | grep "S=1" | cut -c1-170 | head -40
 bash scripts/r6_rehearsal.sh 2>&1 | tail -12
