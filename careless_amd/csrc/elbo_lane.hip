@@ -1232,7 +1232,7 @@ int cl_lane_imgl_supports(const cl_mlp_args& a) {
 int cl_lane_block_supports(const cl_mlp_args& a, int mode) {
     static const bool on = [] { const char* e = getenv("CARELESS_HIP_LANE_BLOCKS"); return !(e != nullptr && e[0] == '0'); }();
     if (!on || !(mode == 1 || mode == 2)) return 0;
-    if (!(a.w >= CL_LANE_DEPTH_WMIN && a.w <= CL_LANE_WMAX && a.d >= 1 && a.d <= DMAX_ALL && (a.L == NL || lane_has_depth(a.L)) && a.n_imgl == 0 &&
+    if (!(a.w >= CL_LANE_DEPTH_WMIN && a.w <= (a.L == NL ? CL_LANE_WMAX : CL_LANE_W12) && a.d >= 1 && a.d <= DMAX_ALL && (a.L == NL || lane_has_depth(a.L)) && a.n_imgl == 0 &&
           a.row_map == nullptr && a.gmeta == nullptr && a.dX_out == nullptr && a.dO_ext == nullptr && a.dZ0_out == nullptr))
         return 0;
     if (mode == 1) return a.act_out != nullptr && a.dH_ext == nullptr && a.loc_out == nullptr && a.sig_out == nullptr;
@@ -1345,6 +1345,10 @@ static int launch_lane_block_w(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_BLOCK_FN2(D) cl_launch_lane_block##D
 #define CL_LANE_BLOCK_FN(D) CL_LANE_BLOCK_FN2(D)
 int CL_LANE_BLOCK_FN(CL_LANE_NL)(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
+    // (widths 11, 12: the per-depth units only -- at the default depth twelve activations per layer spill)
+    if constexpr (NL != CL_MLP_LMAX_W16) {
+        if (a.w > CL_LANE_WMAX) return mode == 1 ? launch_lane_block_w<CL_LANE_W12, 1>(a, grid, st) : launch_lane_block_w<CL_LANE_W12, 2>(a, grid, st);
+    } else if (a.w > CL_LANE_WMAX) return -2;
     if (mode == 1) return a.w <= 8 ? launch_lane_block_w<8, 1>(a, grid, st) : launch_lane_block_w<CL_LANE_WMAX, 1>(a, grid, st);
     return a.w <= 8 ? launch_lane_block_w<8, 2>(a, grid, st) : launch_lane_block_w<CL_LANE_WMAX, 2>(a, grid, st);
 }

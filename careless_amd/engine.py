@@ -252,9 +252,12 @@ class ElboEngine(WidePath):
             # width <= 10 (round 6): the LAST 20 layers and the head run on the lane-per-observation kernel -- the default scaler's own, with its
             # input = the activations of the block in front (w "metadata columns") and dZ_0 out; `cl_chain_dx` turns dZ_0 into the gradient
             # of those activations.  24 x 10 at 4 M observations: 3.13 -> 1.4 ms per step (two blocks of the 16-wide kernel before).
-            self.chain_lane = (self.w <= 10 and not self.laue and max_plain == 20 and os.environ.get("CARELESS_HIP_LANE", "1") != "0" and
-                               os.environ.get("CARELESS_HIP_CHAIN_LANE", "1") != "0")
-            self.blocks = chain_plan(self.d, self.w, self.L, max_plain, last=20 if self.chain_lane else 0)
+            # (widths 11, 12: the last NINETEEN layers -- the deepest twelve-wide instance without spilled registers -- and blocks of at most 19 in front)
+            self.chain_lane = (self.w <= 12 and not self.laue and max_plain == 20 and os.environ.get("CARELESS_HIP_LANE", "1") != "0" and
+                               os.environ.get("CARELESS_HIP_CHAIN_LANE", "1") != "0" and
+                               (self.w <= 10 or os.environ.get("CARELESS_HIP_LANE_W12", "1") != "0"))
+            last = (20 if self.w <= 10 else 19) if self.chain_lane else 0
+            self.blocks = chain_plan(self.d, self.w, self.L, max_plain if last != 19 else 19, last=last)
         # The careless default scaler (20 layers, hidden width <= 10) on more metadata columns than its lane-per-observation kernel holds
         # (31; four positionally encoded keys give 37): the first Dense layer is "peeled" -- its pre-activations come from
         # cl_peel_forward, the fused kernel runs the same scaler with an identity first layer on them (w "metadata columns": the shape it

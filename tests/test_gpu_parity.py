@@ -155,6 +155,8 @@ CASES = {
     "deep_24x10_d12_studentt_S3": dict(N=700, R=40, d0=12, L=24, w=10, S=3, likelihood="studentt", dof=6.0, perturb=0.02, grid=2),
     "deep_45x8_three_blocks": dict(N=500, R=40, d0=5, L=45, w=8, S=2, perturb=0.01),
     "deep_22x6_double_wilson": dict(N=600, R=40, d0=5, L=22, w=6, S=2, double_wilson=True, perturb=0.02),
+    "deep_26x12_d9_S2": dict(N=700, R=40, d0=9, L=26, w=12, S=2, perturb=0.01, grid=2),            # widths 11, 12: seven layers in front, nineteen on the twelve-wide lane instance
+    "deep_45x11_three_blocks": dict(N=400, R=30, d0=5, L=45, w=11, S=1, perturb=0.01),
     "deep_11x32_noimg": dict(N=400, R=40, d0=5, L=11, w=32, S=3, use_image_scales=False),
     "deep_laue_7x64": dict(N=500, R=50, L=7, w=64, S=2, laue=True, two_pass=True),
     "deep_double_wilson_6x64": dict(N=400, R=60, d0=5, L=6, w=64, S=2, double_wilson=True),
@@ -470,7 +472,7 @@ def _random_lane_image_layer_cases(n=10, seed=23):
 
 
 def _random_lane_depth_cases(n=16, seed=61):
-    """Seeded random draws over round 6's routes around the default scaler: widths 5 .. 10 at any depth 2 .. 40 (the lane kernel compiled per
+    """Seeded random draws over round 6's routes around the default scaler: widths 5 .. 12 at any depth 2 .. 40 (the lane kernel compiled per
     depth, chains of lane blocks past 20 layers), 1 .. 40 metadata columns (past 15: the peeled first layer in front of the depth's dZ_0-storing
     instance), mono / single-pass Laue / double-Wilson, any sample count, every likelihood / bijector / reduction switch."""
     rng = np.random.default_rng(seed)
@@ -478,7 +480,7 @@ def _random_lane_depth_cases(n=16, seed=61):
     for i in range(n):
         kind = str(rng.choice(["mono", "laue", "double_wilson"], p=[0.6, 0.25, 0.15]))
         L = int(rng.choice([rng.integers(2, 20), rng.integers(21, 41)], p=[0.75, 0.25]))
-        kw = dict(N=int(rng.integers(40, 1500)), R=int(rng.integers(4, 70)), L=L, w=int(rng.integers(5, 11)), S=int(rng.integers(1, 13)),
+        kw = dict(N=int(rng.integers(40, 1500)), R=int(rng.integers(4, 70)), L=L, w=int(rng.integers(5, 13)), S=int(rng.integers(1, 13)),
                   perturb=0.02 if L > 8 else 0.04)
         if L > 20:
             kw["perturb"] = 0.01

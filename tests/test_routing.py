@@ -31,7 +31,8 @@ TABLE = [
     (5,  64, 21, "elbo_mlp_kernel<64, 32, 5, 0",                  False, None, False),      # the bench line's kernel
     (24, 10, 5,  "elbo_lane_kernel<10, 15, false, false, true",   False, 2,    False),      # deeper than one launch at width <= 10 (round 6): the last 20 layers on the lane kernel (dZ_0 out), 4 in front on the 16-wide one
     (45, 8,  5,  "elbo_lane_kernel<8, 8, false, false, true",     False, 3,    False),
-    (24, 12, 5,  "elbo_mlp_kernel<16, 32, 20, 0, chain",          False, 2,    False),      # ... wider: two layer blocks of the 16-wide kernel (the last one's input is 12 wide)
+    (24, 12, 5,  "elbo_lane_kernel<12, 15, false, false, true, 0, 19>", False, 2, False),   # ... widths 11, 12: the last NINETEEN layers on the twelve-wide lane instance, five in front
+    (24, 14, 5,  "elbo_mlp_kernel<16, 32, 20, 0, chain",          False, 2,    False),      # ... wider: two layer blocks of the 16-wide kernel (the last one's input is 14 wide)
     (12, 64, 5,  "elbo_mlp_kernel<64, 64, 5, 0, chain",           False, 3,    False),
     (3,  128, 5, "wide_sq_kernel",                                False, None, True),       # layer by layer
 ]
