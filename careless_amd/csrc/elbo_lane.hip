@@ -1,7 +1,8 @@
-// Lane-per-observation instance of the fused ELBO step for narrow scalers (gfx950 / CDNA4 only): hidden width <= 10, metadata
-// width <= 31, exactly 20 Dense layers, any number of MC samples -- the geometry of the careless CLI default (--mlp-layers 20,
-// --mlp-width 10, --mc-samples 1: careless/args/scaling.py:21-31), also with the 16 extra metadata columns of
-// --positional-encoding-keys X,Y (careless/utils/positional_encoding.py:3-17); other depths and widths 11-15 run on elbo_narrow.hip.
+// Lane-per-observation instance of the fused ELBO step for narrow scalers (gfx950 / CDNA4 only): hidden width <= 10 (12 with the metadata
+// in registers), metadata width <= 31, any number of MC samples -- the geometry of the careless CLI default (--mlp-layers 20, --mlp-width 10,
+// --mc-samples 1: careless/args/scaling.py:21-31), also with the 16 extra metadata columns of --positional-encoding-keys X,Y
+// (careless/utils/positional_encoding.py:3-17).  The depth is a compile-time constant of the unit: the default build has 20 Dense layers,
+// build.py compiles the file again for every depth 2 .. 19 (round 6: -DCL_LANE_NL); widths 13 - 15 and one-layer scalers run on elbo_narrow.hip.
 //
 // Same arithmetic and the same reference lines as elbo_mlp.hip (scaler forward / sample / predict / likelihood / backward:
 // careless/models/scaling/nn.py:92-120, image.py:53-63, models/merging/variational.py:156-181, 197-202,
