@@ -15,7 +15,7 @@ lines = [l for l in table.split("\n") if l.startswith("|")]
 head, rows = lines[:2], {l.split("`")[1]: l for l in lines[2:]}
 ORDER = ["mono_1M_normal_5x64_S1", "mono_10M_studentt_posenc_5x64_S8", "laue_5M_normal_5x64_S1", "dw_50M_normal_5x64_S1", "mono_10M_cli_default_20x10_S1",
          "laue_5M_normal_20x10_S1", "dw_10M_normal_20x10_S1", "mono_10M_studentt_posenc_20x10_S8", "mono_10M_studentt_posenc4_20x10_S8", "mono_10M_10x10_S1",
-         "mono_10M_24x10_S1", "mono_10M_20x10_img2_S1", "laue_5M_normal_20x10_img2_S1", "mono_10M_studentt_posenc_20x10_img2_S8",
+         "mono_10M_24x10_S1", "mono_10M_20x10_img2_S1", "mono_10M_10x10_img2_S1", "laue_5M_normal_20x10_img2_S1", "mono_10M_studentt_posenc_20x10_img2_S8",
          "mono_10M_studentt_posenc_4x64_img1_S8", "mono_2M_studentt_3x128_S4"]
 NOTES = {"mono_1M_normal_5x64_S1": " (configs[1])", "mono_10M_studentt_posenc_5x64_S8": " (configs[2], **the bench line**)",
          "laue_5M_normal_5x64_S1": " (configs[3], 1 GPU, single pass)", "dw_50M_normal_5x64_S1": " (configs[4], 1 GPU)",
@@ -25,7 +25,9 @@ NOTES = {"mono_1M_normal_5x64_S1": " (configs[1])", "mono_10M_studentt_posenc_5x
          "mono_10M_studentt_posenc4_20x10_S8": " (d = 37: peeled first layer)",
          "mono_10M_studentt_posenc_20x10_img2_S8": " (d = 21: peeled first layer + the dZ₀-storing per-image-layer instance, **back in round 6**; round 5: 4.43 ms, 0.206)"}
 body = []
-for w in ORDER:
+for w in ORDER + sorted(set(rows) - set(ORDER)):
+    if w not in rows:
+        continue
     l = rows[w]
     if w in NOTES:
         l = l.replace(f"| `{w}` |", f"| `{w}`{NOTES[w]} |", 1)
