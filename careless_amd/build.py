@@ -36,6 +36,8 @@ UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=
          ("elbo_lane.hip", "elbo_lane4", ["-DCL_LANE_PART=4", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),      # per-image layers (round 5)
          # ... and the widest instances once more per depth below the default (round 6: `--mlp-layers 2 .. 19` at widths 7 .. 10; 16 - 25 s each)
          *[("elbo_lane.hip", f"elbo_lane_d{D}", ["-DCL_LANE_PART=7", f"-DCL_LANE_NL={D}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN) for D in range(2, 20)],
+         # ... and the per-image-layer instances per depth (`--mlp-layers D --image-layers 1|2`; 10 - 40 s each)
+         *[("elbo_lane.hip", f"elbo_lane_i{D}", ["-DCL_LANE_PART=9", f"-DCL_LANE_NL={D}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN) for D in range(2, 20)],
          ("elbo_lane.hip", "elbo_lane_b20", ["-DCL_LANE_PART=8", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),      # the layer-block launches (act_out / dH_ext) at the default depth
          ("elbo_elem.hip", "elbo_elem", []), ("elbo_laue.hip", "elbo_laue", []), ("wide_gemm.hip", "wide_gemm", []),
          ("elbo_peel.hip", "elbo_peel", []), ("elbo_frozen.hip", "elbo_frozen", []),

@@ -21,6 +21,7 @@ int cl_narrow_kernel_name(const cl_mlp_args& a, char* out, size_t n);
 int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n);     // elbo_mlp.hip: the routing of cl_launch_mlp, as a name
 int cl_lane_imgl_supports(const cl_mlp_args& a);                                    // ... with one or two per-image layers on top (round 5)
 int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st);
+int cl_lane_imgl_kernel_name(const cl_mlp_args& a, char* out, size_t n);
 int cl_lane_block_supports(const cl_mlp_args& a, int mode);                          // ... a head-less layer block's forward / backward launch (round 6)
 int cl_launch_lane_block(const cl_mlp_args& a, int mode, int grid, hipStream_t st);
 int cl_launch_lane(const cl_mlp_args& a, int grid, hipStream_t st);                 // ... the full ELBO step on that kernel

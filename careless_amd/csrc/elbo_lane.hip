@@ -1176,6 +1176,10 @@ CL_LANE_DEPTHS(CL_LANE_DEPTH_DECL)
 CL_LANE_DEPTHS(CL_LANE_BLOCK_DECL)
 CL_LANE_BLOCK_DECL(20)
 #undef CL_LANE_BLOCK_DECL
+// ... and the per-image-layer instances at every depth 2 .. 19 (round 6; CL_LANE_PART = 9, one compilation per depth)
+#define CL_LANE_IMGLD_DECL(D) int cl_launch_lane_imgl_depth##D(const cl_mlp_args& a, int grid, hipStream_t st);
+CL_LANE_DEPTHS(CL_LANE_IMGLD_DECL)
+#undef CL_LANE_IMGLD_DECL
 static inline bool lane_has_depth(int L) {
 #define CL_LANE_DEPTH_TEST(D) if (L == D) return true;
     CL_LANE_DEPTHS(CL_LANE_DEPTH_TEST)
@@ -1222,8 +1226,11 @@ int cl_lane_supports(const cl_mlp_args& a) {
 // w <= 10) on up to 15 metadata columns with one or two per-image layers (`careless mono | poly --image-layers 1|2`) in the packed-by-image
 // layout (Laue data: harmonic groups inside 16-row granules, single pass, as without per-image layers); everything else with per-image
 // layers stays on the IMGL instances of elbo_mlp.hip.
+// Round 6: the same at 2 .. 19 Dense layers (`--mlp-layers D --image-layers 1|2`: the instances of the per-depth units, width >= CL_LANE_DEPTH_WMIN).
 int cl_lane_imgl_supports(const cl_mlp_args& a) {
-    return a.n_imgl >= 1 && a.n_imgl <= CL_LANE_IMGL_MAX && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && a.L == NL &&
+    static const bool depths_on = [] { const char* e = getenv("CARELESS_HIP_LANE_DEPTHS"); return !(e != nullptr && e[0] == '0'); }();
+    const bool depth_ok = a.L == NL || (depths_on && lane_has_depth(a.L) && a.w >= CL_LANE_DEPTH_WMIN);
+    return a.n_imgl >= 1 && a.n_imgl <= CL_LANE_IMGL_MAX && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && depth_ok &&
            a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.dzf_obs == nullptr && a.row_map != nullptr &&
            (a.gmeta == nullptr || a.tile_gmax != nullptr) && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
 }
@@ -1259,7 +1266,18 @@ int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st) {
         return -4;
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
     if (grid < 1) return -1;
+#define CL_LANE_IMGLD_CALL(D) if (a.L == D) return cl_launch_lane_imgl_depth##D(a, grid, st);
+    CL_LANE_DEPTHS(CL_LANE_IMGLD_CALL)
+#undef CL_LANE_IMGLD_CALL
     return cl_launch_lane_imgl_inst(a, grid, st);
+}
+
+// name of the instance cl_launch_lane_imgl runs (cl_mlp_kernel_name)
+int cl_lane_imgl_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
+    const bool full = lane_wants_full(a);
+    const char* dxo = (!full && a.dZ0_out != nullptr) ? "true" : "false";
+    if (a.L != NL) return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d, %d> (image layers)", CL_LANE_WMAX, DMAX_ALL, full ? "true" : "false", dxo, a.n_imgl, a.L);
+    return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d> (image layers)", CL_LANE_WMAX, a.d <= 8 ? 8 : DMAX_ALL, full ? "true" : "false", dxo, a.n_imgl);
 }
 
 // name of the instance cl_launch_lane runs (cl_mlp_kernel_name)
@@ -1352,6 +1370,20 @@ int CL_LANE_BLOCK_FN(CL_LANE_NL)(const cl_mlp_args& a, int mode, int grid, hipSt
     } else if (a.w > CL_LANE_WMAX) return -2;
     if (mode == 1) return a.w <= 8 ? launch_lane_block_w<8, 1>(a, grid, st) : launch_lane_block_w<CL_LANE_WMAX, 1>(a, grid, st);
     return a.w <= 8 ? launch_lane_block_w<8, 2>(a, grid, st) : launch_lane_block_w<CL_LANE_WMAX, 2>(a, grid, st);
+}
+#endif
+#if CL_LANE_PART == 9
+// per-image layers on another depth than the default (-DCL_LANE_NL=D): the widest instance, one metadata capacity, as the Dense-only units
+#define CL_LANE_IMGLD_FN2(D) cl_launch_lane_imgl_depth##D
+#define CL_LANE_IMGLD_FN(D) CL_LANE_IMGLD_FN2(D)
+int CL_LANE_IMGLD_FN(CL_LANE_NL)(const cl_mlp_args& a, int grid, hipStream_t st) {
+    const bool full = lane_wants_full(a);
+#define CL_LANE_IMGL_CASE(NI_) (full ? launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, true, false, NI_>(a, grid, st) : \
+                                (a.dZ0_out != nullptr ? launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, false, true, NI_>(a, grid, st) : \
+                                                        launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, false, false, NI_>(a, grid, st)))
+    if (a.n_imgl == 1) return CL_LANE_IMGL_CASE(1);
+    return CL_LANE_IMGL_CASE(2);
+#undef CL_LANE_IMGL_CASE
 }
 #endif
 #if CL_LANE_PART == 4

@@ -1462,11 +1462,7 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     } else if (a.act_out != nullptr || a.dH_ext != nullptr || a.dX_out != nullptr) unit = ", chain";
     else if (a.n_imgl > 0) {
         if (mode == 0 && cl_lane_imgl_supports(a) && lane_enabled())
-        {
-            const bool full = a.eta != nullptr || a.ipred_out != nullptr || a.ev11 != nullptr;
-            return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d> (image layers)", 10, a.d <= 8 ? 8 : 15, full ? "true" : "false",
-                            (!full && a.dZ0_out != nullptr) ? "true" : "false", a.n_imgl);
-        }
+            return cl_lane_imgl_kernel_name(a, out, n);
         unit = ", image layers";
     } else if (a.row_map != nullptr) { unit = ", packed"; packed = true; }
     if (a.dzf_obs == nullptr && (unit[0] == 0 || packed)) {

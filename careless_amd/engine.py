@@ -273,7 +273,10 @@ class ElboEngine(WidePath):
         # ... and (round 5) the default scaler with one or two per-image layers on more than the 15 columns its lane instances hold
         # (`--image-layers 2 --positional-encoding-keys X,Y`: 21): the peeled layer's w pre-activations are the lane kernel's "metadata"
         # (round 6: Laue data too -- the per-image-layer instances are packed-layout kernels either way, and their dZ_0-storing form is back)
-        if (not self.wide and imgl is not None and lane_shape and imgl.n_image_layers <= 2 and self.d > 15 and self.d > self.w and
+        # (... and at 2 .. 19 Dense layers of width 5 .. 10: the per-depth units carry the per-image-layer instances as well)
+        lane_imgl_shape = lane_shape or (2 <= self.L < 20 and 5 <= self.w <= 10 and os.environ.get("CARELESS_HIP_LANE", "1") != "0" and
+                                         os.environ.get("CARELESS_HIP_LANE_DEPTHS", "1") != "0")
+        if (not self.wide and imgl is not None and lane_imgl_shape and imgl.n_image_layers <= 2 and self.d > 15 and self.d > self.w and
                 bool(self.lib.cl_peel_supported(self.d, self.w, self.L))):
             self.peel = True
         if imgl is not None:

@@ -23,6 +23,7 @@ NOTES = {"mono_1M_normal_5x64_S1": " (configs[1])", "mono_10M_studentt_posenc_5x
          "mono_10M_10x10_S1": " (**round 6**: the lane kernel compiled for depth 10; round 5, narrow kernel: 1.65 ms, 0.23)",
          "mono_10M_24x10_S1": " (**round 6**: a chain of two lane blocks + `cl_chain_dx`; round 5, two blocks of the 16-wide kernel: 7.72 ms)",
          "mono_10M_studentt_posenc4_20x10_S8": " (d = 37: peeled first layer)",
+         "mono_10M_10x10_img2_S1": " (**round 6**: the per-image-layer instance of the depth-10 unit; the 16-wide `IMGL` instance before: 3.98 ms, 0.114)",
          "mono_10M_studentt_posenc_20x10_img2_S8": " (d = 21: peeled first layer + the dZ₀-storing per-image-layer instance, **back in round 6**; round 5: 4.43 ms, 0.206)"}
 body = []
 for w in ORDER + sorted(set(rows) - set(ORDER)):

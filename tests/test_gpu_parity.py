@@ -134,6 +134,14 @@ CASES = {
     "lane_laue_image_layers1_20x10": dict(N=900, R=60, L=20, w=10, S=1, laue=True, n_images=6, image_layers=1, perturb=0.03),
     "lane_laue_image_layers2_20x6_S3_studentt": dict(N=700, R=50, L=20, w=6, S=3, laue=True, n_images=4, image_layers=2, likelihood="studentt", dof=8.0,
                                                      perturb=0.03),
+    # ... at other depths (round 6: the per-depth units' per-image-layer instances)
+    "lane_image_layers2_10x10": dict(N=1500, R=60, d0=5, L=10, w=10, S=2, n_images=9, image_layers=2, perturb=0.03),
+    "lane_image_layers1_2x10_S3": dict(N=900, R=50, d0=5, L=2, w=10, S=3, n_images=6, image_layers=1, perturb=0.04),
+    "lane_image_layers2_2x6_d12": dict(N=900, R=50, d0=12, L=2, w=6, S=2, n_images=6, image_layers=2, perturb=0.04),
+    "lane_image_layers2_19x9_ev11_studentt": dict(N=1200, R=60, d0=7, L=19, w=9, S=2, n_images=7, image_layers=2, ev11=True, likelihood="studentt", dof=8.0, perturb=0.02),
+    "lane_image_layers2_12x10_posenc_d21_peeled": dict(N=1500, R=60, d0=5, posenc=True, L=12, w=10, S=2, n_images=8, image_layers=2, perturb=0.03),
+    "lane_laue_image_layers2_8x10_S3": dict(N=900, R=60, L=8, w=10, S=3, laue=True, n_images=6, image_layers=2, perturb=0.03),
+    "lane_laue_image_layers1_15x7_peeled_d21": dict(N=900, R=40, L=15, w=7, S=2, laue=True, image_layers=1, n_images=7, extra_meta=15, perturb=0.02),
     "lane_image_layers2_20x10_rows_in_arbitrary_order": dict(N=1200, R=60, d0=5, L=20, w=10, S=2, n_images=11, image_layers=2, shuffle_rows=True,
                                                              perturb=0.03),
     "laue_image_layers1_2x32": dict(N=600, R=60, L=2, w=32, S=3, laue=True, n_images=4, image_layers=1),
@@ -439,7 +447,7 @@ def _random_engine_cases(n=12, seed=11):
     return cases
 
 
-def _random_lane_image_layer_cases(n=10, seed=23):
+def _random_lane_image_layer_cases(n=10, seed=23, depths=False):
     """Seeded random draws over what the lane kernel's per-image-layer instances take (round 5: 20 Dense layers, width 1 .. 10, 1 .. 15 metadata
     columns, one or two per-image layers, mono and single-pass Laue, any sample count, every likelihood / bijector / reduction switch)."""
     rng = np.random.default_rng(seed)
@@ -448,12 +456,14 @@ def _random_lane_image_layer_cases(n=10, seed=23):
         laue = rng.random() < 0.3
         kw = dict(N=int(rng.integers(60, 2500)), R=int(rng.integers(4, 90)), L=20, w=int(rng.integers(1, 11)), S=int(rng.integers(1, 13)),
                   image_layers=int(rng.integers(1, 3)), n_images=int(rng.integers(2, 30)), perturb=0.03)
+        if depths:                      # (round 6: 2 .. 19 Dense layers at widths 5 .. 10, more than 15 columns behind a peeled first layer)
+            kw.update(L=int(rng.integers(2, 20)), w=int(rng.integers(5, 11)))
         if laue:
             kw["laue"] = True
             kw["N"] = max(kw["N"], 150)
             kw["n_images"] = min(kw["n_images"], 8)
         else:
-            kw["d0"] = int(rng.integers(1, 16))
+            kw["d0"] = int(rng.integers(1, 16)) if not depths or rng.random() < 0.7 else int(rng.integers(16, 41))
             if rng.random() < 0.3:
                 kw["shuffle_rows"] = True
         if rng.random() < 0.5:
@@ -467,7 +477,7 @@ def _random_lane_image_layer_cases(n=10, seed=23):
         if rng.random() < 0.4:
             kw["grid"] = int(rng.integers(1, 4))
         kw["R"] = min(kw["R"], kw["N"])
-        cases[f"random_lane_imgl_{i:02d}_{'laue' if laue else 'mono'}_20x{kw['w']}_K{kw['image_layers']}_S{kw['S']}"] = kw
+        cases[f"random_lane_imgl_{'depth_' if depths else ''}{i:02d}_{'laue' if laue else 'mono'}_{kw['L']}x{kw['w']}_K{kw['image_layers']}_S{kw['S']}"] = kw
     return cases
 
 
@@ -518,6 +528,7 @@ def _random_lane_depth_cases(n=16, seed=61):
 RANDOM_ENGINE_CASES = _random_engine_cases(int(os.environ.get("ENGINE_RANDOM_N", "12")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")))
 RANDOM_ENGINE_CASES.update(_random_lane_depth_cases(int(os.environ.get("LANE_DEPTH_RANDOM_N", "16")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")) + 50))
 RANDOM_ENGINE_CASES.update(_random_lane_image_layer_cases(int(os.environ.get("LANE_IMGL_RANDOM_N", "10")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")) + 12))
+RANDOM_ENGINE_CASES.update(_random_lane_image_layer_cases(int(os.environ.get("LANE_IMGL_DEPTH_RANDOM_N", "12")), int(os.environ.get("ENGINE_RANDOM_SEED", "11")) + 31, depths=True))
 
 
 @pytest.mark.parametrize("name", list(RANDOM_ENGINE_CASES))

@@ -309,6 +309,14 @@ def test_kernel_name_follows_the_librarys_routing():
     assert name(d=5, w=12, L=20, S=1) == "elbo_lane_kernel<12, 8, false, false>"
     assert name(d=12, w=11, L=14, S=2, row_map=1) == "elbo_lane_kernel<12, 15, true, true, false, 0, 14>"
     assert name(d=21, w=12, L=20, S=1).startswith("elbo_mlp_kernel<16, 32, 20, 0")
+    # per-image layers (packed by image): the lane kernel's instances at the default depth and (round 6) at 2 .. 19 layers of width 5 .. 10
+    imgl = dict(n_imgl=2, row_map=1, imgl=1, d_imgl=1, tile_img=1, n_images=7, use_img=0)
+    assert name(d=5, w=10, L=20, S=2, **imgl) == "elbo_lane_kernel<10, 8, true, false, false, 2> (image layers)"
+    assert name(d=10, w=10, L=20, S=2, dZ0_out=1, **imgl) == "elbo_lane_kernel<10, 15, true, false, true, 2> (image layers)"
+    assert name(d=5, w=10, L=10, S=2, **imgl) == "elbo_lane_kernel<10, 15, true, false, false, 2, 10> (image layers)"
+    assert name(d=7, w=7, L=3, S=1, ev11=1, **dict(imgl, n_imgl=1)) == "elbo_lane_kernel<10, 15, true, true, false, 1, 3> (image layers)"
+    assert name(d=5, w=4, L=10, S=2, **imgl).startswith("elbo_mlp_kernel<16, 8, 24, 0, image layers")
+    assert name(d=5, w=10, L=20, S=2, **dict(imgl, n_imgl=3)).startswith("elbo_mlp_kernel<16, 8, 24, 0, image layers")
     assert name(d=21, w=64, L=5, S=8) == "elbo_mlp_kernel<64, 32, 5, 0, KS=4>"
     assert name(d=21, w=64, L=5, S=8, mode=1) == "elbo_mlp_kernel<64, 32, 5, 1, KS=4>"
     assert name(d=5, w=10, L=20, S=1, act_out=1, mode=1).startswith("elbo_mlp_kernel<16, 8, 20, 1, chain")

@@ -69,6 +69,13 @@ for ni in (1, 2):
         CASES[f"image_layers{ni}_full_ev11_dm{dm}"] = _imgl(ni, dm, full=True)
     CASES[f"image_layers{ni}_dz0_out_dm15"] = _imgl(ni, 15, dxo=True)
     CASES[f"image_layers{ni}_dz0_out_dm8"] = _imgl(ni, 8, dxo=True, w=8)
+# ... and the per-image-layer instances of the per-depth units (round 6)
+for depth in (2, 10, 19):
+    for ni in (1, 2):
+        for tag, base in (("", _imgl(ni, 15)), ("_full_ev11", _imgl(ni, 15, full=True)), ("_dz0_out", _imgl(ni, 15, dxo=True))):
+            full, dxo = ("true" if tag == "_full_ev11" else "false"), ("true" if tag == "_dz0_out" else "false")
+            CASES[f"depth{depth}_image_layers{ni}{tag}"] = dict(kw=dict(base["kw"], L=depth), det=False,
+                                                               name=f"elbo_lane_kernel<10, 15, true, {full}, {dxo}, {ni}, {depth}> (image layers)")
 laue_il = _imgl(2, 15, dxo=True)
 laue_il["kw"] = dict(R=40, L=20, w=10, S=2, perturb=0.02, image_layers=2, n_images=17, laue=True, extra_meta=15)      # Laue data on 21 columns (round 6)
 CASES["image_layers2_dz0_out_laue_d21"] = laue_il

@@ -49,3 +49,35 @@ def test_training_step_runs_on_the_kernel_the_design_names(L, w, d, frag, peel, 
     assert (eng.blocks is None) == (blocks is None) and (blocks is None or len(eng.blocks) == blocks)
     eng.alloc_history(1)
     eng.train_step(0)                                           # ... and the step it names runs
+
+
+#              L   w   d   K  laue   kernel-name fragment                                                  peel
+IMGL_TABLE = [
+    (20, 10, 5,  2, False, "elbo_lane_kernel<10, 8, true, false, false, 2> (image layers)",        False),   # `--image-layers 2` on the CLI default
+    (20, 10, 21, 2, False, "elbo_lane_kernel<10, 15, true, false, true, 2> (image layers)",        True),    # ... + two encoded keys: peeled, dZ_0 out
+    (10, 10, 5,  2, False, "elbo_lane_kernel<10, 15, true, false, false, 2, 10> (image layers)",   False),   # other depths (round 6): the depth's per-image-layer instance
+    (14, 7,  12, 1, False, "elbo_lane_kernel<10, 15, true, false, false, 1, 14> (image layers)",   False),
+    (6,  10, 21, 1, False, "elbo_lane_kernel<10, 15, true, false, true, 1, 6> (image layers)",     True),
+    (12, 8,  0,  2, True,  "elbo_lane_kernel<10, 15, true, false, false, 2, 12> (image layers)",   False),   # single-pass Laue
+    (10, 4,  5,  2, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),   # narrower than 5 at another depth: the 16-wide IMGL instance
+    (20, 10, 5,  3, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),   # three per-image layers: the same
+]
+
+
+@pytest.mark.parametrize("L,w,d,K,laue,frag,peel", IMGL_TABLE, ids=[f"{r[0]}x{r[1]}_d{r[2]}_K{r[3]}{'_laue' if r[4] else ''}" for r in IMGL_TABLE])
+def test_per_image_layers_run_on_the_kernel_the_design_names(L, w, d, K, laue, frag, peel):
+    """`--image-layers K` (careless/args/scaling.py:33-37) at the default and at other depths"""
+    from careless_amd.engine import ElboEngine
+    kw = dict(N=600, R=30, L=L, w=w, S=1, perturb=0.02, image_layers=K, n_images=5)
+    if laue:
+        kw.update(laue=True)
+    else:
+        kw.update(d0=d)
+    data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+    eng = ElboEngine(util.build_model(data, cfg, params, L, w), util.reference_inputs(data), seed=1)
+    name = eng.kernel_name()
+    assert frag in name, name
+    assert bool(eng.peel) == peel
+    eng.alloc_history(1)
+    eng.train_step(0)
+
