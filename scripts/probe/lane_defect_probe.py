@@ -32,6 +32,7 @@ CONFIGS = {
     "narrow_12x12": dict(R=40, d0=5, L=12, w=12, S=2, perturb=0.03),
     "depth10_10x10": dict(R=40, d0=5, L=10, w=10, S=1, perturb=0.03),
     "chain_24x10": dict(R=40, d0=5, L=24, w=10, S=1, perturb=0.01),
+    "image_layers2_depth10": dict(R=40, d0=5, L=10, w=10, S=2, perturb=0.03, image_layers=2, n_images=23),
 }
 
 

@@ -3,9 +3,9 @@
 # profiles/traffic.json and profiles/INDEX.md, print DESIGN section 6's table.   bash scripts/r6_store.sh
 set -e
 bash scripts/store_profiles.sh r6 | tail -1
-keep=$(sed -n '/^Randomized sweep/,$p' profiles/r6_gpu_suite.txt 2>/dev/null || true)
+
 cp gpurun_out/r6/gpu_suite.txt profiles/r6_gpu_suite.txt
-[ -n "$keep" ] && printf "\n%s\n" "$keep" >> profiles/r6_gpu_suite.txt
+
 cp gpurun_out/r6_rehearsal_gloo.txt profiles/r6_rehearsal_gloo.txt
 cp gpurun_out/r6/envelope.txt profiles/r6_envelope.txt
 cp gpurun_out/r6/envelope_before.txt profiles/r6_envelope_before.txt
