@@ -43,7 +43,7 @@ resolution(s) — `profiles/r6_gpu_suite.txt`).  Every row: the bench line of `p
 (`profiles/r6_bench_W.json`), the `rocprofv3 --kernel-trace --stats` summary of the same command run again (`profiles/r6_kernel_stats_W.csv`; in
 brackets: the scaler's kernels summed per step), the PMC passes — separate `--pmc` runs, `profiles/r6_pmc_W.txt` → `profiles/traffic.json`.
 Fractions live event-timed on the dominant kernel(s), on step time in brackets.  `profiles/INDEX.md` lists the files row by row; the table is
-`python scripts/design_table.py r6`.  (Every call gets another box of the pool: the same kernel reads 0.725–0.729 on the bench line across
+`python scripts/design_table.py r6`.  (Every call gets another box of the pool: the same kernel reads 0.725–0.732 on the bench line across
 the round's calls.)
 
 ''' + "\n".join(head + body) + "\n\n"
