@@ -412,9 +412,31 @@ void elbo_lane_kernel(const cl_mlp_args A) {
     };
     // wave tiles of this wave: strided over all waves of the launch, or (NI) one contiguous range so that image changes are rare
     const int gwv = (int)blockIdx.x * NWV + wv;
-    const int wt_begin = NI > 0 ? (int)((long long)gwv * n_wt / wt_step) : gwv;
-    const int wt_end = NI > 0 ? (int)((long long)(gwv + 1) * n_wt / wt_step) : n_wt;
+    int wt_begin = NI > 0 ? (int)((long long)gwv * n_wt / wt_step) : gwv;
+    int wt_end = NI > 0 ? (int)((long long)(gwv + 1) * n_wt / wt_step) : n_wt;
     const int wt_inc = NI > 0 ? 1 : wt_step;
+    if constexpr (NI > 0 && FULL) {
+        // Deterministic mode (round 6): both borders of the range move up to the next image border (tile_img ascends: obs.pack_by_image /
+        // pack_laue), so that ONE wave holds all tiles of an image and its per-image gradient leaves as one addition per element onto the
+        // cleared buffer -- no order for the float atomics to depend on.  (The same function of the even split on both sides: the ranges
+        // still partition the tiles.)
+        if (det) {
+            auto img_of = [&](int t) { return uniform(A.tile_img[(t * WT) / CL_MLP_TILE]); };
+            auto align = [&](int t) -> int {
+                if (t <= 0 || t >= n_wt) return t < n_wt ? t : n_wt;
+                const int prev = img_of(t - 1);
+                if (img_of(t) != prev) return t;
+                int lo = t, hi = n_wt;               // first wave tile past t whose image is not `prev`
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (img_of(mid) != prev) hi = mid; else lo = mid + 1;
+                }
+                return lo;
+            };
+            wt_begin = align(wt_begin);
+            wt_end = align(wt_end);
+        }
+    }
     if (wt_begin < wt_end) prefetch(wt_begin, 0);
 
     // ---- per-image layers: this wave's gradient flush and weight reload on an image change ------------------------------------------
@@ -1231,7 +1253,7 @@ int cl_lane_imgl_supports(const cl_mlp_args& a) {
     static const bool depths_on = [] { const char* e = getenv("CARELESS_HIP_LANE_DEPTHS"); return !(e != nullptr && e[0] == '0'); }();
     const bool depth_ok = a.L == NL || (depths_on && lane_has_depth(a.L) && a.w >= CL_LANE_DEPTH_WMIN);
     return a.n_imgl >= 1 && a.n_imgl <= CL_LANE_IMGL_MAX && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && depth_ok &&
-           a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.dzf_obs == nullptr && a.row_map != nullptr &&
+           a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.row_map != nullptr &&
            (a.gmeta == nullptr || a.tile_gmax != nullptr) && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
 }
 
@@ -1266,6 +1288,11 @@ int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st) {
         return -4;
     if ((a.eta != nullptr || a.ipred_out != nullptr) && 4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
     if (grid < 1) return -1;
+    if (a.dzf_obs != nullptr) {          // deterministic mode (round 6), as cl_launch_lane; the per-image gradients: one wave per image (elbo_lane_kernel)
+        if (a.ev11 != nullptr && a.ev11_part == nullptr) return -2;
+        if (a.nll_part == nullptr) return -1;
+        if (4ull * (unsigned long long)a.n_pad * (unsigned long long)a.S >= (1ull << 32)) return -4;
+    }
 #define CL_LANE_IMGLD_CALL(D) if (a.L == D) return cl_launch_lane_imgl_depth##D(a, grid, st);
     CL_LANE_DEPTHS(CL_LANE_IMGLD_CALL)
 #undef CL_LANE_IMGLD_CALL
@@ -1276,8 +1303,9 @@ int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st) {
 int cl_lane_imgl_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
     const bool full = lane_wants_full(a);
     const char* dxo = (!full && a.dZ0_out != nullptr) ? "true" : "false";
-    if (a.L != NL) return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d, %d> (image layers)", CL_LANE_WMAX, DMAX_ALL, full ? "true" : "false", dxo, a.n_imgl, a.L);
-    return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d> (image layers)", CL_LANE_WMAX, a.d <= 8 ? 8 : DMAX_ALL, full ? "true" : "false", dxo, a.n_imgl);
+    const char* det = a.dzf_obs != nullptr ? " (deterministic stores)" : "";
+    if (a.L != NL) return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d, %d> (image layers)%s", CL_LANE_WMAX, DMAX_ALL, full ? "true" : "false", dxo, a.n_imgl, a.L, det);
+    return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d> (image layers)%s", CL_LANE_WMAX, a.d <= 8 ? 8 : DMAX_ALL, full ? "true" : "false", dxo, a.n_imgl, det);
 }
 
 // name of the instance cl_launch_lane runs (cl_mlp_kernel_name)

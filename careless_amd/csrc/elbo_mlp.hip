@@ -1407,6 +1407,8 @@ int cl_launch_mlp(const cl_mlp_args& a, int mode, int grid, hipStream_t st) {
         // deterministic mode: the default scaler's shapes keep their own kernels (round 4: elbo_lane.hip / elbo_narrow.hip store per
         // observation when dzf_obs is given), every other width <= 64 runs the deterministic compilation of this file.  (The forward-only
         // and backward-only launches of a layer-block chain have no float atomics: they take the chain unit below.)
+        // per-image layers (round 6): the lane kernel's instances only (one wave per image); the IMGL instances of this file keep their float atomics
+        if (a.n_imgl > 0) return lane_imgl_route ? cl_launch_lane_imgl(a, grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid, st) : -2;
         if (mode == 0 && a.dX_out != nullptr) return cl_launch_mlp_chain_det(a, mode, grid, st);       // the chain's last block: the one with the epilogue
         if (mode == 0 && (a.ev11 == nullptr || a.ev11_part != nullptr) && a.n_pad > 0 && a.n_pad % CL_TILE == 0 && grid >= 1) {
             const int g = grid > a.n_pad / CL_TILE ? a.n_pad / CL_TILE : grid;
@@ -1456,6 +1458,7 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     const char* unit = "";
     bool packed = false;
     if (a.dzf_obs != nullptr && (mode == 0 || (a.act_out == nullptr && a.dH_ext == nullptr))) {
+        if (a.n_imgl > 0) return (mode == 0 && cl_lane_imgl_supports(a) && lane_enabled()) ? cl_lane_imgl_kernel_name(a, out, n) : snprintf(out, n, "(unsupported)");
         if (mode == 0 && (a.ev11 == nullptr || a.ev11_part != nullptr) && cl_lane_supports(a) && lane_enabled()) return cl_lane_kernel_name(a, out, n);
         if (mode == 0 && (a.ev11 == nullptr || a.ev11_part != nullptr) && cl_narrow_supports(a) && narrow_enabled()) return cl_narrow_kernel_name(a, out, n);
         unit = (mode == 0 && a.dX_out != nullptr) ? ", chain deterministic" : ((a.row_map != nullptr && a.n_imgl == 0) ? ", packed deterministic" : ", deterministic");

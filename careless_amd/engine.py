@@ -292,12 +292,18 @@ class ElboEngine(WidePath):
         # (wide scalers: monochromatic rows only -- they are their own slots and one kernel holds every float atomic of the path --, with a
         #  sample count that divides 64, so that a row's samples sit inside one wave)
         wide_det_ok = self.wide and not self.laue and 64 % int(model.mc_sample_size) == 0
-        if self.deterministic and (two_pass or (self.wide and not wide_det_ok) or imgl is not None or
+        # (per-image layers, round 6: where the step runs the lane kernel's per-image-layer instances -- one or two of them on 2 .. 20 Dense
+        #  layers of width <= 10, up to 15 columns or behind the peeled first layer -- one wave holds all tiles of an image in this mode)
+        imgl_det_ok = (imgl is not None and not self.wide and imgl.n_image_layers <= 2 and lane_imgl_shape and (self.d <= 15 or self.peel) and
+                       os.environ.get("CARELESS_HIP_LANE", "1") != "0")
+        if self.deterministic and (two_pass or (self.wide and not wide_det_ok) or (imgl is not None and not imgl_det_ok) or
                                    (self.blocks is not None and self.laue) or (self.double_wilson and prior.r_raw is not None)):
             raise NotImplementedError("deterministic mode covers monochromatic and single-pass Laue data, the Wilson and the double-Wilson prior "
                                       "(fixed r), Normal / Student-T likelihoods with or without the Evans-2011 error model, scalers of any depth up to "
-                                      "width 64 and, for monochromatic data with a sample count that divides 64, scalers wider than 64; the two-pass "
-                                      "Laue path (also under a chained scaler), a trainable double-Wilson r and per-image layers keep their float atomics")
+                                      "width 64, one or two per-image layers on 2 .. 20 Dense layers of width 5 .. 10 (the default scaler's kernels) and, "
+                                      "for monochromatic data with a sample count that divides 64, scalers wider than 64; the two-pass "
+                                      "Laue path (also under a chained scaler), a trainable double-Wilson r and every other shape with per-image layers "
+                                      "keep their float atomics")
         if self.deterministic and self.double_wilson:
             # parents pull their children's terms in list order instead of children scattering with atomics (cl_dw_prior_forward)
             par = np.asarray(prior.reflids).astype(np.int64)
@@ -447,9 +453,9 @@ class ElboEngine(WidePath):
         orders (by reflection, by image; stable, so sums run in row order) that `cl_det_reduce` walks."""
         dev = self.device
         if pieces[0].row_map is not None:
-            # packed layout (single-pass Laue): the kernels store by the caller's local row (row_map), so the ids go back to that order
+            # packed layout (single-pass Laue; per-image layers, round 6): the kernels store by the caller's local row (row_map), so the ids go back to that order
             p0 = pieces[0]
-            if not p0.fused_laue:
+            if self.laue and not p0.fused_laue:
                 raise NotImplementedError("deterministic mode: harmonic groups of more than 16 rows take the two-pass Laue path, which keeps its float atomics")
             rm = p0.row_map.cpu().numpy()
             ok = rm >= 0

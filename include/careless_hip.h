@@ -188,7 +188,10 @@ typedef struct cl_mlp_args {
      * not).  With dzf_obs non-NULL cl_elbo_mono_fwd_bwd (plain layout, width <= 64, no Evans-2011 terms) issues NO atomic: the
      * amplitude gradient of every (observation, sample) is STORED in dzf_obs, the image-scale gradient of every observation in
      * dimg_obs, every workgroup's NLL in nll_part; cl_det_reduce then sums them per reflection / per image / per launch in a fixed
-     * order.  Two runs on the same inputs give bit-identical gradients.                                                        */
+     * order.  Two runs on the same inputs give bit-identical gradients.  Per-image layers (n_imgl > 0; round 6): only where the launch
+     * runs the lane kernel's instances (cl_mlp_kernel_name says "elbo_lane_kernel<...> (image layers)": n_imgl <= 2 on 2 .. 20 Dense layers
+     * of width <= 10) -- one wave then holds all tiles of an image, its gradient is ONE addition per element onto the cleared d_imgl;
+     * every other shape with per-image layers returns -2 in this mode.                                                          */
     float* dzf_obs;             /* [n_obs][S]                                                                          */
     float* dimg_obs;            /* [n_obs]                                                                             */
     double* nll_part;           /* [grid]                                                                              */

@@ -540,6 +540,17 @@ def test_random_engine_configurations(name):
     _assert_grads(g_hip, grads, prob, name)
 
 
+def test_deterministic_mode_refuses_per_image_layers_off_the_lane_kernel():
+    """the IMGL instances of elbo_mlp.hip keep their float atomics: the mode raises instead of running with them"""
+    from careless_amd.engine import ElboEngine
+    for kw in (dict(N=500, R=40, d0=5, L=2, w=32, S=2, n_images=5, image_layers=1), dict(N=500, R=40, d0=5, L=20, w=10, S=2, n_images=5, image_layers=3)):
+        data, cfg, params, x, u_f, eta = util.make_problem(**kw)
+        model = util.build_model(data, cfg, params, kw["L"], kw["w"])
+        model.deterministic = True
+        with pytest.raises(NotImplementedError):
+            ElboEngine(model, util.reference_inputs(data), seed=1)
+
+
 def test_refl_gather_is_bit_exact():
     """ipred = z_scale * z_f[refl_id]^2: with loc=1, sigma~0 and no image scales, ipred/1 must equal z_f[refl_id]^2 exactly."""
     kw = dict(N=300, R=40, d0=5, L=2, w=32, S=2, use_image_scales=False, perturb=0.0)
@@ -1334,11 +1345,19 @@ def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
                                 dict(N=900, R=50, d0=5, L=2, w=80, S=4, ev11=True),
                                 # a peeled first layer (round 5): its weight gradient sums per-workgroup partials in index order
                                 dict(N=1100, R=50, d0=41, L=20, w=10, S=3, likelihood="studentt", dof=8.0, perturb=0.02, n_images=6),
-                                dict(N=900, R=50, d0=5, L=12, w=16, S=3, perturb=0.02)],
+                                dict(N=900, R=50, d0=5, L=12, w=16, S=3, perturb=0.02),
+                                # per-image layers on the lane kernel's instances (round 6): one wave holds all tiles of an image
+                                dict(N=1200, R=50, d0=5, L=20, w=10, S=2, n_images=7, image_layers=2, perturb=0.03),
+                                dict(N=1000, R=50, d0=7, L=10, w=9, S=3, n_images=6, image_layers=1, ev11=True, perturb=0.03, likelihood="studentt", dof=8.0),
+                                dict(N=1300, R=50, d0=5, posenc=True, L=20, w=10, S=2, n_images=8, image_layers=2, perturb=0.03),
+                                dict(N=900, R=60, L=20, w=10, S=2, laue=True, n_images=6, image_layers=1, perturb=0.03),
+                                dict(N=2600, R=60, d0=5, L=6, w=10, S=9, n_images=3, image_layers=2, perturb=0.03, shuffle_rows=True)],
                          ids=["mono_5x64", "cli_default_20x10", "rows_in_arbitrary_order_S8", "no_image_scales_klweight",
                               "lane_posenc_d21_S8", "lane_20x8_S11", "narrow_6x10_S5", "narrow_9x13_d12", "laue_lane_20x10_S3", "laue_narrow_4x12", "laue_5x64_S3", "laue_3x32_d20_S9",
                               "double_wilson_5x64", "double_wilson_lane_20x10", "wide_3x128_S4", "wide_2x96_noimg", "deep_12x64_S3", "deep_25x10",
-                              "ev11_5x64", "ev11_lane_20x10", "ev11_narrow_6x10_S5", "ev11_laue_3x32", "ev11_wide_2x80_S4", "peel_20x10_d41_S3", "w16_12x16_S3"])
+                              "ev11_5x64", "ev11_lane_20x10", "ev11_narrow_6x10_S5", "ev11_laue_3x32", "ev11_wide_2x80_S4", "peel_20x10_d41_S3", "w16_12x16_S3",
+                              "image_layers2_lane_20x10", "image_layers1_lane_10x9_ev11", "image_layers2_lane_peeled_d21", "laue_image_layers1_lane_20x10",
+                              "image_layers2_lane_6x10_S9_three_large_images"])
 def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypatch):
     """`model.deterministic = True` (or CARELESS_HIP_DETERMINISTIC=1): the fused kernel stores per-observation contributions instead of
     issuing float atomics and `cl_det_reduce` sums them in row order (include/careless_hip.h).  Same parity bar against the oracle,
@@ -1373,7 +1392,7 @@ def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypat
     _assert_grads([g.cpu().numpy() for g in eng.grad_tensors()], grads, (data, cfg, params, u_f, eta), "deterministic")
     runs = []
     for cut in (False, False, True):
-        if cut and (kw.get("laue") or w > 64):
+        if cut and (kw.get("laue") or w > 64 or kw.get("image_layers")):
             break                                   # (packed layouts and the layer-by-layer path are not cut into launches)
         if cut:
             d = np.asarray(data["metadata"]).shape[1]

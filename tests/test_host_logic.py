@@ -317,6 +317,10 @@ def test_kernel_name_follows_the_librarys_routing():
     assert name(d=7, w=7, L=3, S=1, ev11=1, **dict(imgl, n_imgl=1)) == "elbo_lane_kernel<10, 15, true, true, false, 1, 3> (image layers)"
     assert name(d=5, w=4, L=10, S=2, **imgl).startswith("elbo_mlp_kernel<16, 8, 24, 0, image layers")
     assert name(d=5, w=10, L=20, S=2, **dict(imgl, n_imgl=3)).startswith("elbo_mlp_kernel<16, 8, 24, 0, image layers")
+    # ... in deterministic mode (round 6): the lane instances only
+    assert name(d=5, w=10, L=20, S=2, dzf_obs=1, **imgl) == "elbo_lane_kernel<10, 8, true, true, false, 2> (image layers) (deterministic stores)"
+    assert name(d=5, w=10, L=7, S=2, dzf_obs=1, **imgl) == "elbo_lane_kernel<10, 15, true, true, false, 2, 7> (image layers) (deterministic stores)"
+    assert name(d=5, w=32, L=2, S=2, dzf_obs=1, **imgl) == "(unsupported)"
     assert name(d=21, w=64, L=5, S=8) == "elbo_mlp_kernel<64, 32, 5, 0, KS=4>"
     assert name(d=21, w=64, L=5, S=8, mode=1) == "elbo_mlp_kernel<64, 32, 5, 1, KS=4>"
     assert name(d=5, w=10, L=20, S=1, act_out=1, mode=1).startswith("elbo_mlp_kernel<16, 8, 20, 1, chain")

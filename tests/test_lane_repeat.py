@@ -76,6 +76,12 @@ for depth in (2, 10, 19):
             full, dxo = ("true" if tag == "_full_ev11" else "false"), ("true" if tag == "_dz0_out" else "false")
             CASES[f"depth{depth}_image_layers{ni}{tag}"] = dict(kw=dict(base["kw"], L=depth), det=False,
                                                                name=f"elbo_lane_kernel<10, 15, true, {full}, {dxo}, {ni}, {depth}> (image layers)")
+# ... and in deterministic mode (round 6: one wave per image; the whole flat gradient bit for bit)
+for key_, depth, ni, dm in (("det_image_layers2_dm8", 20, 2, 8), ("det_image_layers1_dm15", 20, 1, 15), ("det_depth10_image_layers2", 10, 2, 15)):
+    base = _imgl(ni, dm)
+    suffix = f", {depth}>" if depth != 20 else ">"
+    CASES[key_] = dict(kw=dict(base["kw"], L=depth), det=True,
+                       name=f"elbo_lane_kernel<10, {dm if depth == 20 else 15}, true, true, false, {ni}{suffix} (image layers) (deterministic stores)")
 laue_il = _imgl(2, 15, dxo=True)
 laue_il["kw"] = dict(R=40, L=20, w=10, S=2, perturb=0.02, image_layers=2, n_images=17, laue=True, extra_meta=15)      # Laue data on 21 columns (round 6)
 CASES["image_layers2_dz0_out_laue_d21"] = laue_il
