@@ -243,7 +243,9 @@ def test_deterministic_command_line_runs_write_identical_files(tmp_path, monkeyp
     assert np.array_equal(ha["NLL"], hb["NLL"])
     # ... and `--refine-uncertainties` on the default scaler's depth and on a scaler wider than 64 (round 4: the Evans-2011 gradients
     # leave the kernels as per-wave stores; the layer-by-layer path's slot kernel stores per (row, sample))
-    for tag, extra in (("ev11", "--refine-uncertainties --mlp-layers 20 --mc-samples 2"), ("wide", "--mlp-layers 2 --mlp-width 72 --mc-samples 4")):
+    # ... and `--image-layers 2` on the default scaler and on a shallower one (round 6: the lane kernel's per-image-layer instances, one wave per image)
+    for tag, extra in (("ev11", "--refine-uncertainties --mlp-layers 20 --mc-samples 2"), ("wide", "--mlp-layers 2 --mlp-width 72 --mc-samples 4"),
+                       ("imgl", "--image-layers 2 --mc-samples 2"), ("imgl_depth", "--image-layers 1 --mlp-layers 6 --mc-samples 3 --studentt-likelihood-dof 8")):
         flags = f"mono --iterations={niter} --disable-progress-bar {extra} dHKL,image_id"
         outs = []
         for k in range(2):
