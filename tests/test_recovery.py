@@ -34,13 +34,20 @@ def _problem(kind, N):
 
 
 @pytest.mark.parametrize("kind,N,L,w", [("mono", 1_000_000, 5, 64), ("laue", 200_000, 5, 64), ("double_wilson", 200_000, 5, 64),
-                                        ("mono", 300_000, 20, 10), ("mono_posenc4", 300_000, 20, 10), ("mono", 300_000, 10, 16)],
+                                        ("mono", 300_000, 20, 10), ("mono_posenc4", 300_000, 20, 10), ("mono", 300_000, 10, 16),
+                                        # round 6's routes: the lane kernel compiled for another depth, a chain of lane blocks, per-image layers
+                                        # at the default and at another depth, Laue data on the default scaler
+                                        ("mono", 300_000, 10, 10), ("mono", 300_000, 24, 10), ("mono_img2", 300_000, 20, 10), ("mono_img2", 300_000, 8, 10),
+                                        ("laue", 200_000, 20, 10)],
                          ids=["mono_1M_normal_5x64_S1", "laue_200k_5x64", "double_wilson_200k_5x64", "mono_300k_cli_default_20x10",
-                              "mono_300k_four_encoded_keys_20x10_peeled", "mono_300k_10x16"])
+                              "mono_300k_four_encoded_keys_20x10_peeled", "mono_300k_10x16", "mono_300k_10x10", "mono_300k_24x10_lane_chain",
+                              "mono_300k_20x10_image_layers2", "mono_300k_8x10_image_layers2", "laue_200k_cli_default_20x10"])
 def test_training_recovers_the_true_amplitudes_and_half_datasets_agree(kind, N, L, w):
     from careless_amd.manager import DataManager, default_args, merge_half_datasets
     steps = 1500
-    d, inputs, extra, dw = _problem(kind, N)
+    d, inputs, extra, dw = _problem(kind.replace("_img2", ""), N)
+    if kind.endswith("_img2"):
+        extra = dict(extra, image_layers=2)                     # `--image-layers 2` (careless/args/scaling.py:33-37)
     args = default_args(mlp_layers=L, mlp_width=w, iterations=steps, learning_rate=0.01, **extra)
     np.random.seed(args.seed)                                   # reference parser.py:22-23 (the half-dataset split draws from it)
     dm = DataManager(inputs, d["centric"], d["multiplicity"], parser=args, double_wilson=dw)
