@@ -65,11 +65,11 @@ with open(f"{P}/INDEX.md", "w") as out:
               f"`{tag}_profiles_summary.txt` = the call's own one-line-per-workload summary; `{tag}_sources.txt` = the hash.\n\n")
     extra = [
         (f"{tag}_bench_default_run.json", "the default `python bench.py` run (with the CPU baseline; `traffic_from.stale` false) — DESIGN §6"),
-        (f"{tag}_gpu_suite.txt", "`pytest -m gpu` of the same call, with the count of LeakyReLU branch-flip resolutions"),
+        (f"{tag}_gpu_suite.txt", "`pytest -m gpu` of the same call, with the count of LeakyReLU branch-flip resolutions; below it the randomized sweeps of the second call (600 draws on two more seeds)"),
         (f"{tag}_lane_defect.txt", "the run-to-run defect: hazard probe on the hardware + A/B of the withdrawn instance's variants — DESIGN §4.14, NOTEBOOK R6.1"),
         (f"{tag}_ab_lrelu.txt", "round 5's library against round 6's (LeakyReLU as a compiler-known v_max_f32), alternating — DESIGN §4.14"),
         (f"{tag}_lane_repeat.txt", "tests/test_lane_repeat.py on the hardware (first run of the round)"),
-        (f"{tag}_soak.txt", "60 launches at 10 M observations of three lane instances (CLI default, dZ0-storing, per-image layers + dZ0) against the first"),
+        (f"{tag}_soak.txt", "60 launches at 10 M observations of eight kernel instances (CLI default, dZ0-storing, per-image layers + dZ0, another depth, a lane-block chain, per-image layers at another depth, the headline kernel, 12 x 12) against the first; second call on the same sources (scripts/r6_final_b.sh)"),
         (f"{tag}_frozen_step.txt", "the frozen-scaler step, `cl_frozen_rows` against round 5's slot kernels — DESIGN §5.1b"),
         (f"{tag}_kernel_stats_frozen_*.csv / {tag}_pmc_frozen_*.txt", "kernel trace and PMC traffic of the frozen step"),
         (f"{tag}_envelope.txt / {tag}_envelope_before.txt", "depth × width × columns × samples around the default scaler, with the per-depth lane units and lane-block chains on / off — DESIGN §4.4d, §4.6"),
