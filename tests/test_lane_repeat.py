@@ -4,7 +4,8 @@ Round 5 shipped a guard over ten instances at 5 000 rows, because two instances 
 nothing in the source to explain it.  Round 6 named the cause (an inline-assembly v_max_f32 one wait state in front of an MFMA reading
 its result: gfx950 wants two, hipcc pads only pairs it knows -- NOTEBOOK R6.1), removed it at the source and holds the code objects to
 the rule without a GPU (tests/test_lane_isa.py).  This is the run-time half: every (width, metadata, layout, optional-input, dZ_0,
-per-image-layer) instance `cl_mlp_kernel_name` can name at the default depth, and a sample of the instances compiled for other depths, eight runs on identical inputs --
+per-image-layer) instance `cl_mlp_kernel_name` can name at the default depth, and a sample of the instances compiled for other depths
+(Dense-only and per-image-layer units, deterministic-mode per-image-layer instances), eight runs on identical inputs --
 
   * the scaler's gradient is BIT-identical (its partials are summed in index order in every mode: any operand read early shows here);
   * where the deterministic mode exists (no float atomics at all) the whole flat gradient and the NLL are bit-identical;
