@@ -34,6 +34,8 @@ UNITS = [("cl_api.hip", "cl_api", []), ("elbo_mlp.hip", "elbo_mlp", ["-DCL_IMGL=
          ("elbo_lane.hip", "elbo_lane2", ["-DCL_LANE_PART=2", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),
          ("elbo_lane.hip", "elbo_lane3", ["-DCL_LANE_PART=3", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),
          ("elbo_lane.hip", "elbo_lane4", ["-DCL_LANE_PART=4", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN),      # per-image layers (round 5)
+         # three per-image layers on the default depth: WITHOUT the option above (its AGPR-copy rewrite pass crashes on the 23-layer instances)
+         ("elbo_lane.hip", "elbo_lane5", ["-DCL_LANE_PART=5"] + NNAN),
          # ... and the widest instances once more per depth below the default (round 6: `--mlp-layers 2 .. 19` at widths 7 .. 10; 16 - 25 s each)
          *[("elbo_lane.hip", f"elbo_lane_d{D}", ["-DCL_LANE_PART=7", f"-DCL_LANE_NL={D}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + NNAN) for D in range(2, 20)],
          # ... and the per-image-layer instances per depth (`--mlp-layers D --image-layers 1|2`; 10 - 40 s each)
@@ -123,7 +125,7 @@ def _build(LIB: str, extra, verbose: bool) -> str:
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17"] + list(extra) + flags + ["-c", os.path.join(CSRC, s), "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            while sum(1 for _, p in procs if p.poll() is None) >= jobs:      # (38 units: not all compilers at once on a small box)
+            while sum(1 for _, p in procs if p.poll() is None) >= jobs:      # (63 units: not all compilers at once on a small box)
                 time.sleep(0.2)
             procs.append((cmd, subprocess.Popen(cmd)))
             objs.append(o)

@@ -80,6 +80,12 @@ __device__ __forceinline__ f32x4 mfma_bk(float a, float b, f32x4 c) { return __b
 // wait states between them; the only other reader is the flush, a barrier later.)
 // Diagnostic switches of round 6 (scripts/probe/build_lane_variants.py; NOTEBOOK R6.1): CL_LANE_MFMA_BUILTIN / CL_LANE_SEL_C replace one
 // kind of inline-assembly statement by code the compiler knows, CL_LANE_LRELU_ASM brings the inline-assembly LeakyReLU back; CL_LANE_PAD_PRE / CL_LANE_PAD_POST pad the MFMA statement.
+// (The unit of the three-per-image-layer instances -- CL_LANE_PART 5, compiled WITHOUT -amdgpu-mfma-vgpr-form: see there -- spills accumulator
+//  registers, and the compiler's reload copies land one instruction in front of the statement whose MFMA reads them: two wait states in front of
+//  every such MFMA, in that unit only.)
+#if !defined(CL_LANE_PAD_PRE) && defined(CL_LANE_PART) && CL_LANE_PART == 5
+#define CL_LANE_PAD_PRE "s_nop 1\n\t"
+#endif
 #ifndef CL_LANE_PAD_PRE
 #define CL_LANE_PAD_PRE ""
 #endif
@@ -1162,7 +1168,8 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #ifndef CL_LANE_WMAX
 #define CL_LANE_WMAX 10
 #endif
-#define CL_LANE_IMGL_MAX 2          /* per-image layers of the lane instances */
+#define CL_LANE_IMGL_MAX 2          /* per-image layers of the lane instances ... */
+#define CL_LANE_IMGL_MAX_NL 3       /* ... at the default depth: a third one in a unit of its own (CL_LANE_PART = 5) */
 #ifndef CL_LANE_DEPTH_WMIN
 #define CL_LANE_DEPTH_WMIN 5        /* narrowest scaler the other-depth instances (compiled at widths 8 and 10) take */
 #endif
@@ -1188,6 +1195,7 @@ int cl_launch_lane_packed_reg(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_plain_rows(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_packed_rows(const cl_mlp_args& a, int grid, hipStream_t st);
 int cl_launch_lane_imgl_inst(const cl_mlp_args& a, int grid, hipStream_t st);
+int cl_launch_lane_imgl3(const cl_mlp_args& a, int grid, hipStream_t st);
 // other depths than the default (round 6): one compilation per depth, CL_LANE_PART = 7
 #define CL_LANE_DEPTHS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19)
 #define CL_LANE_DEPTH_DECL(D) int cl_launch_lane_depth##D(const cl_mlp_args& a, int grid, hipStream_t st);
@@ -1252,7 +1260,7 @@ int cl_lane_supports(const cl_mlp_args& a) {
 int cl_lane_imgl_supports(const cl_mlp_args& a) {
     static const bool depths_on = [] { const char* e = getenv("CARELESS_HIP_LANE_DEPTHS"); return !(e != nullptr && e[0] == '0'); }();
     const bool depth_ok = a.L == NL || (depths_on && lane_has_depth(a.L) && a.w >= CL_LANE_DEPTH_WMIN);
-    return a.n_imgl >= 1 && a.n_imgl <= CL_LANE_IMGL_MAX && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && depth_ok &&
+    return a.n_imgl >= 1 && a.n_imgl <= (a.L == NL ? CL_LANE_IMGL_MAX_NL : CL_LANE_IMGL_MAX) && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && depth_ok &&
            a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.row_map != nullptr &&
            (a.gmeta == nullptr || a.tile_gmax != nullptr) && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
 }
@@ -1296,16 +1304,18 @@ int cl_launch_lane_imgl(const cl_mlp_args& a, int grid, hipStream_t st) {
 #define CL_LANE_IMGLD_CALL(D) if (a.L == D) return cl_launch_lane_imgl_depth##D(a, grid, st);
     CL_LANE_DEPTHS(CL_LANE_IMGLD_CALL)
 #undef CL_LANE_IMGLD_CALL
+    if (a.n_imgl == CL_LANE_IMGL_MAX_NL) return cl_launch_lane_imgl3(a, grid, st);
     return cl_launch_lane_imgl_inst(a, grid, st);
 }
 
 // name of the instance cl_launch_lane_imgl runs (cl_mlp_kernel_name)
 int cl_lane_imgl_kernel_name(const cl_mlp_args& a, char* out, size_t n) {
-    const bool full = lane_wants_full(a);
+    const bool full = lane_wants_full(a) || (a.n_imgl > CL_LANE_IMGL_MAX && a.dZ0_out != nullptr);       // (three layers + dZ_0 out: the full instance)
     const char* dxo = (!full && a.dZ0_out != nullptr) ? "true" : "false";
     const char* det = a.dzf_obs != nullptr ? " (deterministic stores)" : "";
     if (a.L != NL) return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d, %d> (image layers)%s", CL_LANE_WMAX, DMAX_ALL, full ? "true" : "false", dxo, a.n_imgl, a.L, det);
-    return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d> (image layers)%s", CL_LANE_WMAX, a.d <= 8 ? 8 : DMAX_ALL, full ? "true" : "false", dxo, a.n_imgl, det);
+    return snprintf(out, n, "elbo_lane_kernel<%d, %d, true, %s, %s, %d> (image layers)%s", CL_LANE_WMAX, (a.d <= 8 && a.n_imgl <= CL_LANE_IMGL_MAX) ? 8 : DMAX_ALL,
+                    full ? "true" : "false", dxo, a.n_imgl, det);
 }
 
 // name of the instance cl_launch_lane runs (cl_mlp_kernel_name)
@@ -1398,6 +1408,18 @@ int CL_LANE_BLOCK_FN(CL_LANE_NL)(const cl_mlp_args& a, int mode, int grid, hipSt
     } else if (a.w > CL_LANE_WMAX) return -2;
     if (mode == 1) return a.w <= 8 ? launch_lane_block_w<8, 1>(a, grid, st) : launch_lane_block_w<CL_LANE_WMAX, 1>(a, grid, st);
     return a.w <= 8 ? launch_lane_block_w<8, 2>(a, grid, st) : launch_lane_block_w<CL_LANE_WMAX, 2>(a, grid, st);
+}
+#endif
+#if CL_LANE_PART == 5
+// THREE per-image layers on the default depth (round 6): 23 layers of activations.  With the four parked layers the LDS has room for
+// (157.5 of 160 KB) hipcc's `AMDGPU Rewrite AGPR-Copy-MFMA` pass -- what -amdgpu-mfma-vgpr-form=1 switches on -- crashes on these
+// instances, so this unit is compiled WITHOUT that option (build.py): 97 .. 145 spilled registers, still ahead of the 16-wide IMGL
+// instance of elbo_mlp.hip these scalers ran on.  One metadata capacity; behind a peeled first layer (dZ_0 out) the FULL instance: without
+// the option the dZ_0-storing production instance comes out with accumulator-register copies one instruction in front of the inline-assembly
+// MFMAs that read them (the build's wait-state scan refuses it: scripts/check_lane_isa.py, rule R1).
+int cl_launch_lane_imgl3(const cl_mlp_args& a, int grid, hipStream_t st) {
+    if (lane_wants_full(a) || a.dZ0_out != nullptr) return launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, true, false, CL_LANE_IMGL_MAX_NL>(a, grid, st);
+    return launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, false, false, CL_LANE_IMGL_MAX_NL>(a, grid, st);
 }
 #endif
 #if CL_LANE_PART == 9

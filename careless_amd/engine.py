@@ -276,7 +276,8 @@ class ElboEngine(WidePath):
         # (... and at 2 .. 19 Dense layers of width 5 .. 10: the per-depth units carry the per-image-layer instances as well)
         lane_imgl_shape = lane_shape or (2 <= self.L < 20 and 5 <= self.w <= 10 and os.environ.get("CARELESS_HIP_LANE", "1") != "0" and
                                          os.environ.get("CARELESS_HIP_LANE_DEPTHS", "1") != "0")
-        if (not self.wide and imgl is not None and lane_imgl_shape and imgl.n_image_layers <= 2 and self.d > 15 and self.d > self.w and
+        lane_imgl_max = 3 if self.L == 20 else 2          # (a third per-image layer at the default depth only: csrc/elbo_lane.hip, CL_LANE_PART 5)
+        if (not self.wide and imgl is not None and lane_imgl_shape and imgl.n_image_layers <= lane_imgl_max and self.d > 15 and self.d > self.w and
                 bool(self.lib.cl_peel_supported(self.d, self.w, self.L))):
             self.peel = True
         if imgl is not None:
@@ -294,13 +295,13 @@ class ElboEngine(WidePath):
         wide_det_ok = self.wide and not self.laue and 64 % int(model.mc_sample_size) == 0
         # (per-image layers, round 6: where the step runs the lane kernel's per-image-layer instances -- one or two of them on 2 .. 20 Dense
         #  layers of width <= 10, up to 15 columns or behind the peeled first layer -- one wave holds all tiles of an image in this mode)
-        imgl_det_ok = (imgl is not None and not self.wide and imgl.n_image_layers <= 2 and lane_imgl_shape and (self.d <= 15 or self.peel) and
+        imgl_det_ok = (imgl is not None and not self.wide and imgl.n_image_layers <= lane_imgl_max and lane_imgl_shape and (self.d <= 15 or self.peel) and
                        os.environ.get("CARELESS_HIP_LANE", "1") != "0")
         if self.deterministic and (two_pass or (self.wide and not wide_det_ok) or (imgl is not None and not imgl_det_ok) or
                                    (self.blocks is not None and self.laue) or (self.double_wilson and prior.r_raw is not None)):
             raise NotImplementedError("deterministic mode covers monochromatic and single-pass Laue data, the Wilson and the double-Wilson prior "
                                       "(fixed r), Normal / Student-T likelihoods with or without the Evans-2011 error model, scalers of any depth up to "
-                                      "width 64, one or two per-image layers on 2 .. 20 Dense layers of width 5 .. 10 (the default scaler's kernels) and, "
+                                      "width 64, one or two per-image layers on 2 .. 20 Dense layers of width 5 .. 10 (three on 20; the default scaler's kernels) and, "
                                       "for monochromatic data with a sample count that divides 64, scalers wider than 64; the two-pass "
                                       "Laue path (also under a chained scaler), a trainable double-Wilson r and every other shape with per-image layers "
                                       "keep their float atomics")

@@ -43,6 +43,8 @@ WORKLOADS: Dict[str, dict] = {
     "dw_10M_normal_20x10_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, kind="double_wilson"),
     "mono_10M_20x10_img2_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, image_layers=2),
     "mono_10M_studentt_posenc_20x10_img2_S8": dict(N=10_000_000, d0=5, posenc=True, L=20, w=10, S=8, dof=16.0, outliers=True, image_layers=2),
+    # (round 6) `--image-layers 3`: the lane kernel's three-layer instance (a unit compiled without -amdgpu-mfma-vgpr-form)
+    "mono_10M_20x10_img3_S1": dict(N=10_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, image_layers=3),
     # (round 6) `--mlp-layers 10 --image-layers 2`: the per-image-layer instance of the lane kernel's depth-10 unit
     "mono_10M_10x10_img2_S1": dict(N=10_000_000, d0=5, posenc=False, L=10, w=10, S=1, dof=None, outliers=False, image_layers=2),
     "laue_5M_normal_20x10_img2_S1": dict(N=5_000_000, d0=5, posenc=False, L=20, w=10, S=1, dof=None, outliers=False, kind="laue", image_layers=2),

@@ -15,7 +15,7 @@ lines = [l for l in table.split("\n") if l.startswith("|")]
 head, rows = lines[:2], {l.split("`")[1]: l for l in lines[2:]}
 ORDER = ["mono_1M_normal_5x64_S1", "mono_10M_studentt_posenc_5x64_S8", "laue_5M_normal_5x64_S1", "dw_50M_normal_5x64_S1", "mono_10M_cli_default_20x10_S1",
          "laue_5M_normal_20x10_S1", "dw_10M_normal_20x10_S1", "mono_10M_studentt_posenc_20x10_S8", "mono_10M_studentt_posenc4_20x10_S8", "mono_10M_10x10_S1",
-         "mono_10M_24x10_S1", "mono_10M_20x10_img2_S1", "mono_10M_10x10_img2_S1", "laue_5M_normal_20x10_img2_S1", "mono_10M_studentt_posenc_20x10_img2_S8",
+         "mono_10M_24x10_S1", "mono_10M_20x10_img2_S1", "mono_10M_20x10_img3_S1", "mono_10M_10x10_img2_S1", "laue_5M_normal_20x10_img2_S1", "mono_10M_studentt_posenc_20x10_img2_S8",
          "mono_10M_studentt_posenc_4x64_img1_S8", "mono_2M_studentt_3x128_S4"]
 NOTES = {"mono_1M_normal_5x64_S1": " (configs[1])", "mono_10M_studentt_posenc_5x64_S8": " (configs[2], **the bench line**)",
          "laue_5M_normal_5x64_S1": " (configs[3], 1 GPU, single pass)", "dw_50M_normal_5x64_S1": " (configs[4], 1 GPU)",
@@ -23,6 +23,7 @@ NOTES = {"mono_1M_normal_5x64_S1": " (configs[1])", "mono_10M_studentt_posenc_5x
          "mono_10M_10x10_S1": " (**round 6**: the lane kernel compiled for depth 10; round 5, narrow kernel: 1.65 ms, 0.23)",
          "mono_10M_24x10_S1": " (**round 6**: a chain of two lane blocks + `cl_chain_dx`; round 5, two blocks of the 16-wide kernel: 7.72 ms)",
          "mono_10M_studentt_posenc4_20x10_S8": " (d = 37: peeled first layer)",
+         "mono_10M_20x10_img3_S1": " (**round 6**: three per-image layers, a lane unit without the MFMA-in-VGPR option; the 16-wide `IMGL` instance before: 5.56 ms, 0.157)",
          "mono_10M_10x10_img2_S1": " (**round 6**: the per-image-layer instance of the depth-10 unit; the 16-wide `IMGL` instance before: 3.98 ms, 0.114)",
          "mono_10M_studentt_posenc_20x10_img2_S8": " (d = 21: peeled first layer + the dZ₀-storing per-image-layer instance, **back in round 6**; round 5: 4.43 ms, 0.206)"}
 body = []

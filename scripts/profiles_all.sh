@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT}" || exit 1
 out=gpurun_out/rprof; mkdir -p $out
 python3 -c "from careless_amd.build import source_hash; print(source_hash())" > $out/sources.txt
-ALL="mono_10M_10x10_S1 mono_10M_10x10_img2_S1 mono_10M_24x10_S1 mono_10M_studentt_posenc_5x64_S8 mono_1M_normal_5x64_S1 laue_5M_normal_5x64_S1 mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_20x10_S8 mono_10M_studentt_posenc4_20x10_S8 mono_10M_studentt_posenc_4x64_img1_S8 mono_2M_studentt_3x128_S4 dw_50M_normal_5x64_S1 mono_10M_20x10_img2_S1 laue_5M_normal_20x10_S1 laue_5M_normal_20x10_img2_S1 dw_10M_normal_20x10_S1 mono_10M_studentt_posenc_20x10_img2_S8"
+ALL="mono_10M_10x10_S1 mono_10M_10x10_img2_S1 mono_10M_20x10_img3_S1 mono_10M_24x10_S1 mono_10M_studentt_posenc_5x64_S8 mono_1M_normal_5x64_S1 laue_5M_normal_5x64_S1 mono_10M_cli_default_20x10_S1 mono_10M_studentt_posenc_20x10_S8 mono_10M_studentt_posenc4_20x10_S8 mono_10M_studentt_posenc_4x64_img1_S8 mono_2M_studentt_3x128_S4 dw_50M_normal_5x64_S1 mono_10M_20x10_img2_S1 laue_5M_normal_20x10_S1 laue_5M_normal_20x10_img2_S1 dw_10M_normal_20x10_S1 mono_10M_studentt_posenc_20x10_img2_S8"
 WLS=${WLS:-$ALL}
 for wl in $WLS; do
   # the bench line from a run of its own (round 6: a line taken under the tracer is profiler-perturbed), then the same command under the tracer

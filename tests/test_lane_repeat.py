@@ -77,6 +77,12 @@ for depth in (2, 10, 19):
             full, dxo = ("true" if tag == "_full_ev11" else "false"), ("true" if tag == "_dz0_out" else "false")
             CASES[f"depth{depth}_image_layers{ni}{tag}"] = dict(kw=dict(base["kw"], L=depth), det=False,
                                                                name=f"elbo_lane_kernel<10, 15, true, {full}, {dxo}, {ni}, {depth}> (image layers)")
+# three per-image layers at the default depth (round 6: one metadata capacity, a unit compiled without -amdgpu-mfma-vgpr-form)
+CASES["image_layers3_dm15"] = _imgl(3, 15)
+CASES["image_layers3_d5"] = dict(kw=dict(_imgl(3, 8)["kw"]), det=False, name="elbo_lane_kernel<10, 15, true, false, false, 3> (image layers)")
+CASES["image_layers3_full_ev11_dm15"] = _imgl(3, 15, full=True)
+CASES["image_layers3_dz0_out_dm15"] = dict(kw=_imgl(3, 15, dxo=True)["kw"], det=False, name="elbo_lane_kernel<10, 15, true, true, false, 3> (image layers)")
+CASES["det_image_layers3"] = dict(kw=dict(_imgl(3, 15)["kw"]), det=True, name="elbo_lane_kernel<10, 15, true, true, false, 3> (image layers) (deterministic stores)")
 # ... and in deterministic mode (round 6: one wave per image; the whole flat gradient bit for bit)
 for key_, depth, ni, dm in (("det_image_layers2_dm8", 20, 2, 8), ("det_image_layers1_dm15", 20, 1, 15), ("det_depth10_image_layers2", 10, 2, 15)):
     base = _imgl(ni, dm)
