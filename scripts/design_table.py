@@ -69,6 +69,7 @@ with open(f"{P}/INDEX.md", "w") as out:
         (f"{tag}_lane_defect.txt", "the run-to-run defect: hazard probe on the hardware + A/B of the withdrawn instance's variants — DESIGN §4.14, NOTEBOOK R6.1"),
         (f"{tag}_ab_lrelu.txt", "round 5's library against round 6's (LeakyReLU as a compiler-known v_max_f32), alternating — DESIGN §4.14"),
         (f"{tag}_lane_repeat.txt", "tests/test_lane_repeat.py on the hardware (first run of the round)"),
+        (f"{tag}_lane_repeat_8engines.txt", "the 4 M-row half of tests/test_lane_repeat.py with EIGHT fresh engines for every one of the 100 instance kinds (the suite does that for a dozen, two engines x four launches for all)"),
         (f"{tag}_soak.txt", "60 launches at 10 M observations of eight kernel instances (CLI default, dZ0-storing, per-image layers + dZ0, another depth, a lane-block chain, per-image layers at another depth, the headline kernel, 12 x 12) against the first; second call on the same sources (scripts/r6_final_b.sh)"),
         (f"{tag}_frozen_step.txt", "the frozen-scaler step, `cl_frozen_rows` against round 5's slot kernels — DESIGN §5.1b"),
         (f"{tag}_kernel_stats_frozen_*.csv / {tag}_pmc_frozen_*.txt", "kernel trace and PMC traffic of the frozen step"),

@@ -12,7 +12,7 @@ per-image-layer) instance `cl_mlp_kernel_name` can name at the default depth, an
   * elsewhere the amplitude gradients differ by the order of their float atomics only (2e-6 of the max-norm) and the NLL by rounding;
 
 once at 5 000 rows on eight fresh engines (a tile or less per wave) and once at >= 4 M rows, eight launches on two fresh engines (full
-grid, the steady-state prefetch / flush loop of a production launch)."""
+grid, the steady-state prefetch / flush loop of a production launch) -- on eight fresh engines for a dozen of the kinds."""
 import numpy as np
 import pytest
 import torch
@@ -144,3 +144,15 @@ def test_lane_instance_repeats_at_4M_rows(key):
     case = CASES[key]
     n_img = 3001 if case["kw"].get("image_layers") else 4000
     _run(case, 4_000_000, 2, n_images=n_img, R=20000, launches=4)       # eight launches on two fresh engines
+
+
+# ... and on EIGHT fresh engines at that size for the kinds that carried round 5's defect and one of every family (every kind that way would
+# add five minutes of host-side packing to the suite: profiles/r6_lane_repeat_8engines.txt has that run, 100 of 100)
+EIGHT = ["plain_w10_dm8", "plain_full_det_w10_dm15", "packed_laue_w10_dm8", "dz0_out_w10", "image_layers2_dm8", "image_layers2_dz0_out_dm15",
+         "image_layers3_dm15", "det_image_layers2_dm8", "depth10_plain", "depth10_image_layers2", "depth19_dz0_out", "plain_w10_dm0"]
+
+
+@pytest.mark.parametrize("key", EIGHT)
+def test_lane_instance_repeats_at_4M_rows_on_eight_fresh_engines(key):
+    case = CASES[key]
+    _run(case, 4_000_000, 8, n_images=3001 if case["kw"].get("image_layers") else 4000, R=20000)
