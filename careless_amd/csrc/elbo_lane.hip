@@ -1168,8 +1168,9 @@ static int launch_lane_one(const cl_mlp_args& a, int grid, hipStream_t st) {
 #ifndef CL_LANE_WMAX
 #define CL_LANE_WMAX 10
 #endif
-#define CL_LANE_IMGL_MAX 2          /* per-image layers of the lane instances ... */
-#define CL_LANE_IMGL_MAX_NL 3       /* ... at the default depth: a third one in a unit of its own (CL_LANE_PART = 5) */
+#define CL_LANE_IMGL_MAX 2          /* per-image layers of the lane instances with all three forms (production, full, dZ_0 out) ... */
+#define CL_LANE_IMGL_MAX_NL 3       /* ... a third one: production and full form; at the default depth in a unit of its own (CL_LANE_PART = 5) */
+#define CL_LANE_IMGL3_DEPTH_MAX 18  /* ... the third one on 2 .. 18 and on 20 Dense layers (19: see CL_LANE_PART 9) */
 #ifndef CL_LANE_DEPTH_WMIN
 #define CL_LANE_DEPTH_WMIN 5        /* narrowest scaler the other-depth instances (compiled at widths 8 and 10) take */
 #endif
@@ -1260,7 +1261,7 @@ int cl_lane_supports(const cl_mlp_args& a) {
 int cl_lane_imgl_supports(const cl_mlp_args& a) {
     static const bool depths_on = [] { const char* e = getenv("CARELESS_HIP_LANE_DEPTHS"); return !(e != nullptr && e[0] == '0'); }();
     const bool depth_ok = a.L == NL || (depths_on && lane_has_depth(a.L) && a.w >= CL_LANE_DEPTH_WMIN);
-    return a.n_imgl >= 1 && a.n_imgl <= (a.L == NL ? CL_LANE_IMGL_MAX_NL : CL_LANE_IMGL_MAX) && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && depth_ok &&
+    return a.n_imgl >= 1 && a.n_imgl <= ((a.L == NL || a.L <= CL_LANE_IMGL3_DEPTH_MAX) ? CL_LANE_IMGL_MAX_NL : CL_LANE_IMGL_MAX) && a.w >= 1 && a.w <= CL_LANE_WMAX && a.S >= 1 && a.d >= 1 && a.d <= DMAX_ALL && depth_ok &&
            a.act_out == nullptr && a.dH_ext == nullptr && a.dX_out == nullptr && a.row_map != nullptr &&
            (a.gmeta == nullptr || a.tile_gmax != nullptr) && !a.use_img && a.imgl != nullptr && a.d_imgl != nullptr && a.tile_img != nullptr && a.n_images >= 1;
 }
@@ -1432,8 +1433,16 @@ int CL_LANE_IMGLD_FN(CL_LANE_NL)(const cl_mlp_args& a, int grid, hipStream_t st)
                                 (a.dZ0_out != nullptr ? launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, false, true, NI_>(a, grid, st) : \
                                                         launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, false, false, NI_>(a, grid, st)))
     if (a.n_imgl == 1) return CL_LANE_IMGL_CASE(1);
-    return CL_LANE_IMGL_CASE(2);
+    if (a.n_imgl == 2) return CL_LANE_IMGL_CASE(2);
 #undef CL_LANE_IMGL_CASE
+    // three per-image layers: production and full instance (behind a peeled first layer the full one, as at the default depth) -- up to
+    // CL_LANE_IMGL3_DEPTH_MAX Dense layers: on 19 the full instance (22 layers) crashes the compiler pass named at CL_LANE_PART 5
+#if CL_LANE_NL <= CL_LANE_IMGL3_DEPTH_MAX
+    if (full || a.dZ0_out != nullptr) return launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, true, false, CL_LANE_IMGL_MAX_NL>(a, grid, st);
+    return launch_lane_inst<CL_LANE_WMAX, DMAX_ALL, true, false, false, CL_LANE_IMGL_MAX_NL>(a, grid, st);
+#else
+    return -2;
+#endif
 }
 #endif
 #if CL_LANE_PART == 4

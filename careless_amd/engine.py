@@ -276,7 +276,7 @@ class ElboEngine(WidePath):
         # (... and at 2 .. 19 Dense layers of width 5 .. 10: the per-depth units carry the per-image-layer instances as well)
         lane_imgl_shape = lane_shape or (2 <= self.L < 20 and 5 <= self.w <= 10 and os.environ.get("CARELESS_HIP_LANE", "1") != "0" and
                                          os.environ.get("CARELESS_HIP_LANE_DEPTHS", "1") != "0")
-        lane_imgl_max = 3 if self.L == 20 else 2          # (a third per-image layer at the default depth only: csrc/elbo_lane.hip, CL_LANE_PART 5)
+        lane_imgl_max = 2 if self.L == 19 else 3          # (csrc/elbo_lane.hip: CL_LANE_IMGL_MAX_NL, CL_LANE_IMGL3_DEPTH_MAX)
         if (not self.wide and imgl is not None and lane_imgl_shape and imgl.n_image_layers <= lane_imgl_max and self.d > 15 and self.d > self.w and
                 bool(self.lib.cl_peel_supported(self.d, self.w, self.L))):
             self.peel = True
@@ -301,7 +301,7 @@ class ElboEngine(WidePath):
                                    (self.blocks is not None and self.laue) or (self.double_wilson and prior.r_raw is not None)):
             raise NotImplementedError("deterministic mode covers monochromatic and single-pass Laue data, the Wilson and the double-Wilson prior "
                                       "(fixed r), Normal / Student-T likelihoods with or without the Evans-2011 error model, scalers of any depth up to "
-                                      "width 64, one or two per-image layers on 2 .. 20 Dense layers of width 5 .. 10 (three on 20; the default scaler's kernels) and, "
+                                      "width 64, up to three per-image layers on 2 .. 20 Dense layers of width 5 .. 10 (two on 19; the default scaler's kernels) and, "
                                       "for monochromatic data with a sample count that divides 64, scalers wider than 64; the two-pass "
                                       "Laue path (also under a chained scaler), a trainable double-Wilson r and every other shape with per-image layers "
                                       "keep their float atomics")

@@ -189,8 +189,8 @@ typedef struct cl_mlp_args {
      * amplitude gradient of every (observation, sample) is STORED in dzf_obs, the image-scale gradient of every observation in
      * dimg_obs, every workgroup's NLL in nll_part; cl_det_reduce then sums them per reflection / per image / per launch in a fixed
      * order.  Two runs on the same inputs give bit-identical gradients.  Per-image layers (n_imgl > 0; round 6): only where the launch
-     * runs the lane kernel's instances (cl_mlp_kernel_name says "elbo_lane_kernel<...> (image layers)": n_imgl <= 2 on 2 .. 20 Dense layers
-     * of width <= 10, n_imgl = 3 on 20) -- one wave then holds all tiles of an image, its gradient is ONE addition per element onto the cleared d_imgl;
+     * runs the lane kernel's instances (cl_mlp_kernel_name says "elbo_lane_kernel<...> (image layers)": n_imgl <= 3 on 2 .. 20 Dense layers
+     * of width <= 10, <= 2 on 19) -- one wave then holds all tiles of an image, its gradient is ONE addition per element onto the cleared d_imgl;
      * every other shape with per-image layers returns -2 in this mode.                                                          */
     float* dzf_obs;             /* [n_obs][S]                                                                          */
     float* dimg_obs;            /* [n_obs]                                                                             */

@@ -140,6 +140,11 @@ CASES = {
     "lane_image_layers3_20x10_posenc_d21_peeled": dict(N=1500, R=60, d0=5, posenc=True, L=20, w=10, S=2, n_images=8, image_layers=3, perturb=0.02),
     "lane_laue_image_layers3_20x10_S3": dict(N=900, R=60, L=20, w=10, S=3, laue=True, n_images=6, image_layers=3, perturb=0.02),
     # ... at other depths (round 6: the per-depth units' per-image-layer instances)
+    "lane_image_layers3_10x10": dict(N=1500, R=60, d0=5, L=10, w=10, S=2, n_images=9, image_layers=3, perturb=0.03),
+    "lane_image_layers3_2x8_ev11": dict(N=900, R=50, d0=9, L=2, w=8, S=3, n_images=6, image_layers=3, ev11=True, perturb=0.04),
+    "lane_image_layers3_18x10_studentt": dict(N=1200, R=60, d0=5, L=18, w=10, S=2, n_images=7, image_layers=3, likelihood="studentt", dof=8.0, perturb=0.02),
+    "lane_image_layers3_7x10_posenc_d21_peeled": dict(N=1500, R=60, d0=5, posenc=True, L=7, w=10, S=2, n_images=8, image_layers=3, perturb=0.03),
+    "lane_laue_image_layers3_14x9": dict(N=900, R=60, L=14, w=9, S=2, laue=True, n_images=6, image_layers=3, perturb=0.02),
     "lane_image_layers2_10x10": dict(N=1500, R=60, d0=5, L=10, w=10, S=2, n_images=9, image_layers=2, perturb=0.03),
     "lane_image_layers1_2x10_S3": dict(N=900, R=50, d0=5, L=2, w=10, S=3, n_images=6, image_layers=1, perturb=0.04),
     "lane_image_layers2_2x6_d12": dict(N=900, R=50, d0=12, L=2, w=6, S=2, n_images=6, image_layers=2, perturb=0.04),
@@ -463,8 +468,8 @@ def _random_lane_image_layer_cases(n=10, seed=23, depths=False):
                   image_layers=int(rng.integers(1, 3)), n_images=int(rng.integers(2, 30)), perturb=0.03)
         if depths:                      # (round 6: 2 .. 19 Dense layers at widths 5 .. 10, more than 15 columns behind a peeled first layer)
             kw.update(L=int(rng.integers(2, 20)), w=int(rng.integers(5, 11)))
-        elif rng.random() < 0.3:
-            kw["image_layers"] = 3      # (round 6: a third per-image layer at the default depth)
+        if rng.random() < 0.3:
+            kw["image_layers"] = 3      # (round 6: a third per-image layer)
         if laue:
             kw["laue"] = True
             kw["N"] = max(kw["N"], 150)
@@ -1359,13 +1364,14 @@ def test_shard_cut_into_several_launches_equals_one_launch(kw, monkeypatch):
                                 dict(N=1300, R=50, d0=5, posenc=True, L=20, w=10, S=2, n_images=8, image_layers=2, perturb=0.03),
                                 dict(N=900, R=60, L=20, w=10, S=2, laue=True, n_images=6, image_layers=1, perturb=0.03),
                                 dict(N=2600, R=60, d0=5, L=6, w=10, S=9, n_images=3, image_layers=2, perturb=0.03, shuffle_rows=True),
-                                dict(N=1200, R=50, d0=5, L=20, w=10, S=2, n_images=7, image_layers=3, perturb=0.02)],
+                                dict(N=1200, R=50, d0=5, L=20, w=10, S=2, n_images=7, image_layers=3, perturb=0.02),
+                                dict(N=1200, R=50, d0=5, L=9, w=10, S=3, n_images=7, image_layers=3, perturb=0.03)],
                          ids=["mono_5x64", "cli_default_20x10", "rows_in_arbitrary_order_S8", "no_image_scales_klweight",
                               "lane_posenc_d21_S8", "lane_20x8_S11", "narrow_6x10_S5", "narrow_9x13_d12", "laue_lane_20x10_S3", "laue_narrow_4x12", "laue_5x64_S3", "laue_3x32_d20_S9",
                               "double_wilson_5x64", "double_wilson_lane_20x10", "wide_3x128_S4", "wide_2x96_noimg", "deep_12x64_S3", "deep_25x10",
                               "ev11_5x64", "ev11_lane_20x10", "ev11_narrow_6x10_S5", "ev11_laue_3x32", "ev11_wide_2x80_S4", "peel_20x10_d41_S3", "w16_12x16_S3",
                               "image_layers2_lane_20x10", "image_layers1_lane_10x9_ev11", "image_layers2_lane_peeled_d21", "laue_image_layers1_lane_20x10",
-                              "image_layers2_lane_6x10_S9_three_large_images", "image_layers3_lane_20x10"])
+                              "image_layers2_lane_6x10_S9_three_large_images", "image_layers3_lane_20x10", "image_layers3_lane_9x10"])
 def test_deterministic_mode_matches_oracle_and_repeats_bit_for_bit(kw, monkeypatch):
     """`model.deterministic = True` (or CARELESS_HIP_DETERMINISTIC=1): the fused kernel stores per-observation contributions instead of
     issuing float atomics and `cl_det_reduce` sums them in row order (include/careless_hip.h).  Same parity bar against the oracle,

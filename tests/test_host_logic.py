@@ -317,7 +317,8 @@ def test_kernel_name_follows_the_librarys_routing():
     assert name(d=7, w=7, L=3, S=1, ev11=1, **dict(imgl, n_imgl=1)) == "elbo_lane_kernel<10, 15, true, true, false, 1, 3> (image layers)"
     assert name(d=5, w=4, L=10, S=2, **imgl).startswith("elbo_mlp_kernel<16, 8, 24, 0, image layers")
     assert name(d=5, w=10, L=20, S=2, **dict(imgl, n_imgl=3)) == "elbo_lane_kernel<10, 15, true, false, false, 3> (image layers)"     # (three: the default depth only)
-    assert name(d=5, w=10, L=12, S=2, **dict(imgl, n_imgl=3)).startswith("elbo_mlp_kernel<16, 8, 24, 0, image layers")
+    assert name(d=5, w=10, L=12, S=2, **dict(imgl, n_imgl=3)) == "elbo_lane_kernel<10, 15, true, false, false, 3, 12> (image layers)"
+    assert name(d=8, w=9, L=12, S=2, dZ0_out=1, **dict(imgl, n_imgl=3)) == "elbo_lane_kernel<10, 15, true, true, false, 3, 12> (image layers)"
     assert name(d=5, w=10, L=20, S=2, **dict(imgl, n_imgl=4)).startswith("elbo_mlp_kernel<16, 8, 24, 0, image layers")
     # ... in deterministic mode (round 6): the lane instances only
     assert name(d=5, w=10, L=20, S=2, dzf_obs=1, **imgl) == "elbo_lane_kernel<10, 8, true, true, false, 2> (image layers) (deterministic stores)"

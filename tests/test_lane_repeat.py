@@ -83,6 +83,12 @@ CASES["image_layers3_d5"] = dict(kw=dict(_imgl(3, 8)["kw"]), det=False, name="el
 CASES["image_layers3_full_ev11_dm15"] = _imgl(3, 15, full=True)
 CASES["image_layers3_dz0_out_dm15"] = dict(kw=_imgl(3, 15, dxo=True)["kw"], det=False, name="elbo_lane_kernel<10, 15, true, true, false, 3> (image layers)")
 CASES["det_image_layers3"] = dict(kw=dict(_imgl(3, 15)["kw"]), det=True, name="elbo_lane_kernel<10, 15, true, true, false, 3> (image layers) (deterministic stores)")
+for depth in (4, 12, 18):
+    CASES[f"depth{depth}_image_layers3"] = dict(kw=dict(_imgl(3, 15)["kw"], L=depth), det=False, name=f"elbo_lane_kernel<10, 15, true, false, false, 3, {depth}> (image layers)")
+    CASES[f"depth{depth}_image_layers3_dz0_out"] = dict(kw=dict(_imgl(3, 15, dxo=True)["kw"], L=depth), det=False,
+                                                        name=f"elbo_lane_kernel<10, 15, true, true, false, 3, {depth}> (image layers)")
+CASES["det_depth12_image_layers3"] = dict(kw=dict(_imgl(3, 15)["kw"], L=12), det=True,
+                                          name="elbo_lane_kernel<10, 15, true, true, false, 3, 12> (image layers) (deterministic stores)")
 # ... and in deterministic mode (round 6: one wave per image; the whole flat gradient bit for bit)
 for key_, depth, ni, dm in (("det_image_layers2_dm8", 20, 2, 8), ("det_image_layers1_dm15", 20, 1, 15), ("det_depth10_image_layers2", 10, 2, 15)):
     base = _imgl(ni, dm)

@@ -62,8 +62,10 @@ IMGL_TABLE = [
     (10, 4,  5,  2, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),   # narrower than 5 at another depth: the 16-wide IMGL instance
     (20, 10, 5,  3, False, "elbo_lane_kernel<10, 15, true, false, false, 3> (image layers)",       False),   # three per-image layers on the default depth: a unit of their own
     (20, 8,  21, 3, False, "elbo_lane_kernel<10, 15, true, true, false, 3> (image layers)",        True),    # (... behind a peeled layer: the full instance)
-    (12, 10, 5,  3, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),   # ... on another depth, or four of them: the 16-wide IMGL instance
-    (20, 10, 5,  4, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),
+    (12, 10, 5,  3, False, "elbo_lane_kernel<10, 15, true, false, false, 3, 12> (image layers)",   False),   # ... on another depth
+    (5,  6,  21, 3, False, "elbo_lane_kernel<10, 15, true, true, false, 3, 5> (image layers)",     True),
+    (19, 10, 5,  3, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),   # (19 + 3: the compiler gives up on the 22-layer full instance)
+    (20, 10, 5,  4, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),   # four of them: the 16-wide IMGL instance
 ]
 
 
