@@ -1330,7 +1330,13 @@ template <int MODE>
 static int launch_mode(const cl_mlp_args& a, int grid, hipStream_t st) {
     if (a.L < 1 || a.w < 1 || a.d < 1) return -2;
     if (a.w > 64 || a.d > 64) return -2;
-    if (a.w <= 15) {
+    // Per-image layers on more than 32 metadata columns at hidden width <= 15: the 16-wide instance <16, 64, 24, IMGL> (864 - 880 bytes of
+    // scratch per lane, the largest of the library) ends in a GPU memory fault when a workgroup walks more than one tile and crosses an
+    // image border (found by a random draw late in round 6: scripts/probe/imgl_abort_probe.py, NOTEBOOK R6.4; the forward-only launch
+    // is not affected).  Those shapes take the 32-wide instance, which holds up to CL_MLP_LMAX_W32 layers (deeper: the caller's
+    // layer-by-layer path, as for any scaler deeper than one launch).
+    const bool imgl_d64 = (CL_IMGL == 1) && MODE != 1 && a.n_imgl > 0 && a.d > 32;
+    if (a.w <= 15 && !imgl_d64) {
         // the narrow instance comes in three step counts (hidden width <= 8, <= 12, <= 15); the forward-only launch keeps all four
         constexpr int L16 = (CL_IMGL == 1 ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16);
         if (MODE != 1 && a.w <= 8) return launch_dp<16, L16, MODE, 2>(a, grid, st);
@@ -1475,10 +1481,11 @@ int cl_mlp_kernel_name_of(const cl_mlp_args& a, int mode, char* out, size_t n) {
     if (a.w < 1 || a.w > 64 || a.d < 1 || a.d > 64) return snprintf(out, n, "(unsupported)");
     const int imgl = a.n_imgl > 0 ? a.n_imgl : 0;
     const bool w16 = a.w == 16 && imgl == 0;                     // width exactly 16: the 16-wide instance without the constant-one feature (KS = 5)
-    const int WP = (a.w <= 15 || w16) ? 16 : (a.w <= 32 ? 32 : 64);
+    const bool imgl_d64 = imgl > 0 && mode != 1 && a.d > 32;     // (launch_mode: these shapes take the 32-wide instance)
+    const int WP = ((a.w <= 15 && !imgl_d64) || w16) ? 16 : (a.w <= 32 ? 32 : 64);
     const int DP = a.d <= 8 ? 8 : (a.d <= 32 ? 32 : 64);
-    const int LM = (a.w <= 15 || w16) ? (imgl ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16) : (a.w <= 32 ? (a.L + imgl <= 5 ? 5 : CL_MLP_LMAX_W32) : CL_MLP_LMAX_W64);
-    const int KS = w16 ? 5 : ((a.w <= 15 && mode != 1) ? (a.w <= 8 ? 2 : (a.w <= 12 ? 3 : 4)) : 4);
+    const int LM = WP == 16 ? (imgl ? CL_MLP_LMAX_W16_IMGL : CL_MLP_LMAX_W16) : (WP == 32 ? (a.L + imgl <= 5 ? 5 : CL_MLP_LMAX_W32) : CL_MLP_LMAX_W64);
+    const int KS = w16 ? 5 : ((WP == 16 && mode != 1) ? (a.w <= 8 ? 2 : (a.w <= 12 ? 3 : 4)) : 4);
     return snprintf(out, n, "elbo_mlp_kernel<%d, %d, %d, %d%s, KS=%d>", WP, DP, LM, mode, unit, KS);
 }
 

@@ -244,7 +244,7 @@ class ElboEngine(WidePath):
         # blocks, so the scaler runs unfused -- one fp32-MFMA GEMM launch (csrc/wide_gemm.hip) per layer and direction, activations
         # through HBM -- around the same HIP likelihood kernels (_data_term_wide)
         self.wide = self.w > 64 or self.d > 64
-        if imgl is not None and not self.wide and self.L + imgl.n_image_layers > int(self.lib.cl_mlp_max_layers_imgl(self.w)):
+        if imgl is not None and not self.wide and self.L + imgl.n_image_layers > self._imgl_layer_cap(imgl.n_image_layers):
             self.wide = True        # more hidden layers (Dense + per-image) than one fused launch holds: layer by layer as well
         max_plain = 1 if self.wide else int(self.lib.cl_mlp_max_layers(self.w))
         if not self.wide and imgl is None and self.L > max_plain:
@@ -282,7 +282,7 @@ class ElboEngine(WidePath):
             self.peel = True
         if imgl is not None:
             imgl.build(self.d)
-            max_l = int(self.lib.cl_mlp_max_layers_imgl(self.w))
+            max_l = self._imgl_layer_cap(imgl.n_image_layers)
             if not self.wide and self.L + imgl.n_image_layers > max_l:
                 raise NotImplementedError(f"{self.L} Dense + {imgl.n_image_layers} image layers of width {self.w}: the HIP engine "
                                           f"supports {max_l} hidden layers in total at this width")
@@ -490,6 +490,18 @@ class ElboEngine(WidePath):
             obs.det["ev11"] = torch.zeros(3 * (_lib.CL_EV11_WAVES * len(pieces) * pieces[0].grid + 4 * _lib.CL_LAUE_LIK_MAX_BLOCKS), dtype=torch.float32, device=dev)
         for k, p in enumerate(pieces):
             p.det_parent, p.det_index = obs, k
+
+    def _imgl_layer_cap(self, K: int) -> int:
+        """Hidden layers (Dense + per-image) one fused training launch holds at this width.  Width <= 15 on more than 32 metadata columns
+        takes the 32-wide instance (`cl_launch_mlp`: the 16-wide <16, 64, 24, image layers> instance is withdrawn -- csrc/elbo_mlp.hip,
+        launch_mode) unless the step runs the lane kernel's per-image-layer instances behind a peeled first layer."""
+        lane = os.environ.get("CARELESS_HIP_LANE", "1") != "0"
+        depths = lane and os.environ.get("CARELESS_HIP_LANE_DEPTHS", "1") != "0"
+        lane_route = ((self.L == 20 and self.w <= 10 and K <= 3 and lane) or
+                      (2 <= self.L <= 19 and 5 <= self.w <= 10 and K <= (2 if self.L == 19 else 3) and depths))
+        if self.w <= 15 and self.d > 32 and not lane_route:
+            return int(self.lib.cl_mlp_max_layers_imgl(32))
+        return int(self.lib.cl_mlp_max_layers_imgl(self.w))
 
     def _max_images(self):
         if self.img is not None:

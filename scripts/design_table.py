@@ -76,6 +76,7 @@ with open(f"{P}/INDEX.md", "w") as out:
         (f"{tag}_envelope.txt / {tag}_envelope_before.txt", "depth × width × columns × samples around the default scaler, with the per-depth lane units and lane-block chains on / off — DESIGN §4.4d, §4.6"),
         (f"{tag}_imgl_depth.txt", "`--mlp-layers D --image-layers 2` on the per-depth units' per-image-layer instances, on / off (first run on the hardware) — DESIGN §4.4c"),
         (f"{tag}_imgl3.txt", "three per-image layers on the lane kernel (default depth): cases + `--image-layers 3` at 10 M observations with the lane kernel on / off — DESIGN §4.4c"),
+        (f"{tag}_imgl_abort_probe.txt", "the GPU memory fault of `elbo_mlp_kernel<16, 64, 24, 0, image layers>` (a random draw on a new seed): which variations fault — DESIGN §4.7"),
         (f"{tag}_imgl_det.txt", "deterministic mode with per-image layers on the lane kernel's instances: cases + what the mode costs — DESIGN §4.10"),
         (f"{tag}_e2e.txt", "`--merge-half-datasets` and `--mlp-layers 10` through the command line on 5 M observations, wall time by stage — DESIGN §5.1b"),
         (f"{tag}_rehearsal_gloo.txt", "eight-rank gloo rehearsal of `bench.py --gpus N` + rank 0's shard of 8-rank jobs on one device — DESIGN §5.2"),

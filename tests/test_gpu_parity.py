@@ -134,6 +134,12 @@ CASES = {
     "lane_laue_image_layers1_20x10": dict(N=900, R=60, L=20, w=10, S=1, laue=True, n_images=6, image_layers=1, perturb=0.03),
     "lane_laue_image_layers2_20x6_S3_studentt": dict(N=700, R=50, L=20, w=6, S=3, laue=True, n_images=4, image_layers=2, likelihood="studentt", dof=8.0,
                                                      perturb=0.03),
+    # per-image layers at hidden width <= 15 on MORE THAN 32 columns: the 32-wide instance (round 6: the 16-wide <16, 64, 24> instance faulted when a
+    # workgroup crossed an image border -- the first case is the random draw that found it), deeper than it holds: layer by layer
+    "image_layers2_2x11_d36_workgroups_cross_images": dict(N=323, R=67, L=2, w=11, S=7, perturb=0.05, d0=36, image_layers=2, n_images=7, bijector="softplus", shift=0.0, grid=2),
+    "image_layers2_2x15_d36_one_workgroup": dict(N=323, R=67, L=2, w=15, S=2, perturb=0.05, d0=36, image_layers=2, n_images=3, grid=1),
+    "image_layers1_8x13_d50_S3_studentt": dict(N=900, R=60, L=8, w=13, S=3, perturb=0.03, d0=50, image_layers=1, n_images=6, likelihood="studentt", dof=8.0, grid=3),
+    "image_layers1_12x12_d36_layer_by_layer": dict(N=700, R=50, d0=36, L=12, w=12, S=2, n_images=5, image_layers=1, perturb=0.02),
     # three per-image layers on the default depth (round 6: a lane unit of their own)
     "lane_image_layers3_20x10": dict(N=1500, R=60, d0=5, L=20, w=10, S=2, n_images=9, image_layers=3, perturb=0.02),
     "lane_image_layers3_20x7_d12_ev11_studentt_S5": dict(N=1200, R=60, d0=12, L=20, w=7, S=5, n_images=7, image_layers=3, ev11=True, likelihood="studentt", dof=8.0, perturb=0.02),

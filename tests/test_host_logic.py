@@ -320,6 +320,10 @@ def test_kernel_name_follows_the_librarys_routing():
     assert name(d=5, w=10, L=12, S=2, **dict(imgl, n_imgl=3)) == "elbo_lane_kernel<10, 15, true, false, false, 3, 12> (image layers)"
     assert name(d=8, w=9, L=12, S=2, dZ0_out=1, **dict(imgl, n_imgl=3)) == "elbo_lane_kernel<10, 15, true, true, false, 3, 12> (image layers)"
     assert name(d=5, w=10, L=20, S=2, **dict(imgl, n_imgl=4)).startswith("elbo_mlp_kernel<16, 8, 24, 0, image layers")
+    # width <= 15 on more than 32 columns: the training launch takes the 32-wide instance (the 16-wide one is withdrawn), the forward-only launch keeps it
+    assert name(d=36, w=11, L=2, S=2, **imgl) == "elbo_mlp_kernel<32, 64, 5, 0, image layers, KS=4>"
+    assert name(d=50, w=13, L=8, S=2, **dict(imgl, n_imgl=1)) == "elbo_mlp_kernel<32, 64, 10, 0, image layers, KS=4>"
+    assert name(d=36, w=11, L=2, S=2, mode=1, **imgl) == "elbo_mlp_kernel<16, 64, 24, 1, image layers, KS=4>"
     # ... in deterministic mode (round 6): the lane instances only
     assert name(d=5, w=10, L=20, S=2, dzf_obs=1, **imgl) == "elbo_lane_kernel<10, 8, true, true, false, 2> (image layers) (deterministic stores)"
     assert name(d=5, w=10, L=7, S=2, dzf_obs=1, **imgl) == "elbo_lane_kernel<10, 15, true, true, false, 2, 7> (image layers) (deterministic stores)"

@@ -65,6 +65,9 @@ IMGL_TABLE = [
     (12, 10, 5,  3, False, "elbo_lane_kernel<10, 15, true, false, false, 3, 12> (image layers)",   False),   # ... on another depth
     (5,  6,  21, 3, False, "elbo_lane_kernel<10, 15, true, true, false, 3, 5> (image layers)",     True),
     (19, 10, 5,  3, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),   # (19 + 3: the compiler gives up on the 22-layer full instance)
+    (2,  11, 36, 2, False, "elbo_mlp_kernel<32, 64, 5, 0, image layers",                           False),   # width <= 15 on more than 32 columns: the 32-wide instance (the 16-wide one is withdrawn)
+    (8,  13, 50, 1, False, "elbo_mlp_kernel<32, 64, 10, 0, image layers",                          False),
+    (12, 12, 36, 1, False, "wide_gemm_kernel",                                                     False),   # ... deeper than it holds: layer by layer
     (20, 10, 5,  4, False, "elbo_mlp_kernel<16, 8, 24, 0, image layers",                           False),   # four of them: the 16-wide IMGL instance
 ]
 
